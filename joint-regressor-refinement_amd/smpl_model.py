@@ -1,0 +1,190 @@
+"""SMPL model constants: optional real-model loader and the seeded synthetic generator.
+
+The reference builds its body model with `SMPL("SPIN/data/smpl", batch_size=1)`
+(/root/reference/scripts/optimize.py:96-99); the model file is licence-gated and absent, so
+benchmarks and tests use a synthetic model of identical shapes.
+
+Arrays (float32 unless noted), named as in smplx:
+  v_template (6890,3)  shapedirs (6890,3,10)  posedirs (207, 20670)
+  J_regressor (24,6890)  lbs_weights (6890,24)  parents (24,) int32  faces (F,3) int32
+"""
+from __future__ import annotations
+
+import os
+import pickle
+from typing import Dict, Optional
+
+import numpy as np
+
+NUM_VERTS = 6890
+NUM_JOINTS = 24
+NUM_BETAS = 10
+NUM_H36M = 17
+SMPL_PARENTS = np.array([-1, 0, 0, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 9, 9, 12, 13, 14, 16, 17, 18, 19, 20, 21],
+                        dtype=np.int32)
+
+# Rough rest-pose joint centres (metres) of a T-posed body, used only to place synthetic vertices.
+_REST_JOINTS = np.array([
+    [0.00, -0.22, 0.03], [0.07, -0.31, 0.01], [-0.07, -0.31, 0.01], [0.00, -0.10, 0.00],
+    [0.10, -0.69, 0.01], [-0.10, -0.69, 0.01], [0.00, 0.03, 0.00], [0.09, -1.09, -0.03],
+    [-0.09, -1.09, -0.03], [0.00, 0.09, 0.02], [0.11, -1.15, 0.09], [-0.11, -1.15, 0.09],
+    [0.00, 0.30, -0.01], [0.08, 0.21, -0.01], [-0.08, 0.21, -0.01], [0.00, 0.38, 0.03],
+    [0.17, 0.23, -0.02], [-0.17, 0.23, -0.02], [0.43, 0.22, -0.03], [-0.43, 0.22, -0.03],
+    [0.68, 0.23, -0.03], [-0.68, 0.23, -0.03], [0.76, 0.22, -0.03], [-0.76, 0.22, -0.03]], dtype=np.float64)
+
+
+def synthetic_smpl(seed: int = 1234, max_influences: int = 4) -> Dict[str, np.ndarray]:
+    """Seeded synthetic body model with SMPL's shapes and structural properties:
+    body-scale template, shapedirs ~ N(0, 0.01^2), posedirs ~ N(0, 0.002^2), sparse
+    non-negative J_regressor rows summing to 1, <= `max_influences` skinning weights per
+    vertex summing to 1, canonical SMPL parents."""
+    rng = np.random.RandomState(seed)
+    V = NUM_VERTS
+    # each vertex is attached to a "home" joint and scattered around it
+    home = rng.randint(0, NUM_JOINTS, size=V)
+    v_template = _REST_JOINTS[home] + rng.normal(0.0, 0.06, size=(V, 3))
+    shapedirs = rng.normal(0.0, 0.01, size=(V, 3, NUM_BETAS))
+    posedirs = rng.normal(0.0, 0.002, size=(207, V * 3))
+    # skinning weights: home joint + up to 3 kinematic neighbours
+    W = np.zeros((V, NUM_JOINTS))
+    for v in range(V):
+        j = home[v]
+        cand = [j]
+        if SMPL_PARENTS[j] >= 0:
+            cand.append(int(SMPL_PARENTS[j]))
+        cand += [int(c) for c in np.where(SMPL_PARENTS == j)[0]]
+        cand = cand[:max_influences]
+        w = rng.uniform(0.05, 1.0, size=len(cand))
+        w[0] += 1.0
+        W[v, cand] = w / w.sum()
+    # rest-joint regressor: each joint regresses from 12 vertices homed at it
+    J_regressor = np.zeros((NUM_JOINTS, V))
+    for j in range(NUM_JOINTS):
+        idx = np.where(home == j)[0]
+        pick = rng.choice(idx, size=min(12, len(idx)), replace=False)
+        w = rng.uniform(0.2, 1.0, size=len(pick))
+        J_regressor[j, pick] = w / w.sum()
+    faces = np.stack([np.arange(0, 13776) % V, (np.arange(0, 13776) * 7 + 1) % V,
+                      (np.arange(0, 13776) * 13 + 2) % V], axis=1).astype(np.int32)
+    return dict(v_template=v_template.astype(np.float32), shapedirs=shapedirs.astype(np.float32),
+                posedirs=posedirs.astype(np.float32), J_regressor=J_regressor.astype(np.float32),
+                lbs_weights=W.astype(np.float32), parents=SMPL_PARENTS.copy(), faces=faces)
+
+
+def load_smpl_model(model_dir: Optional[str]) -> Dict[str, np.ndarray]:
+    """Load a real SMPL model if the user supplies one (`<dir>/SMPL_NEUTRAL.pkl` or `.npz`, the
+    layout smplx expects at scripts/optimize.py:96-99); otherwise return the synthetic model."""
+    if model_dir:
+        for name in ('SMPL_NEUTRAL.npz', 'SMPL_NEUTRAL.pkl', 'smpl_neutral.npz'):
+            path = os.path.join(model_dir, name)
+            if not os.path.exists(path):
+                continue
+            if path.endswith('.npz'):
+                d = dict(np.load(path, allow_pickle=True))
+            else:
+                with open(path, 'rb') as f:
+                    d = pickle.load(f, encoding='latin1')
+            V = NUM_VERTS
+            shapedirs = np.asarray(d['shapedirs'], dtype=np.float32)[:, :, :NUM_BETAS]
+            posedirs = np.asarray(d['posedirs'], dtype=np.float32)            # (6890,3,207)
+            if posedirs.ndim == 3:
+                posedirs = posedirs.reshape(V * 3, -1).T                       # smplx: (207, 20670)
+            Jr = d['J_regressor']
+            Jr = np.asarray(Jr.todense() if hasattr(Jr, 'todense') else Jr, dtype=np.float32)
+            parents = np.asarray(d['kintree_table'])[0].astype(np.int32) if 'kintree_table' in d \
+                else SMPL_PARENTS.copy()
+            parents[0] = -1
+            return dict(v_template=np.asarray(d['v_template'], dtype=np.float32), shapedirs=shapedirs,
+                        posedirs=np.ascontiguousarray(posedirs), J_regressor=Jr,
+                        lbs_weights=np.asarray(d['weights'], dtype=np.float32), parents=parents,
+                        faces=np.asarray(d['f'], dtype=np.int32))
+    return synthetic_smpl()
+
+
+# The 107 non-zero entries of the shipped /root/reference/models/retrained_J_Regressor.pt are the
+# default H36M regressor initialisation when no SPIN/data/J_regressor_h36m.npy is supplied
+# (scripts/optimize.py:105-107).  They are stored as (row, col, value) triplets in
+# tests/golden/j_regressor_triplets.npz (data, not code) and mirrored in assets/.
+def j_regressor_from_triplets(rows, cols, vals) -> np.ndarray:
+    J = np.zeros((NUM_H36M, NUM_VERTS), dtype=np.float32)
+    J[np.asarray(rows), np.asarray(cols)] = np.asarray(vals, dtype=np.float32)
+    return J
+
+
+def synthetic_h36m_regressor(model: Dict[str, np.ndarray], seed: int = 7, support: int = 6,
+                             with_negatives: bool = True) -> np.ndarray:
+    """Seeded sparse (17,6890) regressor with the shipped checkpoint's structure: a few positive
+    entries per row (not normalised) plus a few negative entries that ReLU removes."""
+    rng = np.random.RandomState(seed)
+    J = np.zeros((NUM_H36M, NUM_VERTS), dtype=np.float32)
+    for i in range(NUM_H36M):
+        idx = rng.choice(NUM_VERTS, size=support, replace=False)
+        J[i, idx[:support - 2]] = rng.uniform(0.1, 0.6, size=support - 2)
+        if with_negatives:
+            J[i, idx[support - 2:]] = -rng.uniform(0.01, 0.2, size=2)
+        else:
+            J[i, idx[support - 2:]] = rng.uniform(0.1, 0.6, size=2)
+    return J
+
+
+def synthetic_batch(model: Dict[str, np.ndarray], J_h36m: np.ndarray, B: int, seed: int = 0):
+    """Seeded "SPIN-init" batch: per-joint axis-angle ~ N(0,0.3^2) -> R ->
+    6-D (first two columns interleaved as x[2i+k] = R[i,k]) + N(0,0.01^2) off-manifold noise;
+    betas ~ N(0,1) clipped to +-3; cam = (0,0,2*5000/(224*0.9)); gt_j3d (mm) = 1000 x the
+    pelvis-centred H36M joints of a perturbed pose (axis-angle noise 0.1) + N(0,10^2 mm).
+
+    Ground truth is produced with a float64 numpy LBS of the same synthetic model (data
+    generation, not the product path)."""
+    rng = np.random.RandomState(seed)
+    aa = rng.normal(0.0, 0.3, size=(B, NUM_JOINTS, 3))
+    R = _rodrigues_np(aa.reshape(-1, 3)).reshape(B, NUM_JOINTS, 3, 3)
+    x6 = R[:, :, :, :2].reshape(B, NUM_JOINTS, 6) + rng.normal(0.0, 0.01, size=(B, NUM_JOINTS, 6))
+    betas = np.clip(rng.normal(0.0, 1.0, size=(B, NUM_BETAS)), -3, 3)
+    cam = np.tile(np.array([[0.0, 0.0, 2 * 5000 / (224 * 0.9)]]), (B, 1))
+    aa_gt = aa + rng.normal(0.0, 0.1, size=aa.shape)
+    R_gt = _rodrigues_np(aa_gt.reshape(-1, 3)).reshape(B, NUM_JOINTS, 3, 3)
+    Jn = np.maximum(J_h36m.astype(np.float64), 0)
+    Jn = Jn / Jn.sum(1, keepdims=True)
+    gt = np.empty((B, NUM_H36M, 3))
+    for s in range(0, B, 256):
+        verts = _lbs_np(model, R_gt[s:s + 256], betas[s:s + 256])
+        j = np.einsum('iv,bvc->bic', Jn, verts)
+        gt[s:s + 256] = (j - j[:, :1]) * 1000.0
+    gt = gt + rng.normal(0.0, 10.0, size=gt.shape)
+    gt = gt - gt[:, :1]
+    return dict(pose6d=x6.astype(np.float32), betas=betas.astype(np.float32), cam=cam.astype(np.float32),
+                gt_j3d=gt.astype(np.float32))
+
+
+def _rodrigues_np(aa: np.ndarray) -> np.ndarray:
+    angle = np.linalg.norm(aa + 1e-8, axis=1, keepdims=True)
+    axis = aa / angle
+    c, s = np.cos(angle)[:, :, None], np.sin(angle)[:, :, None]
+    K = np.zeros((aa.shape[0], 3, 3))
+    K[:, 0, 1], K[:, 0, 2] = -axis[:, 2], axis[:, 1]
+    K[:, 1, 0], K[:, 1, 2] = axis[:, 2], -axis[:, 0]
+    K[:, 2, 0], K[:, 2, 1] = -axis[:, 1], axis[:, 0]
+    return np.eye(3)[None] + s * K + (1 - c) * (K @ K)
+
+
+def _lbs_np(model, R, betas):
+    """float64 numpy LBS used only to synthesise ground-truth joints for benchmark batches."""
+    B = R.shape[0]
+    vt = model['v_template'].astype(np.float64)
+    v_shaped = vt[None] + np.einsum('bl,vkl->bvk', betas, model['shapedirs'].astype(np.float64))
+    J = np.einsum('jv,bvk->bjk', model['J_regressor'].astype(np.float64), v_shaped)
+    pf = (R[:, 1:] - np.eye(3)).reshape(B, -1)
+    v_posed = v_shaped + (pf @ model['posedirs'].astype(np.float64)).reshape(B, -1, 3)
+    parents = model['parents']
+    G_R = np.empty((B, NUM_JOINTS, 3, 3))
+    G_t = np.empty((B, NUM_JOINTS, 3))
+    G_R[:, 0], G_t[:, 0] = R[:, 0], J[:, 0]
+    for i in range(1, NUM_JOINTS):
+        p = parents[i]
+        G_R[:, i] = G_R[:, p] @ R[:, i]
+        G_t[:, i] = np.einsum('brc,bc->br', G_R[:, p], J[:, i] - J[:, p]) + G_t[:, p]
+    A_t = G_t - np.einsum('bjrc,bjc->bjr', G_R, J)
+    W = model['lbs_weights'].astype(np.float64)
+    T_R = np.einsum('vj,bjrc->bvrc', W, G_R)
+    T_t = np.einsum('vj,bjr->bvr', W, A_t)
+    return np.einsum('bvrc,bvc->bvr', T_R, v_posed) + T_t

@@ -1,0 +1,104 @@
+"""Known-answer tests for the parity-unpinned SMPL LBS restatement. CPU only."""
+import numpy as np
+import torch
+
+import oracle
+
+T = torch.from_numpy
+
+
+def _model64(m):
+    return {k: (T(np.asarray(v)).double() if k != 'parents' else T(np.asarray(v)).long()) for k, v in m.items()
+            if k in ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'lbs_weights', 'parents')}
+
+
+def _rand_rot(n, seed, scale=0.4):
+    g = torch.Generator().manual_seed(seed)
+    return oracle.rodrigues(torch.randn(n, 3, generator=g, dtype=torch.float64) * scale)
+
+
+def test_k1_identity(smpl_model_np):
+    m = _model64(smpl_model_np)
+    R = torch.eye(3, dtype=torch.float64).expand(2, 24, 3, 3)
+    verts, joints = oracle.smpl_lbs(m, R, torch.zeros(2, 10, dtype=torch.float64))
+    assert torch.allclose(verts, m['v_template'].expand(2, -1, -1), atol=1e-12)
+    assert torch.allclose(joints, (m['J_regressor'] @ m['v_template']).expand(2, -1, -1), atol=1e-12)
+
+
+def test_k2_global_rotation_is_rigid_about_root(smpl_model_np):
+    m = _model64(smpl_model_np)
+    R = torch.eye(3, dtype=torch.float64).repeat(3, 24, 1, 1)
+    R0 = _rand_rot(3, 5, 1.0)
+    R[:, 0] = R0
+    verts, _ = oracle.smpl_lbs(m, R, torch.zeros(3, 10, dtype=torch.float64))
+    j0 = (m['J_regressor'] @ m['v_template'])[0]
+    expect = torch.einsum('brc,vc->bvr', R0, m['v_template'] - j0) + j0
+    assert torch.allclose(verts, expect, atol=1e-10)
+
+
+def test_k3_shape_only_is_linear(smpl_model_np):
+    m = _model64(smpl_model_np)
+    g = torch.Generator().manual_seed(2)
+    b = torch.randn(2, 10, generator=g, dtype=torch.float64)
+    R = torch.eye(3, dtype=torch.float64).expand(2, 24, 3, 3)
+    verts, joints, aux = oracle.smpl_lbs(m, R, b, return_all=True)
+    expect = m['v_template'] + torch.einsum('bl,vkl->bvk', b, m['shapedirs'])
+    assert torch.allclose(verts, expect, atol=1e-10)
+    assert torch.allclose(aux['J'], torch.einsum('jv,bvk->bjk', m['J_regressor'], expect), atol=1e-10)
+
+
+def test_k4_child_rotation_leaves_unweighted_vertices(smpl_model_np):
+    m = _model64(smpl_model_np)
+    m = dict(m)
+    m['posedirs'] = torch.zeros_like(m['posedirs'])      # isolate the skinning term
+    R = torch.eye(3, dtype=torch.float64).repeat(1, 24, 1, 1)
+    R[:, 18] = _rand_rot(1, 9, 1.0)                       # left elbow: subtree {18,20,22}
+    verts, _ = oracle.smpl_lbs(m, R, torch.zeros(1, 10, dtype=torch.float64))
+    sub = m['lbs_weights'][:, [18, 20, 22]].sum(1)
+    fixed = sub == 0
+    assert fixed.sum() > 1000 and (~fixed).sum() > 10
+    assert torch.allclose(verts[0, fixed], m['v_template'][fixed], atol=1e-12)
+    assert (verts[0, ~fixed] - m['v_template'][~fixed]).abs().max() > 1e-3
+
+
+def test_k5_translation_equivariance(smpl_model_np):
+    m = _model64(smpl_model_np)
+    assert torch.allclose(m['lbs_weights'].sum(1), torch.ones(6890, dtype=torch.float64), atol=1e-6)
+    assert torch.allclose(m['J_regressor'].sum(1), torch.ones(24, dtype=torch.float64), atol=1e-6)
+    R = _rand_rot(24, 11).view(1, 24, 3, 3)
+    b = torch.zeros(1, 10, dtype=torch.float64)
+    v1, _ = oracle.smpl_lbs(m, R, b)
+    m2 = dict(m)
+    t = torch.tensor([0.3, -0.2, 0.5], dtype=torch.float64)
+    m2['v_template'] = m['v_template'] + t
+    v2, _ = oracle.smpl_lbs(m2, R, b)
+    # rows of W and J_regressor sum to 1 (to float32 rounding of the stored model)
+    assert torch.allclose(v2, v1 + t, atol=1e-6)
+
+
+def test_k6_gradcheck_fp64(smpl_model_np, j_h36m_np):
+    m = _model64(smpl_model_np)
+    Jn = oracle.normalize_j_regressor(T(j_h36m_np).double())
+    g = torch.Generator().manual_seed(4)
+    x6 = torch.randn(1, 24, 6, generator=g, dtype=torch.float64)
+    b = torch.randn(1, 10, generator=g, dtype=torch.float64) * 0.5
+    gt = torch.randn(1, 17, 3, generator=g, dtype=torch.float64) * 0.2
+
+    def f(x6, b):
+        R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(1, 24, 3, 3)
+        verts, _ = oracle.smpl_lbs(m, R, b)
+        return ((oracle.move_pelvis(Jn @ verts) - gt) ** 2).mean()
+
+    x6r, br = x6.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    gx, gb = torch.autograd.grad(f(x6r, br), [x6r, br])
+    eps = 1e-6
+    for idx in [(0, 0, 0), (0, 3, 4), (0, 18, 1), (0, 23, 5)]:
+        d = torch.zeros_like(x6)
+        d[idx] = eps
+        fd = (f(x6 + d, b) - f(x6 - d, b)) / (2 * eps)
+        assert abs(float(fd) - float(gx[idx])) < 1e-6 * max(1.0, abs(float(fd)))
+    for l in (0, 7):
+        d = torch.zeros_like(b)
+        d[0, l] = eps
+        fd = (f(x6, b + d) - f(x6, b - d)) / (2 * eps)
+        assert abs(float(fd) - float(gb[0, l])) < 1e-6 * max(1.0, abs(float(fd)))
