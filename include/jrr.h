@@ -1,0 +1,157 @@
+/*
+ * jrr.h -- C ABI of the MI355X (gfx950) pose-refinement hot path.
+ *
+ * Drop-in boundary for the inner loop of the reference's scripts/optimize.py
+ * (ubc-vision/joint-regressor-refinement).  The reference has no FFI layer: its boundary is
+ * Python-level.  Each entry point below names the reference
+ * interface (file:line in /root/reference) whose arithmetic it replaces; the Python host
+ * code in joint-regressor-refinement_amd/ binds these through ctypes.
+ *
+ * Conventions
+ *  - plain pointers and sizes only; no torch / C++ types cross the boundary.
+ *  - every `*_dev` pointer is device memory owned by the caller (PyTorch's allocator);
+ *    every `*_host` pointer is host memory read synchronously during the call.
+ *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
+ *    kernels are enqueued on it, no entry point synchronises the device unless stated.
+ *  - return value: 0 on success, negative jrr_status otherwise; nothing throws.
+ *  - one caller thread per engine; engines on different devices/processes are independent.
+ *  - all floating point is IEEE fp32 (the reference runs `.float()`, optimize.py:160);
+ *    matrix products use the exact-fp32 MFMA v_mfma_f32_32x32x2_f32.
+ */
+#ifndef JRR_H
+#define JRR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+  JRR_OK = 0,
+  JRR_ERR_ARG = -1,       /* null pointer / bad size */
+  JRR_ERR_HIP = -2,       /* a HIP runtime call failed; see jrr_last_error() */
+  JRR_ERR_WORKSPACE = -3, /* workspace too small */
+  JRR_ERR_STATE = -4      /* engine not configured for the requested op */
+} jrr_status;
+
+enum {
+  JRR_NUM_VERTS = 6890,
+  JRR_NUM_JOINTS = 24,
+  JRR_NUM_H36M = 17,
+  JRR_NUM_BETAS = 10,
+  JRR_POSE6D = 144,        /* 24 joints x 6 */
+  JRR_DISC_PARAMS = 1840153,
+  JRR_SHAPE_DISC_PARAMS = 171
+};
+
+/* engine flags */
+enum {
+  JRR_FLAG_POSE_DISC = 1,   /* allocate / run the pose-discriminator term (optimize.py:241-247) */
+  JRR_FLAG_SHAPE_DISC = 2,  /* shape-discriminator term (optimize.py:244,249-250) */
+  JRR_FLAG_KEEP_VERTS = 4   /* reserve a (B,6890,3) vertex buffer for return_verts / J step */
+};
+
+typedef struct jrr_model jrr_model_t;   /* device-resident, re-laid-out SMPL constants */
+typedef struct jrr_engine jrr_engine_t; /* per-batch plan: workspace carve-up + launch geometry */
+
+const char* jrr_last_error(void);
+int jrr_version(void);
+
+/* ---- SMPL model ---------------------------------------------------------------------------
+ * Replaces SMPL("SPIN/data/smpl", batch_size=1).to(device) (scripts/optimize.py:96-99;
+ * wrapper scripts/smpl.py:61-85).  Host arrays in smplx layout:
+ *   v_template (6890,3)  shapedirs (6890,3,10)  posedirs (207,20670)
+ *   J_regressor (24,6890)  lbs_weights (6890,24)  parents (24)
+ * Uploads tile-major copies of the blend basis / skinning weights and the folded rest-joint
+ * regressor (J_template, J_shapedirs).  Synchronous.                                         */
+int jrr_model_create(const float* v_template_host, const float* shapedirs_host,
+                     const float* posedirs_host, const float* J_regressor_host,
+                     const float* lbs_weights_host, const int32_t* parents_host,
+                     jrr_model_t** out);
+void jrr_model_destroy(jrr_model_t* m);
+
+/* ---- engine -------------------------------------------------------------------------------
+ * `batch` = poses on this device; `batch_norm` = divisor batch of the MSE means
+ * (== batch single-GPU; == global batch under data parallelism so that a sharded run equals
+ * the single-process run).  The caller owns `workspace_dev`.         */
+size_t jrr_engine_workspace_bytes(int batch, int flags);
+int jrr_engine_create(const jrr_model_t* model, int batch, int batch_norm, void* workspace_dev,
+                      size_t workspace_bytes, int flags, jrr_engine_t** out);
+void jrr_engine_destroy(jrr_engine_t* e);
+int jrr_engine_set_batch_norm(jrr_engine_t* e, int batch_norm);
+
+/* J*mask -> ReLU -> row-normalise (scripts/utils.py:87-92), into the engine's tile-major
+ * copies.  J_dev: (17,6890) row-major raw parameter; mask_dev may be NULL.                   */
+int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J_dev, const float* mask_dev, void* stream);
+
+/* Pose-discriminator weights (scripts/discriminator.py:7-30) as ONE flat fp32 vector in
+ * state_dict order: conv_operations.{0,2}.{weight,bias}, linears.{0..23}.{weight,bias},
+ * linear_operations.{0,2,4}.{weight,bias} (1 840 153 floats).  Shape discriminator
+ * (discriminator.py:57-68): shape_operations.{0,2,4}.{weight,bias} (171 floats).            */
+int jrr_engine_set_pose_disc(jrr_engine_t* e, const float* params_dev, void* stream);
+int jrr_engine_set_shape_disc(jrr_engine_t* e, const float* params_dev, void* stream);
+
+/* ---- operator-level entry points (autograd.Function backends) ------------------------------ */
+
+/* rot6d_to_rotmat, scripts/utils.py:190-204: x (n,6) -> R (n,3,3); and its adjoint.          */
+int jrr_rot6d_forward(const float* x6d_dev, float* R_dev, int n, void* stream);
+int jrr_rot6d_backward(const float* x6d_dev, const float* dR_dev, float* dx6d_dev, int n, void* stream);
+
+/* find_joints, scripts/utils.py:85-103 (SMPL forward + J_regressor contraction).
+ * Exactly one of x6d_dev (B,24,6) / R_dev (B,24,3,3) is non-NULL.  joints_dev (B,17,3).
+ * verts_dev (B,6890,3) may be NULL (return_verts=False).                                      */
+int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d_dev, const float* R_dev,
+                            const float* betas_dev, float* joints_dev, float* verts_dev, void* stream);
+/* Adjoint of the call above for the SAME inputs (must follow it): djoints (B,17,3) ->
+ * dx6d (B,24,6) or dR (B,24,3,3), dbetas (B,10), dJ (17,6890) w.r.t. the RAW J_regressor
+ * (through the normalisation + ReLU + mask).  Any output pointer may be NULL.                 */
+int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d_dev, const float* R_dev,
+                             const float* betas_dev, const float* djoints_dev, float* dx6d_dev,
+                             float* dR_dev, float* dbetas_dev, float* dJ_dev, void* stream);
+
+/* move_pelvis + MSELoss, scripts/utils.py:106-114 + scripts/optimize.py:238-239:
+ * sqerr_dev[b] = sum_{i,c} (joints[b,i,c]-joints[b,0,c] - gt_mm[b,i,c]/1000)^2 ;
+ * djoints = d(weight * mean)/d joints with mean over batch_norm*51.                            */
+int jrr_joint_loss(const float* joints_dev, const float* gt_centred_mm_dev, float weight,
+                   int batch, int batch_norm, float* sqerr_dev, float* djoints_dev, void* stream);
+
+/* Discriminator.forward, scripts/discriminator.py:32-54: x (B,24,6) -> out (B,25) sigmoid.    */
+int jrr_pose_disc_forward(jrr_engine_t* e, const float* x6d_dev, float* out_dev, void* stream);
+/* d[ weight * mean((D(x)-target)^2) ] / dx for the forward just run (optimize.py:246-247).    */
+int jrr_pose_disc_backward_input(jrr_engine_t* e, const float* x6d_dev, float weight, float target,
+                                 float* dx6d_dev, void* stream);
+/* weight gradients of  mean((D(x)-target)^2)  accumulated (+=) into a flat vector laid out like
+ * the parameter vector (optimize.py:276-284).                                                 */
+int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d_dev, float target,
+                                  float* dparams_dev, void* stream);
+
+/* torch.optim.Adam single-tensor update (defaults used at scripts/optimize.py:116-126,201):
+ * step_dev holds the 1-based step count of THIS update.                                        */
+int jrr_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, size_t n,
+                  const int32_t* step_dev, float lr, float beta1, float beta2, float eps, void* stream);
+
+/* ---- fused inner loop ---------------------------------------------------------------------
+ * n_iters iterations of scripts/optimize.py:220-265 restricted to the engine's loss terms:
+ * rot6d->R, SMPL, J-regress, pelvis-centre, MSE x10000 [+ pose-D x10] [+ shape-D x10],
+ * analytic backward to (pose6d, betas), Adam(lr) in place.  x6d (B,24,6) holds orient (joint 0)
+ * and pose (joints 1..23); adam_m/adam_v (B,154) = [144 pose | 10 betas]; step_dev counts
+ * completed Adam steps (0 before the first).  sqerr_dev (B) receives the per-pose squared
+ * joint error of the LAST iteration's forward (may be NULL).                                  */
+int jrr_refine_run(jrr_engine_t* e, float* x6d_dev, float* betas_dev, const float* gt_centred_mm_dev,
+                   float* adam_m_dev, float* adam_v_dev, int32_t* step_dev, float lr, int n_iters,
+                   float* sqerr_dev, void* stream);
+
+/* J step, scripts/optimize.py:300-312: gradient of mean((move_pelvis(joints)-gt/1000)^2) w.r.t.
+ * the raw J_regressor for the current (detached) poses; dJ_dev (17,6890).                      */
+int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev,
+                         const float* gt_centred_mm_dev, float* dJ_dev, float* sqerr_dev, void* stream);
+
+/* name of the dominant kernels (for profile matching) and launch geometry of the last run */
+int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* JRR_H */

@@ -1,0 +1,89 @@
+"""ctypes binding of libjrr_hip.so (the C ABI declared in include/jrr.h).
+
+The product path has NO fallback: if the HIP library is missing or fails to load, importing the
+compute modules raises.  torch is imported first so that the library's libamdhip64.so.7
+dependency resolves to the HIP runtime torch already loaded (one runtime per process).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_p
+
+import torch  # noqa: F401  (must precede CDLL, see module docstring)
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, 'libjrr_hip.so')
+
+# every exported symbol of include/jrr.h with (restype, argtypes)
+_P = c_void_p
+SIGNATURES = {
+    'jrr_last_error': (c_char_p, []),
+    'jrr_version': (c_int, []),
+    'jrr_model_create': (c_int, [_P, _P, _P, _P, _P, _P, POINTER(_P)]),
+    'jrr_model_destroy': (None, [_P]),
+    'jrr_engine_workspace_bytes': (c_size_t, [c_int, c_int]),
+    'jrr_engine_create': (c_int, [_P, c_int, c_int, _P, c_size_t, c_int, POINTER(_P)]),
+    'jrr_engine_destroy': (None, [_P]),
+    'jrr_engine_set_batch_norm': (c_int, [_P, c_int]),
+    'jrr_engine_set_j_regressor': (c_int, [_P, _P, _P, _P]),
+    'jrr_engine_set_pose_disc': (c_int, [_P, _P, _P]),
+    'jrr_engine_set_shape_disc': (c_int, [_P, _P, _P]),
+    'jrr_rot6d_forward': (c_int, [_P, _P, c_int, _P]),
+    'jrr_rot6d_backward': (c_int, [_P, _P, _P, c_int, _P]),
+    'jrr_find_joints_forward': (c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    'jrr_find_joints_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'jrr_joint_loss': (c_int, [_P, _P, c_float, c_int, c_int, _P, _P, _P]),
+    'jrr_pose_disc_forward': (c_int, [_P, _P, _P, _P]),
+    'jrr_pose_disc_backward_input': (c_int, [_P, _P, c_float, c_float, _P, _P]),
+    'jrr_pose_disc_backward_params': (c_int, [_P, _P, c_float, _P, _P]),
+    'jrr_adam_step': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, _P]),
+    'jrr_refine_run': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),
+    'jrr_j_regressor_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    'jrr_engine_info': (c_int, [_P, POINTER(c_int32), c_int]),
+}
+
+_lib = None
+
+
+class JrrError(RuntimeError):
+    pass
+
+
+def load(build_if_missing: bool = False) -> ctypes.CDLL:
+    """Load the HIP library; raise loudly if it is absent (no CPU fallback exists)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        if build_if_missing:
+            from . import build as _build
+            _build.build(verbose=False)
+        else:
+            raise JrrError(f'{LIB_PATH} not found: build it with `python {os.path.join(HERE, "build.py")}` '
+                           f'(the HIP path has no CPU fallback)')
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)      # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ''):
+    if rc != 0:
+        msg = load().jrr_last_error()
+        raise JrrError(f'{what} failed (status {rc}): {msg.decode() if msg else ""}')
+
+
+def ptr(t):
+    """Device/host pointer of a contiguous float32/int32 tensor (or None)."""
+    if t is None:
+        return None
+    assert t.is_contiguous(), 'jrr expects contiguous tensors'
+    return c_void_p(t.data_ptr())
+
+
+def stream_ptr(device=None):
+    return c_void_p(torch.cuda.current_stream(device).cuda_stream)

@@ -1,0 +1,118 @@
+"""Build the gfx950 shared library (csrc/*.hip -> libjrr_hip.so) with hipcc, in-tree.
+
+    python joint-regressor-refinement_amd/build.py [--force] [--report]
+
+hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels with the
+repo snapshot to the GPU box.
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, 'csrc')
+OBJ = os.path.join(HERE, 'build')
+LIB = os.path.join(HERE, 'libjrr_hip.so')
+SOURCES = ['api.hip', 'prep.hip', 'lbs.hip', 'gemm.hip', 'disc.hip']
+HEADERS = ['jrr_common.h', 'kernels.h', os.path.join('..', '..', 'include', 'jrr.h')]
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
+
+
+def _hipcc() -> str:
+    for c in (os.environ.get('HIPCC'), '/opt/rocm/bin/hipcc', 'hipcc'):
+        if c and (os.path.sep not in c or os.path.exists(c)):
+            return c
+    return 'hipcc'
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
+
+
+def _summarise(out: str) -> str:
+    """Condense -Rpass-analysis=kernel-resource-usage remarks to one line per kernel."""
+    import re
+    rows, cur = [], None
+    for line in out.splitlines():
+        m = re.search(r'remark: Function Name: (\S+)', line)
+        if m:
+            name = m.group(1)
+            try:
+                name = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip() or name
+            except OSError:
+                pass
+            cur = {'name': name.split('(')[0][:70]}
+            rows.append(cur)
+            continue
+        for key, pat in (('vgpr', r'remark:\s+VGPRs: (\d+)'), ('agpr', r'AGPRs: (\d+)'), ('scratch', r'ScratchSize \[bytes/lane\]: (\d+)'),
+                         ('occ', r'Occupancy \[waves/SIMD\]: (\d+)'), ('lds', r'LDS Size \[bytes/block\]: (\d+)'),
+                         ('sgpr', r'remark:\s+SGPRs: (\d+)'), ('vspill', r'VGPRs Spill: (\d+)')):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = m.group(1)
+        if 'warning' in line or 'error' in line:
+            rows.append({'name': line})
+    txt = ''
+    for r in rows:
+        if 'vgpr' in r:
+            txt += (f"  {r['name']:<72s} vgpr={r.get('vgpr')} agpr={r.get('agpr')} sgpr={r.get('sgpr')} scratch={r.get('scratch')} "
+                    f"vspill={r.get('vspill')} occ={r.get('occ')} lds={r.get('lds')}\n")
+        else:
+            txt += r['name'] + '\n'
+    return txt
+
+
+def build(force: bool = False, report: bool = False, verbose: bool = True) -> str:
+    os.makedirs(OBJ, exist_ok=True)
+    hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
+    jobs = []
+    for src in SOURCES:
+        s = os.path.join(CSRC, src)
+        o = os.path.join(OBJ, src.replace('.hip', '.o'))
+        if force or report or _stale(o, [s] + hdrs):
+            cmd = [_hipcc()] + FLAGS + ['-c', s, '-o', o]
+            if report:
+                cmd.append('-Rpass-analysis=kernel-resource-usage')
+            jobs.append((src, cmd))
+
+    def run(job):
+        src, cmd = job
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        return src, p.returncode, p.stdout + p.stderr
+
+    if jobs:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 5)) as ex:
+            for src, rc, out in ex.map(run, jobs):
+                if rc != 0:
+                    sys.stderr.write(out)
+                elif report:
+                    sys.stderr.write(_summarise(out))
+                if rc != 0:
+                    raise RuntimeError(f'hipcc failed on {src}')
+                if verbose:
+                    print(f'[jrr build] compiled {src}')
+    objs = [os.path.join(OBJ, s.replace('.hip', '.o')) for s in SOURCES]
+    if force or jobs or _stale(LIB, objs):
+        cmd = [_hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', LIB]
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        if p.returncode != 0:
+            sys.stderr.write(p.stdout + p.stderr)
+            raise RuntimeError('hipcc link failed')
+        if verbose:
+            print(f'[jrr build] linked {LIB}')
+    return LIB
+
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--force', action='store_true')
+    ap.add_argument('--report', action='store_true', help='print per-kernel VGPR/LDS/occupancy')
+    a = ap.parse_args()
+    build(force=a.force, report=a.report)

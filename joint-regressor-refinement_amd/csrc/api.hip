@@ -1,0 +1,530 @@
+// C ABI (include/jrr.h): model upload, engine/workspace planning and the launch sequences.
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <vector>
+
+#include "jrr_common.h"
+#include "kernels.h"
+
+using namespace jrr;
+
+static thread_local char g_err[512] = "";
+void jrr_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+extern "C" const char* jrr_last_error(void) { return g_err; }
+extern "C" int jrr_version(void) { return 100; }
+
+#define CHECK_LAUNCH()                                                            \
+  do {                                                                            \
+    hipError_t _e = hipGetLastError();                                            \
+    if (_e != hipSuccess) {                                                       \
+      jrr_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(_e), __FILE__, __LINE__); \
+      return JRR_ERR_HIP;                                                         \
+    }                                                                             \
+  } while (0)
+
+// =============================================================================================
+// model
+// =============================================================================================
+extern "C" int jrr_model_create(const float* vt, const float* sd, const float* pd, const float* Jr, const float* W,
+                                const int32_t* parents, jrr_model_t** out) {
+  if (!vt || !sd || !pd || !Jr || !W || !parents || !out) { jrr_set_error("jrr_model_create: null argument"); return JRR_ERR_ARG; }
+  for (int j = 0; j < NJ; ++j)
+    if (parents[j] >= j || (j > 0 && parents[j] < 0)) { jrr_set_error("parents[%d]=%d is not a topologically ordered tree", j, parents[j]); return JRR_ERR_ARG; }
+  const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
+  const size_t nJt = 72 + 24, nJS = 720 + 16;   // padded to keep 16-byte alignment of what follows
+  std::vector<float> h(nDk + nDn + nWjv + nWvj + nJt + nJS, 0.f);
+  float* Dk = h.data();
+  float* Dn = Dk + nDk;
+  float* Wjv = Dn + nDn;
+  float* Wvj = Wjv + nWjv;
+  float* Jt = Wvj + nWvj;
+  float* JS = Jt + nJt;
+  for (int v = 0; v < V; ++v) {
+    const int t = v >> 5, vv = v & 31;
+    for (int c = 0; c < 3; ++c) {
+      for (int k = 0; k < KF; ++k) {
+        float val;
+        if (k < 207) val = pd[(size_t)k * (V * 3) + v * 3 + c];
+        else if (k < 217) val = sd[((size_t)v * 3 + c) * NB + (k - 207)];
+        else val = vt[v * 3 + c];
+        Dk[(((size_t)t * KFP + k) * 3 + c) * 32 + vv] = val;
+        Dn[((size_t)c * VP + v) * KFP + k] = val;
+      }
+    }
+    for (int j = 0; j < NJ; ++j) {
+      Wjv[((size_t)t * NJ + j) * 32 + vv] = W[(size_t)v * NJ + j];
+      Wvj[((size_t)t * 32 + vv) * 32 + j] = W[(size_t)v * NJ + j];
+    }
+  }
+  // folded rest-joint regressor: J(beta) = Jt + JS beta   (smplx vertices2joints(J_regressor, v_shaped))
+  for (int j = 0; j < NJ; ++j)
+    for (int c = 0; c < 3; ++c) {
+      double acc = 0;
+      double accs[NB] = {0};
+      for (int v = 0; v < V; ++v) {
+        const double w = Jr[(size_t)j * V + v];
+        if (w == 0.0) continue;
+        acc += w * vt[v * 3 + c];
+        for (int l = 0; l < NB; ++l) accs[l] += w * sd[((size_t)v * 3 + c) * NB + l];
+      }
+      Jt[j * 3 + c] = (float)acc;
+      for (int l = 0; l < NB; ++l) JS[(j * 3 + c) * NB + l] = (float)accs[l];
+    }
+  jrr_model* m = new jrr_model();
+  void* base = nullptr;
+  hipError_t e = hipMalloc(&base, h.size() * sizeof(float));
+  if (e != hipSuccess) { delete m; jrr_set_error("hipMalloc(model) failed: %s", hipGetErrorString(e)); return JRR_ERR_HIP; }
+  e = hipMemcpy(base, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
+  if (e != hipSuccess) { (void)hipFree(base); delete m; jrr_set_error("hipMemcpy(model) failed: %s", hipGetErrorString(e)); return JRR_ERR_HIP; }
+  float* d = (float*)base;
+  m->base = base;
+  m->d.Dk = d;
+  m->d.Dn = d + nDk;
+  m->d.Wjv = m->d.Dn + nDn;
+  m->d.Wvj = m->d.Wjv + nWjv;
+  m->d.Jt = m->d.Wvj + nWvj;
+  m->d.JS = m->d.Jt + nJt;
+  for (int j = 0; j < NJ; ++j) m->d.parents.p[j] = parents[j];
+  *out = m;
+  return JRR_OK;
+}
+
+extern "C" void jrr_model_destroy(jrr_model_t* m) {
+  if (!m) return;
+  if (m->base) (void)hipFree(m->base);
+  delete m;
+}
+
+// =============================================================================================
+// engine
+// =============================================================================================
+struct jrr_engine {
+  Model m;
+  int B, BP, bnorm, flags;
+  int nvc, nvcb, nsplit, nsplitJ;
+  bool have_J, have_mask, have_pd, have_sd;
+  // workspace sections
+  float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv;
+  float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr;
+  float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx;
+  float *Ps, *gb;
+  float *verts, *djpad, *dJnp, *dJn, *dj;
+  bool verts_zeroed;
+  int32_t* step_scratch;
+};
+
+static void plan_geometry(int BP, int& nvc, int& nvcb, int& nsplit, int& nsplitJ) {
+  const int nbg = BP / BG;
+  nvc = (512 + nbg - 1) / nbg;
+  if (nvc > 54) nvc = 54;
+  if (nvc < 1) nvc = 1;
+  const int witems = (BP / BT) * 3;
+  nvcb = (2048 + witems - 1) / witems;
+  if (nvcb > 36) nvcb = 36;
+  if (nvcb < 1) nvcb = 1;
+  nsplit = (512 + nbg - 1) / nbg;
+  if (nsplit > 32) nsplit = 32;
+  if (nsplit < 1) nsplit = 1;
+  nsplitJ = 8;
+  if (BP / 16 < nsplitJ) nsplitJ = BP / 16;
+}
+
+struct Carver {
+  char* base; size_t off;
+  float* take(size_t nfloats) {
+    float* p = base ? (float*)(base + off) : nullptr;
+    off += round_up(nfloats * sizeof(float), 256);
+    return p;
+  }
+};
+
+static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
+  const int BP = (int)round_up((size_t)B, BG);
+  int nvc, nvcb, nsplit, nsplitJ;
+  plan_geometry(BP, nvc, nvcb, nsplit, nsplitJ);
+  Carver c{(char*)ws, 0};
+  jrr_engine tmp;
+  jrr_engine* t = e ? e : &tmp;
+  t->rowsum = c.take(32);
+  t->Jraw = c.take((size_t)NH * V);
+  t->Jmask = c.take((size_t)NH * V);
+  t->Jn = c.take((size_t)NH * V);
+  t->Jn_vi = c.take((size_t)VT * 1024);
+  t->Jn_iv = c.take((size_t)VT * NHP * 32);
+  t->FT = c.take((size_t)KFP * BP);
+  t->AT = c.take((size_t)12 * NJ * BP);
+  t->VPb = c.take((size_t)3 * VP * BP);
+  t->JP = c.take((size_t)nvc * 3 * NH * BP);
+  t->dJT = c.take((size_t)3 * NHP * BP);
+  t->DVP = c.take((size_t)3 * VP * BP);
+  t->dATp = c.take((size_t)nvcb * 12 * NJ * BP);
+  t->dFTp = c.take((size_t)nsplit * KFP * BP);
+  t->joints = c.take((size_t)BP * NH * 3);
+  t->sqerr = c.take((size_t)BP);
+  t->step_scratch = (int32_t*)c.take(64);
+  if (flags & JRR_FLAG_POSE_DISC) {
+    t->Pd = c.take(DP_TOTAL);
+    t->W0T = c.take((size_t)768 * 1024);
+    t->W2T = c.take((size_t)1024 * 1024);
+    t->H2T = c.take((size_t)768 * BP);
+    t->A1T = c.take((size_t)1024 * BP);
+    t->A2T = c.take((size_t)1024 * BP);
+    t->dA2T = c.take((size_t)1024 * BP);
+    t->dA1T = c.take((size_t)1024 * BP);
+    t->dH2T = c.take((size_t)768 * BP);
+    t->gx = c.take((size_t)BP * JRR_POSE6D);
+  }
+  if (flags & JRR_FLAG_SHAPE_DISC) {
+    t->Ps = c.take(256);
+    t->gb = c.take((size_t)BP * NB);
+  }
+  if (flags & JRR_FLAG_KEEP_VERTS) {
+    t->verts = c.take((size_t)BP * VP * 3);
+    t->djpad = c.take((size_t)BP * 64);
+    t->dJnp = c.take((size_t)nsplitJ * 64 * VP * 3);
+    t->dJn = c.take((size_t)NH * VP);
+    t->dj = c.take((size_t)BP * 51);
+  }
+  if (e) {
+    e->BP = BP; e->nvc = nvc; e->nvcb = nvcb; e->nsplit = nsplit; e->nsplitJ = nsplitJ;
+  }
+  return c.off;
+}
+
+extern "C" size_t jrr_engine_workspace_bytes(int batch, int flags) {
+  if (batch <= 0) return 0;
+  return carve(nullptr, nullptr, batch, flags);
+}
+
+extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_norm, void* ws, size_t ws_bytes,
+                                 int flags, jrr_engine_t** out) {
+  if (!model || !ws || !out || batch <= 0) { jrr_set_error("jrr_engine_create: bad argument"); return JRR_ERR_ARG; }
+  if (((uintptr_t)ws & 255) != 0) { jrr_set_error("workspace must be 256-byte aligned"); return JRR_ERR_ARG; }
+  const size_t need = jrr_engine_workspace_bytes(batch, flags);
+  if (ws_bytes < need) { jrr_set_error("workspace too small: %zu < %zu", ws_bytes, need); return JRR_ERR_WORKSPACE; }
+  jrr_engine* e = new jrr_engine();
+  memset((void*)e, 0, sizeof(*e));
+  e->m = model->d;
+  e->B = batch;
+  e->bnorm = batch_norm > 0 ? batch_norm : batch;
+  e->flags = flags;
+  carve(e, ws, batch, flags);
+  *out = e;
+  return JRR_OK;
+}
+
+extern "C" void jrr_engine_destroy(jrr_engine_t* e) { delete e; }
+
+extern "C" int jrr_engine_set_batch_norm(jrr_engine_t* e, int bn) {
+  if (!e || bn <= 0) return JRR_ERR_ARG;
+  e->bnorm = bn;
+  return JRR_OK;
+}
+
+extern "C" int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n) {
+  if (!e || !out) return JRR_ERR_ARG;
+  int32_t v[8] = {e->B, e->BP, e->bnorm, e->nvc, e->nvcb, e->nsplit, e->nsplitJ, e->flags};
+  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  return JRR_OK;
+}
+
+extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const float* mask, void* stream) {
+  if (!e || !J) { jrr_set_error("set_j_regressor: null"); return JRR_ERR_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
+  if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
+  e->have_mask = mask != nullptr;
+  launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, s);
+  CHECK_LAUNCH();
+  e->have_J = true;
+  return JRR_OK;
+}
+
+extern "C" int jrr_engine_set_pose_disc(jrr_engine_t* e, const float* P, void* stream) {
+  if (!e || !P) return JRR_ERR_ARG;
+  if (!(e->flags & JRR_FLAG_POSE_DISC)) { jrr_set_error("engine created without JRR_FLAG_POSE_DISC"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  JRR_HIP(hipMemcpyAsync(e->Pd, P, (size_t)DP_TOTAL * 4, hipMemcpyDeviceToDevice, s));
+  launch_transpose(e->Pd + DP_FC0_W, e->W0T, 1024, 768, s);    // [out][in] -> [in][out]
+  launch_transpose(e->Pd + DP_FC2_W, e->W2T, 1024, 1024, s);
+  CHECK_LAUNCH();
+  e->have_pd = true;
+  return JRR_OK;
+}
+
+extern "C" int jrr_engine_set_shape_disc(jrr_engine_t* e, const float* P, void* stream) {
+  if (!e || !P) return JRR_ERR_ARG;
+  if (!(e->flags & JRR_FLAG_SHAPE_DISC)) { jrr_set_error("engine created without JRR_FLAG_SHAPE_DISC"); return JRR_ERR_STATE; }
+  JRR_HIP(hipMemcpyAsync(e->Ps, P, (size_t)JRR_SHAPE_DISC_PARAMS * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  e->have_sd = true;
+  return JRR_OK;
+}
+
+// =============================================================================================
+// operator-level entry points
+// =============================================================================================
+extern "C" int jrr_rot6d_forward(const float* x, float* R, int n, void* stream) {
+  if (!x || !R || n < 0) return JRR_ERR_ARG;
+  if (n == 0) return JRR_OK;
+  launch_rot6d_fwd(x, R, n, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+extern "C" int jrr_rot6d_backward(const float* x, const float* dR, float* dx, int n, void* stream) {
+  if (!x || !dR || !dx || n < 0) return JRR_ERR_ARG;
+  if (n == 0) return JRR_OK;
+  launch_rot6d_bwd(x, dR, dx, n, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,
+                        float* verts, int ldv, int32_t* step_inc, hipStream_t s) {
+  launch_prep_fwd(e->m, x6d, R, betas, e->FT, e->AT, e->B, e->BP, step_inc, s);
+  launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, keep_vp ? e->VPb : nullptr, e->JP, verts, ldv, e->B, e->BP, e->nvc, s);
+  return 0;
+}
+
+// the padded internal vertex buffer (row stride VP*3) must hold zeros outside [0,B) x [0,6890*3)
+static int ensure_verts_zeroed(jrr_engine* e, hipStream_t s) {
+  if (e->verts_zeroed) return JRR_OK;
+  JRR_HIP(hipMemsetAsync(e->verts, 0, (size_t)e->BP * VP * 3 * 4, s));
+  e->verts_zeroed = true;
+  return JRR_OK;
+}
+
+extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const float* R, const float* betas,
+                                       float* joints, float* verts, void* stream) {
+  if (!e || !betas || !joints || ((x6d == nullptr) == (R == nullptr))) { jrr_set_error("find_joints_forward: bad argument"); return JRR_ERR_ARG; }
+  if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  if (e->flags & JRR_FLAG_KEEP_VERTS) {
+    // keep a padded copy for the J-regressor adjoint; hand the caller a compact copy if asked
+    int rc = ensure_verts_zeroed(e, s);
+    if (rc) return rc;
+    smpl_forward(e, x6d, R, betas, true, e->verts, VP * 3, nullptr, s);
+    if (verts)
+      JRR_HIP(hipMemcpy2DAsync(verts, (size_t)V * 3 * 4, e->verts, (size_t)VP * 3 * 4, (size_t)V * 3 * 4, e->B,
+                               hipMemcpyDeviceToDevice, s));
+  } else {
+    smpl_forward(e, x6d, R, betas, true, verts, V * 3, nullptr, s);
+  }
+  launch_joints_loss(e->JP, e->nvc, nullptr, nullptr, 0.f, joints, nullptr, nullptr, e->B, e->BP, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+static int blend_adjoint_gemm(jrr_engine* e, hipStream_t s) {
+  GemmArgs g;
+  g.A = e->m.Dn; g.lda = KFP;
+  g.Bm = e->DVP; g.ldb = e->BP;
+  g.Out = e->dFTp; g.ldo = e->BP;
+  g.bias = nullptr; g.mask = nullptr;
+  g.M = KFP; g.N = e->BP; g.K = 3 * VP;
+  g.split_stride = (size_t)KFP * e->BP;
+  return launch_gemm_224(g, EPI_STORE, e->nsplit, s);
+}
+
+static int j_grad_from_verts(jrr_engine* e, const float* djoints_Bx51, float* dJ, hipStream_t s);
+
+extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const float* R, const float* betas,
+                                        const float* djoints, float* dx6d, float* dR, float* dbetas, float* dJ,
+                                        void* stream) {
+  if (!e || !betas || !djoints || ((x6d == nullptr) == (R == nullptr))) { jrr_set_error("find_joints_backward: bad argument"); return JRR_ERR_ARG; }
+  if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  if (dx6d || dR || dbetas) {
+    launch_joints_loss(nullptr, 0, nullptr, djoints, 0.f, nullptr, nullptr, e->dJT, e->B, e->BP, s);
+    launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
+    int rc = blend_adjoint_gemm(e, s);
+    if (rc) return rc;
+    PrepBwdLaunch L;
+    L.x6d_in = x6d; L.R_in = R; L.betas_in = betas;
+    L.dATp = e->dATp; L.nvc = e->nvcb; L.dFTp = e->dFTp; L.nsplit = e->nsplit;
+    L.dx6d = dx6d; L.dR = dR; L.dbetas = dbetas;
+    L.B = e->B; L.BP = e->BP;
+    launch_prep_bwd(L, e->m, s);
+    CHECK_LAUNCH();
+  }
+  if (dJ) {
+    int rc = j_grad_from_verts(e, djoints, dJ, s);
+    if (rc) return rc;
+  }
+  return JRR_OK;
+}
+
+extern "C" int jrr_joint_loss(const float* joints, const float* gt_mm, float weight, int batch, int batch_norm,
+                              float* sqerr, float* djoints, void* stream) {
+  if (!joints || !gt_mm || batch <= 0 || batch_norm <= 0) return JRR_ERR_ARG;
+  const float scale = (float)(2.0 * (double)weight / ((double)batch_norm * 51.0));
+  launch_joint_loss_plain(joints, gt_mm, scale, sqerr, djoints, batch, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+// ---- pose discriminator --------------------------------------------------------------------
+static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t s) {
+  launch_disc_conv_fwd(e->Pd, x6d, e->H2T, out, e->B, e->BP, s);
+  GemmArgs g;
+  g.mask = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
+  g.A = e->W0T; g.lda = 1024; g.Bm = e->H2T; g.Out = e->A1T; g.bias = e->Pd + DP_FC0_B; g.M = 1024; g.K = 768;
+  int rc = launch_gemm_128(g, EPI_BIAS_RELU, 1, s);
+  if (rc) return rc;
+  g.A = e->W2T; g.lda = 1024; g.Bm = e->A1T; g.Out = e->A2T; g.bias = e->Pd + DP_FC2_B; g.M = 1024; g.K = 1024;
+  return launch_gemm_128(g, EPI_BIAS_RELU, 1, s);
+}
+
+static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, float scale, float target, float* gx,
+                               hipStream_t s) {
+  launch_disc_out(e->Pd, e->A2T, out, e->dA2T, scale, target, e->B, e->BP, s);
+  GemmArgs g;
+  g.bias = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
+  // dA1T[k][b] = relu'(A1T) * sum_n fc2.w[n][k] dA2T[n][b]
+  g.A = e->Pd + DP_FC2_W; g.lda = 1024; g.Bm = e->dA2T; g.Out = e->dA1T; g.mask = e->A1T; g.M = 1024; g.K = 1024;
+  int rc = launch_gemm_128(g, EPI_MASK, 1, s);
+  if (rc) return rc;
+  // dH2T[k][b] = sum_n fc0.w[n][k] dA1T[n][b]
+  g.A = e->Pd + DP_FC0_W; g.lda = 768; g.Bm = e->dA1T; g.Out = e->dH2T; g.mask = nullptr; g.M = 768; g.K = 1024;
+  rc = launch_gemm_128(g, EPI_STORE, 1, s);
+  if (rc) return rc;
+  launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, scale, target, gx, e->B, e->BP, s);
+  return 0;
+}
+
+extern "C" int jrr_pose_disc_forward(jrr_engine_t* e, const float* x6d, float* out, void* stream) {
+  if (!e || !x6d || !out) return JRR_ERR_ARG;
+  if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  int rc = disc_forward(e, x6d, out, s);
+  if (rc) return rc;
+  launch_disc_out(e->Pd, e->A2T, out, nullptr, 0.f, 0.f, e->B, e->BP, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_pose_disc_backward_input(jrr_engine_t* e, const float* x6d, float weight, float target, float* dx,
+                                            void* stream) {
+  if (!e || !x6d || !dx) return JRR_ERR_ARG;
+  if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
+  const float scale = (float)(2.0 * (double)weight / ((double)e->bnorm * 25.0));
+  int rc = disc_backward_input(e, x6d, nullptr, scale, target, dx, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d, float target, float* dparams,
+                                             void* stream) {
+  (void)e; (void)x6d; (void)target; (void)dparams; (void)stream;
+  jrr_set_error("jrr_pose_disc_backward_params: not implemented in this build");
+  return JRR_ERR_STATE;
+}
+
+extern "C" int jrr_adam_step(float* p, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr,
+                             float beta1, float beta2, float eps, void* stream) {
+  if (!p || !g || !m || !v || !step) return JRR_ERR_ARG;
+  if (n == 0) return JRR_OK;
+  launch_adam_flat(p, g, m, v, n, step, lr, beta1, beta2, eps, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+// =============================================================================================
+// fused inner loop (scripts/optimize.py:220-265)
+// =============================================================================================
+extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const float* gt_mm, float* adam_m,
+                              float* adam_v, int32_t* step, float lr, int n_iters, float* sqerr, void* stream) {
+  if (!e || !x6d || !betas || !gt_mm || !adam_m || !adam_v || !step || n_iters < 0) { jrr_set_error("refine_run: bad argument"); return JRR_ERR_ARG; }
+  if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
+  const bool pd = (e->flags & JRR_FLAG_POSE_DISC) && e->have_pd;
+  const bool sd = (e->flags & JRR_FLAG_SHAPE_DISC) && e->have_sd;
+  hipStream_t s = (hipStream_t)stream;
+  const float jscale = (float)(2.0 * 10000.0 / ((double)e->bnorm * 51.0));   // optimize.py:252 weight 10000
+  const float dscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 25.0));      // optimize.py:253 weight 10
+  const float sscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 1.0));
+  for (int it = 0; it < n_iters; ++it) {
+    smpl_forward(e, x6d, nullptr, betas, true, nullptr, 0, step, s);
+    launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, jscale, e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);
+    launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
+    int rc = blend_adjoint_gemm(e, s);
+    if (rc) return rc;
+    if (pd) {
+      rc = disc_forward(e, x6d, nullptr, s);
+      if (rc) return rc;
+      rc = disc_backward_input(e, x6d, nullptr, dscale, 1.f, e->gx, s);
+      if (rc) return rc;
+    }
+    if (sd) launch_shape_disc(e->Ps, betas, nullptr, e->gb, sscale, 1.f, e->B, s);
+    PrepBwdLaunch L;
+    L.x6d_in = x6d; L.betas_in = betas;
+    L.dATp = e->dATp; L.nvc = e->nvcb; L.dFTp = e->dFTp; L.nsplit = e->nsplit;
+    L.gx_extra = pd ? e->gx : nullptr; L.gb_extra = sd ? e->gb : nullptr;
+    L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step;
+    L.lr = lr; L.B = e->B; L.BP = e->BP;
+    launch_prep_bwd(L, e->m, s);
+  }
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+// =============================================================================================
+// J step (scripts/optimize.py:300-312)
+// =============================================================================================
+__global__ void k_pad_dj(const float* __restrict__ dj, float* __restrict__ out, int B, int BP) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= BP * 64) return;
+  int b = idx >> 6, k = idx & 63;
+  out[idx] = (b < B && k < 51) ? dj[(size_t)b * 51 + k] : 0.f;
+}
+
+// dJn[i][v] = sum_split sum_c P[split][i*3+c][v*3+c]
+__global__ void k_djn_reduce(const float* __restrict__ P, int nsplit, float* __restrict__ dJn) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= NH * VP) return;
+  int i = idx / VP, v = idx % VP;
+  float acc = 0.f;
+  for (int s = 0; s < nsplit; ++s)
+    for (int c = 0; c < 3; ++c) acc += P[((size_t)s * 64 + i * 3 + c) * (VP * 3) + v * 3 + c];
+  dJn[idx] = acc;
+}
+
+namespace jrr { int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s); }
+
+static int j_grad_from_verts(jrr_engine* e, const float* djoints, float* dJ, hipStream_t s) {
+  if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("dJ requires an engine created with JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
+  hipLaunchKernelGGL(k_pad_dj, dim3((e->BP * 64 + 255) / 256), dim3(256), 0, s, djoints, e->djpad, e->B, e->BP);
+  GemmArgs g;
+  g.A = e->djpad; g.lda = 64;            // A[k=b][m=(i,c)]
+  g.Bm = e->verts; g.ldb = VP * 3;       // Bm[k=b][n=(v,c)]
+  g.Out = e->dJnp; g.ldo = VP * 3;
+  g.bias = nullptr; g.mask = nullptr;
+  g.M = 64; g.N = VP * 3; g.K = e->BP;
+  g.split_stride = (size_t)64 * VP * 3;
+  int rc = jrr::launch_gemm_64(g, EPI_STORE, e->nsplitJ, s);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_djn_reduce, dim3((NH * VP + 255) / 256), dim3(256), 0, s, e->dJnp, e->nsplitJ, e->dJn);
+  launch_jreg_bwd(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->Jn, e->rowsum, e->dJn, VP, dJ, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d, const float* betas, const float* gt_mm,
+                                    float* dJ, float* sqerr, void* stream) {
+  if (!e || !x6d || !betas || !gt_mm || !dJ) return JRR_ERR_ARG;
+  if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
+  if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("J step requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  int rc = ensure_verts_zeroed(e, s);
+  if (rc) return rc;
+  smpl_forward(e, x6d, nullptr, betas, false, e->verts, VP * 3, nullptr, s);
+  const float scale = (float)(2.0 * 1.0 / ((double)e->bnorm * 51.0));   // optimize.py:307 unweighted MSE
+  launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, scale, e->joints, sqerr ? sqerr : e->sqerr, nullptr, e->B, e->BP, s);
+  launch_joint_loss_plain(e->joints, gt_mm, scale, nullptr, e->dj, e->B, s);
+  return j_grad_from_verts(e, e->dj, dJ, s);
+}

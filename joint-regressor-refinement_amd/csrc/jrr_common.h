@@ -1,0 +1,83 @@
+// Shared constants, layouts and MFMA helpers for the gfx950 kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/jrr.h"
+
+namespace jrr {
+
+constexpr int V = 6890;        // SMPL vertices
+constexpr int VT = 216;        // vertex tiles of 32
+constexpr int VP = VT * 32;    // 6912 padded vertices
+constexpr int NJ = 24;         // SMPL joints
+constexpr int NH = 17;         // H36M joints
+constexpr int NHP = 18;        // H36M joints padded to the MFMA K granule (2)
+constexpr int NB = 10;         // betas
+constexpr int KF = 218;        // blend features: 207 pose + 10 shape + 1 template
+constexpr int KFP = 224;       // padded to 7 tiles of 32
+constexpr int KCH = 32;        // feature rows per staged chunk of the blend basis
+constexpr int NKCH = KFP / KCH;  // 7
+constexpr int BT = 32;         // poses per wave tile
+constexpr int BG = 128;        // poses per forward workgroup (4 waves)
+constexpr int NPARAM = 154;    // 144 pose6d + 10 betas per pose
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// v_mfma_f32_32x32x2_f32: D[32x32] += A[32x2] * B[2x32], exact fp32.
+//   A operand: lane l holds A[m = l&31][k = l>>5]
+//   B operand: lane l holds B[k = l>>5][n = l&31]
+//   C/D:       reg r of lane l holds D[row = (r&3) + 8*(r>>2) + 4*(l>>5)][col = l&31]
+// (verified on hardware by tools/probe/mfma_probe.hip)
+__device__ __forceinline__ f32x16 mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+__device__ __forceinline__ int acc_row(int reg, int half) { return (reg & 3) + 8 * (reg >> 2) + 4 * half; }
+
+__device__ __forceinline__ f32x16 zero16() {
+  f32x16 z;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) z[i] = 0.f;
+  return z;
+}
+
+// XCD-aware bijective remap of a linear block id: blocks with equal (id % 8) share an XCD's L2,
+// so give each XCD a contiguous range of logical work (guide T1, bijective form).
+__device__ __forceinline__ int xcd_remap(int id, int n) {
+  int xcd = id & 7, q = n >> 3, r = n & 7;
+  int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return base + (id >> 3);
+}
+
+struct Parents { int p[NJ]; };
+
+// ---- device-resident SMPL model ------------------------------------------------------------
+struct Model {
+  float* Dk;    // [VT][KFP][3][32]  blend basis, feature-major inside a vertex tile
+  float* Dn;    // [3][VP][KFP]      blend basis, feature-contiguous (for the dF GEMM)
+  float* Wjv;   // [VT][24][32]      skinning weights W^T tile  (lane = vertex)
+  float* Wvj;   // [VT][32][32]      skinning weights tile [vertex][joint padded to 32] (lane = joint)
+  float* Jt;    // [24][3]           rest joints of the template
+  float* JS;    // [24][3][10]       rest-joint shape directions
+  Parents parents;
+};
+
+inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
+
+}  // namespace jrr
+
+struct jrr_model {
+  jrr::Model d;
+  void* base;
+};
+
+// error plumbing (api.hip)
+void jrr_set_error(const char* fmt, ...);
+#define JRR_HIP(expr)                                                                 \
+  do {                                                                                \
+    hipError_t _e = (expr);                                                           \
+    if (_e != hipSuccess) {                                                           \
+      jrr_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+      return JRR_ERR_HIP;                                                             \
+    }                                                                                 \
+  } while (0)

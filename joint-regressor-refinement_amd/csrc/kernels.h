@@ -1,0 +1,75 @@
+// Internal launcher interface between api.hip and the kernel translation units.
+#pragma once
+#include "jrr_common.h"
+
+namespace jrr {
+
+// flat pose-discriminator parameter offsets (state_dict order, scripts/discriminator.py:7-30)
+constexpr int DP_CONV0_W = 0, DP_CONV0_B = 192, DP_CONV2_W = 224, DP_CONV2_B = 1248, DP_HEADS = 1280;
+constexpr int DP_FC0_W = 2072, DP_FC0_B = 788504, DP_FC2_W = 789528, DP_FC2_B = 1838104;
+constexpr int DP_FC4_W = 1839128, DP_FC4_B = 1840152, DP_TOTAL = 1840153;
+
+enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_BIAS = 3 };
+
+struct GemmArgs {
+  const float* A; int lda;      // A[k][m]
+  const float* Bm; int ldb;     // Bm[k][n]
+  float* Out; int ldo;          // Out[m][n]
+  const float* bias;            // [m]      (EPI_BIAS_RELU / EPI_BIAS)
+  const float* mask;            // [m][ldo] (EPI_MASK: keep where mask > 0)
+  int M, N, K;
+  size_t split_stride;          // floats between split-K partial slabs
+};
+
+struct PrepBwdLaunch {
+  const float* x6d_in = nullptr; const float* R_in = nullptr; const float* betas_in = nullptr;
+  const float* dATp = nullptr; int nvc = 0; const float* dFTp = nullptr; int nsplit = 0;
+  const float* gx_extra = nullptr; const float* gb_extra = nullptr;
+  float* dx6d = nullptr; float* dR = nullptr; float* dbetas = nullptr;
+  float* x6d_io = nullptr; float* betas_io = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;
+  const int32_t* step = nullptr;
+  float lr = 0, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
+  int B = 0, BP = 0;
+};
+
+// prep.hip
+int launch_rot6d_fwd(const float* x, float* R, int n, hipStream_t s);
+int launch_rot6d_bwd(const float* x, const float* dR, float* dx, int n, hipStream_t s);
+int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT, int B,
+                    int BP, int32_t* step_inc, hipStream_t s);
+int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float* djoints_in, float scale,
+                       float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s);
+int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale, float* sqerr, float* djoints, int B,
+                            hipStream_t s);
+int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s);
+int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr, float b1,
+                     float b2, float eps, hipStream_t s);
+
+// lbs.hip
+int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
+                   float* verts, int ldv, int B, int BP, int nvc, hipStream_t s);
+int launch_lbs_bwd(const Model& m, const float* Jn_iv, const float* AT, const float* VPb, const float* dJT,
+                   const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s);
+int launch_dverts_transpose(const float* dverts, float* dVT, int B, int BP, hipStream_t s);
+int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv,
+                          hipStream_t s);
+int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
+                    float* dJ, hipStream_t s);
+
+// gemm.hip
+int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+int launch_gemm_32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+
+// disc.hip
+int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
+int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s);
+int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, float scale, float target, int B, int BP,
+                    hipStream_t s);
+int launch_disc_conv_bwd(const float* P, const float* x6d, const float* dH2T, float scale, float target, float* gx,
+                         int B, int BP, hipStream_t s);
+int launch_shape_disc(const float* P, const float* betas, float* out, float* gb, float scale, float target, int B,
+                      hipStream_t s);
+
+}  // namespace jrr

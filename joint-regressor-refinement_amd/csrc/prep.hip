@@ -1,0 +1,601 @@
+// Per-pose kernels (one pose per lane): 6-D rotation -> R, blend features, kinematic chain (forward
+// and adjoint), joint loss, and the fused per-pose Adam update.
+//
+// Reference arithmetic restated here:
+//   rot6d_to_rotmat            /root/reference/scripts/utils.py:190-204
+//   rigid chain / A matrices   smplx 0.1.26 lbs.batch_rigid_transform
+//   move_pelvis + MSELoss      scripts/utils.py:106-114, scripts/optimize.py:238-239
+//   Adam                       torch.optim.Adam defaults, scripts/optimize.py:201-202,263-265
+#include "jrr_common.h"
+#include "kernels.h"
+
+namespace jrr {
+
+// ------------------------------------------------------------------------------------------
+// 6-D rotation representation
+// ------------------------------------------------------------------------------------------
+struct Rot6 {
+  float b1[3], b2[3], a2[3];
+  float n1, nu, s;   // |a1|, |u|, b1.a2
+};
+
+__device__ __forceinline__ void rot6d_fwd(const float x[6], float R[9], Rot6& c) {
+  const float eps = 1e-12f;
+  float a1[3] = {x[0], x[2], x[4]};
+  c.a2[0] = x[1]; c.a2[1] = x[3]; c.a2[2] = x[5];
+  c.n1 = sqrtf(a1[0] * a1[0] + a1[1] * a1[1] + a1[2] * a1[2]);
+  float d1 = fmaxf(c.n1, eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c.b1[i] = a1[i] / d1;
+  c.s = c.b1[0] * c.a2[0] + c.b1[1] * c.a2[1] + c.b1[2] * c.a2[2];
+  float u[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) u[i] = c.a2[i] - c.s * c.b1[i];
+  c.nu = sqrtf(u[0] * u[0] + u[1] * u[1] + u[2] * u[2]);
+  float d2 = fmaxf(c.nu, eps);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) c.b2[i] = u[i] / d2;
+  float b3[3] = {c.b1[1] * c.b2[2] - c.b1[2] * c.b2[1], c.b1[2] * c.b2[0] - c.b1[0] * c.b2[2],
+                 c.b1[0] * c.b2[1] - c.b1[1] * c.b2[0]};
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    R[r * 3 + 0] = c.b1[r];
+    R[r * 3 + 1] = c.b2[r];
+    R[r * 3 + 2] = b3[r];
+  }
+}
+
+__device__ __forceinline__ void rot6d_bwd(const Rot6& c, const float dR[9], float dx[6]) {
+  const float eps = 1e-12f;
+  float db1[3], db2[3], db3[3];
+#pragma unroll
+  for (int r = 0; r < 3; ++r) { db1[r] = dR[r * 3 + 0]; db2[r] = dR[r * 3 + 1]; db3[r] = dR[r * 3 + 2]; }
+  // b3 = b1 x b2
+  db1[0] += c.b2[1] * db3[2] - c.b2[2] * db3[1];
+  db1[1] += c.b2[2] * db3[0] - c.b2[0] * db3[2];
+  db1[2] += c.b2[0] * db3[1] - c.b2[1] * db3[0];
+  db2[0] += db3[1] * c.b1[2] - db3[2] * c.b1[1];
+  db2[1] += db3[2] * c.b1[0] - db3[0] * c.b1[2];
+  db2[2] += db3[0] * c.b1[1] - db3[1] * c.b1[0];
+  // b2 = u / max(|u|, eps)
+  float du[3];
+  if (c.nu >= eps) {
+    float t = c.b2[0] * db2[0] + c.b2[1] * db2[1] + c.b2[2] * db2[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) du[i] = (db2[i] - c.b2[i] * t) / c.nu;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) du[i] = db2[i] / eps;
+  }
+  // u = a2 - (b1.a2) b1
+  float t2 = c.b1[0] * du[0] + c.b1[1] * du[1] + c.b1[2] * du[2];
+  float da2[3];
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+    da2[i] = du[i] - c.b1[i] * t2;
+    db1[i] += -c.a2[i] * t2 - c.s * du[i];
+  }
+  // b1 = a1 / max(|a1|, eps)
+  float da1[3];
+  if (c.n1 >= eps) {
+    float t = c.b1[0] * db1[0] + c.b1[1] * db1[1] + c.b1[2] * db1[2];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) da1[i] = (db1[i] - c.b1[i] * t) / c.n1;
+  } else {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) da1[i] = db1[i] / eps;
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { dx[2 * i] = da1[i]; dx[2 * i + 1] = da2[i]; }
+}
+
+__global__ void k_rot6d_fwd(const float* __restrict__ x, float* __restrict__ R, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float xv[6], Rv[9];
+  Rot6 c;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xv[k] = x[(size_t)i * 6 + k];
+  rot6d_fwd(xv, Rv, c);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = Rv[k];
+}
+
+__global__ void k_rot6d_bwd(const float* __restrict__ x, const float* __restrict__ dR, float* __restrict__ dx, int n) {
+  int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float xv[6], Rv[9], g[9], dxv[6];
+  Rot6 c;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xv[k] = x[(size_t)i * 6 + k];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g[k] = dR[(size_t)i * 9 + k];
+  rot6d_fwd(xv, Rv, c);
+  rot6d_bwd(c, g, dxv);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) dx[(size_t)i * 6 + k] = dxv[k];
+}
+
+// ------------------------------------------------------------------------------------------
+// helpers
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void load_rot(const float* __restrict__ x6d, const float* __restrict__ Rin, int b, int j,
+                                         float R[9], Rot6& c) {
+  if (Rin) {
+#pragma unroll
+    for (int k = 0; k < 9; ++k) R[k] = Rin[((size_t)b * NJ + j) * 9 + k];
+  } else {
+    float xv[6];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) xv[k] = x6d[((size_t)b * NJ + j) * 6 + k];
+    rot6d_fwd(xv, R, c);
+  }
+}
+
+__device__ __forceinline__ void rest_joint(const float* __restrict__ Jt, const float* __restrict__ JS, int j,
+                                           const float beta[NB], float J[3]) {
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float acc = Jt[j * 3 + c];
+#pragma unroll
+    for (int l = 0; l < NB; ++l) acc = fmaf(JS[(j * 3 + c) * NB + l], beta[l], acc);
+    J[c] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_prep_fwd: per pose -> FT [KFP][BP] (blend features, transposed), AT [12][24][BP] (skinning
+// transforms A_j = G_j - [0 | G_j.R J_j], entry e = r*4+c).  Poses b >= B are written as zeros.
+// LDS: G (12 floats) per joint per lane.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_prep_fwd(const float* __restrict__ x6d, const float* __restrict__ Rin,
+                                                 const float* __restrict__ betas, const float* __restrict__ Jt,
+                                                 const float* __restrict__ JS, Parents par, float* __restrict__ FT,
+                                                 float* __restrict__ AT, int B, int BP, int32_t* step_inc) {
+  extern __shared__ float lds[];   // [24][12][64]
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  if (step_inc && blockIdx.x == 0 && lane == 0) step_inc[0] += 1;   // Adam step count of this iteration
+  if (b >= BP) return;
+  if (b >= B) {
+    for (int k = 0; k < KFP; ++k) FT[(size_t)k * BP + b] = 0.f;
+    for (int k = 0; k < 12 * NJ; ++k) AT[(size_t)k * BP + b] = 0.f;
+    return;
+  }
+  float beta[NB];
+#pragma unroll
+  for (int l = 0; l < NB; ++l) beta[l] = betas[(size_t)b * NB + l];
+  for (int j = 0; j < NJ; ++j) {
+    float R[9], J[3], G[12];
+    Rot6 c;
+    load_rot(x6d, Rin, b, j, R, c);
+    rest_joint(Jt, JS, j, beta, J);
+    if (j > 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) FT[(size_t)((j - 1) * 9 + k) * BP + b] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
+    }
+    if (j == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) G[r * 4 + cc] = R[r * 3 + cc];
+        G[r * 4 + 3] = J[r];
+      }
+    } else {
+      const int p = par.p[j];
+      float Gp[12], Jp[3], rel[3];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) Gp[e] = lds[(p * 12 + e) * 64 + lane];
+      rest_joint(Jt, JS, p, beta, Jp);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) rel[cc] = J[cc] - Jp[cc];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+          G[r * 4 + cc] = Gp[r * 4 + 0] * R[0 * 3 + cc] + Gp[r * 4 + 1] * R[1 * 3 + cc] + Gp[r * 4 + 2] * R[2 * 3 + cc];
+        G[r * 4 + 3] = Gp[r * 4 + 0] * rel[0] + Gp[r * 4 + 1] * rel[1] + Gp[r * 4 + 2] * rel[2] + Gp[r * 4 + 3];
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) lds[(j * 12 + e) * 64 + lane] = G[e];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) AT[(size_t)((r * 4 + cc) * NJ + j) * BP + b] = G[r * 4 + cc];
+      AT[(size_t)((r * 4 + 3) * NJ + j) * BP + b] =
+          G[r * 4 + 3] - (G[r * 4 + 0] * J[0] + G[r * 4 + 1] * J[1] + G[r * 4 + 2] * J[2]);
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < NB; ++l) FT[(size_t)(207 + l) * BP + b] = beta[l];
+  FT[(size_t)217 * BP + b] = 1.f;
+  for (int k = KF; k < KFP; ++k) FT[(size_t)k * BP + b] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_joints_loss: reduce the per-vertex-chunk joint partials, write joints (B,17,3), and
+// (optionally) the joint-loss adjoint dJT [3][18][BP] = d(weight*mean((move_pelvis(j)-gt/1000)^2))/dj.
+//   scale = 2*weight/(batch_norm*51).  If djoints_in != NULL it is used as the adjoint instead
+//   (operator-level backward), transposed into dJT.
+// ------------------------------------------------------------------------------------------
+__global__ void k_joints_loss(const float* __restrict__ JP, int nvc, const float* __restrict__ gt_mm,
+                              const float* __restrict__ djoints_in, float scale, float* __restrict__ joints_out,
+                              float* __restrict__ sqerr, float* __restrict__ dJT, int B, int BP) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= BP) return;
+  if (b >= B) {
+    if (dJT)
+      for (int k = 0; k < 3 * NHP; ++k) dJT[(size_t)k * BP + b] = 0.f;
+    return;
+  }
+  float j[NH][3];
+  if (JP) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int i = 0; i < NH; ++i) {
+        float acc = 0.f;
+        for (int ch = 0; ch < nvc; ++ch) acc += JP[(size_t)((ch * 3 + c) * NH + i) * BP + b];
+        j[i][c] = acc;
+      }
+    if (joints_out) {
+#pragma unroll
+      for (int i = 0; i < NH; ++i)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) joints_out[((size_t)b * NH + i) * 3 + c] = j[i][c];
+    }
+  }
+  if (djoints_in) {
+    if (dJT) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+#pragma unroll
+        for (int i = 0; i < NH; ++i) dJT[(size_t)(c * NHP + i) * BP + b] = djoints_in[((size_t)b * NH + i) * 3 + c];
+        dJT[(size_t)(c * NHP + NH) * BP + b] = 0.f;
+      }
+    }
+    return;
+  }
+  if (!gt_mm) return;
+  float err = 0.f;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float gsum = 0.f;
+#pragma unroll
+    for (int i = 1; i < NH; ++i) {
+      float d = (j[i][c] - j[0][c]) - gt_mm[((size_t)b * NH + i) * 3 + c] / 1000.f;
+      err += d * d;
+      float g = scale * d;
+      gsum += g;
+      if (dJT) dJT[(size_t)(c * NHP + i) * BP + b] = g;
+    }
+    // joint 0: centred value is identically 0; gt is pelvis-centred by the caller (optimize.py:162)
+    float d0 = -gt_mm[((size_t)b * NH + 0) * 3 + c] / 1000.f;
+    err += d0 * d0;
+    if (dJT) {
+      dJT[(size_t)(c * NHP + 0) * BP + b] = -gsum;   // move_pelvis adjoint: -sum_i g_i (g_0 cancels)
+      dJT[(size_t)(c * NHP + NH) * BP + b] = 0.f;
+    }
+  }
+  if (sqerr) sqerr[b] = err;
+}
+
+// standalone joint loss on (B,17,3) joints (operator-level API: jrr_joint_loss)
+__global__ void k_joint_loss_plain(const float* __restrict__ joints, const float* __restrict__ gt_mm, float scale,
+                                   float* __restrict__ sqerr, float* __restrict__ djoints, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float err = 0.f;
+  for (int c = 0; c < 3; ++c) {
+    float j0 = joints[((size_t)b * NH) * 3 + c];
+    float gsum = 0.f;
+    for (int i = 1; i < NH; ++i) {
+      float d = (joints[((size_t)b * NH + i) * 3 + c] - j0) - gt_mm[((size_t)b * NH + i) * 3 + c] / 1000.f;
+      err += d * d;
+      float g = scale * d;
+      gsum += g;
+      if (djoints) djoints[((size_t)b * NH + i) * 3 + c] = g;
+    }
+    float d0 = -gt_mm[((size_t)b * NH) * 3 + c] / 1000.f;
+    err += d0 * d0;
+    if (djoints) djoints[((size_t)b * NH) * 3 + c] = -gsum;
+  }
+  if (sqerr) sqerr[b] = err;
+}
+
+// ------------------------------------------------------------------------------------------
+// Adam (torch single-tensor formula): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), bias corrections evaluated in double like
+// torch's Python scalars.
+// ------------------------------------------------------------------------------------------
+struct AdamScalars { float step_size, bc2_sqrt, beta1, beta2, eps; };
+
+__device__ __forceinline__ AdamScalars adam_scalars(int step, float lr, float beta1, float beta2, float eps) {
+  AdamScalars s;
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  s.step_size = (float)((double)lr / bc1);
+  s.bc2_sqrt = (float)sqrt(bc2);
+  s.beta1 = beta1; s.beta2 = beta2; s.eps = eps;
+  return s;
+}
+
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamScalars& s) {
+  m = m * s.beta1 + (1.f - s.beta1) * g;
+  v = v * s.beta2 + (1.f - s.beta2) * g * g;
+  float denom = sqrtf(v) / s.bc2_sqrt + s.eps;
+  return p - s.step_size * (m / denom);
+}
+
+__global__ void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                            float* __restrict__ v, size_t n, const int32_t* __restrict__ step, float lr, float beta1,
+                            float beta2, float eps) {
+  __shared__ AdamScalars sc;
+  if (threadIdx.x == 0) sc = adam_scalars(step[0], lr, beta1, beta2, eps);
+  __syncthreads();
+  AdamScalars s = sc;
+  for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    float mm = m[i], vv = v[i];
+    p[i] = adam_update(p[i], g[i], mm, vv, s);
+    m[i] = mm;
+    v[i] = vv;
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// k_prep_bwd: adjoint of k_prep_fwd (+ optional fused Adam).
+//   inputs : dATp [nvc][12][24][BP] partial dL/dA^T, dFTp [nsplit][KFP][BP] partial dL/dF^T,
+//            gx_extra (B,24,6) / gb_extra (B,10): extra gradients added before the update
+//            (discriminator terms), may be NULL.
+//   outputs: mode GRAD : dx6d (B,24,6) or dR (B,24,3,3), dbetas (B,10)
+//            mode ADAM : x6d/betas/m/v updated in place.
+// LDS per lane: G.R (9) and dG (12) per joint.
+// ------------------------------------------------------------------------------------------
+struct PrepBwdArgs {
+  const float* x6d_in;      // (B,24,6) or NULL
+  const float* R_in;        // (B,24,3,3) or NULL
+  const float* betas_in;    // (B,10)
+  const float* Jt; const float* JS;
+  const float* dATp; int nvc;
+  const float* dFTp; int nsplit;
+  const float* gx_extra; const float* gb_extra;
+  float* dx6d; float* dR; float* dbetas;           // GRAD outputs (nullable)
+  float* x6d_io; float* betas_io; float* adam_m; float* adam_v; const int32_t* step;   // ADAM (x6d_io nullable)
+  float lr, beta1, beta2, eps;
+  int B, BP;
+};
+
+__global__ __launch_bounds__(64) void k_prep_bwd(PrepBwdArgs a, Parents par) {
+  extern __shared__ float lds[];
+  float* GR = lds;                  // [24][9][64]
+  float* dG = lds + NJ * 9 * 64;    // [24][12][64]
+  const int lane = threadIdx.x;
+  const int b = blockIdx.x * 64 + lane;
+  if (b >= a.B) return;
+  const int BP = a.BP;
+  const bool do_adam = a.x6d_io != nullptr;
+  AdamScalars sc;
+  if (do_adam) sc = adam_scalars(a.step[0], a.lr, a.beta1, a.beta2, a.eps);
+
+  float beta[NB], dbeta[NB];
+#pragma unroll
+  for (int l = 0; l < NB; ++l) { beta[l] = a.betas_in[(size_t)b * NB + l]; dbeta[l] = 0.f; }
+
+  // ---- forward recompute of G.R, and dG initialised from dA ----
+  for (int j = 0; j < NJ; ++j) {
+    float R[9], J[3], G9[9];
+    Rot6 c;
+    load_rot(a.x6d_in, a.R_in, b, j, R, c);
+    rest_joint(a.Jt, a.JS, j, beta, J);
+    if (j == 0) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) G9[k] = R[k];
+    } else {
+      const int p = par.p[j];
+      float Gp[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Gp[k] = GR[(p * 9 + k) * 64 + lane];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+          G9[r * 3 + cc] = Gp[r * 3 + 0] * R[0 * 3 + cc] + Gp[r * 3 + 1] * R[1 * 3 + cc] + Gp[r * 3 + 2] * R[2 * 3 + cc];
+    }
+#pragma unroll
+    for (int k = 0; k < 9; ++k) GR[(j * 9 + k) * 64 + lane] = G9[k];
+    // dA_j (reduce partials)
+    float dA[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) {
+      float acc = 0.f;
+      for (int ch = 0; ch < a.nvc; ++ch) acc += a.dATp[(size_t)((ch * 12 + e) * NJ + j) * BP + b];
+      dA[e] = acc;
+    }
+    // A.R = G.R ; A.t = G.t - G.R J  =>  dG.R = dA.R - dA.t J^T ; dG.t = dA.t ; dJ += -G.R^T dA.t
+    float dJ[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) {
+        dG[(j * 12 + r * 4 + cc) * 64 + lane] = dA[r * 4 + cc] - dA[r * 4 + 3] * J[cc];
+        dJ[cc] -= G9[r * 3 + cc] * dA[r * 4 + 3];
+      }
+      dG[(j * 12 + r * 4 + 3) * 64 + lane] = dA[r * 4 + 3];
+    }
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+      for (int l = 0; l < NB; ++l) dbeta[l] = fmaf(dJ[cc], a.JS[(j * 3 + cc) * NB + l], dbeta[l]);
+  }
+
+  // ---- backward over the chain, children before parents ----
+  for (int i = NJ - 1; i >= 0; --i) {
+    float R[9], dRi[9], dGi[12];
+    Rot6 c;
+    load_rot(a.x6d_in, a.R_in, b, i, R, c);
+#pragma unroll
+    for (int e = 0; e < 12; ++e) dGi[e] = dG[(i * 12 + e) * 64 + lane];
+    if (i == 0) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) dRi[r * 3 + cc] = dGi[r * 4 + cc];
+      // G_0.t = J_0
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int l = 0; l < NB; ++l) dbeta[l] = fmaf(dGi[cc * 4 + 3], a.JS[(0 * 3 + cc) * NB + l], dbeta[l]);
+    } else {
+      const int p = par.p[i];
+      float Gp[9], Ji[3], Jp[3], rel[3], drel[3];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) Gp[k] = GR[(p * 9 + k) * 64 + lane];
+      rest_joint(a.Jt, a.JS, i, beta, Ji);
+      rest_joint(a.Jt, a.JS, p, beta, Jp);
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) rel[cc] = Ji[cc] - Jp[cc];
+      // G_i.R = Gp.R R_i ; G_i.t = Gp.R rel + Gp.t
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+          dRi[r * 3 + cc] = Gp[0 * 3 + r] * dGi[0 * 4 + cc] + Gp[1 * 3 + r] * dGi[1 * 4 + cc] + Gp[2 * 3 + r] * dGi[2 * 4 + cc];
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+        drel[cc] = Gp[0 * 3 + cc] * dGi[0 * 4 + 3] + Gp[1 * 3 + cc] * dGi[1 * 4 + 3] + Gp[2 * 3 + cc] * dGi[2 * 4 + 3];
+      // dGp.R += dG_i.R R_i^T + dG_i.t rel^T ; dGp.t += dG_i.t
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) {
+          float add = dGi[r * 4 + 0] * R[cc * 3 + 0] + dGi[r * 4 + 1] * R[cc * 3 + 1] + dGi[r * 4 + 2] * R[cc * 3 + 2] +
+                      dGi[r * 4 + 3] * rel[cc];
+          dG[(p * 12 + r * 4 + cc) * 64 + lane] += add;
+        }
+        dG[(p * 12 + r * 4 + 3) * 64 + lane] += dGi[r * 4 + 3];
+      }
+      // rel = J_i - J_p
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+        for (int l = 0; l < NB; ++l)
+          dbeta[l] = fmaf(drel[cc], a.JS[(i * 3 + cc) * NB + l] - a.JS[(p * 3 + cc) * NB + l], dbeta[l]);
+      // pose-feature adjoint: F[(i-1)*9 + k] = R_i[k] - I
+#pragma unroll
+      for (int k = 0; k < 9; ++k) {
+        float acc = 0.f;
+        for (int s = 0; s < a.nsplit; ++s) acc += a.dFTp[(size_t)(s * KFP + (i - 1) * 9 + k) * BP + b];
+        dRi[k] += acc;
+      }
+    }
+    if (a.R_in) {
+      if (a.dR) {
+#pragma unroll
+        for (int k = 0; k < 9; ++k) a.dR[((size_t)b * NJ + i) * 9 + k] = dRi[k];
+      }
+    } else {
+      float dx[6];
+      rot6d_bwd(c, dRi, dx);
+      if (a.gx_extra) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dx[k] += a.gx_extra[((size_t)b * NJ + i) * 6 + k];
+      }
+      if (a.dx6d) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) a.dx6d[((size_t)b * NJ + i) * 6 + k] = dx[k];
+      }
+      if (do_adam) {
+#pragma unroll
+        for (int k = 0; k < 6; ++k) {
+          size_t pi = ((size_t)b * NJ + i) * 6 + k;
+          size_t si = (size_t)b * NPARAM + i * 6 + k;
+          float mm = a.adam_m[si], vv = a.adam_v[si];
+          a.x6d_io[pi] = adam_update(a.x6d_io[pi], dx[k], mm, vv, sc);
+          a.adam_m[si] = mm;
+          a.adam_v[si] = vv;
+        }
+      }
+    }
+  }
+  // shape-feature adjoint
+#pragma unroll
+  for (int l = 0; l < NB; ++l) {
+    float acc = 0.f;
+    for (int s = 0; s < a.nsplit; ++s) acc += a.dFTp[(size_t)(s * KFP + 207 + l) * BP + b];
+    dbeta[l] += acc;
+    if (a.gb_extra) dbeta[l] += a.gb_extra[(size_t)b * NB + l];
+    if (a.dbetas) a.dbetas[(size_t)b * NB + l] = dbeta[l];
+    if (do_adam) {
+      size_t si = (size_t)b * NPARAM + JRR_POSE6D + l;
+      float mm = a.adam_m[si], vv = a.adam_v[si];
+      a.betas_io[(size_t)b * NB + l] = adam_update(a.betas_io[(size_t)b * NB + l], dbeta[l], mm, vv, sc);
+      a.adam_m[si] = mm;
+      a.adam_v[si] = vv;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// launchers
+// ------------------------------------------------------------------------------------------
+int launch_rot6d_fwd(const float* x, float* R, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_rot6d_fwd, dim3((n + 255) / 256), dim3(256), 0, s, x, R, n);
+  return 0;
+}
+int launch_rot6d_bwd(const float* x, const float* dR, float* dx, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_rot6d_bwd, dim3((n + 255) / 256), dim3(256), 0, s, x, dR, dx, n);
+  return 0;
+}
+
+static bool g_attr_set = false;
+static void ensure_attrs() {
+  if (g_attr_set) return;
+  (void)hipFuncSetAttribute((const void*)k_prep_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, NJ * 12 * 64 * 4);
+  (void)hipFuncSetAttribute((const void*)k_prep_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, NJ * 21 * 64 * 4);
+  g_attr_set = true;
+}
+
+int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT,
+                    int B, int BP, int32_t* step_inc, hipStream_t s) {
+  ensure_attrs();
+  hipLaunchKernelGGL(k_prep_fwd, dim3(BP / 64), dim3(64), NJ * 12 * 64 * 4, s, x6d, Rin, betas, m.Jt, m.JS, m.parents,
+                     FT, AT, B, BP, step_inc);
+  return 0;
+}
+
+int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float* djoints_in, float scale,
+                       float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s) {
+  hipLaunchKernelGGL(k_joints_loss, dim3(BP / 64), dim3(64), 0, s, JP, nvc, gt_mm, djoints_in, scale, joints_out, sqerr,
+                     dJT, B, BP);
+  return 0;
+}
+
+int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale, float* sqerr, float* djoints, int B,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k_joint_loss_plain, dim3((B + 63) / 64), dim3(64), 0, s, joints, gt_mm, scale, sqerr, djoints, B);
+  return 0;
+}
+
+int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
+  ensure_attrs();
+  PrepBwdArgs a;
+  a.x6d_in = L.x6d_in; a.R_in = L.R_in; a.betas_in = L.betas_in; a.Jt = m.Jt; a.JS = m.JS;
+  a.dATp = L.dATp; a.nvc = L.nvc; a.dFTp = L.dFTp; a.nsplit = L.nsplit;
+  a.gx_extra = L.gx_extra; a.gb_extra = L.gb_extra;
+  a.dx6d = L.dx6d; a.dR = L.dR; a.dbetas = L.dbetas;
+  a.x6d_io = L.x6d_io; a.betas_io = L.betas_io; a.adam_m = L.adam_m; a.adam_v = L.adam_v; a.step = L.step;
+  a.lr = L.lr; a.beta1 = L.beta1; a.beta2 = L.beta2; a.eps = L.eps; a.B = L.B; a.BP = L.BP;
+  hipLaunchKernelGGL(k_prep_bwd, dim3((L.B + 63) / 64), dim3(64), NJ * 21 * 64 * 4, s, a, m.parents);
+  return 0;
+}
+
+int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr, float b1,
+                     float b2, float eps, hipStream_t s) {
+  int blocks = (int)((n + 255) / 256);
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(k_adam_flat, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, step, lr, b1, b2, eps);
+  return 0;
+}
+
+}  // namespace jrr

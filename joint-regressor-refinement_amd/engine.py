@@ -1,0 +1,224 @@
+"""Thin Python wrappers over the C ABI: device model, per-batch engine, free operator functions.
+
+All tensors are torch CUDA (ROCm) float32 tensors; PyTorch owns every buffer including the
+engine workspace, and kernels are enqueued on torch's current stream.
+"""
+from __future__ import annotations
+
+import ctypes
+from ctypes import byref, c_int32, c_void_p
+from typing import Dict, Optional
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import check, ptr, stream_ptr
+
+FLAG_POSE_DISC = 1
+FLAG_SHAPE_DISC = 2
+FLAG_KEEP_VERTS = 4
+
+NUM_VERTS, NUM_JOINTS, NUM_H36M, NUM_BETAS = 6890, 24, 17, 10
+DISC_PARAMS = 1840153
+SHAPE_DISC_PARAMS = 171
+
+DISC_KEYS = (['conv_operations.0.weight', 'conv_operations.0.bias', 'conv_operations.2.weight', 'conv_operations.2.bias']
+             + [k for i in range(24) for k in (f'linears.{i}.weight', f'linears.{i}.bias')]
+             + ['linear_operations.0.weight', 'linear_operations.0.bias', 'linear_operations.2.weight',
+                'linear_operations.2.bias', 'linear_operations.4.weight', 'linear_operations.4.bias'])
+SHAPE_DISC_KEYS = ['shape_operations.0.weight', 'shape_operations.0.bias', 'shape_operations.2.weight',
+                   'shape_operations.2.bias', 'shape_operations.4.weight', 'shape_operations.4.bias']
+
+
+def flatten_state_dict(sd: Dict[str, torch.Tensor], keys) -> torch.Tensor:
+    """state_dict -> the flat parameter vector the C ABI expects (state_dict order)."""
+    return torch.cat([sd[k].detach().reshape(-1).float() for k in keys])
+
+
+def unflatten_state_dict(flat: torch.Tensor, like: Dict[str, torch.Tensor], keys) -> Dict[str, torch.Tensor]:
+    out, off = {}, 0
+    for k in keys:
+        n = like[k].numel()
+        out[k] = flat[off:off + n].view_as(like[k])
+        off += n
+    return out
+
+
+def _f32c(a) -> np.ndarray:
+    return np.ascontiguousarray(np.asarray(a, dtype=np.float32))
+
+
+class DeviceModel:
+    """SMPL constants uploaded in the kernels' tile-major layouts (jrr_model_create)."""
+
+    def __init__(self, model: Dict[str, np.ndarray], device='cuda:0'):
+        self.lib = _lib.load()
+        self.device = torch.device(device)
+        vt, sd, pd = _f32c(model['v_template']), _f32c(model['shapedirs']), _f32c(model['posedirs'])
+        jr, w = _f32c(model['J_regressor']), _f32c(model['lbs_weights'])
+        par = np.ascontiguousarray(np.asarray(model['parents'], dtype=np.int32))
+        assert vt.shape == (NUM_VERTS, 3) and sd.shape == (NUM_VERTS, 3, NUM_BETAS) and pd.shape == (207, NUM_VERTS * 3)
+        assert jr.shape == (NUM_JOINTS, NUM_VERTS) and w.shape == (NUM_VERTS, NUM_JOINTS) and par.shape == (NUM_JOINTS,)
+        self.faces = model.get('faces')
+        h = c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.jrr_model_create(vt.ctypes.data, sd.ctypes.data, pd.ctypes.data, jr.ctypes.data,
+                                            w.ctypes.data, par.ctypes.data, byref(h)), 'jrr_model_create')
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.jrr_model_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+
+class RefineEngine:
+    """Per-batch plan over a caller-owned (torch) workspace: jrr_engine_*."""
+
+    def __init__(self, model: DeviceModel, batch: int, batch_norm: Optional[int] = None, flags: int = 0):
+        self.lib = model.lib
+        self.model = model
+        self.device = model.device
+        self.batch = int(batch)
+        self.flags = int(flags)
+        nbytes = self.lib.jrr_engine_workspace_bytes(self.batch, self.flags)
+        # zero-filled: padded rows/columns of several sections are read by the GEMM kernels
+        self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = (self.workspace.data_ptr() + 255) // 256 * 256
+        h = c_void_p()
+        with torch.cuda.device(self.device):
+            check(self.lib.jrr_engine_create(model.handle, self.batch, int(batch_norm or batch), c_void_p(base), nbytes,
+                                             self.flags, byref(h)), 'jrr_engine_create')
+        self.handle = h
+        info = (c_int32 * 8)()
+        self.lib.jrr_engine_info(self.handle, info, 8)
+        self.info = dict(zip(['B', 'BP', 'batch_norm', 'nvc', 'nvcb', 'nsplit', 'nsplitJ', 'flags'], list(info)))
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.jrr_engine_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    # -- helpers ---------------------------------------------------------------------------
+    def _s(self):
+        return stream_ptr(self.device)
+
+    def _chk(self, t, shape, name):
+        assert t.is_cuda and t.dtype == torch.float32 and t.is_contiguous() and tuple(t.shape) == tuple(shape), \
+            f'{name}: expected contiguous float32 cuda tensor of shape {tuple(shape)}, got {tuple(t.shape)} {t.dtype}'
+        return t
+
+    # -- configuration ---------------------------------------------------------------------
+    def set_batch_norm(self, n: int):
+        check(self.lib.jrr_engine_set_batch_norm(self.handle, int(n)), 'set_batch_norm')
+
+    def set_j_regressor(self, J: torch.Tensor, mask: Optional[torch.Tensor] = None):
+        J = J.detach().to(self.device, torch.float32).contiguous()      # any stride / device tag
+        self._chk(J, (NUM_H36M, NUM_VERTS), 'J_regressor')
+        if mask is not None:
+            mask = self._chk(mask.detach().to(self.device, torch.float32).contiguous(), (NUM_H36M, NUM_VERTS), 'mask')
+        check(self.lib.jrr_engine_set_j_regressor(self.handle, ptr(J), ptr(mask), self._s()), 'set_j_regressor')
+
+    def set_pose_disc(self, flat: torch.Tensor):
+        flat = self._chk(flat.detach().to(self.device, torch.float32).contiguous(), (DISC_PARAMS,), 'disc params')
+        check(self.lib.jrr_engine_set_pose_disc(self.handle, ptr(flat), self._s()), 'set_pose_disc')
+
+    def set_shape_disc(self, flat: torch.Tensor):
+        flat = self._chk(flat.detach().to(self.device, torch.float32).contiguous(), (SHAPE_DISC_PARAMS,), 'shape disc params')
+        check(self.lib.jrr_engine_set_shape_disc(self.handle, ptr(flat), self._s()), 'set_shape_disc')
+
+    # -- operators --------------------------------------------------------------------------
+    def find_joints_forward(self, betas, x6d=None, R=None, return_verts=False):
+        B = self.batch
+        self._chk(betas, (B, NUM_BETAS), 'betas')
+        if x6d is not None:
+            self._chk(x6d, (B, NUM_JOINTS, 6), 'x6d')
+        if R is not None:
+            self._chk(R, (B, NUM_JOINTS, 3, 3), 'R')
+        joints = torch.empty(B, NUM_H36M, 3, device=self.device)
+        verts = torch.empty(B, NUM_VERTS, 3, device=self.device) if return_verts else None
+        check(self.lib.jrr_find_joints_forward(self.handle, ptr(x6d), ptr(R), ptr(betas), ptr(joints), ptr(verts),
+                                               self._s()), 'find_joints_forward')
+        return (joints, verts) if return_verts else joints
+
+    def find_joints_backward(self, betas, djoints, x6d=None, R=None, want_dJ=False):
+        B = self.batch
+        self._chk(djoints, (B, NUM_H36M, 3), 'djoints')
+        dx = torch.empty(B, NUM_JOINTS, 6, device=self.device) if x6d is not None else None
+        dR = torch.empty(B, NUM_JOINTS, 3, 3, device=self.device) if R is not None else None
+        db = torch.empty(B, NUM_BETAS, device=self.device)
+        dJ = torch.empty(NUM_H36M, NUM_VERTS, device=self.device) if want_dJ else None
+        check(self.lib.jrr_find_joints_backward(self.handle, ptr(x6d), ptr(R), ptr(betas), ptr(djoints), ptr(dx), ptr(dR),
+                                                ptr(db), ptr(dJ), self._s()), 'find_joints_backward')
+        return (dx if x6d is not None else dR), db, dJ
+
+    def pose_disc_forward(self, x6d):
+        self._chk(x6d, (self.batch, NUM_JOINTS, 6), 'x6d')
+        out = torch.empty(self.batch, 25, device=self.device)
+        check(self.lib.jrr_pose_disc_forward(self.handle, ptr(x6d), ptr(out), self._s()), 'pose_disc_forward')
+        return out
+
+    def pose_disc_backward_input(self, x6d, weight: float, target: float):
+        dx = torch.empty(self.batch, NUM_JOINTS, 6, device=self.device)
+        check(self.lib.jrr_pose_disc_backward_input(self.handle, ptr(x6d), float(weight), float(target), ptr(dx),
+                                                    self._s()), 'pose_disc_backward_input')
+        return dx
+
+    def refine_run(self, x6d, betas, gt_centred_mm, adam_m, adam_v, step, lr: float, n_iters: int, sqerr=None):
+        B = self.batch
+        self._chk(x6d, (B, NUM_JOINTS, 6), 'x6d')
+        self._chk(betas, (B, NUM_BETAS), 'betas')
+        self._chk(gt_centred_mm, (B, NUM_H36M, 3), 'gt')
+        self._chk(adam_m, (B, 154), 'adam_m')
+        self._chk(adam_v, (B, 154), 'adam_v')
+        assert step.dtype == torch.int32 and step.is_cuda
+        check(self.lib.jrr_refine_run(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(adam_m), ptr(adam_v),
+                                      ptr(step), float(lr), int(n_iters), ptr(sqerr), self._s()), 'refine_run')
+
+    def j_regressor_grad(self, x6d, betas, gt_centred_mm, sqerr=None):
+        dJ = torch.empty(NUM_H36M, NUM_VERTS, device=self.device)
+        check(self.lib.jrr_j_regressor_grad(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(dJ), ptr(sqerr),
+                                            self._s()), 'j_regressor_grad')
+        return dJ
+
+
+# ---- free operator functions -----------------------------------------------------------------
+def rot6d_forward(x: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x = x.contiguous().view(-1, 6)
+    R = torch.empty(x.shape[0], 3, 3, device=x.device)
+    check(lib.jrr_rot6d_forward(ptr(x), ptr(R), x.shape[0], stream_ptr(x.device)), 'rot6d_forward')
+    return R
+
+
+def rot6d_backward(x: torch.Tensor, dR: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    x = x.contiguous().view(-1, 6)
+    dR = dR.contiguous()
+    dx = torch.empty_like(x)
+    check(lib.jrr_rot6d_backward(ptr(x), ptr(dR), ptr(dx), x.shape[0], stream_ptr(x.device)), 'rot6d_backward')
+    return dx
+
+
+def joint_loss(joints, gt_centred_mm, weight: float, batch_norm: Optional[int] = None, want_grad=True):
+    lib = _lib.load()
+    B = joints.shape[0]
+    sq = torch.empty(B, device=joints.device)
+    dj = torch.empty_like(joints) if want_grad else None
+    check(lib.jrr_joint_loss(ptr(joints.contiguous()), ptr(gt_centred_mm.contiguous()), float(weight), B,
+                             int(batch_norm or B), ptr(sq), ptr(dj), stream_ptr(joints.device)), 'joint_loss')
+    return sq, dj
+
+
+def adam_step(p, g, m, v, step, lr, beta1=0.9, beta2=0.999, eps=1e-8):
+    lib = _lib.load()
+    assert p.is_contiguous() and g.is_contiguous() and m.is_contiguous() and v.is_contiguous()
+    check(lib.jrr_adam_step(ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), ptr(step), float(lr), float(beta1), float(beta2),
+                            float(eps), stream_ptr(p.device)), 'adam_step')

@@ -1,0 +1,257 @@
+"""HIP path vs the CPU oracle, through the C ABI.  Needs a real MI355X: pytest -m gpu.
+
+Tolerances: north_star states regressed 3-D joints within 1e-4 m of the reference on identical
+(theta, beta); the assertions below are tighter (fp32 round-off of the exact-fp32 MFMA path).
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import load_golden, PKG_NAME
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = 'cuda:0'
+
+
+@pytest.fixture(scope='module')
+def eng_mod():
+    return importlib.import_module(PKG_NAME + '.engine')
+
+
+@pytest.fixture(scope='module')
+def dmodel(eng_mod, smpl_model_np):
+    return eng_mod.DeviceModel(smpl_model_np, DEV)
+
+
+def _batch(smpl_model_np, j_h36m_np, B, seed):
+    sm = importlib.import_module(PKG_NAME + '.smpl_model')
+    return sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=seed)
+
+
+def _oracle_joints(smpl_model_np, J, x6d, betas, dtype=torch.float64, return_verts=False):
+    smpl = oracle.OracleSMPL(smpl_model_np, dtype=dtype)
+    R = oracle.rot6d_to_rotmat(x6d.to(dtype).reshape(-1, 6)).view(-1, 24, 3, 3)
+    return oracle.find_joints(smpl, betas.to(dtype), R[:, :1], R[:, 1:], J.to(dtype), mask=oracle.find_j_reg_mask(J.to(dtype)),
+                              return_verts=return_verts)
+
+
+def test_rot6d_forward_backward(eng_mod):
+    g = load_golden('g1_rot6d.npz')
+    x = T(g['x']).to(DEV)
+    R = eng_mod.rot6d_forward(x)
+    np.testing.assert_allclose(R.cpu().numpy(), g['R'], rtol=0, atol=2e-6)
+    xr = T(g['x'][:256]).clone().requires_grad_(True)
+    gen = torch.Generator().manual_seed(0)
+    dR = torch.randn(256, 3, 3, generator=gen)
+    (oracle.rot6d_to_rotmat(xr) * dR).sum().backward()
+    dx = eng_mod.rot6d_backward(x[:256].contiguous(), dR.to(DEV))
+    np.testing.assert_allclose(dx.cpu().numpy(), xr.grad.numpy(), rtol=2e-4, atol=2e-5)
+
+
+@pytest.mark.parametrize('B', [4, 37, 130])
+def test_find_joints_forward_and_verts(eng_mod, dmodel, smpl_model_np, j_h36m_np, B):
+    batch = _batch(smpl_model_np, j_h36m_np, B, seed=11)
+    x6d, betas = T(batch['pose6d']), T(batch['betas'])
+    eng = eng_mod.RefineEngine(dmodel, B)
+    eng.set_j_regressor(T(j_h36m_np))
+    joints, verts = eng.find_joints_forward(betas.to(DEV), x6d=x6d.to(DEV), return_verts=True)
+    ref_j, ref_v = _oracle_joints(smpl_model_np, T(j_h36m_np), x6d, betas, return_verts=True)
+    assert (verts.cpu().double() - ref_v).abs().max().item() < 2e-5
+    assert (joints.cpu().double() - ref_j).abs().max().item() < 2e-5      # north_star bar: 1e-4 m
+    # the same through rotation matrices (the reference's own calling convention, utils.py:94-95)
+    R = oracle.rot6d_to_rotmat(x6d.reshape(-1, 6)).view(B, 24, 3, 3).contiguous()
+    joints_r = eng.find_joints_forward(betas.to(DEV), R=R.to(DEV))
+    assert (joints_r.cpu().double() - ref_j).abs().max().item() < 2e-5
+
+
+def test_find_joints_with_mask_and_dense_J(eng_mod, dmodel, smpl_model_np):
+    B = 8
+    gen = torch.Generator().manual_seed(5)
+    J = torch.randn(17, 6890, generator=gen) * 0.1        # dense, half negative
+    sm = importlib.import_module(PKG_NAME + '.smpl_model')
+    batch = sm.synthetic_batch(smpl_model_np, np.abs(J.numpy()), B, seed=2)
+    x6d, betas = T(batch['pose6d']), T(batch['betas'])
+    mask = (torch.rand(17, 6890, generator=gen) > 0.3).float()
+    eng = eng_mod.RefineEngine(dmodel, B)
+    eng.set_j_regressor(J, mask)
+    joints = eng.find_joints_forward(betas.to(DEV), x6d=x6d.to(DEV))
+    smpl = oracle.OracleSMPL(smpl_model_np, dtype=torch.float64)
+    R = oracle.rot6d_to_rotmat(x6d.double().reshape(-1, 6)).view(-1, 24, 3, 3)
+    ref = oracle.find_joints(smpl, betas.double(), R[:, :1], R[:, 1:], J.double(), mask=mask.double())
+    assert (joints.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+@pytest.mark.parametrize('B,use_R', [(4, False), (37, False), (37, True)])
+def test_find_joints_backward(eng_mod, dmodel, smpl_model_np, j_h36m_np, B, use_R):
+    batch = _batch(smpl_model_np, j_h36m_np, B, seed=12)
+    x6d, betas = T(batch['pose6d']).double(), T(batch['betas']).double()
+    gen = torch.Generator().manual_seed(3)
+    dj = torch.randn(B, 17, 3, generator=gen, dtype=torch.float64)
+    J = T(j_h36m_np).double().requires_grad_(True)
+    smpl = oracle.OracleSMPL(smpl_model_np, dtype=torch.float64)
+    b_r = betas.clone().requires_grad_(True)
+    if use_R:
+        R = oracle.rot6d_to_rotmat(x6d.reshape(-1, 6)).view(B, 24, 3, 3).clone().requires_grad_(True)
+        leaf = R
+    else:
+        leaf = x6d.clone().requires_grad_(True)
+        R = oracle.rot6d_to_rotmat(leaf.reshape(-1, 6)).view(B, 24, 3, 3)
+    joints = oracle.find_joints(smpl, b_r, R[:, :1], R[:, 1:], J, mask=oracle.find_j_reg_mask(J.detach()))
+    (joints * dj).sum().backward()
+
+    eng = eng_mod.RefineEngine(dmodel, B, flags=eng_mod.FLAG_KEEP_VERTS)
+    eng.set_j_regressor(T(j_h36m_np))
+    kw = dict(R=leaf.detach().float().contiguous().to(DEV)) if use_R else dict(x6d=leaf.detach().float().contiguous().to(DEV))
+    bd = betas.float().to(DEV)
+    eng.find_joints_forward(bd, **kw)
+    dpose, db, dJ = eng.find_joints_backward(bd, dj.float().to(DEV), want_dJ=True, **kw)
+
+    def relerr(a, b):
+        return ((a.cpu().double() - b).abs().max() / b.abs().max()).item()
+    assert relerr(dpose, leaf.grad) < 2e-4
+    assert relerr(db, b_r.grad) < 2e-4
+    assert relerr(dJ, J.grad) < 2e-4
+    assert (dJ.cpu()[T(j_h36m_np) <= 0] == 0).all()        # ReLU'(x<=0) = 0: zeros stay zero (G8)
+
+
+def test_joint_loss_and_adam(eng_mod):
+    g3 = load_golden('g3_pelvis_loss.npz')
+    j, gt_c = T(g3['j']).to(DEV), T(g3['gt_moved']).to(DEV)
+    sq, dj = eng_mod.joint_loss(j, gt_c, 10000.0)
+    np.testing.assert_allclose(float(sq.sum()) / (4 * 51) * 10000.0, float(g3['joint_loss_w']), rtol=1e-5)
+    jr = T(g3['j']).clone().requires_grad_(True)
+    (((oracle.move_pelvis(jr) - T(g3['gt_moved']) / 1000) ** 2).mean() * 10000.0).backward()
+    np.testing.assert_allclose(dj.cpu().numpy(), jr.grad.numpy(), rtol=1e-4, atol=1e-6)
+    g5 = load_golden('g5_adam.npz')
+    p = T(g5['traj'][0]).clone().to(DEV)
+    m, v = torch.zeros_like(p), torch.zeros_like(p)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    for s in range(3):
+        step += 1
+        eng_mod.adam_step(p, T(g5['grads'][s]).to(DEV).contiguous(), m, v, step, 1e-2)
+        np.testing.assert_allclose(p.cpu().numpy(), g5['traj'][s + 1], rtol=0, atol=5e-7)
+
+
+def test_pose_discriminator(eng_mod, dmodel):
+    g = load_golden('g4_disc.npz')
+    sd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+    flat = eng_mod.flatten_state_dict(sd, eng_mod.DISC_KEYS)
+    eng = eng_mod.RefineEngine(dmodel, 4, flags=eng_mod.FLAG_POSE_DISC)
+    eng.set_pose_disc(flat)
+    x = T(g['x']).to(DEV)
+    out = eng.pose_disc_forward(x)
+    np.testing.assert_allclose(out.cpu().numpy(), g['out'][:, :, 0], rtol=0, atol=3e-6)
+    # golden gx is d mean((D-1)^2)/dx : weight 1
+    dx = eng.pose_disc_backward_input(x, 1.0, 1.0)
+    np.testing.assert_allclose(dx.cpu().numpy(), g['gx'], rtol=2e-4, atol=1e-8)
+    # larger ragged batch vs the oracle
+    B = 100
+    gen = torch.Generator().manual_seed(8)
+    xb = torch.randn(B, 24, 6, generator=gen) * 0.7
+    eng2 = eng_mod.RefineEngine(dmodel, B, flags=eng_mod.FLAG_POSE_DISC)
+    eng2.set_pose_disc(flat)
+    out2 = eng2.pose_disc_forward(xb.to(DEV))
+    xr = xb.clone().requires_grad_(True)
+    ref = oracle.discriminator_forward(sd, xr)
+    np.testing.assert_allclose(out2.cpu().numpy(), ref.detach().numpy()[:, :, 0], rtol=0, atol=3e-6)
+    (((ref - 1) ** 2).mean() * 10.0).backward()
+    dx2 = eng2.pose_disc_backward_input(xb.to(DEV), 10.0, 1.0)
+    np.testing.assert_allclose(dx2.cpu().numpy(), xr.grad.numpy(), rtol=5e-4, atol=1e-8)
+
+
+def _run_refine(eng_mod, dmodel, smpl_model_np, j_h36m_np, B, seed, n_iters, pose_d, shape_d):
+    batch = _batch(smpl_model_np, j_h36m_np, B, seed)
+    x6d, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    flags = (eng_mod.FLAG_POSE_DISC if pose_d else 0) | (eng_mod.FLAG_SHAPE_DISC if shape_d else 0)
+    eng = eng_mod.RefineEngine(dmodel, B, flags=flags)
+    eng.set_j_regressor(T(j_h36m_np))
+    dsd = ssd = None
+    if pose_d:
+        dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+        eng.set_pose_disc(eng_mod.flatten_state_dict(dsd, eng_mod.DISC_KEYS))
+    if shape_d:
+        ssd = oracle.formula_state_dict(oracle.SHAPE_DISC_PARAM_SHAPES, seed=1)
+        eng.set_shape_disc(eng_mod.flatten_state_dict(ssd, eng_mod.SHAPE_DISC_KEYS))
+    xd, bd = x6d.clone().to(DEV), betas.clone().to(DEV)
+    m = torch.zeros(B, 154, device=DEV)
+    v = torch.zeros(B, 154, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    sq = torch.zeros(B, device=DEV)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, n_iters, sqerr=sq)
+    torch.cuda.synchronize()
+    assert int(step.item()) == n_iters
+    return dict(x6d=x6d, betas=betas, gt_c=gt_c, xd=xd.cpu(), bd=bd.cpu(), sq=sq.cpu(), dsd=dsd, ssd=ssd)
+
+
+def test_refine_run_matches_golden_inner_loop(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    """10 inner iterations at B=4 against g7 (reference find_joints + Discriminator + torch Adam)."""
+    g = load_golden('g7_inner_loop.npz')
+    r = _run_refine(eng_mod, dmodel, smpl_model_np, j_h36m_np, 4, 3, 10, True, True)
+    # Adam normalises the step, so parameter trajectories agree to ~lr * relative-gradient-error
+    np.testing.assert_allclose(r['xd'][:, 1:].numpy(), g['pose'], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(r['xd'][:, :1].numpy(), g['orient'], rtol=0, atol=3e-4)
+    np.testing.assert_allclose(r['bd'].numpy(), g['betas'], rtol=0, atol=3e-4)
+    # joint loss of the last forward (iteration 9) vs the golden history
+    np.testing.assert_allclose(float(r['sq'].sum()) / (4 * 51), g['hist'][9, 1], rtol=2e-3)
+
+
+@pytest.mark.parametrize('B,pose_d', [(64, False), (200, True)])
+def test_refine_run_matches_oracle(eng_mod, dmodel, smpl_model_np, j_h36m_np, B, pose_d):
+    n = 5
+    r = _run_refine(eng_mod, dmodel, smpl_model_np, j_h36m_np, B, 21, n, pose_d, False)
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    o, p, b, hist = oracle.refine_poses(smpl, T(j_h36m_np), r['x6d'][:, :1], r['x6d'][:, 1:], r['betas'], r['gt_c'], n,
+                                        disc_sd=r['dsd'])
+    ref = torch.cat([o, p], dim=1)
+    assert (r['xd'] - ref).abs().max().item() < 3e-4
+    assert (r['bd'] - b).abs().max().item() < 3e-4
+    np.testing.assert_allclose(float(r['sq'].sum()) / (B * 51), hist[-1]['joint_loss'], rtol=2e-3)
+    # regressed joints of the refined poses: within the north_star bar of the oracle's
+    eng = eng_mod.RefineEngine(dmodel, B)
+    eng.set_j_regressor(T(j_h36m_np))
+    joints = eng.find_joints_forward(r['bd'].to(DEV), x6d=r['xd'].to(DEV).contiguous())
+    ref_j = _oracle_joints(smpl_model_np, T(j_h36m_np), ref, b)
+    assert (joints.cpu().double() - ref_j).abs().max().item() < 1e-4
+
+
+def test_j_regressor_grad(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    B = 50
+    batch = _batch(smpl_model_np, j_h36m_np, B, seed=31)
+    x6d, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    eng = eng_mod.RefineEngine(dmodel, B, flags=eng_mod.FLAG_KEEP_VERTS)
+    eng.set_j_regressor(T(j_h36m_np))
+    dJ = eng.j_regressor_grad(x6d.to(DEV), betas.to(DEV), gt_c.to(DEV).contiguous())
+    smpl = oracle.OracleSMPL(smpl_model_np, dtype=torch.float64)
+    loss, gJ, _ = oracle.j_regressor_loss_and_grad(smpl, T(j_h36m_np).double(), x6d[:, :1].double(), x6d[:, 1:].double(),
+                                                   betas.double(), gt_c.double())
+    assert ((dJ.cpu().double() - gJ).abs().max() / gJ.abs().max()).item() < 2e-4
+    nz = torch.nonzero(dJ.cpu(), as_tuple=False)
+    assert len(nz) == int((T(j_h36m_np) > 0).sum()) == 62        # only the positive support moves (G8)
+
+
+def test_full_size_properties(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    """BASELINE batch (4096): size-independent properties instead of a CPU oracle run.
+    K1: identity rotations + beta=0 -> joints == Jn @ v_template for every pose.
+    K2: a global rotation about the root rotates pelvis-centred joints rigidly."""
+    B = 4096
+    eng = eng_mod.RefineEngine(dmodel, B)
+    eng.set_j_regressor(T(j_h36m_np))
+    ident6 = torch.tensor([1., 0., 0., 1., 0., 0.]).repeat(B, 24, 1)
+    joints = eng.find_joints_forward(torch.zeros(B, 10, device=DEV), x6d=ident6.to(DEV).contiguous())
+    Jn = oracle.normalize_j_regressor(T(j_h36m_np).double())
+    expect = Jn @ T(smpl_model_np['v_template']).double()
+    assert (joints.cpu().double() - expect[None]).abs().max().item() < 5e-6
+    gen = torch.Generator().manual_seed(1)
+    x6 = ident6.clone()
+    R0 = oracle.rodrigues(torch.randn(B, 3, generator=gen))
+    x6[:, 0] = R0[:, :, :2].reshape(B, 6)
+    j2 = eng.find_joints_forward(torch.zeros(B, 10, device=DEV), x6d=x6.to(DEV).contiguous()).cpu().double()
+    j0 = (T(smpl_model_np['J_regressor']).double() @ T(smpl_model_np['v_template']).double())[0]
+    rigid = torch.einsum('brc,ic->bir', R0.double(), expect - j0) + j0
+    assert (j2 - rigid).abs().max().item() < 2e-5
