@@ -1,0 +1,229 @@
+#!/usr/bin/env python3
+"""Headline benchmark: pose-refinement inner-loop iterations/sec at batch 4096 per MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One step = one inner iteration of /root/reference/scripts/optimize.py:220-265 restricted to
+BASELINE.json configs[2] ("batch=4096 full loop: 3D-joint loss + pose-discriminator adversarial
+term"): rot6d->R, SMPL LBS over 6890 vertices, H36M joint regression, pelvis-centred MSE (x10000),
+pose-discriminator forward + adversarial MSE (x10), analytic backward to (pose, orient, betas),
+fused Adam -- all through the C ABI (include/jrr.h) on device-resident synthetic data.
+
+N > 1 is weak scaling: every rank owns 4096 poses (global batch 4096*N), the MSE means are
+normalised by the GLOBAL batch, and the shared J_regressor is stepped every --j_step_every inner
+iterations (reference cadence 100, scripts/optimize.py:300-312) with ONE RCCL all-reduce on its
+gradient.  After the timed region the J step is also timed at cadence 1 (BASELINE configs[3]
+"all-reduce each step") and reported under "j_step".  `value` = batch-4096 iterations per second
+summed over ranks.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+PKG = 'joint-regressor-refinement_amd'
+
+# dense algorithmic FLOP per pose of ONE launch of the dominant kernel
+# (k_lbs_fwd = shape blend + pose blend + skinning blend (12 affine entries) + skinning apply +
+# H36M regressor product).  The rest-joint regression (992 160 FLOP in the survey's table) is
+# folded into a (24x3)x10 table at model upload and is NOT counted.
+FLOP_LBS_FWD_PER_POSE = 2 * 20670 * 10 + 2 * 207 * 20670 + 2 * 6890 * 24 * 12 + 2 * 6890 * 3 * 4 + 2 * 17 * 6890 * 3
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=4096, help='poses per GPU (BASELINE metric: 4096)')
+    ap.add_argument('--config', type=int, default=3, choices=[2, 3],
+                    help='BASELINE config: 2 = joint loss only, 3 = + pose discriminator (headline)')
+    ap.add_argument('--j_step_every', type=int, default=100, help='inner iterations per J_regressor step')
+    ap.add_argument('--no_cpu_baseline', action='store_true')
+    ap.add_argument('--cpu_batch', type=int, default=0, help='cpu_baseline sample batch (default: = --batch)')
+    ap.add_argument('--cpu_iters', type=int, default=2)
+    return ap.parse_args()
+
+
+def default_disc_flat(seed=0):
+    """Pose-discriminator weights: torch default init under a fixed seed."""
+    disc = importlib.import_module(PKG + '.discriminator')
+    torch.manual_seed(seed)
+    d = disc.Discriminator()
+    return d.flat_parameters(), d.state_dict()
+
+
+def cpu_baseline(model_np, J_np, batch_np, disc_sd, B, iters, use_disc):
+    """The oracle (oracle/reference_port.py: torch-CPU restatement in the reference's op order,
+    autograd backward, torch.optim.Adam) timed on this box's host cores on the SAME workload."""
+    import oracle
+    T = torch.from_numpy
+    smpl = oracle.OracleSMPL(model_np)
+    x6 = T(batch_np['pose6d'][:B])
+    betas = T(batch_np['betas'][:B])
+    gt_c = oracle.move_pelvis(T(batch_np['gt_j3d'][:B]))
+    sd = {k: v.clone() for k, v in disc_sd.items()} if use_disc else None
+    # warm-up (1 iteration) then timed
+    oracle.refine_poses(smpl, T(J_np), x6[:, :1], x6[:, 1:], betas, gt_c, 1, disc_sd=sd)
+    t0 = time.perf_counter()
+    oracle.refine_poses(smpl, T(J_np), x6[:, :1], x6[:, 1:], betas, gt_c, iters, disc_sd=sd)
+    dt = time.perf_counter() - t0
+    return iters / dt, dt
+
+
+def main():
+    a = parse()
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=dev)
+
+    sm = importlib.import_module(PKG + '.smpl_model')
+    eng_mod = importlib.import_module(PKG + '.engine')
+    B = a.batch
+    use_disc = a.config == 3
+    model_np = sm.synthetic_smpl(1234)
+    J_np = sm.default_h36m_regressor()
+    batch_np = sm.synthetic_batch(model_np, J_np, B, seed=1000 + rank)
+    dmodel = eng_mod.DeviceModel(model_np, dev)
+    flags = eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0)
+    eng = eng_mod.RefineEngine(dmodel, B, batch_norm=B * world, flags=flags)
+    J = torch.from_numpy(J_np).to(dev)
+    eng.set_j_regressor(J)
+    disc_flat, disc_sd = default_disc_flat(0)
+    if use_disc:
+        eng.set_pose_disc(disc_flat.to(dev))
+
+    x6d = torch.from_numpy(batch_np['pose6d']).to(dev).contiguous()
+    betas = torch.from_numpy(batch_np['betas']).to(dev).contiguous()
+    gt = torch.from_numpy(batch_np['gt_j3d'])
+    gt_c = (gt - gt[:, :1]).to(dev).contiguous()
+    m = torch.zeros(B, 154, device=dev)
+    v = torch.zeros(B, 154, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    sq = torch.zeros(B, device=dev)
+    Jm, Jv = torch.zeros_like(J), torch.zeros_like(J)
+    Jstep = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def j_step():
+        """scripts/optimize.py:300-312 data-parallel: local dJ (normalised by the global batch),
+        one RCCL all-reduce, replicated Adam(lr=args.j_reg_lr=1e-2), re-normalise."""
+        dJ = eng.j_regressor_grad(x6d, betas, gt_c)
+        if dist is not None:
+            dist.all_reduce(dJ)
+        Jstep.add_(1)
+        eng_mod.adam_step(J, dJ, Jm, Jv, Jstep, 1e-2)
+        eng.set_j_regressor(J)
+
+    done = [0]
+
+    def run(n):
+        """n inner iterations with the J step at its cadence"""
+        left = n
+        while left > 0:
+            seg = min(left, a.j_step_every - done[0] % a.j_step_every)
+            eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, seg, sqerr=sq)
+            done[0] += seg
+            left -= seg
+            if done[0] % a.j_step_every == 0:
+                j_step()
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    run(a.warmup)
+    barrier(); torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(a.steps)
+    torch.cuda.synchronize(); barrier()
+    elapsed = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    loss_joint = float(sq.sum().item()) / (B * 51)
+
+    # ---- per-kernel timing (HIP events on the launch stream) over the same number of steps ----
+    eng.set_profiling(True)
+    eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, max(2, min(a.steps, 20)), sqerr=sq)
+    prof = eng.profile_read()
+    eng.set_profiling(False)
+
+    # ---- J step at cadence 1 (BASELINE configs[3]): timed separately, never part of `value` ----
+    torch.cuda.synchronize(); barrier()
+    tj = time.perf_counter()
+    nj = 5
+    for _ in range(nj):
+        j_step()
+    torch.cuda.synchronize(); barrier()
+    j_ms = (time.perf_counter() - tj) / nj * 1e3
+
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = elapsed / a.steps * 1e3
+    it_s = a.steps / elapsed
+    dom_ms, dom_n = prof['k_lbs_fwd']
+    achieved = FLOP_LBS_FWD_PER_POSE * B / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    traffic = None
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get('k_lbs_fwd_hbm_bytes_per_launch')
+        except Exception:
+            traffic = None
+    out = {
+        'metric': 'pose-refinement iters/sec, batch 4096 per GPU',
+        'value': round(it_s * world, 3), 'unit': 'it/s (x4096 poses)', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'BASELINE configs[{a.config - 1}]: batch={B}/GPU inner loop, 3D-joint loss'
+                               + (' + pose-discriminator adversarial term' if use_disc else ''),
+                   'global_batch': B * world, 'poses_per_sec': round(it_s * world * B, 1),
+                   'j_step_every': a.j_step_every, 'parallelism': f'dp{world}', 'joint_loss_last': loss_joint,
+                   'geometry': eng.info},
+        'roofline': {'bound': 'mfma', 'kernel': 'k_lbs_fwd<true,false>', 'achieved': round(achieved, 2),
+                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                     'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'launches_timed': dom_n,
+                     'algorithmic_flop_per_launch': FLOP_LBS_FWD_PER_POSE * B},
+        'kernels_ms': {k: round(t, 4) for k, (t, n) in prof.items() if n},
+        'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
+                   'allreduce_bytes': 17 * 6890 * 4},
+    }
+    if not a.no_cpu_baseline:
+        cb = a.cpu_batch or B
+        torch.set_num_threads(os.cpu_count() or 1)
+        its, dt = cpu_baseline(model_np, J_np, batch_np, disc_sd, cb, a.cpu_iters, use_disc)
+        out['cpu_baseline'] = {'value': round(its * cb / B, 5), 'unit': 'it/s (x4096 poses)', 'cores': torch.get_num_threads(),
+                               'kind': 'port',
+                               'sample': f'{a.cpu_iters} inner iterations at batch {cb} of the same workload '
+                                         f'(oracle/reference_port.py: torch-CPU ops in the reference order, autograd, '
+                                         f'torch.optim.Adam; 1 SMPL eval/iter), {dt:.1f} s'}
+    print(json.dumps(out))
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

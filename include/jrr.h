@@ -148,8 +148,19 @@ int jrr_refine_run(jrr_engine_t* e, float* x6d_dev, float* betas_dev, const floa
 int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev,
                          const float* gt_centred_mm_dev, float* dJ_dev, float* sqerr_dev, void* stream);
 
-/* name of the dominant kernels (for profile matching) and launch geometry of the last run */
+/* launch geometry: {B, BP, batch_norm, nvc, nvcb, nsplit, nsplitJ, flags} */
 int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n);
+
+/* Per-kernel timing of jrr_refine_run with HIP events recorded on the launch stream.
+ * While enabled, every launch group of every iteration is bracketed by an event pair.
+ * jrr_engine_profile_read synchronises on the recorded events and writes the MEAN duration in
+ * milliseconds per launch of each class into ms_host[JRR_PROF_CLASSES] and the number of samples
+ * into counts_host, then clears the recorded events.  Classes:
+ *   0 k_prep_fwd  1 k_lbs_fwd  2 k_joints_loss  3 k_lbs_bwd  4 k_gemm_tn (blend adjoint)
+ *   5 pose discriminator (7 launches)  6 k_shape_disc  7 k_prep_bwd (+Adam)                  */
+enum { JRR_PROF_CLASSES = 8 };
+int jrr_engine_set_profiling(jrr_engine_t* e, int enabled);
+int jrr_engine_profile_read(jrr_engine_t* e, float* ms_host, int32_t* counts_host);
 
 #ifdef __cplusplus
 }

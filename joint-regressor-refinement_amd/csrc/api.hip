@@ -117,6 +117,8 @@ struct jrr_engine {
   float *verts, *djpad, *dJnp, *dJn, *dj;
   bool verts_zeroed;
   int32_t* step_scratch;
+  bool profiling;
+  std::vector<hipEvent_t>* ev[JRR_PROF_CLASSES];
 };
 
 static void plan_geometry(int BP, int& nvc, int& nvcb, int& nsplit, int& nsplitJ) {
@@ -219,7 +221,59 @@ extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_
   return JRR_OK;
 }
 
-extern "C" void jrr_engine_destroy(jrr_engine_t* e) { delete e; }
+static void clear_events(jrr_engine* e) {
+  for (int c = 0; c < JRR_PROF_CLASSES; ++c) {
+    if (!e->ev[c]) continue;
+    for (hipEvent_t ev : *e->ev[c]) (void)hipEventDestroy(ev);
+    e->ev[c]->clear();
+  }
+}
+
+extern "C" void jrr_engine_destroy(jrr_engine_t* e) {
+  if (!e) return;
+  clear_events(e);
+  for (int c = 0; c < JRR_PROF_CLASSES; ++c) delete e->ev[c];
+  delete e;
+}
+
+extern "C" int jrr_engine_set_profiling(jrr_engine_t* e, int enabled) {
+  if (!e) return JRR_ERR_ARG;
+  e->profiling = enabled != 0;
+  for (int c = 0; c < JRR_PROF_CLASSES; ++c)
+    if (!e->ev[c]) e->ev[c] = new std::vector<hipEvent_t>();
+  if (!e->profiling) clear_events(e);
+  return JRR_OK;
+}
+
+extern "C" int jrr_engine_profile_read(jrr_engine_t* e, float* ms_host, int32_t* counts_host) {
+  if (!e || !ms_host) return JRR_ERR_ARG;
+  for (int c = 0; c < JRR_PROF_CLASSES; ++c) {
+    double tot = 0;
+    int n = 0;
+    if (e->ev[c]) {
+      for (size_t i = 0; i + 1 < e->ev[c]->size(); i += 2) {
+        float ms = 0.f;
+        JRR_HIP(hipEventSynchronize((*e->ev[c])[i + 1]));
+        JRR_HIP(hipEventElapsedTime(&ms, (*e->ev[c])[i], (*e->ev[c])[i + 1]));
+        tot += ms;
+        ++n;
+      }
+    }
+    ms_host[c] = n ? (float)(tot / n) : 0.f;
+    if (counts_host) counts_host[c] = n;
+  }
+  clear_events(e);
+  return JRR_OK;
+}
+
+// RAII-less bracket helper: records an event on the stream if profiling is on
+static inline void prof_mark(jrr_engine* e, int cls, hipStream_t s) {
+  if (!e->profiling) return;
+  hipEvent_t ev;
+  if (hipEventCreate(&ev) != hipSuccess) return;
+  (void)hipEventRecord(ev, s);
+  e->ev[cls]->push_back(ev);
+}
 
 extern "C" int jrr_engine_set_batch_norm(jrr_engine_t* e, int bn) {
   if (!e || bn <= 0) return JRR_ERR_ARG;
@@ -449,18 +503,36 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
   const float dscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 25.0));      // optimize.py:253 weight 10
   const float sscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 1.0));
   for (int it = 0; it < n_iters; ++it) {
-    smpl_forward(e, x6d, nullptr, betas, true, nullptr, 0, step, s);
+    prof_mark(e, 0, s);
+    launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->AT, e->B, e->BP, step, s);
+    prof_mark(e, 0, s);
+    prof_mark(e, 1, s);
+    launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, nullptr, 0, e->B, e->BP, e->nvc, s);
+    prof_mark(e, 1, s);
+    prof_mark(e, 2, s);
     launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, jscale, e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);
+    prof_mark(e, 2, s);
+    prof_mark(e, 3, s);
     launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
+    prof_mark(e, 3, s);
+    prof_mark(e, 4, s);
     int rc = blend_adjoint_gemm(e, s);
+    prof_mark(e, 4, s);
     if (rc) return rc;
     if (pd) {
+      prof_mark(e, 5, s);
       rc = disc_forward(e, x6d, nullptr, s);
       if (rc) return rc;
       rc = disc_backward_input(e, x6d, nullptr, dscale, 1.f, e->gx, s);
+      prof_mark(e, 5, s);
       if (rc) return rc;
     }
-    if (sd) launch_shape_disc(e->Ps, betas, nullptr, e->gb, sscale, 1.f, e->B, s);
+    if (sd) {
+      prof_mark(e, 6, s);
+      launch_shape_disc(e->Ps, betas, nullptr, e->gb, sscale, 1.f, e->B, s);
+      prof_mark(e, 6, s);
+    }
+    prof_mark(e, 7, s);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.betas_in = betas;
     L.dATp = e->dATp; L.nvc = e->nvcb; L.dFTp = e->dFTp; L.nsplit = e->nsplit;
@@ -468,6 +540,7 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step;
     L.lr = lr; L.B = e->B; L.BP = e->BP;
     launch_prep_bwd(L, e->m, s);
+    prof_mark(e, 7, s);
   }
   CHECK_LAUNCH();
   return JRR_OK;

@@ -182,6 +182,19 @@ class RefineEngine:
         check(self.lib.jrr_refine_run(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(adam_m), ptr(adam_v),
                                       ptr(step), float(lr), int(n_iters), ptr(sqerr), self._s()), 'refine_run')
 
+    PROF_CLASSES = ['k_prep_fwd', 'k_lbs_fwd', 'k_joints_loss', 'k_lbs_bwd', 'k_gemm_tn_blend_adjoint', 'pose_disc_7_launches',
+                    'k_shape_disc', 'k_prep_bwd']
+
+    def set_profiling(self, on: bool):
+        check(self.lib.jrr_engine_set_profiling(self.handle, int(bool(on))), 'set_profiling')
+
+    def profile_read(self):
+        """mean ms per launch (HIP events on the launch stream) and sample counts per kernel class"""
+        ms = (ctypes.c_float * 8)()
+        n = (c_int32 * 8)()
+        check(self.lib.jrr_engine_profile_read(self.handle, ms, n), 'profile_read')
+        return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.PROF_CLASSES)}
+
     def j_regressor_grad(self, x6d, betas, gt_centred_mm, sqerr=None):
         dJ = torch.empty(NUM_H36M, NUM_VERTS, device=self.device)
         check(self.lib.jrr_j_regressor_grad(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(dJ), ptr(sqerr),

@@ -111,6 +111,15 @@ def j_regressor_from_triplets(rows, cols, vals) -> np.ndarray:
     return J
 
 
+def default_h36m_regressor(path: Optional[str] = None) -> np.ndarray:
+    """H36M regressor initialisation (scripts/optimize.py:105-107): `SPIN/data/J_regressor_h36m.npy`
+    if the user supplies it, else the 107 non-zeros of the shipped checkpoint (assets/)."""
+    if path and os.path.exists(path):
+        return np.load(path).astype(np.float32)
+    t = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', 'j_regressor_h36m_init.npz'))
+    return j_regressor_from_triplets(t['rows'], t['cols'], t['vals'])
+
+
 def synthetic_h36m_regressor(model: Dict[str, np.ndarray], seed: int = 7, support: int = 6,
                              with_negatives: bool = True) -> np.ndarray:
     """Seeded sparse (17,6890) regressor with the shipped checkpoint's structure: a few positive
