@@ -51,7 +51,7 @@ def parse():
                     help='BASELINE config: 2 = joint loss only, 3 = + pose discriminator (headline)')
     ap.add_argument('--j_step_every', type=int, default=100, help='inner iterations per J_regressor step')
     ap.add_argument('--no_cpu_baseline', action='store_true')
-    ap.add_argument('--cpu_batch', type=int, default=0, help='cpu_baseline sample batch (default: = --batch)')
+    ap.add_argument('--cpu_batch', type=int, default=512, help='cpu_baseline sample batch (scaled to batch-4096 units)')
     ap.add_argument('--cpu_iters', type=int, default=2)
     return ap.parse_args()
 

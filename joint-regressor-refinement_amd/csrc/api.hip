@@ -111,7 +111,7 @@ struct jrr_engine {
   bool have_J, have_mask, have_pd, have_sd;
   // workspace sections
   float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv;
-  float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr;
+  float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF;
   float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx;
   float *Ps, *gb;
   float *verts, *djpad, *dJnp, *dJn, *dj;
@@ -158,7 +158,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   t->Jmask = c.take((size_t)NH * V);
   t->Jn = c.take((size_t)NH * V);
   t->Jn_vi = c.take((size_t)VT * 1024);
-  t->Jn_iv = c.take((size_t)VT * NHP * 32);
+  t->Jn_iv = c.take((size_t)VT * 2560);   // backward per-tile operand records [Jn | W^T | W | pad]
   t->FT = c.take((size_t)KFP * BP);
   t->AT = c.take((size_t)12 * NJ * BP);
   t->VPb = c.take((size_t)3 * VP * BP);
@@ -167,6 +167,9 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   t->DVP = c.take((size_t)3 * VP * BP);
   t->dATp = c.take((size_t)nvcb * 12 * NJ * BP);
   t->dFTp = c.take((size_t)nsplit * KFP * BP);
+  t->Jsum = c.take((size_t)3 * NH * BP);
+  t->dA = c.take((size_t)12 * NJ * BP);
+  t->dF = c.take((size_t)KFP * BP);
   t->joints = c.take((size_t)BP * NH * 3);
   t->sqerr = c.take((size_t)BP);
   t->step_scratch = (int32_t*)c.take(64);
@@ -294,6 +297,7 @@ extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const
   JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   e->have_mask = mask != nullptr;
+  launch_bwd_tab_static(e->m, e->Jn_iv, s);
   launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, s);
   CHECK_LAUNCH();
   e->have_J = true;
@@ -338,6 +342,15 @@ extern "C" int jrr_rot6d_backward(const float* x, const float* dR, float* dx, in
   return JRR_OK;
 }
 
+// sum the per-vertex-chunk joint partials (wide, memory-bound) so the per-pose kernel reads 51 values
+static void reduce_joint_partials(jrr_engine* e, hipStream_t s) {
+  launch_reduce_slabs(e->JP, e->nvc, (size_t)3 * NH * e->BP, e->Jsum, (size_t)3 * NH * e->BP, s);
+}
+static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s) {
+  launch_reduce_slabs(e->dATp, e->nvcb, (size_t)12 * NJ * e->BP, e->dA, (size_t)12 * NJ * e->BP, s);
+  launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
+}
+
 static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,
                         float* verts, int ldv, int32_t* step_inc, hipStream_t s) {
   launch_prep_fwd(e->m, x6d, R, betas, e->FT, e->AT, e->B, e->BP, step_inc, s);
@@ -369,7 +382,8 @@ extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const 
   } else {
     smpl_forward(e, x6d, R, betas, true, verts, V * 3, nullptr, s);
   }
-  launch_joints_loss(e->JP, e->nvc, nullptr, nullptr, 0.f, joints, nullptr, nullptr, e->B, e->BP, s);
+  reduce_joint_partials(e, s);
+  launch_joints_loss(e->Jsum, 1, nullptr, nullptr, 0.f, joints, nullptr, nullptr, e->B, e->BP, s);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -398,9 +412,10 @@ extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const
     launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
     int rc = blend_adjoint_gemm(e, s);
     if (rc) return rc;
+    reduce_adjoint_partials(e, s);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.R_in = R; L.betas_in = betas;
-    L.dATp = e->dATp; L.nvc = e->nvcb; L.dFTp = e->dFTp; L.nsplit = e->nsplit;
+    L.dATp = e->dA; L.nvc = 1; L.dFTp = e->dF; L.nsplit = 1;
     L.dx6d = dx6d; L.dR = dR; L.dbetas = dbetas;
     L.B = e->B; L.BP = e->BP;
     launch_prep_bwd(L, e->m, s);
@@ -510,7 +525,8 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, nullptr, 0, e->B, e->BP, e->nvc, s);
     prof_mark(e, 1, s);
     prof_mark(e, 2, s);
-    launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, jscale, e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);
+    reduce_joint_partials(e, s);
+    launch_joints_loss(e->Jsum, 1, gt_mm, nullptr, jscale, e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);
     prof_mark(e, 2, s);
     prof_mark(e, 3, s);
     launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
@@ -533,9 +549,10 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
       prof_mark(e, 6, s);
     }
     prof_mark(e, 7, s);
+    reduce_adjoint_partials(e, s);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.betas_in = betas;
-    L.dATp = e->dATp; L.nvc = e->nvcb; L.dFTp = e->dFTp; L.nsplit = e->nsplit;
+    L.dATp = e->dA; L.nvc = 1; L.dFTp = e->dF; L.nsplit = 1;
     L.gx_extra = pd ? e->gx : nullptr; L.gb_extra = sd ? e->gb : nullptr;
     L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step;
     L.lr = lr; L.B = e->B; L.BP = e->BP;
@@ -597,7 +614,8 @@ extern "C" int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d, const flo
   if (rc) return rc;
   smpl_forward(e, x6d, nullptr, betas, false, e->verts, VP * 3, nullptr, s);
   const float scale = (float)(2.0 * 1.0 / ((double)e->bnorm * 51.0));   // optimize.py:307 unweighted MSE
-  launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, scale, e->joints, sqerr ? sqerr : e->sqerr, nullptr, e->B, e->BP, s);
+  reduce_joint_partials(e, s);
+  launch_joints_loss(e->Jsum, 1, gt_mm, nullptr, scale, e->joints, sqerr ? sqerr : e->sqerr, nullptr, e->B, e->BP, s);
   launch_joint_loss_plain(e->joints, gt_mm, scale, nullptr, e->dj, e->B, s);
   return j_grad_from_verts(e, e->dj, dJ, s);
 }

@@ -42,13 +42,15 @@ int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float
 int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale, float* sqerr, float* djoints, int B,
                             hipStream_t s);
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s);
+int launch_reduce_slabs(const float* P, int nslab, size_t stride, float* out, size_t n, hipStream_t s);
 int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr, float b1,
                      float b2, float eps, hipStream_t s);
 
 // lbs.hip
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
                    float* verts, int ldv, int B, int BP, int nvc, hipStream_t s);
-int launch_lbs_bwd(const Model& m, const float* Jn_iv, const float* AT, const float* VPb, const float* dJT,
+int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s);
+int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s);
 int launch_dverts_transpose(const float* dverts, float* dVT, int B, int BP, hipStream_t s);
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv,

@@ -21,14 +21,41 @@ namespace jrr {
 // ------------------------------------------------------------------------------------------
 // forward
 //   grid.x = (BP/128) * nvc workgroups of 256 threads; wave w owns poses [bg*128 + 32w, +32)
-//   and loops over the vertex tiles of chunk vc.  The blend-basis tile is staged through LDS in
-//   7 chunks of 32 feature rows (12 KB), prefetched into registers one chunk ahead.
-//   outputs: JP [nvc][3][17][BP] joint partials; optional VPb [3][VP][BP] (v_posed, kept for
-//   the backward pass) and verts (B,6890,3).
+//   and loops over the vertex tiles of chunk vc.
+//
+//   EVERY MFMA operand is read from LDS.  Operands are staged by LDS-DMA (global_load_lds_dwordx4:
+//   no VGPR round trip, asynchronous) into a 2-deep ring, one stage ahead of the MFMAs, one
+//   workgroup barrier per stage.  Per vertex tile there are 13 stages:
+//     s = 0..6   blend product, K chunk kc = s: basis rows D[32 k][3][32 v] (12 KB, shared by the
+//                four waves) + feature rows F^T[32 k][128 poses] (16 KB)        48 MFMA / wave
+//     s = 7..12  skinning, half-stage (r, h): two A^T blocks [24 j][128 poses] (24 KB):
+//                h = 0: translation column c = 3 and c = 0;  h = 1: c = 1, 2, then the
+//                regressor product  joints^T += Jn . verts_r                 24 (+16) MFMA / wave
+//   The skinning-weight / regressor tiles (W^T, Jn) ride with stage 0 into a per-tile-parity
+//   region.  outputs: JP [nvc][3][17][BP] joint partials; optional VPb [3][VP][BP] (v_posed,
+//   kept for the backward pass) and verts (B,6890,3).
 // ------------------------------------------------------------------------------------------
-constexpr int DCH_FLOATS = KCH * 96;          // 3072 floats per staged basis chunk
 constexpr int W_FLOATS = NJ * 32;             // 768
 constexpr int JN_FLOATS = 32 * 32;            // 1024
+constexpr int STG_FLOATS = KCH * 96 + KCH * BG;   // 3072 (D chunk) + 4096 (F chunk) = 7168
+constexpr int WJ_FLOATS = W_FLOATS + JN_FLOATS;   // 1792
+constexpr int NSTAGE = NKCH + 6;                  // 13
+// per-tile operand record of the backward kernel: [Jn 18x32 | W^T 24x32 | W 32x32(j) | pad] = 10 KB
+constexpr int TB_JN = 0, TB_WJV = NHP * 32, TB_WVJ = TB_WJV + W_FLOATS, TB_FLOATS = 2560;
+
+#define JRR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define JRR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
+// one wave-instruction: 64 lanes x 16 B from per-lane global addresses into LDS [dst, dst + 1 KB)
+__device__ __forceinline__ void dma16(const float* gsrc_lane, float* lds_dst_wave) {
+  __builtin_amdgcn_global_load_lds(JRR_GLB(gsrc_lane), JRR_LDS(lds_dst_wave), 16, 0, 0);
+}
+// same with the address split as (wave-uniform base, 32-bit per-lane offset in floats).  The base is
+// laundered through an SGPR so the compiler keeps it scalar (saddr form) and cannot fold it into a
+// per-copy VGPR offset or hoist it out of the tile loop (either costs ~2 VGPRs per copy).
+__device__ __forceinline__ void dma16u(const float* base_uniform, unsigned lane_off, float* lds_dst_wave) {
+  asm volatile("" : "+s"(base_uniform));
+  __builtin_amdgcn_global_load_lds(JRR_GLB(base_uniform + lane_off), JRR_LDS(lds_dst_wave), 16, 0, 0);
+}
 
 template <bool STORE_VP, bool STORE_VERTS>
 __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk, const float* __restrict__ Wjv,
@@ -36,10 +63,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
                                                     const float* __restrict__ AT, float* __restrict__ VPb,
                                                     float* __restrict__ JP, float* __restrict__ verts, int ldv, int B,
                                                     int BP, int nvc) {
-  __shared__ float lds[DCH_FLOATS + W_FLOATS + JN_FLOATS];
-  float* ldsD = lds;
-  float* ldsW = lds + DCH_FLOATS;
-  float* ldsJ = ldsW + W_FLOATS;
+  __shared__ float lds[2 * STG_FLOATS + 2 * WJ_FLOATS];
+  float* const ring = lds;
+  float* const wj = lds + 2 * STG_FLOATS;
 
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -48,138 +74,178 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   const int b0 = bg * BG + wave * BT;
   const int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
   const size_t bcol = (size_t)b0 + l31;
+  // DMA addressing = wave-uniform base pointer (SGPR pair) + one 32-bit per-lane offset (VGPR), so
+  // the 78 copies per tile cost scalar address arithmetic only.  Row-pair pattern: lanes 0-31
+  // fetch row 2o, lanes 32-63 row 2o+1, 16 B per lane.
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  const unsigned lane_rp = (unsigned)half * (unsigned)BP + (unsigned)l31 * 4u;   // floats
+  const unsigned lane_ln = (unsigned)lane * 4u;                                  // floats
+  const float* const Fbg = FT + (size_t)bg * BG;
+  const float* const Abg = AT + (size_t)bg * BG;
+
+  // ---- DMA issue for stage s of tile vt into ring slot `slot` ----
+  auto issue = [&](int vt, int s, int slot) {
+    float* dst = ring + slot * STG_FLOATS;
+    if (s < NKCH) {
+      const float* dsrc = Dk + ((size_t)vt * KFP + s * KCH) * 96;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) { const int o = wv + 4 * i; dma16u(dsrc + o * 256, lane_ln, dst + o * 256); }
+      float* fdst = dst + KCH * 96;
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int o = wv + 4 * i;
+        dma16u(Fbg + (size_t)(s * KCH + 2 * o) * BP, lane_rp, fdst + o * 256);
+      }
+      if (s == 0) {
+        float* wdst = wj + (vt & 1) * WJ_FLOATS;
+        if (wv < 3) dma16u(Wjv + (size_t)vt * W_FLOATS + wv * 256, lane_ln, wdst + wv * 256);
+        dma16u(Jn_vi + (size_t)vt * JN_FLOATS + wv * 256, lane_ln, wdst + W_FLOATS + wv * 256);
+      }
+    } else {
+      const int h = s - NKCH, r = h >> 1;
+      const int c0 = (h & 1) ? 1 : 3, c1 = (h & 1) ? 2 : 0;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const int o = wv + 4 * i;   // 12 row pairs per block
+        dma16u(Abg + (size_t)((r * 4 + c0) * NJ + 2 * o) * BP, lane_rp, dst + o * 256);
+        dma16u(Abg + (size_t)((r * 4 + c1) * NJ + 2 * o) * BP, lane_rp, dst + NJ * BG + o * 256);
+      }
+    }
+  };
 
   f32x16 jacc[3] = {zero16(), zero16(), zero16()};
+  f32x16 vp[3];
+  f32x16 vr;
 
-  // register prefetch buffers for the staged data
-  f32x4 preD[3], preJ, preW;
-  auto prefetch = [&](int vt, int kc) {
-    const f32x4* src = reinterpret_cast<const f32x4*>(Dk + ((size_t)vt * KFP + kc * KCH) * 96);
-#pragma unroll
-    for (int i = 0; i < 3; ++i) preD[i] = src[tid + 256 * i];
-    if (kc == 0) {
-      preJ = reinterpret_cast<const f32x4*>(Jn_vi + (size_t)vt * JN_FLOATS)[tid];
-      if (tid < W_FLOATS / 4) preW = reinterpret_cast<const f32x4*>(Wjv + (size_t)vt * W_FLOATS)[tid];
-    }
-  };
-  auto commit = [&](int kc) {
-#pragma unroll
-    for (int i = 0; i < 3; ++i) reinterpret_cast<f32x4*>(ldsD)[tid + 256 * i] = preD[i];
-    if (kc == 0) {
-      reinterpret_cast<f32x4*>(ldsJ)[tid] = preJ;
-      if (tid < W_FLOATS / 4) reinterpret_cast<f32x4*>(ldsW)[tid] = preW;
-    }
-  };
-
-  if (t_begin < t_end) prefetch(t_begin, 0);
+  if (t_begin < t_end) issue(t_begin, 0, 0);
+  int g = 0;   // global stage counter: ring slot = g & 1
   for (int vt = t_begin; vt < t_end; ++vt) {
-    f32x16 vp[3] = {zero16(), zero16(), zero16()};
-    for (int kc = 0; kc < NKCH; ++kc) {
-      __syncthreads();          // previous stage fully consumed
-      commit(kc);
-      __syncthreads();
-      if (kc + 1 < NKCH) prefetch(vt, kc + 1);
-      else if (vt + 1 < t_end) prefetch(vt + 1, 0);
-      const int npairs = (kc == NKCH - 1) ? (KF - (NKCH - 1) * KCH) / 2 : KCH / 2;   // 13 : 16
-      const float* fp = FT + (size_t)(kc * KCH + half) * BP + bcol;
-      const float* dp = ldsD + half * 96 + l31;
-#pragma unroll 4
-      for (int kk = 0; kk < npairs; ++kk) {
-        float f = fp[(size_t)(2 * kk) * BP];
-        float d0 = dp[(2 * kk) * 96], d1 = dp[(2 * kk) * 96 + 32], d2 = dp[(2 * kk) * 96 + 64];
-        vp[0] = mfma(d0, f, vp[0]);
-        vp[1] = mfma(d1, f, vp[1]);
-        vp[2] = mfma(d2, f, vp[2]);
-      }
-    }
-    if (STORE_VP) {
+    const float* ldsW = wj + (vt & 1) * WJ_FLOATS;
+    const float* ldsJ = ldsW + W_FLOATS;
 #pragma unroll
-      for (int c = 0; c < 3; ++c)
+    for (int s = 0; s < NSTAGE; ++s, ++g) {
+      __syncthreads();   // stage g landed (vmcnt(0) + barrier); slot (g+1)&1 is free again
+      if (s + 1 < NSTAGE) issue(vt, s + 1, (g + 1) & 1);
+      else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1);
+      const float* buf = ring + (g & 1) * STG_FLOATS;
+      if (s < NKCH) {
+        if (s == 0) { vp[0] = zero16(); vp[1] = zero16(); vp[2] = zero16(); }
+        const int npairs = (s == NKCH - 1) ? (KF - (NKCH - 1) * KCH) / 2 : KCH / 2;   // 13 : 16
+        const float* dp = buf + half * 96 + l31;
+        const float* fp = buf + KCH * 96 + half * BG + wave * BT + l31;
 #pragma unroll
-        for (int r = 0; r < 16; ++r)
-          VPb[((size_t)c * VP + vt * 32 + acc_row(r, half)) * BP + bcol] = vp[c][r];
-    }
-    // skinning transforms and vertices, one output coordinate r at a time.
-    // The A^T operands do not depend on the vertex tile; launder the pointer so the compiler
-    // re-loads them from L1/L2 per tile instead of hoisting 144 registers out of the loop
-    // (which it then spills to scratch).
-    int at_off = 0;
-    asm volatile("" : "+s"(at_off));
-    const float* ATl = AT + at_off;
-    float w[12];
+        for (int kk = 0; kk < npairs; ++kk) {
+          const float f = fp[(2 * kk) * BG];
+          const float d0 = dp[(2 * kk) * 96], d1 = dp[(2 * kk) * 96 + 32], d2 = dp[(2 * kk) * 96 + 64];
+          vp[0] = mfma(d0, f, vp[0]);
+          vp[1] = mfma(d1, f, vp[1]);
+          vp[2] = mfma(d2, f, vp[2]);
+        }
+      } else {
+        const int h = s - NKCH, r = h >> 1;
+        if (STORE_VP) {   // spread the v_posed stores over the six skinning stages (8 registers each)
+          const int c = h >> 1, q0 = (h & 1) * 8;
 #pragma unroll
-    for (int jp = 0; jp < 12; ++jp) w[jp] = ldsW[(2 * jp + half) * 32 + l31];
+          for (int q = q0; q < q0 + 8; ++q)
+            VPb[((size_t)c * VP + vt * 32 + acc_row(q, half)) * BP + bcol] = vp[c][q];
+        }
+        const float* wp = ldsW + half * 32 + l31;
+        const float* a0 = buf + half * BG + wave * BT + l31;
+        const float* a1 = a0 + NJ * BG;
+        if ((h & 1) == 0) {
+          vr = zero16();
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      // translation column first: vr = T_{r,3}
-      f32x16 vr = zero16();
-      {
-        const float* ap = ATl + (size_t)((r * 4 + 3) * NJ + half) * BP + bcol;
+          for (int jp = 0; jp < 12; ++jp) vr = mfma(wp[(2 * jp) * 32], a0[(2 * jp) * BG], vr);   // T_{r,3}
+          f32x16 T = zero16();
 #pragma unroll
-        for (int jp = 0; jp < 12; ++jp) vr = mfma(w[jp], ap[(size_t)(2 * jp) * BP], vr);
-      }
-      __builtin_amdgcn_sched_barrier(0);
+          for (int jp = 0; jp < 12; ++jp) T = mfma(wp[(2 * jp) * 32], a1[(2 * jp) * BG], T);     // T_{r,0}
+          vr += T * vp[0];
+        } else {
+          f32x16 T = zero16();
 #pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        f32x16 T = zero16();
-        const float* ap = ATl + (size_t)((r * 4 + c) * NJ + half) * BP + bcol;
+          for (int jp = 0; jp < 12; ++jp) T = mfma(wp[(2 * jp) * 32], a0[(2 * jp) * BG], T);     // T_{r,1}
+          vr += T * vp[1];
+          T = zero16();
 #pragma unroll
-        for (int jp = 0; jp < 12; ++jp) T = mfma(w[jp], ap[(size_t)(2 * jp) * BP], T);
-        vr += T * vp[c];
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      if (STORE_VERTS) {
+          for (int jp = 0; jp < 12; ++jp) T = mfma(wp[(2 * jp) * 32], a1[(2 * jp) * BG], T);     // T_{r,2}
+          vr += T * vp[2];
+          if (STORE_VERTS) {
 #pragma unroll
-        for (int q = 0; q < 16; ++q) {
-          int v = vt * 32 + acc_row(q, half);
-          if (v < V && b0 + l31 < B) verts[(size_t)(b0 + l31) * ldv + v * 3 + r] = vr[q];
+            for (int q = 0; q < 16; ++q) {
+              const int v = vt * 32 + acc_row(q, half);
+              if (v < V && b0 + l31 < B) verts[(size_t)(b0 + l31) * ldv + v * 3 + r] = vr[q];
+            }
+          }
+          // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b]
+#pragma unroll
+          for (int q = 0; q < 16; ++q) jacc[r] = mfma(ldsJ[acc_row(q, half) * 32 + l31], vr[q], jacc[r]);
         }
       }
-      // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b]
-#pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        float jn = ldsJ[acc_row(q, half) * 32 + l31];
-        jacc[r] = mfma(jn, vr[q], jacc[r]);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      int i = acc_row(q, half);
+      const int i = acc_row(q, half);
       if (i < NH) JP[((size_t)(vc * 3 + r) * NH + i) * BP + bcol] = jacc[r][q];
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // backward (to v_posed and to the skinning transforms)
-//   one independent wave per (pose tile bt, coordinate plane c in {0,1,2}, vertex chunk vc):
+//   one wave per (pose tile bt, coordinate plane c in {0,1,2}, vertex chunk vc):
 //     dverts_r[v,b] = sum_i Jn[i,v] dj[b,i,r]                (K = 18)        -- or loaded (DVERTS_MEM)
 //     T_{r,c}[v,b]  = sum_j W[v,j] A[b,j,r,c]                (K = 24, recomputed)
 //     dvp_c[v,b]    = sum_r T_{r,c} dverts_r                  -> DVP [3][VP][BP]
 //     dA_{r,c}[j,b] += sum_v W[v,j] dverts_r[v,b] vp_c[v,b]   (sums over the tile's ROW index)
 //     dA_{c,3}[j,b] += sum_v W[v,j] dverts_c[v,b]
-//   No LDS and no barriers: all operands are tiny per-tile tables read straight from L2.
+//   The four waves of a workgroup walk the same vertex tiles, so the per-tile operand tables
+//   (Jn [18][32], W^T [24][32], W [32][32 j]: one contiguous 10 KB record `Tb` per tile) are
+//   staged once per workgroup by LDS-DMA into a 2-deep ring, one tile ahead, one barrier per
+//   tile.  The wave's slice of A^T (36 operand vectors) lives in LDS for the whole kernel; its
+//   v_posed tile is register-prefetched one tile ahead.
 //   outputs: DVP, dATp [nvc][12][24][BP] partials.
 // ------------------------------------------------------------------------------------------
 template <bool DVERTS_MEM>
-__global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Wjv, const float* __restrict__ Wvj,
-                                                    const float* __restrict__ Jn_iv, const float* __restrict__ AT,
+__global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb, const float* __restrict__ AT,
                                                     const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                     const float* __restrict__ dVT, float* __restrict__ DVP,
-                                                    float* __restrict__ dATp, int BP, int nvc, int nitems) {
+                                                    float* __restrict__ dATp, int BP, int nvc, int wg_per_vc) {
+  __shared__ float lds[2 * TB_FLOATS + 4 * 36 * 64];
+  float* const ring = lds;
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-  const int item = xcd_remap(blockIdx.x, gridDim.x) * 4 + wave;
-  if (item >= nitems) return;
-  const int c = item % 3;
-  const int rest = item / 3;
-  const int vc = rest % nvc, bt = rest / nvc;
+  const int wv = __builtin_amdgcn_readfirstlane(wave);
+  float* const ldsA = lds + 2 * TB_FLOATS + wv * 36 * 64;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int vc = L / wg_per_vc, item = (L % wg_per_vc) * 4 + wv;
+  const int c = item % 3, bt = item / 3;
   const int b0 = bt * BT;
   const size_t bcol = (size_t)b0 + l31;
   const int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
+  const unsigned lane_ln = (unsigned)lane * 4u;
+
+  auto issue = [&](int vt, int slot) {
+    const float* src = Tb + (size_t)vt * TB_FLOATS;
+    float* dst = ring + slot * TB_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const int o = wv + 4 * i;
+      if (o < TB_FLOATS / 256) dma16u(src + o * 256, lane_ln, dst + o * 256);
+    }
+  };
+  auto load_vp = [&](int vt, f32x16& dstv) {
+#pragma unroll
+    for (int q = 0; q < 16; ++q) dstv[q] = VPb[((size_t)c * VP + vt * 32 + acc_row(q, half)) * BP + bcol];
+  };
+
+  // this wave's A^T operand vectors (r, j-pair) -> LDS, once
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int jp = 0; jp < 12; ++jp)
+      ldsA[(r * 12 + jp) * 64 + lane] = AT[(size_t)((r * 4 + c) * NJ + 2 * jp + half) * BP + bcol];
 
   float dj[3][9];
   if (!DVERTS_MEM) {
@@ -188,16 +254,22 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Wj
 #pragma unroll
       for (int ip = 0; ip < 9; ++ip) dj[r][ip] = dJT[(size_t)(r * NHP + 2 * ip + half) * BP + bcol];
   }
-  float a_rc[3][12];
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int jp = 0; jp < 12; ++jp) a_rc[r][jp] = AT[(size_t)((r * 4 + c) * NJ + 2 * jp + half) * BP + bcol];
 
   f32x16 dA[3] = {zero16(), zero16(), zero16()};
   f32x16 dA3 = zero16();
+  f32x16 vp_next = zero16();
+  if (t_begin < t_end) {
+    issue(t_begin, 0);
+    load_vp(t_begin, vp_next);
+  }
 
   for (int vt = t_begin; vt < t_end; ++vt) {
+    __syncthreads();   // tables of tile vt landed; the other ring slot is free
+    if (vt + 1 < t_end) issue(vt + 1, (vt - t_begin + 1) & 1);
+    const f32x16 vp = vp_next;
+    if (vt + 1 < t_end) load_vp(vt + 1, vp_next);
+    const float* tab = ring + ((vt - t_begin) & 1) * TB_FLOATS;
+
     f32x16 dv[3];
     if (DVERTS_MEM) {
 #pragma unroll
@@ -206,54 +278,59 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Wj
         for (int q = 0; q < 16; ++q) dv[r][q] = dVT[((size_t)r * VP + vt * 32 + acc_row(q, half)) * BP + bcol];
     } else {
       dv[0] = zero16(); dv[1] = zero16(); dv[2] = zero16();
-      const float* jp_ = Jn_iv + (size_t)vt * NHP * 32 + half * 32 + l31;
+      const float* jp_ = tab + TB_JN + half * 32 + l31;
 #pragma unroll
       for (int ip = 0; ip < 9; ++ip) {
-        float jn = jp_[(2 * ip) * 32];
+        const float jn = jp_[(2 * ip) * 32];
 #pragma unroll
         for (int r = 0; r < 3; ++r) dv[r] = mfma(jn, dj[r][ip], dv[r]);
       }
     }
-    f32x16 vp;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) vp[q] = VPb[((size_t)c * VP + vt * 32 + acc_row(q, half)) * BP + bcol];
 
     f32x16 dvp = zero16();
     {
-      float w[12];
-      const float* wp = Wjv + (size_t)vt * W_FLOATS + half * 32 + l31;
-#pragma unroll
-      for (int jp = 0; jp < 12; ++jp) w[jp] = wp[(2 * jp) * 32];
+      const float* wp = tab + TB_WJV + half * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
         f32x16 T = zero16();
 #pragma unroll
-        for (int jp = 0; jp < 12; ++jp) T = mfma(w[jp], a_rc[r][jp], T);
+        for (int jp = 0; jp < 12; ++jp) T = mfma(wp[(2 * jp) * 32], ldsA[(r * 12 + jp) * 64 + lane], T);
         dvp += T * dv[r];
       }
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) DVP[((size_t)c * VP + vt * 32 + acc_row(q, half)) * BP + bcol] = dvp[q];
 
-    const float* wvp = Wvj + (size_t)vt * 1024 + l31;
+    const float* wvp = tab + TB_WVJ + l31;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      float wv = wvp[acc_row(q, half) * 32];
+      const float wvj = wvp[acc_row(q, half) * 32];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) dA[r] = mfma(wv, dv[r][q] * vp[q], dA[r]);
-      float dvc = (c == 0) ? dv[0][q] : (c == 1) ? dv[1][q] : dv[2][q];
-      dA3 = mfma(wv, dvc, dA3);
+      for (int r = 0; r < 3; ++r) dA[r] = mfma(wvj, dv[r][q] * vp[q], dA[r]);
+      const float dvc = (c == 0) ? dv[0][q] : (c == 1) ? dv[1][q] : dv[2][q];
+      dA3 = mfma(wvj, dvc, dA3);
     }
   }
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    int j = acc_row(q, half);
+    const int j = acc_row(q, half);
     if (j < NJ) {
 #pragma unroll
       for (int r = 0; r < 3; ++r) dATp[((size_t)(vc * 12 + r * 4 + c) * NJ + j) * BP + bcol] = dA[r][q];
       dATp[((size_t)(vc * 12 + c * 4 + 3) * NJ + j) * BP + bcol] = dA3[q];
     }
   }
+}
+
+// static (W) parts of the per-tile backward operand records
+__global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __restrict__ Wvj, float* __restrict__ Tb) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over VT * 2048
+  if (idx >= VT * 2048) return;
+  const int vt = idx >> 11, k = idx & 2047;
+  float* dst = Tb + (size_t)vt * TB_FLOATS;
+  if (k < W_FLOATS) dst[TB_WJV + k] = Wjv[(size_t)vt * W_FLOATS + k];
+  else if (k < W_FLOATS + 1024) dst[TB_WVJ + (k - W_FLOATS)] = Wvj[(size_t)vt * 1024 + (k - W_FLOATS)];
+  else if (k - W_FLOATS - 1024 < TB_FLOATS - TB_WVJ - 1024) dst[TB_WVJ + 1024 + (k - W_FLOATS - 1024)] = 0.f;
 }
 
 // (B,6890,3) -> [3][VP][BP] transpose of an external vertex adjoint (operator-level SMPL backward)
@@ -311,7 +388,7 @@ __global__ void k_jreg_tiles(const float* __restrict__ J, const float* __restric
     Jn[(size_t)i * V + v] = val;
   }
   Jn_vi[(size_t)vt * 1024 + vv * 32 + i] = val;
-  if (i < NHP) Jn_iv[(size_t)vt * NHP * 32 + i * 32 + vv] = val;
+  if (i < NHP) Jn_iv[(size_t)vt * TB_FLOATS + TB_JN + i * 32 + vv] = val;   // backward operand record
 }
 
 // dJ_raw = mask * relu'(J*mask) * (dJn - sum_v(dJn*Jn)) / rowsum      (dJn given as [17][ldn])
@@ -354,14 +431,15 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
   return 0;
 }
 
-int launch_lbs_bwd(const Model& m, const float* Jn_iv, const float* AT, const float* VPb, const float* dJT,
+int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s) {
-  const int nitems = (BP / BT) * 3 * nvc;
-  dim3 grid((nitems + 3) / 4), block(256);
+  (void)m;
+  const int wg_per_vc = (BP / BT) * 3 / 4;     // BP is a multiple of 128, so 3*BP/32 is a multiple of 4
+  dim3 grid(wg_per_vc * nvc), block(256);
   if (dVT)
-    hipLaunchKernelGGL((k_lbs_bwd<true>), grid, block, 0, s, m.Wjv, m.Wvj, Jn_iv, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, nitems);
+    hipLaunchKernelGGL((k_lbs_bwd<true>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, wg_per_vc);
   else
-    hipLaunchKernelGGL((k_lbs_bwd<false>), grid, block, 0, s, m.Wjv, m.Wvj, Jn_iv, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, nitems);
+    hipLaunchKernelGGL((k_lbs_bwd<false>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, wg_per_vc);
   return 0;
 }
 
@@ -374,6 +452,11 @@ int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, floa
                           hipStream_t s) {
   hipLaunchKernelGGL(k_jreg_rowsum, dim3(NH), dim3(256), 0, s, J, mask, rowsum);
   hipLaunchKernelGGL(k_jreg_tiles, dim3(VT * 1024 / 256), dim3(256), 0, s, J, mask, rowsum, Jn, Jn_vi, Jn_iv);
+  return 0;
+}
+
+int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s) {
+  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb);
   return 0;
 }
 

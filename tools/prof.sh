@@ -1,0 +1,33 @@
+#!/bin/bash
+# usage (on the GPU box, from the repo root): bash tools/prof.sh <tag>
+# kernel-trace stats + separate PMC passes (never combined with tracing domains), summaries -> gpurun_out/prof_<tag>/
+TAG=${1:-run}
+OUT=$PWD/gpurun_out/prof_$TAG
+mkdir -p $OUT
+export TMPDIR=/tmp
+CMD="python3 $PWD/bench.py --steps 5 --warmup 2 --no_cpu_baseline"
+cd /tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $CMD > $OUT/trace.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -o pmc -- $CMD > $OUT/pmc_fetch.log 2>&1
+rocprofv3 --pmc WRITE_SIZE GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_write -o pmc -- $CMD > $OUT/pmc_write.log 2>&1
+cd $OUT
+python3 - <<'PY'
+import csv, glob, collections, json, os
+out = {}
+for f in glob.glob('trace/**/*kernel_stats.csv', recursive=True):
+    rows = list(csv.DictReader(open(f)))
+    out['kernel_stats'] = [{k: r[k] for k in r} for r in rows[:25]]
+for name in ('pmc_sq', 'pmc_fetch', 'pmc_write'):
+    agg = collections.defaultdict(lambda: collections.defaultdict(float)); cnt = collections.Counter()
+    for f in glob.glob(name + '/**/*counter_collection.csv', recursive=True):
+        for r in csv.DictReader(open(f)):
+            k = r['Kernel_Name'].split('(')[0][:60]
+            agg[k][r['Counter_Name']] += float(r['Counter_Value'])
+            cnt[(k, r['Counter_Name'])] += 1
+    out[name] = {k: {c: v / cnt[(k, c)] for c, v in d.items()} for k, d in agg.items()}
+json.dump(out, open('summary.json', 'w'), indent=1)
+for r in out.get('kernel_stats', []):
+    print(r.get('Name', '')[:70], r.get('Calls'), r.get('TotalDurationNs'), r.get('AverageNs'), r.get('Percentage'))
+PY
+ls -la $OUT
