@@ -111,7 +111,7 @@ struct jrr_engine {
   bool have_J, have_mask, have_pd, have_sd;
   // workspace sections
   float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv;
-  float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF;
+  float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
   float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx;
   float *Ps, *gb;
   float *verts, *djpad, *dJnp, *dJn, *dj;
@@ -170,6 +170,9 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   t->Jsum = c.take((size_t)3 * NH * BP);
   t->dA = c.take((size_t)12 * NJ * BP);
   t->dF = c.take((size_t)KFP * BP);
+  t->R0T = c.take((size_t)16 * BP);
+  t->dRT = c.take((size_t)NJ * 9 * BP);
+  t->dbT = c.take((size_t)16 * BP);
   t->joints = c.take((size_t)BP * NH * 3);
   t->sqerr = c.take((size_t)BP);
   t->step_scratch = (int32_t*)c.take(64);
@@ -353,7 +356,7 @@ static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s) {
 
 static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,
                         float* verts, int ldv, int32_t* step_inc, hipStream_t s) {
-  launch_prep_fwd(e->m, x6d, R, betas, e->FT, e->AT, e->B, e->BP, step_inc, s);
+  launch_prep_fwd(e->m, x6d, R, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step_inc, s);
   launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, keep_vp ? e->VPb : nullptr, e->JP, verts, ldv, e->B, e->BP, e->nvc, s);
   return 0;
 }
@@ -415,7 +418,7 @@ extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const
     reduce_adjoint_partials(e, s);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.R_in = R; L.betas_in = betas;
-    L.dATp = e->dA; L.nvc = 1; L.dFTp = e->dF; L.nsplit = 1;
+    L.dATp = e->dA; L.dFTp = e->dF; L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
     L.dx6d = dx6d; L.dR = dR; L.dbetas = dbetas;
     L.B = e->B; L.BP = e->BP;
     launch_prep_bwd(L, e->m, s);
@@ -443,10 +446,10 @@ static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t
   GemmArgs g;
   g.mask = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   g.A = e->W0T; g.lda = 1024; g.Bm = e->H2T; g.Out = e->A1T; g.bias = e->Pd + DP_FC0_B; g.M = 1024; g.K = 768;
-  int rc = launch_gemm_128(g, EPI_BIAS_RELU, 1, s);
+  int rc = launch_gemm_128x64(g, EPI_BIAS_RELU, 1, s);
   if (rc) return rc;
   g.A = e->W2T; g.lda = 1024; g.Bm = e->A1T; g.Out = e->A2T; g.bias = e->Pd + DP_FC2_B; g.M = 1024; g.K = 1024;
-  return launch_gemm_128(g, EPI_BIAS_RELU, 1, s);
+  return launch_gemm_128x64(g, EPI_BIAS_RELU, 1, s);
 }
 
 static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, float scale, float target, float* gx,
@@ -456,11 +459,11 @@ static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, floa
   g.bias = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   // dA1T[k][b] = relu'(A1T) * sum_n fc2.w[n][k] dA2T[n][b]
   g.A = e->Pd + DP_FC2_W; g.lda = 1024; g.Bm = e->dA2T; g.Out = e->dA1T; g.mask = e->A1T; g.M = 1024; g.K = 1024;
-  int rc = launch_gemm_128(g, EPI_MASK, 1, s);
+  int rc = launch_gemm_128x64(g, EPI_MASK, 1, s);
   if (rc) return rc;
   // dH2T[k][b] = sum_n fc0.w[n][k] dA1T[n][b]
   g.A = e->Pd + DP_FC0_W; g.lda = 768; g.Bm = e->dA1T; g.Out = e->dH2T; g.mask = nullptr; g.M = 768; g.K = 1024;
-  rc = launch_gemm_128(g, EPI_STORE, 1, s);
+  rc = launch_gemm_128x64(g, EPI_STORE, 1, s);
   if (rc) return rc;
   launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, scale, target, gx, e->B, e->BP, s);
   return 0;
@@ -519,7 +522,7 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
   const float sscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 1.0));
   for (int it = 0; it < n_iters; ++it) {
     prof_mark(e, 0, s);
-    launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->AT, e->B, e->BP, step, s);
+    launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, s);
     prof_mark(e, 0, s);
     prof_mark(e, 1, s);
     launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, nullptr, 0, e->B, e->BP, e->nvc, s);
@@ -552,7 +555,7 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     reduce_adjoint_partials(e, s);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.betas_in = betas;
-    L.dATp = e->dA; L.nvc = 1; L.dFTp = e->dF; L.nsplit = 1;
+    L.dATp = e->dA; L.dFTp = e->dF; L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
     L.gx_extra = pd ? e->gx : nullptr; L.gb_extra = sd ? e->gb : nullptr;
     L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step;
     L.lr = lr; L.B = e->B; L.BP = e->BP;

@@ -3,36 +3,72 @@
 // Activations are kept feature-major ([feature][pose]), so every product of the pose
 // discriminator (scripts/discriminator.py:20-29,32-54), its input-gradient, and the blend-basis
 // adjoint dF = D . dVP is of this form with the pose index on the MFMA column (lane) axis.
-// LDS-staged [16][BM] / [16][BN] chunks, register prefetch one chunk ahead, optional split-K
-// (blockIdx.z) writing partial slabs that the consumer sums.
+// Optional split-K (blockIdx.z) writes partial slabs that the consumer sums.
 #include "jrr_common.h"
 #include "kernels.h"
 
 namespace jrr {
 
-constexpr int GK = 16;   // K rows per staged chunk
+#define JRR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define JRR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 
-template <int WM, int WN, int WAVES_M, int WAVES_N, int EPI>
+// Operand chunks ([GK][BM] of A, [GK][BN] of Bm) are staged by LDS-DMA (global_load_lds_dwordx4)
+// into a 2-deep ring, one chunk ahead of the MFMAs, one workgroup barrier per chunk.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int GK, int EPI>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) {
-  constexpr int NT = 64 * WAVES_M * WAVES_N;
+  constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-  constexpr int A4 = GK * BM / 4, B4 = GK * BN / 4;        // float4s per chunk
-  constexpr int PA = (A4 + NT - 1) / NT, PB = (B4 + NT - 1) / NT;
-  __shared__ float lds[GK * (BM + BN)];
-  float* ldsA = lds;
-  float* ldsB = lds + GK * BM;
+  constexpr int A16 = GK * BM / 4, B16 = GK * BN / 4;       // 16-byte pieces per chunk
+  constexpr int OPA = (A16 + 63) / 64, OPB = (B16 + 63) / 64;   // wave-instructions per chunk
+  constexpr int PA = (OPA + NW - 1) / NW, PB = (OPB + NW - 1) / NW;
+  constexpr int SLOT = GK * (BM + BN);
+  __shared__ float lds[2 * SLOT];
 
   const int tid = threadIdx.x;
-  const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wm = wave / WAVES_N, wn = wave % WAVES_N;
-  const int n_mt = (g.M + BM - 1) / BM, n_nt = g.N / BN;
+  const int n_mt = (g.M + BM - 1) / BM;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = L % n_mt, nt = L / n_mt;     // consecutive blocks share the Bm (activation) panel
-  (void)n_nt;
   const int m0 = mt * BM, n0 = nt * BN;
   const int nchunks = g.K / GK;
   const int split = blockIdx.z, nsplit = gridDim.z;
   const int c_begin = (int)((long)nchunks * split / nsplit), c_end = (int)((long)nchunks * (split + 1) / nsplit);
+
+  // per-lane source offsets (floats) of this wave's DMA pieces; loop-invariant
+  unsigned offA[PA], offB[PB];
+  bool okA[PA], okB[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int p = (wave + NW * i) * 64 + lane;
+    const int row = p / (BM / 4), col = (p % (BM / 4)) * 4;
+    okA[i] = (wave + NW * i) < OPA && p < A16 && (m0 + col) < g.M;
+    offA[i] = (unsigned)row * (unsigned)g.lda + (unsigned)col;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int p = (wave + NW * i) * 64 + lane;
+    const int row = p / (BN / 4), col = (p % (BN / 4)) * 4;
+    okB[i] = (wave + NW * i) < OPB && p < B16;
+    offB[i] = (unsigned)row * (unsigned)g.ldb + (unsigned)col;
+  }
+  const float* const Abase = g.A + m0;
+  const float* const Bbase = g.Bm + n0;
+
+  auto issue = [&](int ch, int slot) {
+    const float* a = Abase + (size_t)ch * GK * g.lda;
+    const float* b = Bbase + (size_t)ch * GK * g.ldb;
+    asm volatile("" : "+s"(a));
+    asm volatile("" : "+s"(b));
+    float* dA = lds + slot * SLOT;
+    float* dB = dA + GK * BM;
+#pragma unroll
+    for (int i = 0; i < PA; ++i)
+      if (okA[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(a + offA[i]), JRR_LDS(dA + (wave + NW * i) * 256), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i)
+      if (okB[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave + NW * i) * 256), 16, 0, 0);
+  };
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -40,51 +76,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
 #pragma unroll
     for (int j = 0; j < WN; ++j) acc[i][j] = zero16();
 
-  f32x4 preA[PA], preB[PB];
-  auto prefetch = [&](int ch) {
-    const int k0 = ch * GK;
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      int f = tid + NT * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (f < A4) {
-        int row = f / (BM / 4), col = (f % (BM / 4)) * 4;
-        if (m0 + col < g.M) v = *reinterpret_cast<const f32x4*>(g.A + (size_t)(k0 + row) * g.lda + m0 + col);
-      }
-      preA[i] = v;
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      int f = tid + NT * i;
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};
-      if (f < B4) {
-        int row = f / (BN / 4), col = (f % (BN / 4)) * 4;
-        v = *reinterpret_cast<const f32x4*>(g.Bm + (size_t)(k0 + row) * g.ldb + n0 + col);
-      }
-      preB[i] = v;
-    }
-  };
-  auto commit = [&]() {
-#pragma unroll
-    for (int i = 0; i < PA; ++i) {
-      int f = tid + NT * i;
-      if (f < A4) reinterpret_cast<f32x4*>(ldsA)[f] = preA[i];
-    }
-#pragma unroll
-    for (int i = 0; i < PB; ++i) {
-      int f = tid + NT * i;
-      if (f < B4) reinterpret_cast<f32x4*>(ldsB)[f] = preB[i];
-    }
-  };
-
-  if (c_begin < c_end) prefetch(c_begin);
+  if (c_begin < c_end) issue(c_begin, 0);
   for (int ch = c_begin; ch < c_end; ++ch) {
-    __syncthreads();
-    commit();
-    __syncthreads();
-    if (ch + 1 < c_end) prefetch(ch + 1);
-    const float* ap = ldsA + half * BM + wm * WM * 32 + l31;
-    const float* bp = ldsB + half * BN + wn * WN * 32 + l31;
+    __syncthreads();   // chunk ch landed (vmcnt(0) + barrier); the other slot is free
+    if (ch + 1 < c_end) issue(ch + 1, (ch - c_begin + 1) & 1);
+    const float* ap = lds + ((ch - c_begin) & 1) * SLOT + half * BM + wm * WM * 32 + l31;
+    const float* bp = lds + ((ch - c_begin) & 1) * SLOT + GK * BM + half * BN + wn * WN * 32 + l31;
 #pragma unroll
     for (int kk = 0; kk < GK / 2; ++kk) {
       float a[WM], b[WN];
@@ -120,32 +117,33 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
     }
 }
 
-template <int WM, int WN, int WAVES_M, int WAVES_N>
+template <int WM, int WN, int WAVES_M, int WAVES_N, int GK>
 static int launch_cfg(const GemmArgs& g, int epi, int nsplit, hipStream_t s) {
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
-  if (g.N % BN != 0 || g.K % GK != 0 || g.lda % 4 != 0 || g.ldb % 4 != 0) {
+  if (g.N % BN != 0 || g.K % GK != 0 || g.lda % 4 != 0 || g.ldb % 4 != 0 || g.M % 4 != 0) {
     jrr_set_error("gemm_tn: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d", g.M, g.N, g.K, g.lda, g.ldb);
     return JRR_ERR_ARG;
   }
   dim3 grid(((g.M + BM - 1) / BM) * (g.N / BN), 1, nsplit), block(64 * WAVES_M * WAVES_N);
   switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, EPI_STORE>), grid, block, 0, s, g); break;
-    case EPI_BIAS_RELU: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, EPI_BIAS_RELU>), grid, block, 0, s, g); break;
-    case EPI_BIAS: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, EPI_BIAS>), grid, block, 0, s, g); break;
-    case EPI_MASK: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, EPI_MASK>), grid, block, 0, s, g); break;
+    case EPI_STORE: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_STORE>), grid, block, 0, s, g); break;
+    case EPI_BIAS_RELU: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_BIAS_RELU>), grid, block, 0, s, g); break;
+    case EPI_BIAS: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_BIAS>), grid, block, 0, s, g); break;
+    case EPI_MASK: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_MASK>), grid, block, 0, s, g); break;
     default: return JRR_ERR_ARG;
   }
   return 0;
 }
 
-// 128x128 block tile (2x2 waves of 64x64): discriminator layers
-int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 2, 2, 2>(g, epi, nsplit, s); }
-// 224x128 block tile (4 waves of 224x32): blend-basis adjoint, M = KFP = 224
-int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<7, 1, 1, 4>(g, epi, nsplit, s); }
-// 32x128 block tile (4 waves of 32x32): skinny-M products (dJn: M = 17..64)
-int launch_gemm_32(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<1, 1, 1, 4>(g, epi, nsplit, s); }
-
+// 128x128 block tile (2x2 waves of 64x64), 32-deep chunks: discriminator layers
+int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 2, 2, 2, 32>(g, epi, nsplit, s); }
+// 128x64 block tile (2x2 waves of 64x32): twice the workgroups of the 128x128 tile (2 per CU at N = 4096)
+int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 2, 2, 32>(g, epi, nsplit, s); }
+// 224x128 block tile (4 waves of 224x32), 16-deep chunks: blend-basis adjoint, M = KFP = 224
+int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<7, 1, 1, 4, 16>(g, epi, nsplit, s); }
+// 32x128 block tile (4 waves of 32x32): skinny-M products
+int launch_gemm_32(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<1, 1, 1, 4, 16>(g, epi, nsplit, s); }
 // 64x128 block tile (4 waves of 64x32): the J-regressor gradient product, M = 51 padded to 64
-int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 1, 4>(g, epi, nsplit, s); }
+int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 1, 4, 16>(g, epi, nsplit, s); }
 
 }  // namespace jrr

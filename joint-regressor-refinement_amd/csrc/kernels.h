@@ -23,7 +23,9 @@ struct GemmArgs {
 
 struct PrepBwdLaunch {
   const float* x6d_in = nullptr; const float* R_in = nullptr; const float* betas_in = nullptr;
-  const float* dATp = nullptr; int nvc = 0; const float* dFTp = nullptr; int nsplit = 0;
+  const float* dATp = nullptr; const float* dFTp = nullptr;    // REDUCED adjoints dA^T [288][BP], dF^T [224][BP]
+  const float* FT = nullptr; const float* R0T = nullptr; const float* AT = nullptr;   // saved by k_prep_fwd
+  float* dRT = nullptr; float* dbT = nullptr;                   // scratch [216][BP], [10][BP]
   const float* gx_extra = nullptr; const float* gb_extra = nullptr;
   float* dx6d = nullptr; float* dR = nullptr; float* dbetas = nullptr;
   float* x6d_io = nullptr; float* betas_io = nullptr; float* adam_m = nullptr; float* adam_v = nullptr;
@@ -35,8 +37,8 @@ struct PrepBwdLaunch {
 // prep.hip
 int launch_rot6d_fwd(const float* x, float* R, int n, hipStream_t s);
 int launch_rot6d_bwd(const float* x, const float* dR, float* dx, int n, hipStream_t s);
-int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT, int B,
-                    int BP, int32_t* step_inc, hipStream_t s);
+int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT,
+                    float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s);
 int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float* djoints_in, float scale,
                        float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s);
 int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale, float* sqerr, float* djoints, int B,
@@ -60,6 +62,7 @@ int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const fl
 
 // gemm.hip
 int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);

@@ -151,7 +151,8 @@ __device__ __forceinline__ void rest_joint(const float* __restrict__ Jt, const f
 __global__ __launch_bounds__(64) void k_prep_fwd(const float* __restrict__ x6d, const float* __restrict__ Rin,
                                                  const float* __restrict__ betas, const float* __restrict__ Jt,
                                                  const float* __restrict__ JS, Parents par, float* __restrict__ FT,
-                                                 float* __restrict__ AT, int B, int BP, int32_t* step_inc) {
+                                                 float* __restrict__ AT, float* __restrict__ R0T, int B, int BP,
+                                                 int32_t* step_inc) {
   extern __shared__ float lds[];   // [24][12][64]
   const int lane = threadIdx.x;
   const int b = blockIdx.x * 64 + lane;
@@ -173,6 +174,9 @@ __global__ __launch_bounds__(64) void k_prep_fwd(const float* __restrict__ x6d, 
     if (j > 0) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) FT[(size_t)((j - 1) * 9 + k) * BP + b] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
+    } else {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) R0T[(size_t)k * BP + b] = R[k];
     }
     if (j == 0) {
 #pragma unroll
@@ -344,192 +348,172 @@ __global__ void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_prep_bwd: adjoint of k_prep_fwd (+ optional fused Adam).
-//   inputs : dATp [nvc][12][24][BP] partial dL/dA^T, dFTp [nsplit][KFP][BP] partial dL/dF^T,
-//            gx_extra (B,24,6) / gb_extra (B,10): extra gradients added before the update
-//            (discriminator terms), may be NULL.
-//   outputs: mode GRAD : dx6d (B,24,6) or dR (B,24,3,3), dbetas (B,10)
-//            mode ADAM : x6d/betas/m/v updated in place.
-// LDS per lane: G.R (9) and dG (12) per joint.
+// Adjoint of k_prep_fwd, in two kernels:
+//
+// k_chain_bwd (one pose per lane, children before parents): dL/dA^T [288][BP] and dL/dF^T [224][BP]
+//   -> dL/dR^T [24*9][BP] and dL/dbeta^T [10][BP].  Every global access is pose-contiguous
+//   (coalesced): R comes back from the feature rows F^T (+ identity) / R0T, the world rotations
+//   G_j.R from the rotation part of A^T, so nothing of the forward chain is recomputed.  LDS holds
+//   only the dG accumulators (12 floats per joint per lane).
+//
+// k_pose_update (one (pose, joint) per thread, joint 24 = betas): 6-D rotation adjoint, extra
+//   (discriminator) gradients, then either the gradient outputs or the fused Adam update.
 // ------------------------------------------------------------------------------------------
-struct PrepBwdArgs {
-  const float* x6d_in;      // (B,24,6) or NULL
-  const float* R_in;        // (B,24,3,3) or NULL
-  const float* betas_in;    // (B,10)
-  const float* Jt; const float* JS;
-  const float* dATp; int nvc;
-  const float* dFTp; int nsplit;
-  const float* gx_extra; const float* gb_extra;
-  float* dx6d; float* dR; float* dbetas;           // GRAD outputs (nullable)
-  float* x6d_io; float* betas_io; float* adam_m; float* adam_v; const int32_t* step;   // ADAM (x6d_io nullable)
-  float lr, beta1, beta2, eps;
-  int B, BP;
-};
-
-__global__ __launch_bounds__(64) void k_prep_bwd(PrepBwdArgs a, Parents par) {
-  extern __shared__ float lds[];
-  float* GR = lds;                  // [24][9][64]
-  float* dG = lds + NJ * 9 * 64;    // [24][12][64]
+__global__ __launch_bounds__(64) void k_chain_bwd(const float* __restrict__ FT, const float* __restrict__ R0T,
+                                                  const float* __restrict__ AT, const float* __restrict__ Jt,
+                                                  const float* __restrict__ JS, Parents par,
+                                                  const float* __restrict__ dA_, const float* __restrict__ dF_,
+                                                  float* __restrict__ dRT, float* __restrict__ dbT, int B, int BP) {
+  extern __shared__ float dG[];   // [24][12][64]
   const int lane = threadIdx.x;
   const int b = blockIdx.x * 64 + lane;
-  if (b >= a.B) return;
-  const int BP = a.BP;
-  const bool do_adam = a.x6d_io != nullptr;
-  AdamScalars sc;
-  if (do_adam) sc = adam_scalars(a.step[0], a.lr, a.beta1, a.beta2, a.eps);
-
+  if (b >= B) return;
   float beta[NB], dbeta[NB];
 #pragma unroll
-  for (int l = 0; l < NB; ++l) { beta[l] = a.betas_in[(size_t)b * NB + l]; dbeta[l] = 0.f; }
+  for (int l = 0; l < NB; ++l) { beta[l] = FT[(size_t)(207 + l) * BP + b]; dbeta[l] = 0.f; }
+  for (int k = 0; k < NJ * 12; ++k) dG[k * 64 + lane] = 0.f;
 
-  // ---- forward recompute of G.R, and dG initialised from dA ----
-  for (int j = 0; j < NJ; ++j) {
-    float R[9], J[3], G9[9];
-    Rot6 c;
-    load_rot(a.x6d_in, a.R_in, b, j, R, c);
-    rest_joint(a.Jt, a.JS, j, beta, J);
-    if (j == 0) {
+  for (int i = NJ - 1; i >= 0; --i) {
+    const int p = par.p[i];
+    float dA[12], GiR[9], R[9], Ji[3];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) G9[k] = R[k];
-    } else {
-      const int p = par.p[j];
-      float Gp[9];
+    for (int e = 0; e < 12; ++e) dA[e] = dA_[(size_t)(e * NJ + i) * BP + b];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Gp[k] = GR[(p * 9 + k) * 64 + lane];
+    for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc)
-          G9[r * 3 + cc] = Gp[r * 3 + 0] * R[0 * 3 + cc] + Gp[r * 3 + 1] * R[1 * 3 + cc] + Gp[r * 3 + 2] * R[2 * 3 + cc];
-    }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) GR[(j * 9 + k) * 64 + lane] = G9[k];
-    // dA_j (reduce partials)
-    float dA[12];
-#pragma unroll
-    for (int e = 0; e < 12; ++e) {
-      float acc = 0.f;
-      for (int ch = 0; ch < a.nvc; ++ch) acc += a.dATp[(size_t)((ch * 12 + e) * NJ + j) * BP + b];
-      dA[e] = acc;
-    }
-    // A.R = G.R ; A.t = G.t - G.R J  =>  dG.R = dA.R - dA.t J^T ; dG.t = dA.t ; dJ += -G.R^T dA.t
-    float dJ[3] = {0.f, 0.f, 0.f};
+      for (int cc = 0; cc < 3; ++cc) GiR[r * 3 + cc] = AT[(size_t)((r * 4 + cc) * NJ + i) * BP + b];
+    rest_joint(Jt, JS, i, beta, Ji);
+    // dG_i = accumulated from children + own: A.R = G.R ; A.t = G.t - G.R J
+    float dGi[12];
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) {
-        dG[(j * 12 + r * 4 + cc) * 64 + lane] = dA[r * 4 + cc] - dA[r * 4 + 3] * J[cc];
-        dJ[cc] -= G9[r * 3 + cc] * dA[r * 4 + 3];
-      }
-      dG[(j * 12 + r * 4 + 3) * 64 + lane] = dA[r * 4 + 3];
+      for (int cc = 0; cc < 3; ++cc) dGi[r * 4 + cc] = dG[(i * 12 + r * 4 + cc) * 64 + lane] + dA[r * 4 + cc] - dA[r * 4 + 3] * Ji[cc];
+      dGi[r * 4 + 3] = dG[(i * 12 + r * 4 + 3) * 64 + lane] + dA[r * 4 + 3];
     }
+    float dJ[3];
 #pragma unroll
-    for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-      for (int l = 0; l < NB; ++l) dbeta[l] = fmaf(dJ[cc], a.JS[(j * 3 + cc) * NB + l], dbeta[l]);
-  }
-
-  // ---- backward over the chain, children before parents ----
-  for (int i = NJ - 1; i >= 0; --i) {
-    float R[9], dRi[9], dGi[12];
-    Rot6 c;
-    load_rot(a.x6d_in, a.R_in, b, i, R, c);
-#pragma unroll
-    for (int e = 0; e < 12; ++e) dGi[e] = dG[(i * 12 + e) * 64 + lane];
+    for (int cc = 0; cc < 3; ++cc) dJ[cc] = -(GiR[0 * 3 + cc] * dA[3] + GiR[1 * 3 + cc] * dA[7] + GiR[2 * 3 + cc] * dA[11]);
+    float dRi[9];
     if (i == 0) {
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) dRi[r * 3 + cc] = dGi[r * 4 + cc];
-      // G_0.t = J_0
+#pragma unroll
+      for (int cc = 0; cc < 3; ++cc) dJ[cc] += dGi[cc * 4 + 3];   // G_0.t = J_0
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
-        for (int l = 0; l < NB; ++l) dbeta[l] = fmaf(dGi[cc * 4 + 3], a.JS[(0 * 3 + cc) * NB + l], dbeta[l]);
+        for (int l = 0; l < NB; ++l) dbeta[l] = fmaf(dJ[cc], JS[(0 * 3 + cc) * NB + l], dbeta[l]);
     } else {
-      const int p = par.p[i];
-      float Gp[9], Ji[3], Jp[3], rel[3], drel[3];
+      float Gp[9], Jp[3], rel[3], drel[3];
 #pragma unroll
-      for (int k = 0; k < 9; ++k) Gp[k] = GR[(p * 9 + k) * 64 + lane];
-      rest_joint(a.Jt, a.JS, i, beta, Ji);
-      rest_joint(a.Jt, a.JS, p, beta, Jp);
+      for (int k = 0; k < 9; ++k) R[k] = FT[(size_t)((i - 1) * 9 + k) * BP + b] + ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) Gp[r * 3 + cc] = AT[(size_t)((r * 4 + cc) * NJ + p) * BP + b];
+      rest_joint(Jt, JS, p, beta, Jp);
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc) rel[cc] = Ji[cc] - Jp[cc];
-      // G_i.R = Gp.R R_i ; G_i.t = Gp.R rel + Gp.t
+      // G_i.R = Gp.R R_i ; G_i.t = Gp.R rel + Gp.t ;  F[(i-1)*9+k] = R_i[k] - I
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc)
-          dRi[r * 3 + cc] = Gp[0 * 3 + r] * dGi[0 * 4 + cc] + Gp[1 * 3 + r] * dGi[1 * 4 + cc] + Gp[2 * 3 + r] * dGi[2 * 4 + cc];
+          dRi[r * 3 + cc] = Gp[0 * 3 + r] * dGi[0 * 4 + cc] + Gp[1 * 3 + r] * dGi[1 * 4 + cc] + Gp[2 * 3 + r] * dGi[2 * 4 + cc] +
+                            dF_[(size_t)((i - 1) * 9 + r * 3 + cc) * BP + b];
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc)
         drel[cc] = Gp[0 * 3 + cc] * dGi[0 * 4 + 3] + Gp[1 * 3 + cc] * dGi[1 * 4 + 3] + Gp[2 * 3 + cc] * dGi[2 * 4 + 3];
-      // dGp.R += dG_i.R R_i^T + dG_i.t rel^T ; dGp.t += dG_i.t
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc) {
-          float add = dGi[r * 4 + 0] * R[cc * 3 + 0] + dGi[r * 4 + 1] * R[cc * 3 + 1] + dGi[r * 4 + 2] * R[cc * 3 + 2] +
-                      dGi[r * 4 + 3] * rel[cc];
+          const float add = dGi[r * 4 + 0] * R[cc * 3 + 0] + dGi[r * 4 + 1] * R[cc * 3 + 1] + dGi[r * 4 + 2] * R[cc * 3 + 2] +
+                            dGi[r * 4 + 3] * rel[cc];
           dG[(p * 12 + r * 4 + cc) * 64 + lane] += add;
         }
         dG[(p * 12 + r * 4 + 3) * 64 + lane] += dGi[r * 4 + 3];
       }
-      // rel = J_i - J_p
+      // J_i enters through -G_i.R J_i (dJ) and rel = J_i - J_p (drel)
 #pragma unroll
       for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
         for (int l = 0; l < NB; ++l)
-          dbeta[l] = fmaf(drel[cc], a.JS[(i * 3 + cc) * NB + l] - a.JS[(p * 3 + cc) * NB + l], dbeta[l]);
-      // pose-feature adjoint: F[(i-1)*9 + k] = R_i[k] - I
-#pragma unroll
-      for (int k = 0; k < 9; ++k) {
-        float acc = 0.f;
-        for (int s = 0; s < a.nsplit; ++s) acc += a.dFTp[(size_t)(s * KFP + (i - 1) * 9 + k) * BP + b];
-        dRi[k] += acc;
-      }
+          dbeta[l] = fmaf(dJ[cc] + drel[cc], JS[(i * 3 + cc) * NB + l], fmaf(-drel[cc], JS[(p * 3 + cc) * NB + l], dbeta[l]));
     }
-    if (a.R_in) {
-      if (a.dR) {
 #pragma unroll
-        for (int k = 0; k < 9; ++k) a.dR[((size_t)b * NJ + i) * 9 + k] = dRi[k];
-      }
-    } else {
-      float dx[6];
-      rot6d_bwd(c, dRi, dx);
-      if (a.gx_extra) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) dx[k] += a.gx_extra[((size_t)b * NJ + i) * 6 + k];
-      }
-      if (a.dx6d) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) a.dx6d[((size_t)b * NJ + i) * 6 + k] = dx[k];
-      }
-      if (do_adam) {
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          size_t pi = ((size_t)b * NJ + i) * 6 + k;
-          size_t si = (size_t)b * NPARAM + i * 6 + k;
-          float mm = a.adam_m[si], vv = a.adam_v[si];
-          a.x6d_io[pi] = adam_update(a.x6d_io[pi], dx[k], mm, vv, sc);
-          a.adam_m[si] = mm;
-          a.adam_v[si] = vv;
-        }
-      }
-    }
+    for (int k = 0; k < 9; ++k) dRT[(size_t)(i * 9 + k) * BP + b] = dRi[k];
   }
-  // shape-feature adjoint
 #pragma unroll
-  for (int l = 0; l < NB; ++l) {
-    float acc = 0.f;
-    for (int s = 0; s < a.nsplit; ++s) acc += a.dFTp[(size_t)(s * KFP + 207 + l) * BP + b];
-    dbeta[l] += acc;
-    if (a.gb_extra) dbeta[l] += a.gb_extra[(size_t)b * NB + l];
-    if (a.dbetas) a.dbetas[(size_t)b * NB + l] = dbeta[l];
-    if (do_adam) {
-      size_t si = (size_t)b * NPARAM + JRR_POSE6D + l;
+  for (int l = 0; l < NB; ++l) dbT[(size_t)l * BP + b] = dbeta[l] + dF_[(size_t)(207 + l) * BP + b];
+}
+
+struct PoseUpdateArgs {
+  const float* x6d_in;      // (B,24,6) or NULL (R mode)
+  const float* dRT; const float* dbT;
+  const float* gx_extra; const float* gb_extra;
+  float* dx6d; float* dR; float* dbetas;                 // gradient outputs (nullable)
+  float* x6d_io; float* betas_io; float* adam_m; float* adam_v; const int32_t* step;   // Adam (x6d_io nullable)
+  float lr, beta1, beta2, eps;
+  int B, BP;
+};
+
+__global__ __launch_bounds__(64) void k_pose_update(PoseUpdateArgs a) {
+  const int b = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y;
+  if (b >= a.B) return;
+  const int BP = a.BP;
+  const bool do_adam = a.x6d_io != nullptr;
+  AdamScalars sc;
+  if (do_adam) sc = adam_scalars(a.step[0], a.lr, a.beta1, a.beta2, a.eps);
+  if (j == NJ) {   // betas
+#pragma unroll
+    for (int l = 0; l < NB; ++l) {
+      float g = a.dbT[(size_t)l * BP + b];
+      if (a.gb_extra) g += a.gb_extra[(size_t)b * NB + l];
+      if (a.dbetas) a.dbetas[(size_t)b * NB + l] = g;
+      if (do_adam) {
+        const size_t si = (size_t)b * NPARAM + JRR_POSE6D + l;
+        float mm = a.adam_m[si], vv = a.adam_v[si];
+        a.betas_io[(size_t)b * NB + l] = adam_update(a.betas_io[(size_t)b * NB + l], g, mm, vv, sc);
+        a.adam_m[si] = mm;
+        a.adam_v[si] = vv;
+      }
+    }
+    return;
+  }
+  float dRi[9];
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dRi[k] = a.dRT[(size_t)(j * 9 + k) * BP + b];
+  if (!a.x6d_in) {
+    if (a.dR) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a.dR[((size_t)b * NJ + j) * 9 + k] = dRi[k];
+    }
+    return;
+  }
+  float xv[6], R[9], dx[6];
+  Rot6 c;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xv[k] = a.x6d_in[((size_t)b * NJ + j) * 6 + k];
+  rot6d_fwd(xv, R, c);
+  rot6d_bwd(c, dRi, dx);
+  if (a.gx_extra) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dx[k] += a.gx_extra[((size_t)b * NJ + j) * 6 + k];
+  }
+  if (a.dx6d) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.dx6d[((size_t)b * NJ + j) * 6 + k] = dx[k];
+  }
+  if (do_adam) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const size_t si = (size_t)b * NPARAM + j * 6 + k;
       float mm = a.adam_m[si], vv = a.adam_v[si];
-      a.betas_io[(size_t)b * NB + l] = adam_update(a.betas_io[(size_t)b * NB + l], dbeta[l], mm, vv, sc);
+      a.x6d_io[((size_t)b * NJ + j) * 6 + k] = adam_update(xv[k], dx[k], mm, vv, sc);
       a.adam_m[si] = mm;
       a.adam_v[si] = vv;
     }
@@ -570,15 +554,15 @@ static bool g_attr_set = false;
 static void ensure_attrs() {
   if (g_attr_set) return;
   (void)hipFuncSetAttribute((const void*)k_prep_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, NJ * 12 * 64 * 4);
-  (void)hipFuncSetAttribute((const void*)k_prep_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, NJ * 21 * 64 * 4);
+  (void)hipFuncSetAttribute((const void*)k_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, NJ * 12 * 64 * 4);
   g_attr_set = true;
 }
 
 int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT,
-                    int B, int BP, int32_t* step_inc, hipStream_t s) {
+                    float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s) {
   ensure_attrs();
   hipLaunchKernelGGL(k_prep_fwd, dim3(BP / 64), dim3(64), NJ * 12 * 64 * 4, s, x6d, Rin, betas, m.Jt, m.JS, m.parents,
-                     FT, AT, B, BP, step_inc);
+                     FT, AT, R0T, B, BP, step_inc);
   return 0;
 }
 
@@ -597,14 +581,14 @@ int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale
 
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
   ensure_attrs();
-  PrepBwdArgs a;
-  a.x6d_in = L.x6d_in; a.R_in = L.R_in; a.betas_in = L.betas_in; a.Jt = m.Jt; a.JS = m.JS;
-  a.dATp = L.dATp; a.nvc = L.nvc; a.dFTp = L.dFTp; a.nsplit = L.nsplit;
-  a.gx_extra = L.gx_extra; a.gb_extra = L.gb_extra;
+  hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + 63) / 64), dim3(64), NJ * 12 * 64 * 4, s, L.FT, L.R0T, L.AT, m.Jt, m.JS,
+                     m.parents, L.dATp, L.dFTp, L.dRT, L.dbT, L.B, L.BP);
+  PoseUpdateArgs a;
+  a.x6d_in = L.x6d_in; a.dRT = L.dRT; a.dbT = L.dbT; a.gx_extra = L.gx_extra; a.gb_extra = L.gb_extra;
   a.dx6d = L.dx6d; a.dR = L.dR; a.dbetas = L.dbetas;
   a.x6d_io = L.x6d_io; a.betas_io = L.betas_io; a.adam_m = L.adam_m; a.adam_v = L.adam_v; a.step = L.step;
   a.lr = L.lr; a.beta1 = L.beta1; a.beta2 = L.beta2; a.eps = L.eps; a.B = L.B; a.BP = L.BP;
-  hipLaunchKernelGGL(k_prep_bwd, dim3((L.B + 63) / 64), dim3(64), NJ * 21 * 64 * 4, s, a, m.parents);
+  hipLaunchKernelGGL(k_pose_update, dim3((L.B + 63) / 64, NJ + 1), dim3(64), 0, s, a);
   return 0;
 }
 
