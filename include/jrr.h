@@ -111,6 +111,15 @@ int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d_dev, const float*
                              const float* betas_dev, const float* djoints_dev, float* dx6d_dev,
                              float* dR_dev, float* dbetas_dev, float* dJ_dev, void* stream);
 
+/* SMPL operator on its own: smpl(global_orient, body_pose, betas, pose2rot=False).vertices
+ * (call sites scripts/utils.py:94-95, scripts/optimize.py:78-79, scripts/renderer.py:32-33).
+ * Forward = jrr_find_joints_forward with verts_dev != NULL.  This is the adjoint w.r.t. the
+ * vertices for the SAME inputs (must follow that forward): dverts (B,6890,3) -> dx6d / dR, dbetas.
+ * Needs JRR_FLAG_KEEP_VERTS (the padded vertex buffer doubles as the transposed adjoint).        */
+int jrr_smpl_vertices_backward(jrr_engine_t* e, const float* x6d_dev, const float* R_dev,
+                               const float* betas_dev, const float* dverts_dev, float* dx6d_dev,
+                               float* dR_dev, float* dbetas_dev, void* stream);
+
 /* move_pelvis + MSELoss, scripts/utils.py:106-114 + scripts/optimize.py:238-239:
  * sqerr_dev[b] = sum_{i,c} (joints[b,i,c]-joints[b,0,c] - gt_mm[b,i,c]/1000)^2 ;
  * djoints = d(weight * mean)/d joints with mean over batch_norm*51.                            */
@@ -122,10 +131,18 @@ int jrr_pose_disc_forward(jrr_engine_t* e, const float* x6d_dev, float* out_dev,
 /* d[ weight * mean((D(x)-target)^2) ] / dx for the forward just run (optimize.py:246-247).    */
 int jrr_pose_disc_backward_input(jrr_engine_t* e, const float* x6d_dev, float weight, float target,
                                  float* dx6d_dev, void* stream);
-/* weight gradients of  mean((D(x)-target)^2)  accumulated (+=) into a flat vector laid out like
- * the parameter vector (optimize.py:276-284).                                                 */
+/* vector-Jacobian product of Discriminator.forward w.r.t. its input for an arbitrary upstream
+ * gradient gout (B,25) (autograd backward of the module); must follow jrr_pose_disc_forward.   */
+int jrr_pose_disc_vjp_input(jrr_engine_t* e, const float* x6d_dev, const float* gout_dev,
+                            float* dx6d_dev, void* stream);
+/* weight gradients of  mean((D(x)-target)^2)  (mean over batch_norm*25) accumulated (+=) into a
+ * flat vector laid out like the parameter vector (one term of scripts/optimize.py:276-284);
+ * sqerr_dev (B, nullable) receives sum_k (D(x)[b,k]-target)^2.                                   */
 int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d_dev, float target,
-                                  float* dparams_dev, void* stream);
+                                  float* dparams_dev, float* sqerr_dev, void* stream);
+/* the same for Shape_Discriminator (scripts/optimize.py:286-293): betas (B,10), 171 parameters */
+int jrr_shape_disc_backward_params(jrr_engine_t* e, const float* betas_dev, float target,
+                                   float* dparams_dev, float* sqerr_dev, void* stream);
 
 /* torch.optim.Adam single-tensor update (defaults used at scripts/optimize.py:116-126,201):
  * step_dev holds the 1-based step count of THIS update.                                        */

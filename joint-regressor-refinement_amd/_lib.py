@@ -33,10 +33,13 @@ SIGNATURES = {
     'jrr_rot6d_backward': (c_int, [_P, _P, _P, c_int, _P]),
     'jrr_find_joints_forward': (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     'jrr_find_joints_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'jrr_smpl_vertices_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'jrr_pose_disc_vjp_input': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_joint_loss': (c_int, [_P, _P, c_float, c_int, c_int, _P, _P, _P]),
     'jrr_pose_disc_forward': (c_int, [_P, _P, _P, _P]),
     'jrr_pose_disc_backward_input': (c_int, [_P, _P, c_float, c_float, _P, _P]),
-    'jrr_pose_disc_backward_params': (c_int, [_P, _P, c_float, _P, _P]),
+    'jrr_pose_disc_backward_params': (c_int, [_P, _P, c_float, _P, _P, _P]),
+    'jrr_shape_disc_backward_params': (c_int, [_P, _P, c_float, _P, _P, _P]),
     'jrr_adam_step': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, _P]),
     'jrr_refine_run': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),
     'jrr_j_regressor_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P]),

@@ -112,7 +112,7 @@ struct jrr_engine {
   // workspace sections
   float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv;
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
-  float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx;
+  float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc;
   float *Ps, *gb;
   float *verts, *djpad, *dJnp, *dJn, *dj;
   bool verts_zeroed;
@@ -187,6 +187,10 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->dA1T = c.take((size_t)1024 * BP);
     t->dH2T = c.take((size_t)768 * BP);
     t->gx = c.take((size_t)BP * JRR_POSE6D);
+    t->TrA = c.take((size_t)BP * 1024);
+    t->TrB = c.take((size_t)BP * 1024);
+    t->dz0 = c.take((size_t)BP);
+    t->dsc = c.take((size_t)BP * 25);
   }
   if (flags & JRR_FLAG_SHAPE_DISC) {
     t->Ps = c.take(256);
@@ -431,6 +435,29 @@ extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const
   return JRR_OK;
 }
 
+extern "C" int jrr_smpl_vertices_backward(jrr_engine_t* e, const float* x6d, const float* R, const float* betas,
+                                          const float* dverts, float* dx6d, float* dR, float* dbetas, void* stream) {
+  if (!e || !betas || !dverts || ((x6d == nullptr) == (R == nullptr))) { jrr_set_error("smpl_vertices_backward: bad argument"); return JRR_ERR_ARG; }
+  if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("smpl_vertices_backward requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
+  if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  // the padded vertex buffer is reused as the transposed adjoint [3][VP][BP] (same size)
+  launch_dverts_transpose(dverts, e->verts, e->B, e->BP, s);
+  e->verts_zeroed = false;
+  launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, nullptr, e->verts, e->DVP, e->dATp, e->BP, e->nvcb, s);
+  int rc = blend_adjoint_gemm(e, s);
+  if (rc) return rc;
+  reduce_adjoint_partials(e, s);
+  PrepBwdLaunch L;
+  L.x6d_in = x6d; L.R_in = R; L.betas_in = betas;
+  L.dATp = e->dA; L.dFTp = e->dF; L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
+  L.dx6d = dx6d; L.dR = dR; L.dbetas = dbetas;
+  L.B = e->B; L.BP = e->BP;
+  launch_prep_bwd(L, e->m, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
 extern "C" int jrr_joint_loss(const float* joints, const float* gt_mm, float weight, int batch, int batch_norm,
                               float* sqerr, float* djoints, void* stream) {
   if (!joints || !gt_mm || batch <= 0 || batch_norm <= 0) return JRR_ERR_ARG;
@@ -452,9 +479,9 @@ static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t
   return launch_gemm_128x64(g, EPI_BIAS_RELU, 1, s);
 }
 
-static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, float scale, float target, float* gx,
-                               hipStream_t s) {
-  launch_disc_out(e->Pd, e->A2T, out, e->dA2T, scale, target, e->B, e->BP, s);
+static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, const float* gout, float scale,
+                               float target, float* gx, hipStream_t s) {
+  launch_disc_out(e->Pd, e->A2T, out, e->dA2T, gout, scale, target, e->B, e->BP, s);
   GemmArgs g;
   g.bias = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   // dA1T[k][b] = relu'(A1T) * sum_n fc2.w[n][k] dA2T[n][b]
@@ -465,7 +492,7 @@ static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, floa
   g.A = e->Pd + DP_FC0_W; g.lda = 768; g.Bm = e->dA1T; g.Out = e->dH2T; g.mask = nullptr; g.M = 768; g.K = 1024;
   rc = launch_gemm_128x64(g, EPI_STORE, 1, s);
   if (rc) return rc;
-  launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, scale, target, gx, e->B, e->BP, s);
+  launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s);
   return 0;
 }
 
@@ -475,7 +502,7 @@ extern "C" int jrr_pose_disc_forward(jrr_engine_t* e, const float* x6d, float* o
   hipStream_t s = (hipStream_t)stream;
   int rc = disc_forward(e, x6d, out, s);
   if (rc) return rc;
-  launch_disc_out(e->Pd, e->A2T, out, nullptr, 0.f, 0.f, e->B, e->BP, s);
+  launch_disc_out(e->Pd, e->A2T, out, nullptr, nullptr, 0.f, 0.f, e->B, e->BP, s);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -485,17 +512,72 @@ extern "C" int jrr_pose_disc_backward_input(jrr_engine_t* e, const float* x6d, f
   if (!e || !x6d || !dx) return JRR_ERR_ARG;
   if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
   const float scale = (float)(2.0 * (double)weight / ((double)e->bnorm * 25.0));
-  int rc = disc_backward_input(e, x6d, nullptr, scale, target, dx, (hipStream_t)stream);
+  int rc = disc_backward_input(e, x6d, nullptr, nullptr, scale, target, dx, (hipStream_t)stream);
   if (rc) return rc;
   CHECK_LAUNCH();
   return JRR_OK;
 }
 
-extern "C" int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d, float target, float* dparams,
+extern "C" int jrr_pose_disc_vjp_input(jrr_engine_t* e, const float* x6d, const float* gout, float* dx, void* stream) {
+  if (!e || !x6d || !gout || !dx) return JRR_ERR_ARG;
+  if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
+  int rc = disc_backward_input(e, x6d, nullptr, gout, 0.f, 0.f, dx, (hipStream_t)stream);
+  if (rc) return rc;
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d, float target, float* dP, float* sqerr,
                                              void* stream) {
-  (void)e; (void)x6d; (void)target; (void)dparams; (void)stream;
-  jrr_set_error("jrr_pose_disc_backward_params: not implemented in this build");
-  return JRR_ERR_STATE;
+  if (!e || !x6d || !dP) return JRR_ERR_ARG;
+  if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  const float scale = (float)(2.0 / ((double)e->bnorm * 25.0));
+  int rc = disc_forward(e, x6d, e->dsc, s);
+  if (rc) return rc;
+  launch_disc_out(e->Pd, e->A2T, e->dsc, e->dA2T, nullptr, scale, target, e->B, e->BP, s, e->dz0);
+  if (sqerr) launch_sqerr_rows(e->dsc, 25, target, sqerr, e->B, s);
+  // fc4: dw[n] += sum_b A2T[n][b] dz0[b] ; db += sum_b dz0[b]
+  launch_rowdot_accum(e->A2T, e->BP, e->dz0, dP + DP_FC4_W, 1024, e->BP, s);
+  launch_rowdot_accum(e->dz0, e->BP, nullptr, dP + DP_FC4_B, 1, e->BP, s);
+  // fc2: dW[n][k] += sum_b dA2T[n][b] A1T[k][b] (pose-major copies feed the K-major GEMM) ; db[n] += sum_b dA2T[n][b]
+  launch_transpose(e->dA2T, e->TrA, 1024, e->BP, s);
+  launch_transpose(e->A1T, e->TrB, 1024, e->BP, s);
+  GemmArgs g;
+  g.bias = nullptr; g.mask = nullptr; g.split_stride = 0;
+  g.A = e->TrA; g.lda = 1024; g.Bm = e->TrB; g.ldb = 1024; g.Out = dP + DP_FC2_W; g.ldo = 1024; g.M = 1024; g.N = 1024; g.K = e->BP;
+  rc = launch_gemm_128(g, EPI_ACCUM, 1, s);
+  if (rc) return rc;
+  launch_rowdot_accum(e->dA2T, e->BP, nullptr, dP + DP_FC2_B, 1024, e->BP, s);
+  // back through fc2
+  g.A = e->Pd + DP_FC2_W; g.lda = 1024; g.Bm = e->dA2T; g.ldb = e->BP; g.Out = e->dA1T; g.ldo = e->BP; g.mask = e->A1T;
+  g.M = 1024; g.N = e->BP; g.K = 1024;
+  rc = launch_gemm_128x64(g, EPI_MASK, 1, s);
+  if (rc) return rc;
+  // fc0
+  launch_transpose(e->dA1T, e->TrA, 1024, e->BP, s);
+  launch_transpose(e->H2T, e->TrB, 768, e->BP, s);
+  g.mask = nullptr;
+  g.A = e->TrA; g.lda = 1024; g.Bm = e->TrB; g.ldb = 768; g.Out = dP + DP_FC0_W; g.ldo = 768; g.M = 1024; g.N = 768; g.K = e->BP;
+  rc = launch_gemm_128(g, EPI_ACCUM, 1, s);
+  if (rc) return rc;
+  launch_rowdot_accum(e->dA1T, e->BP, nullptr, dP + DP_FC0_B, 1024, e->BP, s);
+  g.A = e->Pd + DP_FC0_W; g.lda = 768; g.Bm = e->dA1T; g.ldb = e->BP; g.Out = e->dH2T; g.ldo = e->BP; g.M = 768; g.N = e->BP; g.K = 1024;
+  rc = launch_gemm_128x64(g, EPI_STORE, 1, s);
+  if (rc) return rc;
+  launch_disc_conv_bwd_params(e->Pd, x6d, e->dH2T, scale, target, dP, e->B, e->BP, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_shape_disc_backward_params(jrr_engine_t* e, const float* betas, float target, float* dP, float* sqerr,
+                                              void* stream) {
+  if (!e || !betas || !dP) return JRR_ERR_ARG;
+  if (!e->have_sd) { jrr_set_error("shape discriminator not set"); return JRR_ERR_STATE; }
+  const float scale = (float)(2.0 / ((double)e->bnorm * 1.0));
+  launch_shape_disc_bwd_params(e->Ps, betas, scale, target, dP, sqerr, e->B, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
 }
 
 extern "C" int jrr_adam_step(float* p, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr,
@@ -542,7 +624,7 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
       prof_mark(e, 5, s);
       rc = disc_forward(e, x6d, nullptr, s);
       if (rc) return rc;
-      rc = disc_backward_input(e, x6d, nullptr, dscale, 1.f, e->gx, s);
+      rc = disc_backward_input(e, x6d, nullptr, nullptr, dscale, 1.f, e->gx, s);
       prof_mark(e, 5, s);
       if (rc) return rc;
     }

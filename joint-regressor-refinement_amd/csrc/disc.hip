@@ -64,8 +64,9 @@ __global__ __launch_bounds__(64) void k_disc_conv_fwd(const float* __restrict__ 
 // dA2T[n][b] = relu'(a2[n][b]) * w[n] * dz.  Block = 1024 threads = 16 waves x 64 poses,
 // wave q handles n in [64q, 64q+64).
 __global__ __launch_bounds__(1024) void k_disc_out(const float* __restrict__ P, const float* __restrict__ A2T,
-                                                   float* __restrict__ out, float* __restrict__ dA2T, float scale,
-                                                   float target, int B, int BP) {
+                                                   float* __restrict__ out, float* __restrict__ dA2T,
+                                                   const float* __restrict__ gout, float scale, float target, int B,
+                                                   int BP, float* __restrict__ dz0) {
   __shared__ float red[16][64];
   __shared__ float dzs[64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -81,7 +82,9 @@ __global__ __launch_bounds__(1024) void k_disc_out(const float* __restrict__ P, 
     for (int i = 0; i < 16; ++i) z += red[i][lane];
     float s = sigmoidf(z);
     if (out && b < B) out[(size_t)b * 25] = s;
-    dzs[lane] = (b < B) ? scale * (s - target) * s * (1.f - s) : 0.f;
+    const float up = gout ? ((b < B) ? gout[(size_t)b * 25] : 0.f) : scale * (s - target);
+    dzs[lane] = (b < B) ? up * s * (1.f - s) : 0.f;
+    if (dz0) dz0[b] = dzs[lane];
   }
   __syncthreads();
   if (dA2T) {
@@ -95,8 +98,8 @@ __global__ __launch_bounds__(1024) void k_disc_out(const float* __restrict__ P, 
 
 // input gradient of the per-joint MLP + heads; dH2T is the gradient arriving from fc0 (may be NULL)
 __global__ __launch_bounds__(64) void k_disc_conv_bwd(const float* __restrict__ P, const float* __restrict__ x6d,
-                                                      const float* __restrict__ dH2T, float scale, float target,
-                                                      float* __restrict__ gx, int B, int BP) {
+                                                      const float* __restrict__ dH2T, const float* __restrict__ gout,
+                                                      float scale, float target, float* __restrict__ gx, int B, int BP) {
   const int b = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y;
   if (b >= B) return;
   float x[6], h1[32], h2[32];
@@ -108,7 +111,7 @@ __global__ __launch_bounds__(64) void k_disc_conv_bwd(const float* __restrict__ 
 #pragma unroll
   for (int o = 0; o < 32; ++o) z = fmaf(wh[o], h2[o], z);
   const float s = sigmoidf(z);
-  const float dz = scale * (s - target) * s * (1.f - s);
+  const float dz = (gout ? gout[(size_t)b * 25 + 1 + j] : scale * (s - target)) * s * (1.f - s);
   float dh2[32];
 #pragma unroll
   for (int o = 0; o < 32; ++o) {
@@ -184,6 +187,160 @@ __global__ void k_shape_disc(const float* __restrict__ P, const float* __restric
   }
 }
 
+// ---- weight gradients (outer-step discriminator update, scripts/optimize.py:276-293) ----
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ void wave_atomic_add(float v, float* dst, int lane) {
+  v = wave_sum(v);
+  if (lane == 0) atomicAdd(dst, v);
+}
+
+// out[r] += sum_c M[r][c] * (vec ? vec[c] : 1)
+__global__ void k_rowdot_accum(const float* __restrict__ M, int ld, const float* __restrict__ vec, float* __restrict__ out,
+                               int cols) {
+  __shared__ float red[256];
+  const int r = blockIdx.x;
+  float acc = 0.f;
+  for (int c = threadIdx.x; c < cols; c += blockDim.x) acc += M[(size_t)r * ld + c] * (vec ? vec[c] : 1.f);
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[r] += red[0];
+}
+
+// per-joint MLP + head weight gradients: lane = pose, blockIdx.y = joint; wave-reduce then one atomic
+// per parameter per wave.  dH2T = gradient arriving from fc0.
+__global__ __launch_bounds__(64) void k_disc_conv_bwd_params(const float* __restrict__ P, const float* __restrict__ x6d,
+                                                             const float* __restrict__ dH2T, float scale, float target,
+                                                             float* __restrict__ dP, int B, int BP) {
+  const int lane = threadIdx.x, b = blockIdx.x * 64 + lane, j = blockIdx.y;
+  const bool ok = b < B;
+  float x[6], h1[32], h2[32];
+#pragma unroll
+  for (int c = 0; c < 6; ++c) x[c] = ok ? x6d[((size_t)b * NJ + j) * 6 + c] : 0.f;
+  joint_mlp(P, x, h1, h2);
+  const float* wh = P + DP_HEADS + 33 * j;
+  float z = wh[32];
+#pragma unroll
+  for (int o = 0; o < 32; ++o) z = fmaf(wh[o], h2[o], z);
+  const float s = sigmoidf(z);
+  const float dz = ok ? scale * (s - target) * s * (1.f - s) : 0.f;
+  float dh2[32], dh1[32];
+#pragma unroll
+  for (int o = 0; o < 32; ++o) {
+    float g = dz * wh[o];
+    if (ok) g += dH2T[(size_t)(j * 32 + o) * BP + b];
+    dh2[o] = (ok && h2[o] > 0.f) ? g : 0.f;
+    wave_atomic_add(dz * h2[o], dP + DP_HEADS + 33 * j + o, lane);
+    wave_atomic_add(dh2[o], dP + DP_CONV2_B + o, lane);
+  }
+  wave_atomic_add(dz, dP + DP_HEADS + 33 * j + 32, lane);
+  const float* w2 = P + DP_CONV2_W;
+#pragma unroll
+  for (int c = 0; c < 32; ++c) {
+    float acc = 0.f;
+#pragma unroll
+    for (int o = 0; o < 32; ++o) {
+      acc = fmaf(w2[o * 32 + c], dh2[o], acc);
+      wave_atomic_add(dh2[o] * h1[c], dP + DP_CONV2_W + o * 32 + c, lane);
+    }
+    dh1[c] = (h1[c] > 0.f) ? acc : 0.f;
+    wave_atomic_add(dh1[c], dP + DP_CONV0_B + c, lane);
+  }
+#pragma unroll
+  for (int o = 0; o < 32; ++o)
+#pragma unroll
+    for (int c = 0; c < 6; ++c) wave_atomic_add(dh1[o] * x[c], dP + DP_CONV0_W + o * 6 + c, lane);
+}
+
+// shape discriminator: forward, weight gradients of mean((s-target)^2), per-pose squared error
+__global__ __launch_bounds__(64) void k_shape_disc_bwd_params(const float* __restrict__ P, const float* __restrict__ betas,
+                                                              float scale, float target, float* __restrict__ dP,
+                                                              float* __restrict__ sqerr, int B) {
+  const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
+  const bool ok = b < B;
+  float x[10], h1[10], h2[5];
+#pragma unroll
+  for (int i = 0; i < 10; ++i) x[i] = ok ? betas[(size_t)b * 10 + i] : 0.f;
+#pragma unroll
+  for (int o = 0; o < 10; ++o) {
+    float acc = P[100 + o];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc = fmaf(P[o * 10 + i], x[i], acc);
+    h1[o] = fmaxf(acc, 0.f);
+  }
+#pragma unroll
+  for (int o = 0; o < 5; ++o) {
+    float acc = P[160 + o];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) acc = fmaf(P[110 + o * 10 + i], h1[i], acc);
+    h2[o] = fmaxf(acc, 0.f);
+  }
+  float z = P[170];
+#pragma unroll
+  for (int i = 0; i < 5; ++i) z = fmaf(P[165 + i], h2[i], z);
+  const float s = sigmoidf(z);
+  if (ok && sqerr) sqerr[b] = (s - target) * (s - target);
+  const float dz = ok ? scale * (s - target) * s * (1.f - s) : 0.f;
+  float dh2[5], dh1[10];
+  wave_atomic_add(dz, dP + 170, lane);
+#pragma unroll
+  for (int i = 0; i < 5; ++i) {
+    wave_atomic_add(dz * h2[i], dP + 165 + i, lane);
+    dh2[i] = (h2[i] > 0.f) ? dz * P[165 + i] : 0.f;
+    wave_atomic_add(dh2[i], dP + 160 + i, lane);
+  }
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    float acc = 0.f;
+#pragma unroll
+    for (int o = 0; o < 5; ++o) {
+      acc = fmaf(P[110 + o * 10 + i], dh2[o], acc);
+      wave_atomic_add(dh2[o] * h1[i], dP + 110 + o * 10 + i, lane);
+    }
+    dh1[i] = (h1[i] > 0.f) ? acc : 0.f;
+    wave_atomic_add(dh1[i], dP + 100 + i, lane);
+  }
+#pragma unroll
+  for (int o = 0; o < 10; ++o)
+#pragma unroll
+    for (int i = 0; i < 10; ++i) wave_atomic_add(dh1[o] * x[i], dP + o * 10 + i, lane);
+}
+
+// sqerr[b] = sum_k (out[b][k] - target)^2
+__global__ void k_sqerr_rows(const float* __restrict__ out, int ncol, float target, float* __restrict__ sqerr, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int k = 0; k < ncol; ++k) { const float d = out[(size_t)b * ncol + k] - target; acc += d * d; }
+  sqerr[b] = acc;
+}
+
+int launch_rowdot_accum(const float* M, int ld, const float* vec, float* out, int rows, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(k_rowdot_accum, dim3(rows), dim3(256), 0, s, M, ld, vec, out, cols);
+  return 0;
+}
+int launch_disc_conv_bwd_params(const float* P, const float* x6d, const float* dH2T, float scale, float target,
+                                float* dparams, int B, int BP, hipStream_t s) {
+  hipLaunchKernelGGL(k_disc_conv_bwd_params, dim3((B + 63) / 64, NJ), dim3(64), 0, s, P, x6d, dH2T, scale, target, dparams, B, BP);
+  return 0;
+}
+int launch_shape_disc_bwd_params(const float* P, const float* betas, float scale, float target, float* dparams,
+                                 float* sqerr, int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_shape_disc_bwd_params, dim3((B + 63) / 64), dim3(64), 0, s, P, betas, scale, target, dparams, sqerr, B);
+  return 0;
+}
+int launch_sqerr_rows(const float* out, int ncol, float target, float* sqerr, int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_sqerr_rows, dim3((B + 255) / 256), dim3(256), 0, s, out, ncol, target, sqerr, B);
+  return 0;
+}
+
 // [rows][cols] -> [cols][rows]
 __global__ void k_transpose(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
   __shared__ float t[32][33];
@@ -205,14 +362,14 @@ int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* ou
   hipLaunchKernelGGL(k_disc_conv_fwd, dim3(BP / 64, NJ), dim3(64), 0, s, P, x6d, H2T, out, B, BP);
   return 0;
 }
-int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, float scale, float target, int B, int BP,
-                    hipStream_t s) {
-  hipLaunchKernelGGL(k_disc_out, dim3(BP / 64), dim3(1024), 0, s, P, A2T, out, dA2T, scale, target, B, BP);
+int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
+                    float target, int B, int BP, hipStream_t s, float* dz0) {
+  hipLaunchKernelGGL(k_disc_out, dim3(BP / 64), dim3(1024), 0, s, P, A2T, out, dA2T, gout, scale, target, B, BP, dz0);
   return 0;
 }
-int launch_disc_conv_bwd(const float* P, const float* x6d, const float* dH2T, float scale, float target, float* gx,
-                         int B, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_disc_conv_bwd, dim3((B + 63) / 64, NJ), dim3(64), 0, s, P, x6d, dH2T, scale, target, gx, B, BP);
+int launch_disc_conv_bwd(const float* P, const float* x6d, const float* dH2T, const float* gout, float scale,
+                         float target, float* gx, int B, int BP, hipStream_t s) {
+  hipLaunchKernelGGL(k_disc_conv_bwd, dim3((B + 63) / 64, NJ), dim3(64), 0, s, P, x6d, dH2T, gout, scale, target, gx, B, BP);
   return 0;
 }
 int launch_shape_disc(const float* P, const float* betas, float* out, float* gb, float scale, float target, int B,

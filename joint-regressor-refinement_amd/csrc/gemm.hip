@@ -112,6 +112,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
         if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
         if (EPI == EPI_BIAS) v = v + bias;
         if (EPI == EPI_MASK) v = (g.mask[(size_t)m * g.ldo + n] > 0.f) ? v : 0.f;
+        if (EPI == EPI_ACCUM) v += out[(size_t)m * g.ldo + n];
         out[(size_t)m * g.ldo + n] = v;
       }
     }
@@ -130,6 +131,7 @@ static int launch_cfg(const GemmArgs& g, int epi, int nsplit, hipStream_t s) {
     case EPI_BIAS_RELU: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_BIAS_RELU>), grid, block, 0, s, g); break;
     case EPI_BIAS: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_BIAS>), grid, block, 0, s, g); break;
     case EPI_MASK: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_MASK>), grid, block, 0, s, g); break;
+    case EPI_ACCUM: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_ACCUM>), grid, block, 0, s, g); break;
     default: return JRR_ERR_ARG;
   }
   return 0;

@@ -9,7 +9,7 @@ constexpr int DP_CONV0_W = 0, DP_CONV0_B = 192, DP_CONV2_W = 224, DP_CONV2_B = 1
 constexpr int DP_FC0_W = 2072, DP_FC0_B = 788504, DP_FC2_W = 789528, DP_FC2_B = 1838104;
 constexpr int DP_FC4_W = 1839128, DP_FC4_B = 1840152, DP_TOTAL = 1840153;
 
-enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_BIAS = 3 };
+enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_BIAS = 3, EPI_ACCUM = 4 };
 
 struct GemmArgs {
   const float* A; int lda;      // A[k][m]
@@ -70,10 +70,16 @@ int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 // disc.hip
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
 int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s);
-int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, float scale, float target, int B, int BP,
-                    hipStream_t s);
-int launch_disc_conv_bwd(const float* P, const float* x6d, const float* dH2T, float scale, float target, float* gx,
-                         int B, int BP, hipStream_t s);
+int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
+                    float target, int B, int BP, hipStream_t s, float* dz0 = nullptr);
+int launch_rowdot_accum(const float* M, int ld, const float* vec, float* out, int rows, int cols, hipStream_t s);
+int launch_disc_conv_bwd_params(const float* P, const float* x6d, const float* dH2T, float scale, float target,
+                                float* dparams, int B, int BP, hipStream_t s);
+int launch_shape_disc_bwd_params(const float* P, const float* betas, float scale, float target, float* dparams,
+                                 float* sqerr, int B, hipStream_t s);
+int launch_sqerr_rows(const float* out, int ncol, float target, float* sqerr, int B, hipStream_t s);
+int launch_disc_conv_bwd(const float* P, const float* x6d, const float* dH2T, const float* gout, float scale,
+                         float target, float* gx, int B, int BP, hipStream_t s);
 int launch_shape_disc(const float* P, const float* betas, float* out, float* gb, float scale, float target, int B,
                       hipStream_t s);
 

@@ -51,13 +51,15 @@ class Discriminator(nn.Module):
 class _PoseDiscFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, eng):
+        x = x.detach().contiguous().float()
         ctx.eng = eng
         ctx.save_for_backward(x)
-        return eng.pose_disc_forward(x.detach())
+        return eng.pose_disc_forward(x)
 
     @staticmethod
     def backward(ctx, gout):
-        raise NotImplementedError('use RefineEngine.pose_disc_backward_input (MSE adjoint is fused in the kernel)')
+        (x,) = ctx.saved_tensors
+        return ctx.eng.pose_disc_vjp_input(x, gout.contiguous()), None
 
 
 class Shape_Discriminator(nn.Module):

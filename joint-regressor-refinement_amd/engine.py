@@ -171,6 +171,40 @@ class RefineEngine:
                                                     self._s()), 'pose_disc_backward_input')
         return dx
 
+    def pose_disc_backward_params(self, x6d, target: float, dparams: torch.Tensor):
+        """dparams += d mean((D(x)-target)^2)/d weights; returns per-pose sum_k (D-target)^2"""
+        self._chk(x6d, (self.batch, NUM_JOINTS, 6), 'x6d')
+        self._chk(dparams, (DISC_PARAMS,), 'dparams')
+        sq = torch.empty(self.batch, device=self.device)
+        check(self.lib.jrr_pose_disc_backward_params(self.handle, ptr(x6d), float(target), ptr(dparams), ptr(sq), self._s()),
+              'pose_disc_backward_params')
+        return sq
+
+    def shape_disc_backward_params(self, betas, target: float, dparams: torch.Tensor):
+        self._chk(betas, (self.batch, NUM_BETAS), 'betas')
+        self._chk(dparams, (SHAPE_DISC_PARAMS,), 'dparams')
+        sq = torch.empty(self.batch, device=self.device)
+        check(self.lib.jrr_shape_disc_backward_params(self.handle, ptr(betas), float(target), ptr(dparams), ptr(sq), self._s()),
+              'shape_disc_backward_params')
+        return sq
+
+    def pose_disc_vjp_input(self, x6d, gout):
+        """input gradient for an arbitrary upstream gradient gout (B,25); follows pose_disc_forward"""
+        self._chk(gout, (self.batch, 25), 'gout')
+        dx = torch.empty(self.batch, NUM_JOINTS, 6, device=self.device)
+        check(self.lib.jrr_pose_disc_vjp_input(self.handle, ptr(x6d), ptr(gout), ptr(dx), self._s()), 'pose_disc_vjp_input')
+        return dx
+
+    def smpl_vertices_backward(self, betas, dverts, x6d=None, R=None):
+        B = self.batch
+        self._chk(dverts, (B, NUM_VERTS, 3), 'dverts')
+        dx = torch.empty(B, NUM_JOINTS, 6, device=self.device) if x6d is not None else None
+        dR = torch.empty(B, NUM_JOINTS, 3, 3, device=self.device) if R is not None else None
+        db = torch.empty(B, NUM_BETAS, device=self.device)
+        check(self.lib.jrr_smpl_vertices_backward(self.handle, ptr(x6d), ptr(R), ptr(betas), ptr(dverts), ptr(dx), ptr(dR),
+                                                  ptr(db), self._s()), 'smpl_vertices_backward')
+        return (dx if x6d is not None else dR), db
+
     def refine_run(self, x6d, betas, gt_centred_mm, adam_m, adam_v, step, lr: float, n_iters: int, sqerr=None):
         B = self.batch
         self._chk(x6d, (B, NUM_JOINTS, 6), 'x6d')

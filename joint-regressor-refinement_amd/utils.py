@@ -1,0 +1,125 @@
+"""Joint-regression operators of the reference (/root/reference/scripts/utils.py) on the HIP path.
+
+  find_joints       scripts/utils.py:85-103   fused SMPL + J_regressor contraction, differentiable
+                                               w.r.t. shape, orient, pose and J_regressor
+  move_pelvis       scripts/utils.py:106-114
+  evaluate          scripts/utils.py:117-145  (torch ops on device; "next" row f3 of SURVEY.md)
+  find_j_reg_mask   scripts/utils.py:182-187  (reproduces the reference's all-ones mask)
+  rot6d_to_rotmat   scripts/utils.py:190-204  (row-wise cross product for every N)
+  set_seed          scripts/utils.py:207-215
+"""
+from __future__ import annotations
+
+import random
+
+import numpy as np
+import torch
+
+from . import engine as _engine
+
+
+class _Rot6dFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.detach().contiguous().float()
+        ctx.save_for_backward(x)
+        return _engine.rot6d_forward(x)
+
+    @staticmethod
+    def backward(ctx, dR):
+        (x,) = ctx.saved_tensors
+        return _engine.rot6d_backward(x, dR.contiguous()).view_as(x)
+
+
+def rot6d_to_rotmat(x: torch.Tensor) -> torch.Tensor:
+    """(N*6,) / (N,6) / (...,6) -> (N,3,3); columns of R are b1, b2, b3."""
+    return _Rot6dFn.apply(x.reshape(-1, 6))
+
+
+class _FindJointsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, R, betas, J, mask, eng):
+        R, betas = R.detach().contiguous(), betas.detach().contiguous()
+        eng.set_j_regressor(J.detach(), None if mask is None else mask.detach())
+        joints = eng.find_joints_forward(betas, R=R)
+        ctx.eng = eng
+        ctx.need_dJ = J.requires_grad
+        ctx.save_for_backward(R, betas)
+        return joints
+
+    @staticmethod
+    def backward(ctx, dj):
+        R, betas = ctx.saved_tensors
+        dR, db, dJ = ctx.eng.find_joints_backward(betas, dj.contiguous(), R=R, want_dJ=ctx.need_dJ)
+        return dR, db, dJ, None, None
+
+
+def find_joints(smpl, shape, orient, pose, J_regressor, mask=None, return_verts=False):
+    """J*mask -> ReLU -> row-normalise -> SMPL vertices -> batched J.V product.  `smpl` is a
+    joint-regressor-refinement_amd.smpl.SMPL; orient (B,1,3,3), pose (B,23,3,3), shape (B,10)."""
+    if return_verts:
+        # composition exactly as written in the reference (utils.py:87-101), on the HIP SMPL operator
+        Jm = J_regressor * mask if mask is not None else J_regressor
+        Jn = torch.relu(Jm)
+        Jn = Jn / torch.sum(Jn, dim=1).unsqueeze(1).expand(Jn.shape)
+        verts = smpl(global_orient=orient, body_pose=pose, betas=shape, pose2rot=False).vertices
+        return torch.matmul(Jn[None].expand(verts.shape[0], -1, -1), verts), verts
+    B = shape.shape[0]
+    R = torch.cat([orient.reshape(B, 1, 3, 3), pose.reshape(B, 23, 3, 3)], dim=1).float()
+    flags = _engine.FLAG_KEEP_VERTS if J_regressor.requires_grad else 0
+    eng = smpl.engine(B, flags)
+    return _FindJointsFn.apply(R, shape.float(), J_regressor, mask, eng)
+
+
+def move_pelvis(j3ds: torch.Tensor) -> torch.Tensor:
+    return j3ds - j3ds[:, [0], :]
+
+
+def find_j_reg_mask(j_reg: torch.Tensor) -> torch.Tensor:
+    """The reference builds both branches of torch.where from torch.ones (utils.py:183-184), so its
+    mask is identically 1; reproduced for parity (sparsity is preserved by ReLU'(0) = 0 anyway)."""
+    ones = torch.ones_like(j_reg)
+    return torch.where(j_reg == 0, ones, ones)
+
+
+def batch_compute_similarity_transform_torch(S1, S2):
+    """scripts/eval_utils.py:7-58 (Procrustes alignment), torch ops on the input's device."""
+    transposed = False
+    if S1.shape[0] != 3 and S1.shape[0] != 2:
+        S1, S2 = S1.permute(0, 2, 1), S2.permute(0, 2, 1)
+        transposed = True
+    mu1, mu2 = S1.mean(dim=-1, keepdim=True), S2.mean(dim=-1, keepdim=True)
+    X1, X2 = S1 - mu1, S2 - mu2
+    var1 = torch.sum(X1 ** 2, dim=1).sum(dim=1)
+    K = X1.bmm(X2.permute(0, 2, 1))
+    U, s, Vh = torch.linalg.svd(K.cpu())       # 3x3 SVDs: host LAPACK (logging path only)
+    U, V = U.to(S1.device), Vh.transpose(1, 2).to(S1.device)
+    Z = torch.eye(3, device=S1.device).unsqueeze(0).repeat(U.shape[0], 1, 1)
+    Z[:, -1, -1] *= torch.sign(torch.det(U.bmm(V.permute(0, 2, 1))))
+    R = V.bmm(Z.bmm(U.permute(0, 2, 1)))
+    scale = torch.diagonal(R.bmm(K), dim1=1, dim2=2).sum(1) / var1
+    t = mu2 - scale[:, None, None] * R.bmm(mu1)
+    S1_hat = scale[:, None, None] * R.bmm(S1) + t
+    return S1_hat.permute(0, 2, 1) if transposed else S1_hat
+
+
+def evaluate(pred_j3ds: torch.Tensor, target_j3ds: torch.Tensor):
+    """MPJPE and PA-MPJPE in mm (pred in m, target in mm), scripts/utils.py:117-145."""
+    with torch.no_grad():
+        pred = pred_j3ds.clone().detach()
+        target = target_j3ds.clone().detach() / 1000
+        pred = pred - pred[:, [0], :]
+        target = target - target[:, [0], :]
+        errors = torch.sqrt(((pred - target) ** 2).sum(dim=-1)).mean(dim=-1).cpu().numpy()
+        S1_hat = batch_compute_similarity_transform_torch(pred, target)
+        errors_pa = torch.sqrt(((S1_hat - target) ** 2).sum(dim=-1)).mean(dim=-1).cpu().numpy()
+        return np.mean(errors) * 1000, np.mean(errors_pa) * 1000
+
+
+def set_seed(seed: int):
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed(seed)
+        torch.cuda.manual_seed_all(seed)
+    np.random.seed(seed)
+    random.seed(seed)

@@ -351,7 +351,7 @@ def refine_poses(smpl, J_regressor, orient6d, pose6d, betas, gt_j3d_mm_centred, 
                             g_orient=orient.grad.clone(), g_pose=pose.grad.clone(), g_betas=b.grad.clone(),
                             **{k: v.detach().clone() for k, v in terms.items()}))
         opt.step()
-        hist.append({'loss': float(loss), **{k: float(v) for k, v in terms.items()}})
+        hist.append({"loss": float(loss.detach()), **{k: float(v.detach()) for k, v in terms.items()}})
     return orient.detach(), pose.detach(), b.detach(), hist
 
 

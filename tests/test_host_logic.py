@@ -1,0 +1,151 @@
+"""CPU-only checks: flag surface, checkpoint format, C-ABI export table, data-parallel host logic."""
+import importlib
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import PKG_NAME, ROOT
+
+T = torch.from_numpy
+
+
+def _mod(name):
+    return importlib.import_module(f'{PKG_NAME}.{name}')
+
+
+def test_reference_flags_kept():
+    """the 15 flags of the reference's scripts/args.py:5-21: same names, types, defaults"""
+    a = _mod('args')
+    ns = a.get_args([])
+    for k, v in a.REFERENCE_FLAGS.items():
+        assert hasattr(ns, k), k
+        assert getattr(ns, k) == v, (k, getattr(ns, k), v)
+    ns2 = a.get_args(['--batch_size', '32', '--j_reg_lr', '0.5', '--wandb_log', '--device', 'cuda:1', '--unknown_flag', '3'])
+    assert ns2.batch_size == 32 and ns2.j_reg_lr == 0.5 and ns2.wandb_log is True and ns2.device == 'cuda:1'
+
+
+def test_checkpoint_format_roundtrip(tmp_path, j_h36m_np):
+    ck = _mod('checkpoint')
+    J = T(j_h36m_np)
+    p = str(tmp_path / 'retrained_J_Regressor.pt')
+    ck.save_j_regressor(J, p)
+    raw = torch.load(p, weights_only=True)               # what the reference's readers do (test.py:46-47)
+    assert torch.is_tensor(raw) and raw.shape == (17, 6890) and raw.dtype == torch.float32
+    assert raw.stride() == (1, 17) and raw.requires_grad      # layout of the shipped artefact
+    assert torch.equal(raw.detach(), J)
+    assert torch.equal(ck.load_j_regressor(p), J)
+    # arbitrary strides / requires_grad written by someone else
+    weird = torch.zeros(6890, 17)
+    weird.t()[:] = J
+    torch.save(weird.t().requires_grad_(True), p)
+    assert torch.equal(ck.load_j_regressor(p), J)
+    torch.save(torch.zeros(3, 3), p)
+    with pytest.raises(ValueError):
+        ck.load_j_regressor(p)
+    # 107 non-zeros, 62 positive: the shipped checkpoint's support
+    assert int((J != 0).sum()) == 107 and int((J > 0).sum()) == 62
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """include/jrr.h <-> libjrr_hip.so <-> the ctypes table agree (no compute: no GPU needed)."""
+    hdr = open(os.path.join(ROOT, 'include', 'jrr.h')).read()
+    declared = set(re.findall(r'\b(jrr_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'jrr_status'}
+    lib_mod = _mod('_lib')
+    _mod('build').build(verbose=False)
+    lib = lib_mod.load()
+    assert declared == set(lib_mod.SIGNATURES), declared ^ set(lib_mod.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.jrr_version() >= 100
+    assert lib.jrr_engine_workspace_bytes(4096, 5) > 2 * 3 * 6912 * 4096 * 4
+    # error behaviour: negative status + message, no exception across the boundary
+    import ctypes
+    rc = lib.jrr_engine_create(None, 4, 4, None, 0, 0, ctypes.byref(ctypes.c_void_p()))
+    assert rc == -1 and b'bad argument' in lib.jrr_last_error()
+
+
+def test_product_path_has_no_oracle_import():
+    """only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline may touch oracle/"""
+    pkg_dir = os.path.join(ROOT, PKG_NAME)
+    for dp, _, files in os.walk(pkg_dir):
+        for f in files:
+            if f.endswith(('.py', '.hip', '.h')):
+                src = open(os.path.join(dp, f)).read()
+                assert not re.search(r'^\s*(import|from)\s+oracle', src, re.M), os.path.join(dp, f)
+
+
+def test_shard_bounds_cover_batch():
+    d = _mod('dist')
+    for n, w in [(32768, 8), (4096, 2), (10, 3), (5, 8)]:
+        edges = [d.shard_bounds(n, r, w) for r in range(w)]
+        assert edges[0][0] == 0 and edges[-1][1] == n
+        assert all(edges[i][1] == edges[i + 1][0] for i in range(w - 1))
+        assert max(h - l for l, h in edges) - min(h - l for l, h in edges) <= 1
+
+
+_DP_WORKER = r'''
+import importlib, os, sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+import oracle
+PKG = "joint-regressor-refinement_amd"
+d = importlib.import_module(PKG + ".dist")
+sm = importlib.import_module(PKG + ".smpl_model")
+import torch.distributed as dist
+dist.init_process_group("gloo")
+rank, world = dist.get_rank(), dist.get_world_size()
+T = torch.from_numpy
+model = sm.synthetic_smpl(1234)
+J0 = T(sm.default_h36m_regressor())
+B = 12
+full = sm.synthetic_batch(model, J0.numpy(), B, seed=77)
+lo, hi = d.shard_bounds(B, rank, world)
+smpl = oracle.OracleSMPL(model)
+x6, betas = T(full["pose6d"]), T(full["betas"])
+gt_c = oracle.move_pelvis(T(full["gt_j3d"]))
+# rank-local inner loop with the GLOBAL batch as the MSE normaliser, then the shared J step
+o, p, b, _ = oracle.refine_poses(smpl, J0, x6[lo:hi, :1], x6[lo:hi, 1:], betas[lo:hi], gt_c[lo:hi], 2, batch_norm=B)
+_, gJ, _ = oracle.j_regressor_loss_and_grad(smpl, J0, o, p, b, gt_c[lo:hi], batch_norm=B)
+J = J0.clone(); m = torch.zeros_like(J); v = torch.zeros_like(J)
+d.shared_adam_step(J, gJ, m, v, 1, 1e-2, lambda P, G, M, V, s, lr: oracle.adam_step(P, G, M, V, s, lr))
+# flat bucket all-reduce helper
+a, c = torch.full((3,), float(rank + 1)), torch.full((2, 2), float(rank + 1))
+d.flat_all_reduce_sum_([a, c])
+assert a.tolist() == [sum(range(1, world + 1))] * 3 and c.flatten().tolist() == [sum(range(1, world + 1))] * 4
+if rank == 0:
+    np.savez(sys.argv[2], J=J.numpy(), o=o.numpy(), lo=lo, hi=hi)
+dist.barrier()
+dist.destroy_process_group()
+'''
+
+
+def test_data_parallel_j_step_equals_single_process(tmp_path, smpl_model_np, j_h36m_np):
+    """world_size-2 gloo run of the sharded inner loop + all-reduced J step == the single-process run."""
+    script = tmp_path / 'dp_worker.py'
+    script.write_text(_DP_WORKER)
+    out = str(tmp_path / 'dp.npz')
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', MASTER_PORT='29533', OMP_NUM_THREADS='2')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node=2', '--master-addr', '127.0.0.1',
+           '--master-port', '29533', str(script), ROOT, out]
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    got = np.load(out)
+    sm = _mod('smpl_model')
+    B = 12
+    full = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=77)
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    x6, betas = T(full['pose6d']), T(full['betas'])
+    gt_c = oracle.move_pelvis(T(full['gt_j3d']))
+    J0 = T(j_h36m_np)
+    o, p, b, _ = oracle.refine_poses(smpl, J0, x6[:, :1], x6[:, 1:], betas, gt_c, 2)
+    _, gJ, _ = oracle.j_regressor_loss_and_grad(smpl, J0, o, p, b, gt_c)
+    J = J0.clone()
+    oracle.adam_step(J, gJ, torch.zeros_like(J), torch.zeros_like(J), 1, 1e-2)
+    np.testing.assert_allclose(got['o'], o[int(got['lo']):int(got['hi'])].numpy(), rtol=0, atol=1e-6)
+    np.testing.assert_allclose(got['J'], J.numpy(), rtol=0, atol=1e-6)
