@@ -121,15 +121,29 @@ struct jrr_engine {
   std::vector<hipEvent_t>* ev[JRR_PROF_CLASSES];
 };
 
+// number of vertex chunks such that the grid fills whole "rounds" of the chip's resident
+// workgroup slots (256 CUs x 2 workgroups): a grid of 1.1 rounds costs 2 rounds of time.
+static int pick_chunks(int wg_per_chunk, int max_chunks) {
+  const int slots = 512;
+  int best = 1;
+  double best_score = -1.0;
+  for (int n = 1; n <= max_chunks; ++n) {
+    const int total = wg_per_chunk * n;
+    const int rounds = (total + slots - 1) / slots;
+    const double fill = (double)total / ((double)rounds * slots);
+    // tiles per chunk differ by at most one: the longest chunk sets the time of its round
+    const double tiles = 216.0 / n;
+    const double balance = tiles / (double)((216 + n - 1) / n);
+    const double score = fill * balance - 0.0002 * n;   // prefer fewer chunks at equal efficiency
+    if (score > best_score) { best_score = score; best = n; }
+  }
+  return best;
+}
+
 static void plan_geometry(int BP, int& nvc, int& nvcb, int& nsplit, int& nsplitJ) {
   const int nbg = BP / BG;
-  nvc = (512 + nbg - 1) / nbg;
-  if (nvc > 54) nvc = 54;
-  if (nvc < 1) nvc = 1;
-  const int witems = (BP / BT) * 3;
-  nvcb = (2048 + witems - 1) / witems;
-  if (nvcb > 36) nvcb = 36;
-  if (nvcb < 1) nvcb = 1;
+  nvc = pick_chunks(nbg, 54);                       // forward: one workgroup per (128 poses, chunk)
+  nvcb = pick_chunks((BP / BT) * 3 / 4, 36);        // backward: one workgroup per 4 (pose tile, plane) items
   nsplit = (512 + nbg - 1) / nbg;
   if (nsplit > 32) nsplit = 32;
   if (nsplit < 1) nsplit = 1;
