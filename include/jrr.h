@@ -81,6 +81,10 @@ int jrr_engine_create(const jrr_model_t* model, int batch, int batch_norm, void*
                       size_t workspace_bytes, int flags, jrr_engine_t** out);
 void jrr_engine_destroy(jrr_engine_t* e);
 int jrr_engine_set_batch_norm(jrr_engine_t* e, int batch_norm);
+/* 1 = every launch of jrr_refine_run on the caller's stream; 2 (default) = the discriminator branch
+ * of each iteration runs on an engine-owned second stream, forked from / joined back into the
+ * caller's stream with events (the two branches only meet in the Adam update).                */
+int jrr_engine_set_concurrency(jrr_engine_t* e, int streams);
 
 /* J*mask -> ReLU -> row-normalise (scripts/utils.py:87-92), into the engine's tile-major
  * copies.  J_dev: (17,6890) row-major raw parameter; mask_dev may be NULL.                   */

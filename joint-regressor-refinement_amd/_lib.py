@@ -26,6 +26,7 @@ SIGNATURES = {
     'jrr_engine_create': (c_int, [_P, c_int, c_int, _P, c_size_t, c_int, POINTER(_P)]),
     'jrr_engine_destroy': (None, [_P]),
     'jrr_engine_set_batch_norm': (c_int, [_P, c_int]),
+    'jrr_engine_set_concurrency': (c_int, [_P, c_int]),
     'jrr_engine_set_j_regressor': (c_int, [_P, _P, _P, _P]),
     'jrr_engine_set_pose_disc': (c_int, [_P, _P, _P]),
     'jrr_engine_set_shape_disc': (c_int, [_P, _P, _P]),

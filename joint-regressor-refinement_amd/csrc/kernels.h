@@ -32,6 +32,7 @@ struct PrepBwdLaunch {
   const int32_t* step = nullptr;
   float lr = 0, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
   int B = 0, BP = 0;
+  hipEvent_t wait_before_update = nullptr;   // the update kernel also needs the discriminator branch's gx
 };
 
 // prep.hip

@@ -583,6 +583,7 @@ int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
   ensure_attrs();
   hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + 63) / 64), dim3(64), NJ * 12 * 64 * 4, s, L.FT, L.R0T, L.AT, m.Jt, m.JS,
                      m.parents, L.dATp, L.dFTp, L.dRT, L.dbT, L.B, L.BP);
+  if (L.wait_before_update) (void)hipStreamWaitEvent(s, L.wait_before_update, 0);
   PoseUpdateArgs a;
   a.x6d_in = L.x6d_in; a.dRT = L.dRT; a.dbT = L.dbT; a.gx_extra = L.gx_extra; a.gb_extra = L.gb_extra;
   a.dx6d = L.dx6d; a.dR = L.dR; a.dbetas = L.dbetas;

@@ -119,6 +119,9 @@ class RefineEngine:
     def set_batch_norm(self, n: int):
         check(self.lib.jrr_engine_set_batch_norm(self.handle, int(n)), 'set_batch_norm')
 
+    def set_concurrency(self, streams: int):
+        check(self.lib.jrr_engine_set_concurrency(self.handle, int(streams)), 'set_concurrency')
+
     def set_j_regressor(self, J: torch.Tensor, mask: Optional[torch.Tensor] = None):
         J = J.detach().to(self.device, torch.float32).contiguous()      # any stride / device tag
         self._chk(J, (NUM_H36M, NUM_VERTS), 'J_regressor')
