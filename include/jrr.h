@@ -153,6 +153,21 @@ int jrr_shape_disc_backward_params(jrr_engine_t* e, const float* betas_dev, floa
 int jrr_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, size_t n,
                   const int32_t* step_dev, float lr, float beta1, float beta2, float eps, void* stream);
 
+/* ---- 2-D reprojection --------------------------------------------
+ * return_2d_joints core, scripts/renderer.py:35-49 (pytorch3d 0.3.0 PerspectiveCameras, R = I,
+ * T = cam, focal 5000/224 NDC, 224x224): joints (B,17,3), cam (B,3) -> screen xy (B,17,2).       */
+int jrr_project_joints(const float* joints_dev, const float* cam_dev, float* j2d_dev, int batch, void* stream);
+/* Enable (gt_j2d_dev != NULL) / disable the 2-D term  mean((gt_j2d - joints_2d)^2)/100  of the inner
+ * loop (scripts/optimize.py:231-233,252); the camera translation then joins the Adam parameters
+ * (optimize.py:201-202): cam (B,3) in place, cam_m / cam_v (B,3) its Adam state.                   */
+int jrr_engine_set_reprojection(jrr_engine_t* e, const float* gt_j2d_dev, float* cam_dev, float* cam_m_dev,
+                                float* cam_v_dev);
+/* Camera pre-fit, scripts/optimize.py:187-199: n_steps Adam(lr) steps on cam against the 2-D joints
+ * of the current pose.  The joints do not depend on the camera, so SMPL runs ONCE and the n_steps
+ * run inside one kernel.  sq2d_dev (B, nullable): squared 2-D error at the last evaluation.        */
+int jrr_camera_prefit(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev, const float* gt_j2d_dev,
+                      float* cam_dev, int n_steps, float lr, float* sq2d_dev, void* stream);
+
 /* ---- fused inner loop ---------------------------------------------------------------------
  * n_iters iterations of scripts/optimize.py:220-265 restricted to the engine's loss terms:
  * rot6d->R, SMPL, J-regress, pelvis-centre, MSE x10000 [+ pose-D x10] [+ shape-D x10],

@@ -119,6 +119,8 @@ struct jrr_engine {
   int32_t* step_scratch;
   bool profiling;
   std::vector<hipEvent_t>* ev[JRR_PROF_CLASSES];
+  const float* gt_j2d; float* cam; float* cam_m; float* cam_v;   // 2-D reprojection term (nullable)
+  float *gcam, *sq2d;
   int streams;                 // 1 or 2
   hipStream_t s2;              // discriminator branch
   hipEvent_t ev_fork, ev_join;
@@ -193,6 +195,8 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   t->joints = c.take((size_t)BP * NH * 3);
   t->sqerr = c.take((size_t)BP);
   t->step_scratch = (int32_t*)c.take(64);
+  t->gcam = c.take((size_t)BP * 3);
+  t->sq2d = c.take((size_t)BP);
   if (flags & JRR_FLAG_POSE_DISC) {
     t->Pd = c.take(DP_TOTAL);
     t->W0T = c.take((size_t)768 * 1024);
@@ -620,6 +624,37 @@ extern "C" int jrr_adam_step(float* p, const float* g, float* m, float* v, size_
 }
 
 // =============================================================================================
+// 2-D reprojection (row f1)
+// =============================================================================================
+extern "C" int jrr_project_joints(const float* joints, const float* cam, float* j2d, int batch, void* stream) {
+  if (!joints || !cam || !j2d || batch <= 0) return JRR_ERR_ARG;
+  launch_project_joints(joints, cam, j2d, batch, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_engine_set_reprojection(jrr_engine_t* e, const float* gt_j2d, float* cam, float* cam_m, float* cam_v) {
+  if (!e) return JRR_ERR_ARG;
+  if (gt_j2d && (!cam || !cam_m || !cam_v)) { jrr_set_error("set_reprojection: cam / cam_m / cam_v required"); return JRR_ERR_ARG; }
+  e->gt_j2d = gt_j2d; e->cam = cam; e->cam_m = cam_m; e->cam_v = cam_v;
+  return JRR_OK;
+}
+
+extern "C" int jrr_camera_prefit(jrr_engine_t* e, const float* x6d, const float* betas, const float* gt_j2d, float* cam,
+                                 int n_steps, float lr, float* sq2d, void* stream) {
+  if (!e || !x6d || !betas || !gt_j2d || !cam || n_steps < 0) return JRR_ERR_ARG;
+  if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  smpl_forward(e, x6d, nullptr, betas, false, nullptr, 0, nullptr, s);
+  reduce_joint_partials(e, s);
+  launch_joints_loss(e->Jsum, 1, nullptr, nullptr, 0.f, e->joints, nullptr, nullptr, e->B, e->BP, s);
+  const float scale2d = (float)(2.0 / ((double)e->bnorm * 34.0));     // optimize.py:193 unweighted MSE
+  launch_camera_fit(e->joints, gt_j2d, cam, scale2d, n_steps, lr, sq2d, e->B, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+// =============================================================================================
 // fused inner loop (scripts/optimize.py:220-265)
 // =============================================================================================
 extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const float* gt_mm, float* adam_m,
@@ -658,7 +693,9 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     prof_mark(e, 1, s);
     prof_mark(e, 2, s);
     reduce_joint_partials(e, s);
-    launch_joints_loss(e->Jsum, 1, gt_mm, nullptr, jscale, e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);
+    ReprojLaunch rl{e->gt_j2d, e->cam, e->gcam, e->sq2d, (float)(2.0 * 0.01 / ((double)e->bnorm * 34.0))};   // weight 1/100
+    launch_joints_loss(e->Jsum, 1, gt_mm, nullptr, jscale, e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s,
+                       e->gt_j2d ? &rl : nullptr);
     prof_mark(e, 2, s);
     prof_mark(e, 3, s);
     launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
@@ -689,6 +726,7 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step;
     L.lr = lr; L.B = e->B; L.BP = e->BP;
     L.wait_before_update = fork ? e->ev_join : nullptr;
+    if (e->gt_j2d) { L.gcam = e->gcam; L.cam_io = e->cam; L.cam_m = e->cam_m; L.cam_v = e->cam_v; }
     launch_prep_bwd(L, e->m, s);
     prof_mark(e, 7, s);
   }

@@ -32,8 +32,11 @@ struct PrepBwdLaunch {
   const int32_t* step = nullptr;
   float lr = 0, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
   int B = 0, BP = 0;
+  const float* gcam = nullptr; float* cam_io = nullptr; float* cam_m = nullptr; float* cam_v = nullptr;
   hipEvent_t wait_before_update = nullptr;   // the update kernel also needs the discriminator branch's gx
 };
+
+struct ReprojLaunch { const float* gt_j2d; const float* cam; float* gcam; float* sq2d; float scale2d; };
 
 // prep.hip
 int launch_rot6d_fwd(const float* x, float* R, int n, hipStream_t s);
@@ -41,7 +44,11 @@ int launch_rot6d_bwd(const float* x, const float* dR, float* dx, int n, hipStrea
 int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT,
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s);
 int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float* djoints_in, float scale,
-                       float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s);
+                       float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s,
+                       const ReprojLaunch* r = nullptr);
+int launch_project_joints(const float* joints, const float* cam, float* out, int B, hipStream_t s);
+int launch_camera_fit(const float* joints, const float* gt_j2d, float* cam, float scale2d, int nsteps, float lr, float* sq2d,
+                      int B, hipStream_t s);
 int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale, float* sqerr, float* djoints, int B,
                             hipStream_t s);
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s);

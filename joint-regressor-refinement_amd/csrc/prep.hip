@@ -218,14 +218,76 @@ __global__ __launch_bounds__(64) void k_prep_fwd(const float* __restrict__ x6d, 
 }
 
 // ------------------------------------------------------------------------------------------
-// k_joints_loss: reduce the per-vertex-chunk joint partials, write joints (B,17,3), and
-// (optionally) the joint-loss adjoint dJT [3][18][BP] = d(weight*mean((move_pelvis(j)-gt/1000)^2))/dj.
+// Adam (torch single-tensor formula): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
+// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), bias corrections evaluated in double like
+// torch's Python scalars.
+// ------------------------------------------------------------------------------------------
+struct AdamScalars { float step_size, bc2_sqrt, beta1, beta2, eps; };
+
+__device__ __forceinline__ AdamScalars adam_scalars(int step, float lr, float beta1, float beta2, float eps) {
+  AdamScalars s;
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  s.step_size = (float)((double)lr / bc1);
+  s.bc2_sqrt = (float)sqrt(bc2);
+  s.beta1 = beta1; s.beta2 = beta2; s.eps = eps;
+  return s;
+}
+
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamScalars& s) {
+  m = m * s.beta1 + (1.f - s.beta1) * g;
+  v = v * s.beta2 + (1.f - s.beta2) * g * g;
+  float denom = sqrtf(v) / s.bc2_sqrt + s.eps;
+  return p - s.step_size * (m / denom);
+}
+
+// ------------------------------------------------------------------------------------------
+// Perspective projection of the regressed joints (scripts/renderer.py:35-49 with pytorch3d 0.3.0
+// PerspectiveCameras, R = I, T = cam, focal 5000/224 in NDC, principal point 0, 224x224 screen;
+// SURVEY.md Appendix B):  X = -2x + tx, Y = -2y + ty, Z = 2z + tz ;  x_ndc = f X / Z ;
+// x_screen = (W-1)/2 (1 - x_ndc)  (same for y).
+// ------------------------------------------------------------------------------------------
+constexpr float PROJ_F = 5000.f / 224.f;
+constexpr float PROJ_HALF = (224.f - 1.f) * 0.5f;
+
+__device__ __forceinline__ void project_point(const float p[3], const float t[3], float& xs, float& ys, float& invZ,
+                                              float& X, float& Y) {
+  X = -2.f * p[0] + t[0];
+  Y = -2.f * p[1] + t[1];
+  const float Z = 2.f * p[2] + t[2];
+  invZ = 1.f / Z;
+  xs = PROJ_HALF * (1.f - PROJ_F * X * invZ);
+  ys = PROJ_HALF * (1.f - PROJ_F * Y * invZ);
+}
+
+// adjoint of the 2-D squared error of one joint: g2 = dL/d(xs,ys) -> accumulates dL/dp (3) and dL/dt (3)
+__device__ __forceinline__ void project_point_bwd(float gxs, float gys, float invZ, float X, float Y, float gp[3],
+                                                  float gt[3]) {
+  const float gxn = -PROJ_HALF * gxs, gyn = -PROJ_HALF * gys;       // d/dx_ndc
+  const float gX = gxn * PROJ_F * invZ, gY = gyn * PROJ_F * invZ;
+  const float gZ = -(gxn * X + gyn * Y) * PROJ_F * invZ * invZ;
+  gp[0] += -2.f * gX; gp[1] += -2.f * gY; gp[2] += 2.f * gZ;
+  gt[0] += gX; gt[1] += gY; gt[2] += gZ;
+}
+
+struct Reproj {
+  const float* gt_j2d;   // (B,17,2) or NULL (term disabled)
+  const float* cam;      // (B,3)
+  float* gcam;           // (B,3) out: dL/dcam
+  float* sq2d;           // (B) out: sum of squared 2-D errors (nullable)
+  float scale2d;         // 2*weight/(batch_norm*34)
+};
+
+// ------------------------------------------------------------------------------------------
+// k_joints_loss: joints (from the reduced partials [3][17][BP]) -> joints (B,17,3), per-pose squared
+// error, and the adjoint dJT [3][18][BP] of
+//     weight * mean((move_pelvis(j) - gt/1000)^2)   [+ weight2d * mean((gt_j2d - project(j, cam))^2)]
 //   scale = 2*weight/(batch_norm*51).  If djoints_in != NULL it is used as the adjoint instead
 //   (operator-level backward), transposed into dJT.
 // ------------------------------------------------------------------------------------------
 __global__ void k_joints_loss(const float* __restrict__ JP, int nvc, const float* __restrict__ gt_mm,
                               const float* __restrict__ djoints_in, float scale, float* __restrict__ joints_out,
-                              float* __restrict__ sqerr, float* __restrict__ dJT, int B, int BP) {
+                              float* __restrict__ sqerr, float* __restrict__ dJT, Reproj rp, int B, int BP) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= BP) return;
   if (b >= B) {
@@ -262,6 +324,7 @@ __global__ void k_joints_loss(const float* __restrict__ JP, int nvc, const float
     return;
   }
   if (!gt_mm) return;
+  float g[NH][3];
   float err = 0.f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
@@ -270,19 +333,96 @@ __global__ void k_joints_loss(const float* __restrict__ JP, int nvc, const float
     for (int i = 1; i < NH; ++i) {
       float d = (j[i][c] - j[0][c]) - gt_mm[((size_t)b * NH + i) * 3 + c] / 1000.f;
       err += d * d;
-      float g = scale * d;
-      gsum += g;
-      if (dJT) dJT[(size_t)(c * NHP + i) * BP + b] = g;
+      g[i][c] = scale * d;
+      gsum += g[i][c];
     }
     // joint 0: centred value is identically 0; gt is pelvis-centred by the caller (optimize.py:162)
     float d0 = -gt_mm[((size_t)b * NH + 0) * 3 + c] / 1000.f;
     err += d0 * d0;
-    if (dJT) {
-      dJT[(size_t)(c * NHP + 0) * BP + b] = -gsum;   // move_pelvis adjoint: -sum_i g_i (g_0 cancels)
+    g[0][c] = -gsum;   // move_pelvis adjoint: -sum_i g_i (g_0 cancels)
+  }
+  if (sqerr) sqerr[b] = err;
+  if (rp.gt_j2d) {     // 2-D reprojection term on the UN-centred joints (optimize.py:231-233)
+    float t[3] = {rp.cam[(size_t)b * 3], rp.cam[(size_t)b * 3 + 1], rp.cam[(size_t)b * 3 + 2]};
+    float gt3[3] = {0.f, 0.f, 0.f};
+    float e2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      float xs, ys, invZ, X, Y;
+      project_point(j[i], t, xs, ys, invZ, X, Y);
+      const float dx = xs - rp.gt_j2d[((size_t)b * NH + i) * 2], dy = ys - rp.gt_j2d[((size_t)b * NH + i) * 2 + 1];
+      e2 += dx * dx + dy * dy;
+      project_point_bwd(rp.scale2d * dx, rp.scale2d * dy, invZ, X, Y, g[i], gt3);
+    }
+    if (rp.sq2d) rp.sq2d[b] = e2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) rp.gcam[(size_t)b * 3 + c] = gt3[c];
+  }
+  if (dJT) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+#pragma unroll
+      for (int i = 0; i < NH; ++i) dJT[(size_t)(c * NHP + i) * BP + b] = g[i][c];
       dJT[(size_t)(c * NHP + NH) * BP + b] = 0.f;
     }
   }
-  if (sqerr) sqerr[b] = err;
+}
+
+// return_2d_joints core: joints (B,17,3), cam (B,3) -> screen coordinates (B,17,2)
+__global__ void k_project_joints(const float* __restrict__ joints, const float* __restrict__ cam, float* __restrict__ out,
+                                 int n) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over B*17
+  if (idx >= n) return;
+  const int b = idx / NH;
+  float p[3] = {joints[(size_t)idx * 3], joints[(size_t)idx * 3 + 1], joints[(size_t)idx * 3 + 2]};
+  float t[3] = {cam[(size_t)b * 3], cam[(size_t)b * 3 + 1], cam[(size_t)b * 3 + 2]};
+  float xs, ys, invZ, X, Y;
+  project_point(p, t, xs, ys, invZ, X, Y);
+  out[(size_t)idx * 2] = xs;
+  out[(size_t)idx * 2 + 1] = ys;
+}
+
+// Camera pre-fit (scripts/optimize.py:187-199): n Adam steps on the camera translation only, against the
+// 2-D joints.  The reference re-runs the whole SMPL forward every step although the joints do not depend
+// on the camera; here the joints are computed once and each thread runs its pose's n steps in registers.
+__global__ void k_camera_fit(const float* __restrict__ joints, const float* __restrict__ gt_j2d, float* __restrict__ cam,
+                             float scale2d, int nsteps, float lr, float* __restrict__ sq2d, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float j[NH][3], q[NH][2];
+#pragma unroll
+  for (int i = 0; i < NH; ++i) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) j[i][c] = joints[((size_t)b * NH + i) * 3 + c];
+    q[i][0] = gt_j2d[((size_t)b * NH + i) * 2];
+    q[i][1] = gt_j2d[((size_t)b * NH + i) * 2 + 1];
+  }
+  float t[3] = {cam[(size_t)b * 3], cam[(size_t)b * 3 + 1], cam[(size_t)b * 3 + 2]};
+  float m[3] = {0.f, 0.f, 0.f}, v[3] = {0.f, 0.f, 0.f};
+  double b1p = 1.0, b2p = 1.0;
+  float e2 = 0.f;
+  for (int s = 1; s <= nsteps; ++s) {
+    float gt3[3] = {0.f, 0.f, 0.f}, dummy[3] = {0.f, 0.f, 0.f};
+    e2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < NH; ++i) {
+      float xs, ys, invZ, X, Y;
+      project_point(j[i], t, xs, ys, invZ, X, Y);
+      const float dx = xs - q[i][0], dy = ys - q[i][1];
+      e2 += dx * dx + dy * dy;
+      project_point_bwd(scale2d * dx, scale2d * dy, invZ, X, Y, dummy, gt3);
+    }
+    b1p *= 0.9; b2p *= 0.999;
+    AdamScalars sc;
+    sc.step_size = (float)((double)lr / (1.0 - b1p));
+    sc.bc2_sqrt = (float)sqrt(1.0 - b2p);
+    sc.beta1 = 0.9f; sc.beta2 = 0.999f; sc.eps = 1e-8f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) t[c] = adam_update(t[c], gt3[c], m[c], v[c], sc);
+  }
+#pragma unroll
+  for (int c = 0; c < 3; ++c) cam[(size_t)b * 3 + c] = t[c];
+  if (sq2d) sq2d[b] = e2;     // error at the LAST evaluated camera (before the final update), as the reference's loss
 }
 
 // standalone joint loss on (B,17,3) joints (operator-level API: jrr_joint_loss)
@@ -306,30 +446,6 @@ __global__ void k_joint_loss_plain(const float* __restrict__ joints, const float
     if (djoints) djoints[((size_t)b * NH) * 3 + c] = -gsum;
   }
   if (sqerr) sqerr[b] = err;
-}
-
-// ------------------------------------------------------------------------------------------
-// Adam (torch single-tensor formula): m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ;
-// p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), bias corrections evaluated in double like
-// torch's Python scalars.
-// ------------------------------------------------------------------------------------------
-struct AdamScalars { float step_size, bc2_sqrt, beta1, beta2, eps; };
-
-__device__ __forceinline__ AdamScalars adam_scalars(int step, float lr, float beta1, float beta2, float eps) {
-  AdamScalars s;
-  double bc1 = 1.0 - pow((double)beta1, (double)step);
-  double bc2 = 1.0 - pow((double)beta2, (double)step);
-  s.step_size = (float)((double)lr / bc1);
-  s.bc2_sqrt = (float)sqrt(bc2);
-  s.beta1 = beta1; s.beta2 = beta2; s.eps = eps;
-  return s;
-}
-
-__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamScalars& s) {
-  m = m * s.beta1 + (1.f - s.beta1) * g;
-  v = v * s.beta2 + (1.f - s.beta2) * g * g;
-  float denom = sqrtf(v) / s.bc2_sqrt + s.eps;
-  return p - s.step_size * (m / denom);
 }
 
 __global__ void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
@@ -459,6 +575,7 @@ struct PoseUpdateArgs {
   float* x6d_io; float* betas_io; float* adam_m; float* adam_v; const int32_t* step;   // Adam (x6d_io nullable)
   float lr, beta1, beta2, eps;
   int B, BP;
+  const float* gcam; float* cam_io; float* cam_m; float* cam_v;     // camera translation (2-D term), nullable
 };
 
 __global__ __launch_bounds__(64) void k_pose_update(PoseUpdateArgs a) {
@@ -480,6 +597,16 @@ __global__ __launch_bounds__(64) void k_pose_update(PoseUpdateArgs a) {
         a.betas_io[(size_t)b * NB + l] = adam_update(a.betas_io[(size_t)b * NB + l], g, mm, vv, sc);
         a.adam_m[si] = mm;
         a.adam_v[si] = vv;
+      }
+    }
+    if (do_adam && a.cam_io) {   // Adam over [pose, orient, betas, cam] (optimize.py:201-202)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        const size_t si = (size_t)b * 3 + c;
+        float mm = a.cam_m[si], vv = a.cam_v[si];
+        a.cam_io[si] = adam_update(a.cam_io[si], a.gcam[si], mm, vv, sc);
+        a.cam_m[si] = mm;
+        a.cam_v[si] = vv;
       }
     }
     return;
@@ -567,9 +694,24 @@ int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const fl
 }
 
 int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float* djoints_in, float scale,
-                       float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s) {
+                       float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s, const ReprojLaunch* r) {
+  Reproj rp;
+  rp.gt_j2d = r ? r->gt_j2d : nullptr; rp.cam = r ? r->cam : nullptr; rp.gcam = r ? r->gcam : nullptr;
+  rp.sq2d = r ? r->sq2d : nullptr; rp.scale2d = r ? r->scale2d : 0.f;
   hipLaunchKernelGGL(k_joints_loss, dim3(BP / 64), dim3(64), 0, s, JP, nvc, gt_mm, djoints_in, scale, joints_out, sqerr,
-                     dJT, B, BP);
+                     dJT, rp, B, BP);
+  return 0;
+}
+
+int launch_project_joints(const float* joints, const float* cam, float* out, int B, hipStream_t s) {
+  const int n = B * NH;
+  hipLaunchKernelGGL(k_project_joints, dim3((n + 255) / 256), dim3(256), 0, s, joints, cam, out, n);
+  return 0;
+}
+
+int launch_camera_fit(const float* joints, const float* gt_j2d, float* cam, float scale2d, int nsteps, float lr, float* sq2d,
+                      int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_camera_fit, dim3((B + 63) / 64), dim3(64), 0, s, joints, gt_j2d, cam, scale2d, nsteps, lr, sq2d, B);
   return 0;
 }
 
@@ -589,6 +731,7 @@ int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
   a.dx6d = L.dx6d; a.dR = L.dR; a.dbetas = L.dbetas;
   a.x6d_io = L.x6d_io; a.betas_io = L.betas_io; a.adam_m = L.adam_m; a.adam_v = L.adam_v; a.step = L.step;
   a.lr = L.lr; a.beta1 = L.beta1; a.beta2 = L.beta2; a.eps = L.eps; a.B = L.B; a.BP = L.BP;
+  a.gcam = L.gcam; a.cam_io = L.cam_io; a.cam_m = L.cam_m; a.cam_v = L.cam_v;
   hipLaunchKernelGGL(k_pose_update, dim3((L.B + 63) / 64, NJ + 1), dim3(64), 0, s, a);
   return 0;
 }

@@ -208,6 +208,21 @@ class RefineEngine:
                                                   ptr(db), self._s()), 'smpl_vertices_backward')
         return (dx if x6d is not None else dR), db
 
+    def set_reprojection(self, gt_j2d=None, cam=None, cam_m=None, cam_v=None):
+        """enable (tensors) / disable (None) the 2-D term of refine_run; the tensors must outlive the runs"""
+        if gt_j2d is not None:
+            self._chk(gt_j2d, (self.batch, NUM_H36M, 2), 'gt_j2d')
+            for t, n in ((cam, 'cam'), (cam_m, 'cam_m'), (cam_v, 'cam_v')):
+                self._chk(t, (self.batch, 3), n)
+        self._reproj_refs = (gt_j2d, cam, cam_m, cam_v)
+        check(self.lib.jrr_engine_set_reprojection(self.handle, ptr(gt_j2d), ptr(cam), ptr(cam_m), ptr(cam_v)), 'set_reprojection')
+
+    def camera_prefit(self, x6d, betas, gt_j2d, cam, n_steps: int = 1000, lr: float = 1e-2):
+        sq = torch.empty(self.batch, device=self.device)
+        check(self.lib.jrr_camera_prefit(self.handle, ptr(x6d), ptr(betas), ptr(gt_j2d), ptr(cam), int(n_steps), float(lr),
+                                         ptr(sq), self._s()), 'camera_prefit')
+        return sq
+
     def refine_run(self, x6d, betas, gt_centred_mm, adam_m, adam_v, step, lr: float, n_iters: int, sqerr=None):
         B = self.batch
         self._chk(x6d, (B, NUM_JOINTS, 6), 'x6d')
@@ -255,6 +270,16 @@ def rot6d_backward(x: torch.Tensor, dR: torch.Tensor) -> torch.Tensor:
     dx = torch.empty_like(x)
     check(lib.jrr_rot6d_backward(ptr(x), ptr(dR), ptr(dx), x.shape[0], stream_ptr(x.device)), 'rot6d_backward')
     return dx
+
+
+def project_joints(joints: torch.Tensor, cam: torch.Tensor) -> torch.Tensor:
+    """return_2d_joints core (scripts/renderer.py:35-49): (B,17,3), (B,3) -> screen xy (B,17,2)"""
+    lib = _lib.load()
+    B = joints.shape[0]
+    out = torch.empty(B, NUM_H36M, 2, device=joints.device)
+    check(lib.jrr_project_joints(ptr(joints.contiguous()), ptr(cam.contiguous()), ptr(out), B, stream_ptr(joints.device)),
+          'project_joints')
+    return out
 
 
 def joint_loss(joints, gt_centred_mm, weight: float, batch_norm: Optional[int] = None, want_grad=True):

@@ -89,6 +89,15 @@ def optimize_pose_refiner(log=print) -> Dict:
         step = torch.zeros(1, dtype=torch.int32, device=device)
         sq = torch.zeros(B, device=device)
 
+        # ---- camera pre-fit + 2-D term (:170-173,187-199,231-233; row f1) on synthetic 2-D targets ----
+        loss_j2d = None
+        if args.reprojection:
+            cam = torch.from_numpy(full['cam'][lo:hi]).to(device).contiguous()           # :170-172 pred_cam_t
+            gt_j2d = _synthetic_gt_j2d(eng, x6d, betas, cam, args.seed * 1000 + it)
+            eng.camera_prefit(x6d, betas, gt_j2d, cam, n_steps=args.camera_iters, lr=1e-2)   # :187-199
+            cam_m, cam_v = torch.zeros_like(cam), torch.zeros_like(cam)
+            eng.set_reprojection(gt_j2d, cam, cam_m, cam_v)
+
         t0 = time.perf_counter()
         done = 0
         while done < args.inner_iters:                                                     # :220-265
@@ -98,6 +107,8 @@ def optimize_pose_refiner(log=print) -> Dict:
             if done % args.j_step_every == 0 and done < args.inner_iters:
                 _j_step(eng, J_regressor, J_opt, x6d, betas, gt_j3d, j_reg_mask)
         joint_loss = _global_mean(sq, B_global * 51)
+        if args.reprojection:
+            eng.set_reprojection(None)
 
         # ---- pose-discriminator update (:276-284) ----
         pose_d_loss = None
@@ -145,6 +156,18 @@ def optimize_pose_refiner(log=print) -> Dict:
     if args.save_j_regressor and rank == 0:
         checkpoint.save_j_regressor(J_regressor, args.save_j_regressor)
     return {'history': history, 'J_regressor': J_regressor, 'disc_flat': disc_flat}
+
+
+def _synthetic_gt_j2d(eng, x6d, betas, cam, seed):
+    """2-D targets in the 224-crop pixel frame (scripts/data.py:134-138): the current joints seen through a
+    perturbed camera, plus pixel noise (stand-in for the H36M annotations)."""
+    from . import renderer
+    g = torch.Generator().manual_seed(seed)
+    joints = eng.find_joints_forward(betas, x6d=x6d)
+    B = joints.shape[0]
+    cam_true = cam + (torch.randn(B, 3, generator=g) * torch.tensor([0.3, 0.3, 3.0])).to(cam.device)
+    p = renderer.project_points(joints, cam_true)[..., :2]
+    return (p + (torch.randn(B, 17, 2, generator=g) * 2.0).to(cam.device)).contiguous()
 
 
 def _global_mean(local_sum_tensor: torch.Tensor, denom: int) -> float:

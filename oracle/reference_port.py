@@ -213,6 +213,36 @@ def rodrigues(aa: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------------------
+# scripts/renderer.py:10-51 (return_2d_joints) -- pytorch3d 0.3.0 camera maths, parity unpinned
+# ----------------------------------------------------------------------------------------
+def project_joints(point_cloud: torch.Tensor, cam: torch.Tensor) -> torch.Tensor:
+    """renderer.py:35-49 with PerspectiveCameras(T=cam, R=I, focal=5000/224, principal point 0) and
+    transform_points_screen at 224x224 (pytorch3d is absent: parity unpinned).
+    point_cloud (B,N,3), cam (B,3) -> screen xy (B,N,2)."""
+    f, W = 5000.0 / 224.0, 224.0
+    X = -2 * point_cloud[..., 0] + cam[:, None, 0]
+    Y = -2 * point_cloud[..., 1] + cam[:, None, 1]
+    Z = 2 * point_cloud[..., 2] + cam[:, None, 2]
+    xs = (W - 1) / 2 * (1 - f * X / Z)
+    ys = (W - 1) / 2 * (1 - f * Y / Z)
+    return torch.stack([xs, ys], dim=-1)
+
+
+def camera_prefit(joints: torch.Tensor, gt_j2d: torch.Tensor, cam: torch.Tensor, n_steps: int, lr: float = 1e-2,
+                  batch_norm: Optional[int] = None) -> torch.Tensor:
+    """scripts/optimize.py:187-199: Adam([cam], lr) against MSE(gt_j2d, joints_2d); joints are constant."""
+    cam = cam.clone().detach().requires_grad_(True)
+    nb = joints.shape[0] if batch_norm is None else batch_norm
+    opt = torch.optim.Adam([cam], lr=lr)
+    for _ in range(n_steps):
+        loss = ((gt_j2d - project_joints(joints.detach(), cam)) ** 2).sum() / (nb * NUM_H36M * 2)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+    return cam.detach()
+
+
+# ----------------------------------------------------------------------------------------
 # scripts/discriminator.py (functional restatement over a state_dict)
 # ----------------------------------------------------------------------------------------
 def discriminator_forward(sd: Dict[str, torch.Tensor], rot6d: torch.Tensor) -> torch.Tensor:
@@ -294,8 +324,12 @@ W_POSE_D = 10.0     # scripts/optimize.py:253
 W_SHAPE_D = 10.0    # scripts/optimize.py:253
 
 
+W_J2D = 0.01       # scripts/optimize.py:252  (loss_j2d/100)
+
+
 def inner_losses(smpl, J_regressor, mask, orient6d, pose6d, betas, gt_j3d_mm_centred,
-                 disc_sd=None, shape_disc_sd=None, batch_norm: Optional[int] = None, smpl_evals: int = 1):
+                 disc_sd=None, shape_disc_sd=None, batch_norm: Optional[int] = None, smpl_evals: int = 1,
+                 gt_j2d=None, cam=None):
     """One evaluation of the inner-loop objective (scripts/optimize.py:222-253) without the
     2-D and silhouette terms (BASELINE configs 2-4).  Returns (opt_loss, dict of terms, joints).
 
@@ -315,6 +349,10 @@ def inner_losses(smpl, J_regressor, mask, orient6d, pose6d, betas, gt_j3d_mm_cen
     joint_loss = (diff ** 2).sum() / (nb * NUM_H36M * 3)
     terms = {'joint_loss': joint_loss}
     opt_loss = joint_loss * W_JOINT
+    if gt_j2d is not None:                                                    # :231-233 (mask=None == mask of ones)
+        loss_j2d = ((gt_j2d - project_joints(pred_joints, cam)) ** 2).sum() / (nb * NUM_H36M * 2)
+        terms['loss_j2d'] = loss_j2d
+        opt_loss = opt_loss + loss_j2d * W_J2D
     if disc_sd is not None:
         pred_disc = discriminator_forward(disc_sd, torch.cat([orient6d, pose6d], dim=1))   # :241-242
         pose_d = ((pred_disc - 1) ** 2).sum() / (nb * 25)                     # :246-247
@@ -330,7 +368,7 @@ def inner_losses(smpl, J_regressor, mask, orient6d, pose6d, betas, gt_j3d_mm_cen
 
 def refine_poses(smpl, J_regressor, orient6d, pose6d, betas, gt_j3d_mm_centred, n_iters: int,
                  disc_sd=None, shape_disc_sd=None, lr: float = 1e-2, mask=None,
-                 batch_norm: Optional[int] = None, smpl_evals: int = 1, record=None):
+                 batch_norm: Optional[int] = None, smpl_evals: int = 1, record=None, gt_j2d=None, cam=None):
     """scripts/optimize.py:201-202,220-265: fresh torch Adam over [pose, orient, betas] (cam has
     no gradient in configs 2-4 and is skipped by torch Adam), n_iters inner iterations.
     Inputs are cloned; returns the refined (orient6d, pose6d, betas) and the loss history."""
@@ -339,11 +377,16 @@ def refine_poses(smpl, J_regressor, orient6d, pose6d, betas, gt_j3d_mm_centred, 
     b = betas.clone().detach().requires_grad_(True)
     if mask is None:
         mask = find_j_reg_mask(J_regressor)
-    opt = torch.optim.Adam([pose, orient, b], lr=lr)
+    params = [pose, orient, b]
+    c = None
+    if gt_j2d is not None:
+        c = cam.clone().detach().requires_grad_(True)
+        params.append(c)                                                      # :180-181,201-202
+    opt = torch.optim.Adam(params, lr=lr)
     hist = []
     for it in range(n_iters):
         loss, terms, joints = inner_losses(smpl, J_regressor.detach(), mask, orient, pose, b, gt_j3d_mm_centred,
-                                           disc_sd, shape_disc_sd, batch_norm, smpl_evals)
+                                           disc_sd, shape_disc_sd, batch_norm, smpl_evals, gt_j2d, c)
         opt.zero_grad()
         loss.backward()
         if record is not None:
@@ -352,6 +395,8 @@ def refine_poses(smpl, J_regressor, orient6d, pose6d, betas, gt_j3d_mm_centred, 
                             **{k: v.detach().clone() for k, v in terms.items()}))
         opt.step()
         hist.append({"loss": float(loss.detach()), **{k: float(v.detach()) for k, v in terms.items()}})
+    if c is not None:
+        return orient.detach(), pose.detach(), b.detach(), hist, c.detach()
     return orient.detach(), pose.detach(), b.detach(), hist
 
 

@@ -196,3 +196,58 @@ def test_optimize_pose_refiner_outer_step_matches_oracle(smpl_model_np, j_h36m_n
     assert torch.equal(ck, res['J_regressor'].cpu())
     raw = torch.load(ckpt, weights_only=True)
     assert raw.shape == (17, 6890) and raw.dtype == torch.float32 and raw.stride() == (1, 17)
+
+
+def _synthetic_2d(joints_m, seed, noise=2.0):
+    """gt_j2d in the 224-crop pixel frame: projection of the (noisy) joints through a perturbed camera"""
+    gen = torch.Generator().manual_seed(seed)
+    B = joints_m.shape[0]
+    cam_true = torch.tensor([0.0, 0.0, 2 * 5000 / (224 * 0.9)]).repeat(B, 1) + torch.randn(B, 3, generator=gen) * torch.tensor([0.3, 0.3, 3.0])
+    gt2d = oracle.project_joints(joints_m, cam_true) + torch.randn(B, 17, 2, generator=gen) * noise
+    return gt2d, cam_true
+
+
+def test_projection_and_camera_prefit(smpl_hip, smpl_model_np, j_h36m_np):
+    """row f1: return_2d_joints core and the 1000-step camera pre-fit (scripts/optimize.py:187-199)"""
+    eng_mod = _mod('engine')
+    B = 40
+    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, j_h36m_np, B, seed=13)
+    x6, betas, cam0 = T(batch['pose6d']), T(batch['betas']), T(batch['cam'])
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B)
+    eng.set_j_regressor(T(j_h36m_np))
+    joints = eng.find_joints_forward(betas.to(DEV), x6d=x6.to(DEV))
+    gt2d, _ = _synthetic_2d(joints.cpu(), 1)
+    p2d = eng_mod.project_joints(joints, cam0.to(DEV))
+    np.testing.assert_allclose(p2d.cpu().numpy(), oracle.project_joints(joints.cpu(), cam0).numpy(), rtol=0, atol=2e-3)
+    cam = cam0.clone().to(DEV)
+    sq = eng.camera_prefit(x6.to(DEV), betas.to(DEV), gt2d.to(DEV).contiguous(), cam, n_steps=1000, lr=1e-2)
+    ref = oracle.camera_prefit(joints.cpu(), gt2d, cam0, 1000, lr=1e-2)
+    assert (cam.cpu() - ref).abs().max().item() < 2e-3          # 1000 Adam steps of size <= 1e-2
+    e0 = ((gt2d - oracle.project_joints(joints.cpu(), cam0)) ** 2).sum().item()
+    assert float(sq.sum()) < 0.2 * e0                            # the fit actually reduced the 2-D error
+
+
+def test_refine_run_with_2d_term_matches_oracle(smpl_hip, smpl_model_np, j_h36m_np):
+    eng_mod = _mod('engine')
+    B, n = 24, 5
+    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, j_h36m_np, B, seed=17)
+    x6, betas, cam0 = T(batch['pose6d']), T(batch['betas']), T(batch['cam'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(B, 24, 3, 3)
+    j0 = oracle.find_joints(smpl, betas, R[:, :1], R[:, 1:], T(j_h36m_np))
+    gt2d, _ = _synthetic_2d(j0, 2)
+    o, p, b, hist, c = oracle.refine_poses(smpl, T(j_h36m_np), x6[:, :1], x6[:, 1:], betas, gt_c, n, gt_j2d=gt2d, cam=cam0)
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B)
+    eng.set_j_regressor(T(j_h36m_np))
+    xd, bd, cd = x6.clone().to(DEV), betas.clone().to(DEV), cam0.clone().to(DEV)
+    cm, cv = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV)
+    eng.set_reprojection(gt2d.to(DEV).contiguous(), cd, cm, cv)
+    m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, n)
+    eng.set_reprojection(None)
+    assert (xd.cpu() - torch.cat([o, p], 1)).abs().max().item() < 3e-4
+    assert (bd.cpu() - b).abs().max().item() < 3e-4
+    assert (cd.cpu() - c).abs().max().item() < 3e-4
+    assert (cd.cpu() - cam0).abs().max().item() > 1e-2           # the camera really moved
