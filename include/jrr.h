@@ -153,6 +153,12 @@ int jrr_shape_disc_backward_params(jrr_engine_t* e, const float* betas_dev, floa
 int jrr_adam_step(float* p_dev, const float* g_dev, float* m_dev, float* v_dev, size_t n,
                   const int32_t* step_dev, float lr, float beta1, float beta2, float eps, void* stream);
 
+/* evaluate, scripts/utils.py:117-145 + scripts/eval_utils.py:7-58 (row f3): per-pose mean joint error and
+ * Procrustes-aligned mean joint error in METRES (pred in m, target in mm, both pelvis-centred inside);
+ * MPJPE / PA-MPJPE in mm = 1000 * mean over poses.                                                    */
+int jrr_evaluate(const float* pred_j3d_dev, const float* target_j3d_mm_dev, float* err_dev, float* err_pa_dev,
+                 int batch, void* stream);
+
 /* ---- 2-D reprojection --------------------------------------------
  * return_2d_joints core, scripts/renderer.py:35-49 (pytorch3d 0.3.0 PerspectiveCameras, R = I,
  * T = cam, focal 5000/224 NDC, 224x224): joints (B,17,3), cam (B,3) -> screen xy (B,17,2).       */

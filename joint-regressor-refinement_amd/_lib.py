@@ -42,6 +42,7 @@ SIGNATURES = {
     'jrr_pose_disc_backward_params': (c_int, [_P, _P, c_float, _P, _P, _P]),
     'jrr_shape_disc_backward_params': (c_int, [_P, _P, c_float, _P, _P, _P]),
     'jrr_adam_step': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, _P]),
+    'jrr_evaluate': (c_int, [_P, _P, _P, _P, c_int, _P]),
     'jrr_project_joints': (c_int, [_P, _P, _P, c_int, _P]),
     'jrr_engine_set_reprojection': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_camera_prefit': (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P]),

@@ -2,6 +2,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <vector>
 
 #include "jrr_common.h"
@@ -502,15 +503,24 @@ extern "C" int jrr_joint_loss(const float* joints, const float* gt_mm, float wei
 }
 
 // ---- pose discriminator --------------------------------------------------------------------
+// tile choice for the four discriminator GEMMs (A/B switch for tuning: JRR_DISC_TILE=0|1|2)
+static int disc_gemm(const GemmArgs& g, int epi, int nsplit, hipStream_t s) {
+  static int mode = -1;
+  if (mode < 0) { const char* v = getenv("JRR_DISC_TILE"); mode = v ? atoi(v) : 0; }
+  if (mode == 1) return launch_gemm_128(g, epi, nsplit, s);
+  if (mode == 2) return launch_gemm_128w8(g, epi, nsplit, s);
+  return launch_gemm_128x64(g, epi, nsplit, s);
+}
+
 static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t s) {
   launch_disc_conv_fwd(e->Pd, x6d, e->H2T, out, e->B, e->BP, s);
   GemmArgs g;
   g.mask = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   g.A = e->W0T; g.lda = 1024; g.Bm = e->H2T; g.Out = e->A1T; g.bias = e->Pd + DP_FC0_B; g.M = 1024; g.K = 768;
-  int rc = launch_gemm_128x64(g, EPI_BIAS_RELU, 1, s);
+  int rc = disc_gemm(g, EPI_BIAS_RELU, 1, s);
   if (rc) return rc;
   g.A = e->W2T; g.lda = 1024; g.Bm = e->A1T; g.Out = e->A2T; g.bias = e->Pd + DP_FC2_B; g.M = 1024; g.K = 1024;
-  return launch_gemm_128x64(g, EPI_BIAS_RELU, 1, s);
+  return disc_gemm(g, EPI_BIAS_RELU, 1, s);
 }
 
 static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, const float* gout, float scale,
@@ -520,11 +530,11 @@ static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, cons
   g.bias = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   // dA1T[k][b] = relu'(A1T) * sum_n fc2.w[n][k] dA2T[n][b]
   g.A = e->Pd + DP_FC2_W; g.lda = 1024; g.Bm = e->dA2T; g.Out = e->dA1T; g.mask = e->A1T; g.M = 1024; g.K = 1024;
-  int rc = launch_gemm_128x64(g, EPI_MASK, 1, s);
+  int rc = disc_gemm(g, EPI_MASK, 1, s);
   if (rc) return rc;
   // dH2T[k][b] = sum_n fc0.w[n][k] dA1T[n][b]
   g.A = e->Pd + DP_FC0_W; g.lda = 768; g.Bm = e->dA1T; g.Out = e->dH2T; g.mask = nullptr; g.M = 768; g.K = 1024;
-  rc = launch_gemm_128x64(g, EPI_STORE, 1, s);
+  rc = disc_gemm(g, EPI_STORE, 1, s);
   if (rc) return rc;
   launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s);
   return 0;
@@ -619,6 +629,13 @@ extern "C" int jrr_adam_step(float* p, const float* g, float* m, float* v, size_
   if (!p || !g || !m || !v || !step) return JRR_ERR_ARG;
   if (n == 0) return JRR_OK;
   launch_adam_flat(p, g, m, v, n, step, lr, beta1, beta2, eps, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_evaluate(const float* pred, const float* target_mm, float* err, float* err_pa, int batch, void* stream) {
+  if (!pred || !target_mm || !err || !err_pa || batch <= 0) return JRR_ERR_ARG;
+  launch_evaluate(pred, target_mm, err, err_pa, batch, (hipStream_t)stream);
   CHECK_LAUNCH();
   return JRR_OK;
 }

@@ -9,8 +9,6 @@
 
 namespace jrr {
 
-#define JRR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
-#define JRR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 
 // Operand chunks ([GK][BM] of A, [GK][BN] of Bm) are staged by LDS-DMA (global_load_lds_dwordx4)
 // into a 2-deep ring, one chunk ahead of the MFMAs, one workgroup barrier per chunk.
@@ -141,10 +139,10 @@ static int launch_cfg(const GemmArgs& g, int epi, int nsplit, hipStream_t s) {
 int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 2, 2, 2, 32>(g, epi, nsplit, s); }
 // 128x64 block tile (2x2 waves of 64x32): twice the workgroups of the 128x128 tile (2 per CU at N = 4096)
 int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 2, 2, 32>(g, epi, nsplit, s); }
+// 128x128 block tile, 8 waves (2x4 of 64x32): 2 waves per SIMD with one workgroup per CU
+int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 2, 4, 32>(g, epi, nsplit, s); }
 // 224x128 block tile (4 waves of 224x32), 16-deep chunks: blend-basis adjoint, M = KFP = 224
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<7, 1, 1, 4, 16>(g, epi, nsplit, s); }
-// 32x128 block tile (4 waves of 32x32): skinny-M products
-int launch_gemm_32(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<1, 1, 1, 4, 16>(g, epi, nsplit, s); }
 // 64x128 block tile (4 waves of 64x32): the J-regressor gradient product, M = 51 padded to 64
 int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 1, 4, 16>(g, epi, nsplit, s); }
 

@@ -49,6 +49,12 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
   return base + (id >> 3);
 }
 
+// LDS-DMA (global_load_lds_dwordx4): one wave-instruction copies 64 lanes x 16 B from per-lane global
+// addresses into LDS [dst, dst + 1 KB) -- the LDS address is wave-uniform base + lane*16 (verified by
+// tools/probe/dma_probe.hip).  No VGPR round trip; completion is tracked by vmcnt.
+#define JRR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
+#define JRR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
+
 struct Parents { int p[NJ]; };
 
 // ---- device-resident SMPL model ------------------------------------------------------------

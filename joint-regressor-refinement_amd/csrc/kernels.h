@@ -71,9 +71,12 @@ int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const fl
 // gemm.hip
 int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
-int launch_gemm_32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+
+// eval.hip
+int launch_evaluate(const float* pred, const float* target_mm, float* err, float* err_pa, int B, hipStream_t s);
 
 // disc.hip
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);

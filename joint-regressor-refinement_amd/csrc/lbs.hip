@@ -43,8 +43,6 @@ constexpr int NSTAGE = NKCH + 6;                  // 13
 // per-tile operand record of the backward kernel: [Jn 18x32 | W^T 24x32 | W 32x32(j) | pad] = 10 KB
 constexpr int TB_JN = 0, TB_WJV = NHP * 32, TB_WVJ = TB_WJV + W_FLOATS, TB_FLOATS = 2560;
 
-#define JRR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
-#define JRR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 // one wave-instruction: 64 lanes x 16 B from per-lane global addresses into LDS [dst, dst + 1 KB)
 __device__ __forceinline__ void dma16(const float* gsrc_lane, float* lds_dst_wave) {
   __builtin_amdgcn_global_load_lds(JRR_GLB(gsrc_lane), JRR_LDS(lds_dst_wave), 16, 0, 0);

@@ -489,6 +489,7 @@ __global__ __launch_bounds__(64) void k_chain_bwd(const float* __restrict__ FT, 
   for (int l = 0; l < NB; ++l) { beta[l] = FT[(size_t)(207 + l) * BP + b]; dbeta[l] = 0.f; }
   for (int k = 0; k < NJ * 12; ++k) dG[k * 64 + lane] = 0.f;
 
+#pragma unroll 4
   for (int i = NJ - 1; i >= 0; --i) {
     const int p = par.p[i];
     float dA[12], GiR[9], R[9], Ji[3];

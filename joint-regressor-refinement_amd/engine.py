@@ -282,6 +282,17 @@ def project_joints(joints: torch.Tensor, cam: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def evaluate(pred_j3d: torch.Tensor, target_j3d_mm: torch.Tensor):
+    """per-pose joint error and Procrustes-aligned joint error (metres), on device"""
+    lib = _lib.load()
+    B = pred_j3d.shape[0]
+    err = torch.empty(B, device=pred_j3d.device)
+    err_pa = torch.empty(B, device=pred_j3d.device)
+    check(lib.jrr_evaluate(ptr(pred_j3d.contiguous()), ptr(target_j3d_mm.contiguous()), ptr(err), ptr(err_pa), B,
+                           stream_ptr(pred_j3d.device)), 'evaluate')
+    return err, err_pa
+
+
 def joint_loss(joints, gt_centred_mm, weight: float, batch_norm: Optional[int] = None, want_grad=True):
     lib = _lib.load()
     B = joints.shape[0]

@@ -3,7 +3,7 @@
   find_joints       scripts/utils.py:85-103   fused SMPL + J_regressor contraction, differentiable
                                                w.r.t. shape, orient, pose and J_regressor
   move_pelvis       scripts/utils.py:106-114
-  evaluate          scripts/utils.py:117-145  (torch ops on device; "next" row f3 of SURVEY.md)
+  evaluate          scripts/utils.py:117-145  (k_evaluate: on-device Procrustes, row f3 of SURVEY.md)
   find_j_reg_mask   scripts/utils.py:182-187  (reproduces the reference's all-ones mask)
   rot6d_to_rotmat   scripts/utils.py:190-204  (row-wise cross product for every N)
   set_seed          scripts/utils.py:207-215
@@ -82,38 +82,12 @@ def find_j_reg_mask(j_reg: torch.Tensor) -> torch.Tensor:
     return torch.where(j_reg == 0, ones, ones)
 
 
-def batch_compute_similarity_transform_torch(S1, S2):
-    """scripts/eval_utils.py:7-58 (Procrustes alignment), torch ops on the input's device."""
-    transposed = False
-    if S1.shape[0] != 3 and S1.shape[0] != 2:
-        S1, S2 = S1.permute(0, 2, 1), S2.permute(0, 2, 1)
-        transposed = True
-    mu1, mu2 = S1.mean(dim=-1, keepdim=True), S2.mean(dim=-1, keepdim=True)
-    X1, X2 = S1 - mu1, S2 - mu2
-    var1 = torch.sum(X1 ** 2, dim=1).sum(dim=1)
-    K = X1.bmm(X2.permute(0, 2, 1))
-    U, s, Vh = torch.linalg.svd(K.cpu())       # 3x3 SVDs: host LAPACK (logging path only)
-    U, V = U.to(S1.device), Vh.transpose(1, 2).to(S1.device)
-    Z = torch.eye(3, device=S1.device).unsqueeze(0).repeat(U.shape[0], 1, 1)
-    Z[:, -1, -1] *= torch.sign(torch.det(U.bmm(V.permute(0, 2, 1))))
-    R = V.bmm(Z.bmm(U.permute(0, 2, 1)))
-    scale = torch.diagonal(R.bmm(K), dim1=1, dim2=2).sum(1) / var1
-    t = mu2 - scale[:, None, None] * R.bmm(mu1)
-    S1_hat = scale[:, None, None] * R.bmm(S1) + t
-    return S1_hat.permute(0, 2, 1) if transposed else S1_hat
-
-
 def evaluate(pred_j3ds: torch.Tensor, target_j3ds: torch.Tensor):
-    """MPJPE and PA-MPJPE in mm (pred in m, target in mm), scripts/utils.py:117-145."""
+    """MPJPE and PA-MPJPE in mm (pred in m, target in mm), scripts/utils.py:117-145, on device
+    (k_evaluate: pelvis centring, per-pose Procrustes with an in-register 3x3 SVD)."""
     with torch.no_grad():
-        pred = pred_j3ds.clone().detach()
-        target = target_j3ds.clone().detach() / 1000
-        pred = pred - pred[:, [0], :]
-        target = target - target[:, [0], :]
-        errors = torch.sqrt(((pred - target) ** 2).sum(dim=-1)).mean(dim=-1).cpu().numpy()
-        S1_hat = batch_compute_similarity_transform_torch(pred, target)
-        errors_pa = torch.sqrt(((S1_hat - target) ** 2).sum(dim=-1)).mean(dim=-1).cpu().numpy()
-        return np.mean(errors) * 1000, np.mean(errors_pa) * 1000
+        err, err_pa = _engine.evaluate(pred_j3ds.detach().float(), target_j3ds.detach().float())
+        return float(err.mean().item()) * 1000, float(err_pa.mean().item()) * 1000
 
 
 def set_seed(seed: int):

@@ -255,3 +255,63 @@ def test_full_size_properties(eng_mod, dmodel, smpl_model_np, j_h36m_np):
     j0 = (T(smpl_model_np['J_regressor']).double() @ T(smpl_model_np['v_template']).double())[0]
     rigid = torch.einsum('brc,ic->bir', R0.double(), expect - j0) + j0
     assert (j2 - rigid).abs().max().item() < 2e-5
+
+
+def test_evaluate_on_device(eng_mod):
+    """row f3: MPJPE / PA-MPJPE kernel vs the golden vector captured from the reference's evaluate()"""
+    g = load_golden('g6_evaluate.npz')
+    err, err_pa = eng_mod.evaluate(T(g['pred']).to(DEV), T(g['target_mm']).to(DEV))
+    np.testing.assert_allclose(float(err.mean()) * 1000, float(g['mpjpe']), rtol=1e-5)
+    np.testing.assert_allclose(float(err_pa.mean()) * 1000, float(g['pampjpe']), rtol=1e-4)
+    gen = torch.Generator().manual_seed(6)
+    pred = torch.randn(300, 17, 3, generator=gen) * 0.3
+    # include reflections / large rotations so the det-sign branch is exercised
+    Rr = oracle.rodrigues(torch.randn(300, 3, generator=gen) * 2.0)
+    tgt = (torch.einsum('brc,bic->bir', Rr, pred) * 1.3 + 0.2 + torch.randn(300, 17, 3, generator=gen) * 0.02) * 1000
+    tgt[:50, :, 0] *= -1
+    m, pa = oracle.evaluate(pred, tgt)
+    err, err_pa = eng_mod.evaluate(pred.to(DEV), tgt.to(DEV))
+    np.testing.assert_allclose(float(err.mean()) * 1000, m, rtol=1e-5)
+    np.testing.assert_allclose(float(err_pa.mean()) * 1000, pa, rtol=2e-4)
+
+
+@pytest.mark.parametrize('B', [1, 129])
+def test_edge_batches(eng_mod, dmodel, smpl_model_np, j_h36m_np, B):
+    batch = _batch(smpl_model_np, j_h36m_np, B, seed=40 + B)
+    x6d, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    eng = eng_mod.RefineEngine(dmodel, B)
+    eng.set_j_regressor(T(j_h36m_np))
+    joints = eng.find_joints_forward(betas.to(DEV), x6d=x6d.to(DEV))
+    assert (joints.cpu().double() - _oracle_joints(smpl_model_np, T(j_h36m_np), x6d, betas)).abs().max().item() < 2e-5
+    xd, bd = x6d.clone().to(DEV), betas.clone().to(DEV)
+    m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, 2)
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    o, p, b, _ = oracle.refine_poses(smpl, T(j_h36m_np), x6d[:, :1], x6d[:, 1:], betas, gt_c, 2)
+    assert (xd.cpu() - torch.cat([o, p], 1)).abs().max().item() < 3e-4
+
+
+def test_refine_run_is_deterministic(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    """no atomics on the hot path: two runs from the same state are bit-identical"""
+    outs = []
+    for _ in range(2):
+        r = _run_refine(eng_mod, dmodel, smpl_model_np, j_h36m_np, 200, 5, 4, True, False)
+        outs.append((r['xd'], r['bd']))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
+def test_error_behaviour(eng_mod, dmodel):
+    """errors come back as status codes + message and surface as JrrError (nothing crashes the process)"""
+    lib_mod = importlib.import_module(PKG_NAME + '._lib')
+    eng = eng_mod.RefineEngine(dmodel, 4)
+    with pytest.raises(lib_mod.JrrError, match='J_regressor not set'):
+        eng.find_joints_forward(torch.zeros(4, 10, device=DEV), x6d=torch.zeros(4, 24, 6, device=DEV))
+    with pytest.raises(lib_mod.JrrError, match='JRR_FLAG_POSE_DISC'):
+        eng.set_pose_disc(torch.zeros(eng_mod.DISC_PARAMS, device=DEV))
+    with pytest.raises(AssertionError):
+        eng.set_j_regressor(torch.zeros(17, 100))
+    eng.set_j_regressor(torch.rand(17, 6890))
+    with pytest.raises(lib_mod.JrrError, match='KEEP_VERTS'):
+        eng.j_regressor_grad(torch.zeros(4, 24, 6, device=DEV), torch.zeros(4, 10, device=DEV), torch.zeros(4, 17, 3, device=DEV))
