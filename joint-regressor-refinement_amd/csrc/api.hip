@@ -91,7 +91,12 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   m->d.Wvj = m->d.Wjv + nWjv;
   m->d.Jt = m->d.Wvj + nWvj;
   m->d.JS = m->d.Jt + nJt;
-  for (int j = 0; j < NJ; ++j) m->d.parents.p[j] = parents[j];
+  m->d.parents.maxd = 0;
+  for (int j = 0; j < NJ; ++j) {
+    m->d.parents.p[j] = parents[j];
+    m->d.parents.depth[j] = (j == 0) ? 0 : m->d.parents.depth[parents[j]] + 1;
+    if (m->d.parents.depth[j] > m->d.parents.maxd) m->d.parents.maxd = m->d.parents.depth[j];
+  }
   *out = m;
   return JRR_OK;
 }

@@ -55,7 +55,11 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 #define JRR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 #define JRR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 
-struct Parents { int p[NJ]; };
+struct Parents {
+  int p[NJ];       // parent joint (p[0] = -1), parents precede children
+  int depth[NJ];   // tree depth of each joint (root = 0)
+  int maxd;        // deepest level
+};
 
 // ---- device-resident SMPL model ------------------------------------------------------------
 struct Model {

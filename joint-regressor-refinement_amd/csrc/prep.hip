@@ -144,77 +144,93 @@ __device__ __forceinline__ void rest_joint(const float* __restrict__ Jt, const f
 }
 
 // ------------------------------------------------------------------------------------------
-// k_prep_fwd: per pose -> FT [KFP][BP] (blend features, transposed), AT [12][24][BP] (skinning
-// transforms A_j = G_j - [0 | G_j.R J_j], entry e = r*4+c).  Poses b >= B are written as zeros.
-// LDS: G (12 floats) per joint per lane.
+// k_prep_fwd: 6-D rotation -> R, blend features FT [KFP][BP], kinematic chain -> skinning transforms
+// AT [12][24][BP] (A_j = G_j - [0 | G_j.R J_j], entry e = r*4+c), R0T [9][BP].
+// One thread per (pose, joint): block = 32 poses x 24 joints, lanes run over poses (coalesced
+// feature-major stores).  The chain is walked level by level of the kinematic tree (depth <= 9 for
+// SMPL) with the world transforms exchanged through LDS.  Poses b >= B are written as zeros.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_prep_fwd(const float* __restrict__ x6d, const float* __restrict__ Rin,
-                                                 const float* __restrict__ betas, const float* __restrict__ Jt,
-                                                 const float* __restrict__ JS, Parents par, float* __restrict__ FT,
-                                                 float* __restrict__ AT, float* __restrict__ R0T, int B, int BP,
-                                                 int32_t* step_inc) {
-  extern __shared__ float lds[];   // [24][12][64]
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x * 64 + lane;
-  if (step_inc && blockIdx.x == 0 && lane == 0) step_inc[0] += 1;   // Adam step count of this iteration
-  if (b >= BP) return;
-  if (b >= B) {
-    for (int k = 0; k < KFP; ++k) FT[(size_t)k * BP + b] = 0.f;
-    for (int k = 0; k < 12 * NJ; ++k) AT[(size_t)k * BP + b] = 0.f;
-    return;
-  }
-  float beta[NB];
-#pragma unroll
-  for (int l = 0; l < NB; ++l) beta[l] = betas[(size_t)b * NB + l];
-  for (int j = 0; j < NJ; ++j) {
-    float R[9], J[3], G[12];
-    Rot6 c;
+constexpr int PP = 32;   // poses per block of the (pose, joint)-parallel kernels
+
+__global__ __launch_bounds__(PP * NJ) void k_prep_fwd(const float* __restrict__ x6d, const float* __restrict__ Rin,
+                                                      const float* __restrict__ betas, const float* __restrict__ Jt,
+                                                      const float* __restrict__ JS, Parents par, float* __restrict__ FT,
+                                                      float* __restrict__ AT, float* __restrict__ R0T, int B, int BP,
+                                                      int32_t* step_inc) {
+  __shared__ float Gs[NJ][12][PP];
+  __shared__ float Js[NJ][3][PP];
+  const int bl = threadIdx.x & (PP - 1), j = threadIdx.x / PP;
+  const int b = blockIdx.x * PP + bl;
+  if (step_inc && blockIdx.x == 0 && threadIdx.x == 0) step_inc[0] += 1;   // Adam step count of this iteration
+  const bool ok = b < B;
+  float R[9], J[3] = {0.f, 0.f, 0.f}, beta[NB];
+  Rot6 c;
+  if (ok) {
     load_rot(x6d, Rin, b, j, R, c);
+#pragma unroll
+    for (int l = 0; l < NB; ++l) beta[l] = betas[(size_t)b * NB + l];
     rest_joint(Jt, JS, j, beta, J);
-    if (j > 0) {
+  } else {
 #pragma unroll
-      for (int k = 0; k < 9; ++k) FT[(size_t)((j - 1) * 9 + k) * BP + b] = R[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
-    } else {
+    for (int k = 0; k < 9; ++k) R[k] = 0.f;
 #pragma unroll
-      for (int k = 0; k < 9; ++k) R0T[(size_t)k * BP + b] = R[k];
-    }
-    if (j == 0) {
+    for (int l = 0; l < NB; ++l) beta[l] = 0.f;
+  }
+  // blend features: F[(j-1)*9 + k] = R_j[k] - I  (j >= 1), shape rows, template row, zero padding
+  if (j > 0) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
+    for (int k = 0; k < 9; ++k)
+      FT[(size_t)((j - 1) * 9 + k) * BP + b] = ok ? R[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f) : 0.f;
+  } else {
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) G[r * 4 + cc] = R[r * 3 + cc];
-        G[r * 4 + 3] = J[r];
-      }
-    } else {
-      const int p = par.p[j];
-      float Gp[12], Jp[3], rel[3];
+    for (int k = 0; k < 9; ++k) R0T[(size_t)k * BP + b] = R[k];
 #pragma unroll
-      for (int e = 0; e < 12; ++e) Gp[e] = lds[(p * 12 + e) * 64 + lane];
-      rest_joint(Jt, JS, p, beta, Jp);
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) rel[cc] = J[cc] - Jp[cc];
-#pragma unroll
-      for (int r = 0; r < 3; ++r) {
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc)
-          G[r * 4 + cc] = Gp[r * 4 + 0] * R[0 * 3 + cc] + Gp[r * 4 + 1] * R[1 * 3 + cc] + Gp[r * 4 + 2] * R[2 * 3 + cc];
-        G[r * 4 + 3] = Gp[r * 4 + 0] * rel[0] + Gp[r * 4 + 1] * rel[1] + Gp[r * 4 + 2] * rel[2] + Gp[r * 4 + 3];
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 12; ++e) lds[(j * 12 + e) * 64 + lane] = G[e];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) AT[(size_t)((r * 4 + cc) * NJ + j) * BP + b] = G[r * 4 + cc];
-      AT[(size_t)((r * 4 + 3) * NJ + j) * BP + b] =
-          G[r * 4 + 3] - (G[r * 4 + 0] * J[0] + G[r * 4 + 1] * J[1] + G[r * 4 + 2] * J[2]);
-    }
+    for (int l = 0; l < NB; ++l) FT[(size_t)(207 + l) * BP + b] = beta[l];
+    FT[(size_t)217 * BP + b] = ok ? 1.f : 0.f;
+    for (int k = KF; k < KFP; ++k) FT[(size_t)k * BP + b] = 0.f;
   }
 #pragma unroll
-  for (int l = 0; l < NB; ++l) FT[(size_t)(207 + l) * BP + b] = beta[l];
-  FT[(size_t)217 * BP + b] = 1.f;
-  for (int k = KF; k < KFP; ++k) FT[(size_t)k * BP + b] = 0.f;
+  for (int cc = 0; cc < 3; ++cc) Js[j][cc][bl] = J[cc];
+  __syncthreads();
+  // world transforms, one tree level per step
+  float G[12];
+  const int dj = par.depth[j];
+  for (int d = 0; d <= par.maxd; ++d) {
+    if (dj == d) {
+      if (d == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) G[r * 4 + cc] = R[r * 3 + cc];
+          G[r * 4 + 3] = J[r];
+        }
+      } else {
+        const int p = par.p[j];
+        float Gp[12], rel[3];
+#pragma unroll
+        for (int e = 0; e < 12; ++e) Gp[e] = Gs[p][e][bl];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) rel[cc] = J[cc] - Js[p][cc][bl];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc)
+            G[r * 4 + cc] = Gp[r * 4 + 0] * R[0 * 3 + cc] + Gp[r * 4 + 1] * R[1 * 3 + cc] + Gp[r * 4 + 2] * R[2 * 3 + cc];
+          G[r * 4 + 3] = Gp[r * 4 + 0] * rel[0] + Gp[r * 4 + 1] * rel[1] + Gp[r * 4 + 2] * rel[2] + Gp[r * 4 + 3];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 12; ++e) Gs[j][e][bl] = G[e];
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+#pragma unroll
+    for (int cc = 0; cc < 3; ++cc) AT[(size_t)((r * 4 + cc) * NJ + j) * BP + b] = ok ? G[r * 4 + cc] : 0.f;
+    AT[(size_t)((r * 4 + 3) * NJ + j) * BP + b] =
+        ok ? G[r * 4 + 3] - (G[r * 4 + 0] * J[0] + G[r * 4 + 1] * J[1] + G[r * 4 + 2] * J[2]) : 0.f;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -285,85 +301,89 @@ struct Reproj {
 //   scale = 2*weight/(batch_norm*51).  If djoints_in != NULL it is used as the adjoint instead
 //   (operator-level backward), transposed into dJT.
 // ------------------------------------------------------------------------------------------
-__global__ void k_joints_loss(const float* __restrict__ JP, int nvc, const float* __restrict__ gt_mm,
-                              const float* __restrict__ djoints_in, float scale, float* __restrict__ joints_out,
-                              float* __restrict__ sqerr, float* __restrict__ dJT, Reproj rp, int B, int BP) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= BP) return;
-  if (b >= B) {
-    if (dJT)
-      for (int k = 0; k < 3 * NHP; ++k) dJT[(size_t)k * BP + b] = 0.f;
-    return;
-  }
-  float j[NH][3];
+__global__ __launch_bounds__(PP * NH) void k_joints_loss(const float* __restrict__ JP, int nvc,
+                                                         const float* __restrict__ gt_mm,
+                                                         const float* __restrict__ djoints_in, float scale,
+                                                         float* __restrict__ joints_out, float* __restrict__ sqerr,
+                                                         float* __restrict__ dJT, Reproj rp, int B, int BP) {
+  // one thread per (pose, H36M joint): block = 32 poses x 17 joints, lanes over poses
+  __shared__ float red[NH][8][PP];   // per-joint partials: 0..2 g, 3 err, 4 e2d, 5..7 gcam
+  __shared__ float pel[3][PP];
+  const int bl = threadIdx.x & (PP - 1), i = threadIdx.x / PP;
+  const int b = blockIdx.x * PP + bl;
+  const bool ok = b < B;
+  float j[3] = {0.f, 0.f, 0.f};
   if (JP) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int c = 0; c < 3; ++c) {
+      float acc = 0.f;
+      for (int ch = 0; ch < nvc; ++ch) acc += JP[(size_t)((ch * 3 + c) * NH + i) * BP + b];
+      j[c] = acc;
+    }
+    if (joints_out && ok) {
 #pragma unroll
-      for (int i = 0; i < NH; ++i) {
-        float acc = 0.f;
-        for (int ch = 0; ch < nvc; ++ch) acc += JP[(size_t)((ch * 3 + c) * NH + i) * BP + b];
-        j[i][c] = acc;
-      }
-    if (joints_out) {
-#pragma unroll
-      for (int i = 0; i < NH; ++i)
-#pragma unroll
-        for (int c = 0; c < 3; ++c) joints_out[((size_t)b * NH + i) * 3 + c] = j[i][c];
+      for (int c = 0; c < 3; ++c) joints_out[((size_t)b * NH + i) * 3 + c] = j[c];
     }
   }
-  if (djoints_in) {
+  if (djoints_in) {      // operator-level backward: transpose the caller's adjoint
     if (dJT) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
-#pragma unroll
-        for (int i = 0; i < NH; ++i) dJT[(size_t)(c * NHP + i) * BP + b] = djoints_in[((size_t)b * NH + i) * 3 + c];
-        dJT[(size_t)(c * NHP + NH) * BP + b] = 0.f;
+        dJT[(size_t)(c * NHP + i) * BP + b] = ok ? djoints_in[((size_t)b * NH + i) * 3 + c] : 0.f;
+        if (i == 0) dJT[(size_t)(c * NHP + NH) * BP + b] = 0.f;
       }
     }
     return;
   }
   if (!gt_mm) return;
-  float g[NH][3];
-  float err = 0.f;
+  if (i == 0) { pel[0][bl] = j[0]; pel[1][bl] = j[1]; pel[2][bl] = j[2]; }
+  __syncthreads();
+  float g[3], err = 0.f;
 #pragma unroll
   for (int c = 0; c < 3; ++c) {
-    float gsum = 0.f;
-#pragma unroll
-    for (int i = 1; i < NH; ++i) {
-      float d = (j[i][c] - j[0][c]) - gt_mm[((size_t)b * NH + i) * 3 + c] / 1000.f;
-      err += d * d;
-      g[i][c] = scale * d;
-      gsum += g[i][c];
-    }
-    // joint 0: centred value is identically 0; gt is pelvis-centred by the caller (optimize.py:162)
-    float d0 = -gt_mm[((size_t)b * NH + 0) * 3 + c] / 1000.f;
-    err += d0 * d0;
-    g[0][c] = -gsum;   // move_pelvis adjoint: -sum_i g_i (g_0 cancels)
+    const float gtv = ok ? gt_mm[((size_t)b * NH + i) * 3 + c] / 1000.f : 0.f;
+    // joint 0: the centred value is identically 0; gt is pelvis-centred by the caller (optimize.py:162)
+    const float d = (i == 0) ? -gtv : (j[c] - pel[c][bl]) - gtv;
+    err += d * d;
+    g[c] = (i == 0) ? 0.f : scale * d;
+    red[i][c][bl] = g[c];
   }
-  if (sqerr) sqerr[b] = err;
-  if (rp.gt_j2d) {     // 2-D reprojection term on the UN-centred joints (optimize.py:231-233)
+  float e2 = 0.f, gc[3] = {0.f, 0.f, 0.f}, g2[3] = {0.f, 0.f, 0.f};
+  if (rp.gt_j2d && ok) {     // 2-D reprojection term on the UN-centred joints (optimize.py:231-233)
     float t[3] = {rp.cam[(size_t)b * 3], rp.cam[(size_t)b * 3 + 1], rp.cam[(size_t)b * 3 + 2]};
-    float gt3[3] = {0.f, 0.f, 0.f};
-    float e2 = 0.f;
+    float xs, ys, invZ, X, Y;
+    project_point(j, t, xs, ys, invZ, X, Y);
+    const float dx = xs - rp.gt_j2d[((size_t)b * NH + i) * 2], dy = ys - rp.gt_j2d[((size_t)b * NH + i) * 2 + 1];
+    e2 = dx * dx + dy * dy;
+    project_point_bwd(rp.scale2d * dx, rp.scale2d * dy, invZ, X, Y, g2, gc);
+  }
+  red[i][3][bl] = err;
+  red[i][4][bl] = e2;
 #pragma unroll
-    for (int i = 0; i < NH; ++i) {
-      float xs, ys, invZ, X, Y;
-      project_point(j[i], t, xs, ys, invZ, X, Y);
-      const float dx = xs - rp.gt_j2d[((size_t)b * NH + i) * 2], dy = ys - rp.gt_j2d[((size_t)b * NH + i) * 2 + 1];
-      e2 += dx * dx + dy * dy;
-      project_point_bwd(rp.scale2d * dx, rp.scale2d * dy, invZ, X, Y, g[i], gt3);
+  for (int c = 0; c < 3; ++c) red[i][5 + c][bl] = gc[c];
+  __syncthreads();
+  if (i == 0) {       // fixed-order sums over the 17 joints (deterministic)
+    float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int q = 0; q < NH; ++q)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) s[k] += red[q][k][bl];
+    if (ok) {
+      if (sqerr) sqerr[b] = s[3];
+      if (rp.gt_j2d) {
+        if (rp.sq2d) rp.sq2d[b] = s[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) rp.gcam[(size_t)b * 3 + c] = s[5 + c];
+      }
     }
-    if (rp.sq2d) rp.sq2d[b] = e2;
 #pragma unroll
-    for (int c = 0; c < 3; ++c) rp.gcam[(size_t)b * 3 + c] = gt3[c];
+    for (int c = 0; c < 3; ++c) g[c] = -s[c];     // move_pelvis adjoint: -sum_i g_i
   }
   if (dJT) {
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-#pragma unroll
-      for (int i = 0; i < NH; ++i) dJT[(size_t)(c * NHP + i) * BP + b] = g[i][c];
-      dJT[(size_t)(c * NHP + NH) * BP + b] = 0.f;
+      dJT[(size_t)(c * NHP + i) * BP + b] = ok ? g[c] + g2[c] : 0.f;
+      if (i == 0) dJT[(size_t)(c * NHP + NH) * BP + b] = 0.f;
     }
   }
 }
@@ -385,7 +405,7 @@ __global__ void k_project_joints(const float* __restrict__ joints, const float* 
 // Camera pre-fit (scripts/optimize.py:187-199): n Adam steps on the camera translation only, against the
 // 2-D joints.  The reference re-runs the whole SMPL forward every step although the joints do not depend
 // on the camera; here the joints are computed once and each thread runs its pose's n steps in registers.
-__global__ void k_camera_fit(const float* __restrict__ joints, const float* __restrict__ gt_j2d, float* __restrict__ cam,
+__global__ __launch_bounds__(64) void k_camera_fit(const float* __restrict__ joints, const float* __restrict__ gt_j2d, float* __restrict__ cam,
                              float scale2d, int nsteps, float lr, float* __restrict__ sq2d, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -475,97 +495,126 @@ __global__ void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, 
 // k_pose_update (one (pose, joint) per thread, joint 24 = betas): 6-D rotation adjoint, extra
 //   (discriminator) gradients, then either the gradient outputs or the fused Adam update.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(64) void k_chain_bwd(const float* __restrict__ FT, const float* __restrict__ R0T,
-                                                  const float* __restrict__ AT, const float* __restrict__ Jt,
-                                                  const float* __restrict__ JS, Parents par,
-                                                  const float* __restrict__ dA_, const float* __restrict__ dF_,
-                                                  float* __restrict__ dRT, float* __restrict__ dbT, int B, int BP) {
-  extern __shared__ float dG[];   // [24][12][64]
-  const int lane = threadIdx.x;
-  const int b = blockIdx.x * 64 + lane;
-  if (b >= B) return;
-  float beta[NB], dbeta[NB];
+__global__ __launch_bounds__(PP * NJ) void k_chain_bwd(const float* __restrict__ FT, const float* __restrict__ R0T,
+                                                       const float* __restrict__ AT, const float* __restrict__ Jt,
+                                                       const float* __restrict__ JS, Parents par,
+                                                       const float* __restrict__ dA_, const float* __restrict__ dF_,
+                                                       float* __restrict__ dRT, float* __restrict__ dbT, int B, int BP) {
+  // one thread per (pose, joint); levels of the kinematic tree are processed deepest first.  Each child
+  // leaves its contribution to the parent's dG in its own LDS slot; the parent sums its children in
+  // index order (no atomics: bitwise reproducible).
+  __shared__ float dG[NJ][12][PP];
+  __shared__ float Js[NJ][3][PP];
+  __shared__ float dBs[NJ][NB][PP];
+  const int bl = threadIdx.x & (PP - 1), j = threadIdx.x / PP;
+  const int b = blockIdx.x * PP + bl;
+  const bool ok = b < B;
+  const size_t bb = ok ? (size_t)b : 0;      // padded lanes read pose 0 and write nothing
+  const int p = par.p[j];
+  float beta[NB], dbeta[NB], Ji[3];
 #pragma unroll
-  for (int l = 0; l < NB; ++l) { beta[l] = FT[(size_t)(207 + l) * BP + b]; dbeta[l] = 0.f; }
-  for (int k = 0; k < NJ * 12; ++k) dG[k * 64 + lane] = 0.f;
-
-#pragma unroll 4
-  for (int i = NJ - 1; i >= 0; --i) {
-    const int p = par.p[i];
-    float dA[12], GiR[9], R[9], Ji[3];
+  for (int l = 0; l < NB; ++l) { beta[l] = FT[(size_t)(207 + l) * BP + bb]; dbeta[l] = 0.f; }
+  rest_joint(Jt, JS, j, beta, Ji);
+  // everything this joint needs from global memory, issued up front (independent, pose-contiguous)
+  float dA[12], GiR[9], R[9], Gp[9], dFj[9];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) dA[e] = dA_[(size_t)(e * NJ + i) * BP + b];
+  for (int e = 0; e < 12; ++e) dA[e] = dA_[(size_t)(e * NJ + j) * BP + bb];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+  for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc) GiR[r * 3 + cc] = AT[(size_t)((r * 4 + cc) * NJ + i) * BP + b];
-    rest_joint(Jt, JS, i, beta, Ji);
-    // dG_i = accumulated from children + own: A.R = G.R ; A.t = G.t - G.R J
-    float dGi[12];
-#pragma unroll
-    for (int r = 0; r < 3; ++r) {
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) dGi[r * 4 + cc] = dG[(i * 12 + r * 4 + cc) * 64 + lane] + dA[r * 4 + cc] - dA[r * 4 + 3] * Ji[cc];
-      dGi[r * 4 + 3] = dG[(i * 12 + r * 4 + 3) * 64 + lane] + dA[r * 4 + 3];
+    for (int cc = 0; cc < 3; ++cc) {
+      GiR[r * 3 + cc] = AT[(size_t)((r * 4 + cc) * NJ + j) * BP + bb];
+      Gp[r * 3 + cc] = (j > 0) ? AT[(size_t)((r * 4 + cc) * NJ + p) * BP + bb] : 0.f;
     }
-    float dJ[3];
 #pragma unroll
-    for (int cc = 0; cc < 3; ++cc) dJ[cc] = -(GiR[0 * 3 + cc] * dA[3] + GiR[1 * 3 + cc] * dA[7] + GiR[2 * 3 + cc] * dA[11]);
-    float dRi[9];
-    if (i == 0) {
+  for (int k = 0; k < 9; ++k) {
+    R[k] = (j > 0) ? FT[(size_t)((j - 1) * 9 + k) * BP + bb] + ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f) : 0.f;
+    dFj[k] = (j > 0) ? dF_[(size_t)((j - 1) * 9 + k) * BP + bb] : 0.f;
+  }
 #pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) dRi[r * 3 + cc] = dGi[r * 4 + cc];
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) dJ[cc] += dGi[cc * 4 + 3];   // G_0.t = J_0
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc)
-#pragma unroll
-        for (int l = 0; l < NB; ++l) dbeta[l] = fmaf(dJ[cc], JS[(0 * 3 + cc) * NB + l], dbeta[l]);
-    } else {
-      float Gp[9], Jp[3], rel[3], drel[3];
-#pragma unroll
-      for (int k = 0; k < 9; ++k) R[k] = FT[(size_t)((i - 1) * 9 + k) * BP + b] + ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f);
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc) Gp[r * 3 + cc] = AT[(size_t)((r * 4 + cc) * NJ + p) * BP + b];
-      rest_joint(Jt, JS, p, beta, Jp);
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc) rel[cc] = Ji[cc] - Jp[cc];
-      // G_i.R = Gp.R R_i ; G_i.t = Gp.R rel + Gp.t ;  F[(i-1)*9+k] = R_i[k] - I
-#pragma unroll
-      for (int r = 0; r < 3; ++r)
-#pragma unroll
-        for (int cc = 0; cc < 3; ++cc)
-          dRi[r * 3 + cc] = Gp[0 * 3 + r] * dGi[0 * 4 + cc] + Gp[1 * 3 + r] * dGi[1 * 4 + cc] + Gp[2 * 3 + r] * dGi[2 * 4 + cc] +
-                            dF_[(size_t)((i - 1) * 9 + r * 3 + cc) * BP + b];
-#pragma unroll
-      for (int cc = 0; cc < 3; ++cc)
-        drel[cc] = Gp[0 * 3 + cc] * dGi[0 * 4 + 3] + Gp[1 * 3 + cc] * dGi[1 * 4 + 3] + Gp[2 * 3 + cc] * dGi[2 * 4 + 3];
+  for (int cc = 0; cc < 3; ++cc) Js[j][cc][bl] = Ji[cc];
+  __syncthreads();
+
+  float dRi[9];
+  const int dj = par.depth[j];
+  for (int d = par.maxd; d >= 0; --d) {
+    if (dj == d) {
+      // dG_i = own (A.R = G.R ; A.t = G.t - G.R J) + the contributions of the children (one level deeper)
+      float dGi[12];
 #pragma unroll
       for (int r = 0; r < 3; ++r) {
 #pragma unroll
-        for (int cc = 0; cc < 3; ++cc) {
-          const float add = dGi[r * 4 + 0] * R[cc * 3 + 0] + dGi[r * 4 + 1] * R[cc * 3 + 1] + dGi[r * 4 + 2] * R[cc * 3 + 2] +
-                            dGi[r * 4 + 3] * rel[cc];
-          dG[(p * 12 + r * 4 + cc) * 64 + lane] += add;
-        }
-        dG[(p * 12 + r * 4 + 3) * 64 + lane] += dGi[r * 4 + 3];
+        for (int cc = 0; cc < 3; ++cc) dGi[r * 4 + cc] = dA[r * 4 + cc] - dA[r * 4 + 3] * Ji[cc];
+        dGi[r * 4 + 3] = dA[r * 4 + 3];
       }
-      // J_i enters through -G_i.R J_i (dJ) and rel = J_i - J_p (drel)
+      for (int q = j + 1; q < NJ; ++q) {
+        if (par.p[q] == j) {
 #pragma unroll
-      for (int cc = 0; cc < 3; ++cc)
+          for (int e = 0; e < 12; ++e) dGi[e] += dG[q][e][bl];
+        }
+      }
+      float dJ[3];
 #pragma unroll
-        for (int l = 0; l < NB; ++l)
-          dbeta[l] = fmaf(dJ[cc] + drel[cc], JS[(i * 3 + cc) * NB + l], fmaf(-drel[cc], JS[(p * 3 + cc) * NB + l], dbeta[l]));
+      for (int cc = 0; cc < 3; ++cc) dJ[cc] = -(GiR[0 * 3 + cc] * dA[3] + GiR[1 * 3 + cc] * dA[7] + GiR[2 * 3 + cc] * dA[11]);
+      if (j == 0) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) dRi[r * 3 + cc] = dGi[r * 4 + cc];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) dJ[cc] += dGi[cc * 4 + 3];   // G_0.t = J_0
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+          for (int l = 0; l < NB; ++l) dbeta[l] = fmaf(dJ[cc], JS[(0 * 3 + cc) * NB + l], dbeta[l]);
+      } else {
+        float rel[3], drel[3];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc) rel[cc] = Ji[cc] - Js[p][cc][bl];
+        // G_i.R = Gp.R R_i ; G_i.t = Gp.R rel + Gp.t ;  F[(i-1)*9+k] = R_i[k] - I
+#pragma unroll
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc)
+            dRi[r * 3 + cc] = Gp[0 * 3 + r] * dGi[0 * 4 + cc] + Gp[1 * 3 + r] * dGi[1 * 4 + cc] + Gp[2 * 3 + r] * dGi[2 * 4 + cc] +
+                              dFj[r * 3 + cc];
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+          drel[cc] = Gp[0 * 3 + cc] * dGi[0 * 4 + 3] + Gp[1 * 3 + cc] * dGi[1 * 4 + 3] + Gp[2 * 3 + cc] * dGi[2 * 4 + 3];
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+#pragma unroll
+          for (int cc = 0; cc < 3; ++cc) {
+            const float add = dGi[r * 4 + 0] * R[cc * 3 + 0] + dGi[r * 4 + 1] * R[cc * 3 + 1] + dGi[r * 4 + 2] * R[cc * 3 + 2] +
+                              dGi[r * 4 + 3] * rel[cc];
+            dG[j][r * 4 + cc][bl] = add;                 // this joint's contribution to dG of its parent
+          }
+          dG[j][r * 4 + 3][bl] = dGi[r * 4 + 3];
+        }
+        // J_i enters through -G_i.R J_i (dJ) and rel = J_i - J_p (drel)
+#pragma unroll
+        for (int cc = 0; cc < 3; ++cc)
+#pragma unroll
+          for (int l = 0; l < NB; ++l)
+            dbeta[l] = fmaf(dJ[cc] + drel[cc], JS[(j * 3 + cc) * NB + l], fmaf(-drel[cc], JS[(p * 3 + cc) * NB + l], dbeta[l]));
+      }
     }
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dRT[(size_t)(i * 9 + k) * BP + b] = dRi[k];
+    __syncthreads();
   }
+  if (ok) {
 #pragma unroll
-  for (int l = 0; l < NB; ++l) dbT[(size_t)l * BP + b] = dbeta[l] + dF_[(size_t)(207 + l) * BP + b];
+    for (int k = 0; k < 9; ++k) dRT[(size_t)(j * 9 + k) * BP + b] = dRi[k];
+  }
+  // dL/dbeta: sum the per-joint contributions of each pose (fixed order: deterministic)
+#pragma unroll
+  for (int l = 0; l < NB; ++l) dBs[j][l][bl] = dbeta[l];
+  __syncthreads();
+  if (j < NB && ok) {
+    float acc = dF_[(size_t)(207 + j) * BP + b];
+#pragma unroll
+    for (int q = 0; q < NJ; ++q) acc += dBs[q][j][bl];
+    dbT[(size_t)j * BP + b] = acc;
+  }
 }
 
 struct PoseUpdateArgs {
@@ -678,19 +727,13 @@ int launch_rot6d_bwd(const float* x, const float* dR, float* dx, int n, hipStrea
   return 0;
 }
 
-static bool g_attr_set = false;
-static void ensure_attrs() {
-  if (g_attr_set) return;
-  (void)hipFuncSetAttribute((const void*)k_prep_fwd, hipFuncAttributeMaxDynamicSharedMemorySize, NJ * 12 * 64 * 4);
-  (void)hipFuncSetAttribute((const void*)k_chain_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, NJ * 12 * 64 * 4);
-  g_attr_set = true;
-}
+static void ensure_attrs() {}
 
 int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT,
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s) {
   ensure_attrs();
-  hipLaunchKernelGGL(k_prep_fwd, dim3(BP / 64), dim3(64), NJ * 12 * 64 * 4, s, x6d, Rin, betas, m.Jt, m.JS, m.parents,
-                     FT, AT, R0T, B, BP, step_inc);
+  hipLaunchKernelGGL(k_prep_fwd, dim3(BP / PP), dim3(PP * NJ), 0, s, x6d, Rin, betas, m.Jt, m.JS, m.parents, FT, AT, R0T,
+                     B, BP, step_inc);
   return 0;
 }
 
@@ -699,8 +742,8 @@ int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float
   Reproj rp;
   rp.gt_j2d = r ? r->gt_j2d : nullptr; rp.cam = r ? r->cam : nullptr; rp.gcam = r ? r->gcam : nullptr;
   rp.sq2d = r ? r->sq2d : nullptr; rp.scale2d = r ? r->scale2d : 0.f;
-  hipLaunchKernelGGL(k_joints_loss, dim3(BP / 64), dim3(64), 0, s, JP, nvc, gt_mm, djoints_in, scale, joints_out, sqerr,
-                     dJT, rp, B, BP);
+  hipLaunchKernelGGL(k_joints_loss, dim3(BP / PP), dim3(PP * NH), 0, s, JP, nvc, gt_mm, djoints_in, scale, joints_out,
+                     sqerr, dJT, rp, B, BP);
   return 0;
 }
 
@@ -724,8 +767,8 @@ int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale
 
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
   ensure_attrs();
-  hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + 63) / 64), dim3(64), NJ * 12 * 64 * 4, s, L.FT, L.R0T, L.AT, m.Jt, m.JS,
-                     m.parents, L.dATp, L.dFTp, L.dRT, L.dbT, L.B, L.BP);
+  hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + PP - 1) / PP), dim3(PP * NJ), 0, s, L.FT, L.R0T, L.AT, m.Jt, m.JS, m.parents,
+                     L.dATp, L.dFTp, L.dRT, L.dbT, L.B, L.BP);
   if (L.wait_before_update) (void)hipStreamWaitEvent(s, L.wait_before_update, 0);
   PoseUpdateArgs a;
   a.x6d_in = L.x6d_in; a.dRT = L.dRT; a.dbT = L.dbT; a.gx_extra = L.gx_extra; a.gb_extra = L.gb_extra;
