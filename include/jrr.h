@@ -50,7 +50,8 @@ enum {
 enum {
   JRR_FLAG_POSE_DISC = 1,   /* allocate / run the pose-discriminator term (optimize.py:241-247) */
   JRR_FLAG_SHAPE_DISC = 2,  /* shape-discriminator term (optimize.py:244,249-250) */
-  JRR_FLAG_KEEP_VERTS = 4   /* reserve a (B,6890,3) vertex buffer for return_verts / J step */
+  JRR_FLAG_KEEP_VERTS = 4,  /* reserve a (B,6890,3) vertex buffer for return_verts / J step */
+  JRR_FLAG_FOLDED = 8       /* reserve the folded-regressor tables (jrr_engine_set_folded) */
 };
 
 typedef struct jrr_model jrr_model_t;   /* device-resident, re-laid-out SMPL constants */
@@ -81,9 +82,15 @@ int jrr_engine_create(const jrr_model_t* model, int batch, int batch_norm, void*
                       size_t workspace_bytes, int flags, jrr_engine_t** out);
 void jrr_engine_destroy(jrr_engine_t* e);
 int jrr_engine_set_batch_norm(jrr_engine_t* e, int batch_norm);
-/* 1 = every launch of jrr_refine_run on the caller's stream; 2 (default) = the discriminator branch
- * of each iteration runs on an engine-owned second stream, forked from / joined back into the
- * caller's stream with events (the two branches only meet in the Adam update).                */
+/* Folded joint regression for jrr_refine_run (needs JRR_FLAG_FOLDED): the pose-independent contraction
+ * H = sum_v Jn W D (1224 x 218) is rebuilt at every jrr_engine_set_j_regressor, and each iteration evaluates
+ * joints = A . (H F) instead of skinning 6890 vertices -- the same function of (theta, beta, J) up to fp32
+ * rounding, ~25x fewer FLOP, no vertices.  A separate mode with its own denominator; never the default.   */
+int jrr_engine_set_folded(jrr_engine_t* e, int enabled, void* stream);
+/* 1 (default) = every launch of jrr_refine_run on the caller's stream; 2 = the discriminator branch of
+ * each iteration runs on an engine-owned second stream, forked from / joined back into the caller's
+ * stream with events (the two branches only meet in the Adam update).  Measured gain at batch 4096:
+ * 1.5-3.6 % (tools/exp/ab_streams.py), with one unexplained 20 % slower outlier run, hence opt-in.  */
 int jrr_engine_set_concurrency(jrr_engine_t* e, int streams);
 
 /* J*mask -> ReLU -> row-normalise (scripts/utils.py:87-92), into the engine's tile-major

@@ -27,6 +27,7 @@ SIGNATURES = {
     'jrr_engine_destroy': (None, [_P]),
     'jrr_engine_set_batch_norm': (c_int, [_P, c_int]),
     'jrr_engine_set_concurrency': (c_int, [_P, c_int]),
+    'jrr_engine_set_folded': (c_int, [_P, c_int, _P]),
     'jrr_engine_set_j_regressor': (c_int, [_P, _P, _P, _P]),
     'jrr_engine_set_pose_disc': (c_int, [_P, _P, _P]),
     'jrr_engine_set_shape_disc': (c_int, [_P, _P, _P]),

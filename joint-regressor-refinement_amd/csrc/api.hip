@@ -120,6 +120,8 @@ struct jrr_engine {
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
   float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc;
   float *Ps, *gb;
+  float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
+  bool folded, fold_valid;
   float *verts, *djpad, *dJnp, *dJn, *dj;
   bool verts_zeroed;
   int32_t* step_scratch;
@@ -223,6 +225,14 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->Ps = c.take(256);
     t->gb = c.take((size_t)BP * NB);
   }
+  if (flags & JRR_FLAG_FOLDED) {
+    t->JW = c.take((size_t)VP * FOLD_MJ);
+    t->Hm = c.take((size_t)FOLD_M * KFP);
+    t->Hk = c.take((size_t)KFP * FOLD_M);
+    t->G0 = c.take(FOLD_MJ);
+    t->MT = c.take((size_t)FOLD_M * BP);
+    t->dMT = c.take((size_t)FOLD_M * BP);
+  }
   if (flags & JRR_FLAG_KEEP_VERTS) {
     t->verts = c.take((size_t)BP * VP * 3);
     t->djpad = c.take((size_t)BP * 64);
@@ -254,7 +264,7 @@ extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_
   e->bnorm = batch_norm > 0 ? batch_norm : batch;
   e->flags = flags;
   carve(e, ws, batch, flags);
-  e->streams = 2;
+  e->streams = 1;
   *out = e;
   return JRR_OK;
 }
@@ -338,6 +348,36 @@ extern "C" int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n) {
   return JRR_OK;
 }
 
+// H[(i,j,c)][k] = sum_v Jn[i,v] W[v,j] D_c[k,v]  and  G0 (fold.hip); both layouts of H
+static int fold_rebuild(jrr_engine* e, hipStream_t s) {
+  launch_fold_jw(e->Jn, e->m.Wjv, e->JW, e->G0, s);
+  for (int c = 0; c < 3; ++c) {
+    GemmArgs g;
+    g.A = e->JW; g.lda = FOLD_MJ;                          // A[k = v][m = (i,j)]
+    g.Bm = e->m.Dn + (size_t)c * VP * KFP; g.ldb = KFP;    // Bm[k = v][n = feature]
+    g.Out = e->Hm + (size_t)c * KFP; g.ldo = 3 * KFP;      // row (i,j) of plane c = row (i*24+j)*3 + c of Hm
+    g.bias = nullptr; g.mask = nullptr; g.split_stride = 0;
+    g.M = NH * NJ; g.N = KFP; g.K = VP;
+    int rc = launch_gemm_128x32(g, EPI_STORE, 1, s);
+    if (rc) return rc;
+  }
+  launch_transpose(e->Hm, e->Hk, NH * NJ * 3, KFP, s, KFP, FOLD_M);
+  e->fold_valid = true;
+  return 0;
+}
+
+extern "C" int jrr_engine_set_folded(jrr_engine_t* e, int enabled, void* stream) {
+  if (!e) return JRR_ERR_ARG;
+  if (enabled && !(e->flags & JRR_FLAG_FOLDED)) { jrr_set_error("engine created without JRR_FLAG_FOLDED"); return JRR_ERR_STATE; }
+  e->folded = enabled != 0;
+  if (e->folded && e->have_J && !e->fold_valid) {
+    int rc = fold_rebuild(e, (hipStream_t)stream);
+    if (rc) return rc;
+    CHECK_LAUNCH();
+  }
+  return JRR_OK;
+}
+
 extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const float* mask, void* stream) {
   if (!e || !J) { jrr_set_error("set_j_regressor: null"); return JRR_ERR_ARG; }
   hipStream_t s = (hipStream_t)stream;
@@ -346,6 +386,11 @@ extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const
   e->have_mask = mask != nullptr;
   launch_bwd_tab_static(e->m, e->Jn_iv, s);
   launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, s);
+  e->fold_valid = false;
+  if (e->folded) {
+    int rc = fold_rebuild(e, s);
+    if (rc) return rc;
+  }
   CHECK_LAUNCH();
   e->have_J = true;
   return JRR_OK;
@@ -710,20 +755,39 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     prof_mark(e, 0, s);
     launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, s);
     prof_mark(e, 0, s);
+    const bool folded = e->folded && e->fold_valid;
     prof_mark(e, 1, s);
-    launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, nullptr, 0, e->B, e->BP, e->nvc, s);
+    if (folded) {
+      GemmArgs g;   // M^T[(i,j,c)][b] = sum_k H[(i,j,c)][k] F^T[k][b]
+      g.A = e->Hk; g.lda = FOLD_M; g.Bm = e->FT; g.ldb = e->BP; g.Out = e->MT; g.ldo = e->BP;
+      g.bias = nullptr; g.mask = nullptr; g.split_stride = 0; g.M = FOLD_M; g.N = e->BP; g.K = KFP;
+      int rcf = launch_gemm_128x64(g, EPI_STORE, 1, s);
+      if (rcf) return rcf;
+      launch_fold_fwd(e->MT, e->AT, e->G0, e->Jsum, e->BP, s);
+    } else {
+      launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, nullptr, 0, e->B, e->BP, e->nvc, s);
+    }
     prof_mark(e, 1, s);
     prof_mark(e, 2, s);
-    reduce_joint_partials(e, s);
+    if (!folded) reduce_joint_partials(e, s);
     ReprojLaunch rl{e->gt_j2d, e->cam, e->gcam, e->sq2d, (float)(2.0 * 0.01 / ((double)e->bnorm * 34.0))};   // weight 1/100
     launch_joints_loss(e->Jsum, 1, gt_mm, nullptr, jscale, e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s,
                        e->gt_j2d ? &rl : nullptr);
     prof_mark(e, 2, s);
+    int rc = 0;
     prof_mark(e, 3, s);
-    launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
+    if (folded) launch_fold_bwd(e->dJT, e->AT, e->MT, e->G0, e->dMT, e->dA, e->BP, s);
+    else launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
     prof_mark(e, 3, s);
     prof_mark(e, 4, s);
-    int rc = blend_adjoint_gemm(e, s);
+    if (folded) {
+      GemmArgs g;   // dF^T[k][b] = sum_m H[m][k] dM^T[m][b]   (split over m, partial slabs)
+      g.A = e->Hm; g.lda = KFP; g.Bm = e->dMT; g.ldb = e->BP; g.Out = e->dFTp; g.ldo = e->BP;
+      g.bias = nullptr; g.mask = nullptr; g.split_stride = (size_t)KFP * e->BP; g.M = KFP; g.N = e->BP; g.K = FOLD_M;
+      rc = launch_gemm_224(g, EPI_STORE, e->nsplit, s);
+    } else {
+      rc = blend_adjoint_gemm(e, s);
+    }
     prof_mark(e, 4, s);
     if (rc) return rc;
     if (pd && !fork) {
@@ -740,7 +804,8 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
       prof_mark(e, 6, s);
     }
     prof_mark(e, 7, s);
-    reduce_adjoint_partials(e, s);
+    if (folded) launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
+    else reduce_adjoint_partials(e, s);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.betas_in = betas;
     L.dATp = e->dA; L.dFTp = e->dF; L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;

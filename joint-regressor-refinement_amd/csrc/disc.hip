@@ -342,19 +342,20 @@ int launch_sqerr_rows(const float* out, int ncol, float target, float* sqerr, in
 }
 
 // [rows][cols] -> [cols][rows]
-__global__ void k_transpose(const float* __restrict__ in, float* __restrict__ out, int rows, int cols) {
+__global__ void k_transpose(const float* __restrict__ in, float* __restrict__ out, int rows, int cols, int ldin, int ldout) {
   __shared__ float t[32][33];
   int c = blockIdx.x * 32 + threadIdx.x, r0 = blockIdx.y * 32;
   for (int i = threadIdx.y; i < 32; i += blockDim.y)
-    if (r0 + i < rows && c < cols) t[i][threadIdx.x] = in[(size_t)(r0 + i) * cols + c];
+    if (r0 + i < rows && c < cols) t[i][threadIdx.x] = in[(size_t)(r0 + i) * ldin + c];
   __syncthreads();
   int r = r0 + threadIdx.x, c0 = blockIdx.x * 32;
   for (int i = threadIdx.y; i < 32; i += blockDim.y)
-    if (c0 + i < cols && r < rows) out[(size_t)(c0 + i) * rows + r] = t[threadIdx.x][i];
+    if (c0 + i < cols && r < rows) out[(size_t)(c0 + i) * ldout + r] = t[threadIdx.x][i];
 }
 
-int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s) {
-  hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s, in, out, rows, cols);
+int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s, int ldin, int ldout) {
+  hipLaunchKernelGGL(k_transpose, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(32, 8), 0, s, in, out, rows, cols,
+                     ldin ? ldin : cols, ldout ? ldout : rows);
   return 0;
 }
 

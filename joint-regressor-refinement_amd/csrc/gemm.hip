@@ -141,6 +141,8 @@ int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { ret
 int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 2, 2, 32>(g, epi, nsplit, s); }
 // 128x128 block tile, 8 waves (2x4 of 64x32): 2 waves per SIMD with one workgroup per CU
 int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 2, 4, 32>(g, epi, nsplit, s); }
+// 128x32 block tile (4 waves stacked in M): narrow-N products (folded-regressor table, N = 224 per plane)
+int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<1, 1, 4, 1, 16>(g, epi, nsplit, s); }
 // 224x128 block tile (4 waves of 224x32), 16-deep chunks: blend-basis adjoint, M = KFP = 224
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<7, 1, 1, 4, 16>(g, epi, nsplit, s); }
 // 64x128 block tile (4 waves of 64x32): the J-regressor gradient product, M = 51 padded to 64

@@ -19,6 +19,8 @@ constexpr int KCH = 32;        // feature rows per staged chunk of the blend bas
 constexpr int NKCH = KFP / KCH;  // 7
 constexpr int BT = 32;         // poses per wave tile
 constexpr int BG = 128;        // poses per forward workgroup (4 waves)
+constexpr int FOLD_MJ = 512;   // (H36M joint, SMPL joint) pairs 17*24 = 408, padded
+constexpr int FOLD_M = 1280;   // (i, j, c) triples 1224, padded to 10 x 128
 constexpr int NPARAM = 154;    // 144 pose6d + 10 betas per pose
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

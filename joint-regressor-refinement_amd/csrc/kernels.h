@@ -72,14 +72,21 @@ int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const fl
 int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+
+// fold.hip
+int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, hipStream_t s);
+int launch_fold_fwd(const float* MT, const float* AT, const float* G0, float* Jsum, int BP, hipStream_t s);
+int launch_fold_bwd(const float* dJT, const float* AT, const float* MT, const float* G0, float* dMT, float* dA, int BP,
+                    hipStream_t s);
 
 // eval.hip
 int launch_evaluate(const float* pred, const float* target_mm, float* err, float* err_pa, int B, hipStream_t s);
 
 // disc.hip
-int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s);
+int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s, int ldin = 0, int ldout = 0);
 int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s);
 int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
                     float target, int B, int BP, hipStream_t s, float* dz0 = nullptr);

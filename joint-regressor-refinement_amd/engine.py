@@ -18,6 +18,7 @@ from ._lib import check, ptr, stream_ptr
 FLAG_POSE_DISC = 1
 FLAG_SHAPE_DISC = 2
 FLAG_KEEP_VERTS = 4
+FLAG_FOLDED = 8
 
 NUM_VERTS, NUM_JOINTS, NUM_H36M, NUM_BETAS = 6890, 24, 17, 10
 DISC_PARAMS = 1840153
@@ -118,6 +119,10 @@ class RefineEngine:
     # -- configuration ---------------------------------------------------------------------
     def set_batch_norm(self, n: int):
         check(self.lib.jrr_engine_set_batch_norm(self.handle, int(n)), 'set_batch_norm')
+
+    def set_folded(self, enabled: bool):
+        """refine_run through the folded regressor tables (engine must have FLAG_FOLDED)"""
+        check(self.lib.jrr_engine_set_folded(self.handle, int(bool(enabled)), self._s()), 'set_folded')
 
     def set_concurrency(self, streams: int):
         check(self.lib.jrr_engine_set_concurrency(self.handle, int(streams)), 'set_concurrency')

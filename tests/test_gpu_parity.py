@@ -315,3 +315,37 @@ def test_error_behaviour(eng_mod, dmodel):
     eng.set_j_regressor(torch.rand(17, 6890))
     with pytest.raises(lib_mod.JrrError, match='KEEP_VERTS'):
         eng.j_regressor_grad(torch.zeros(4, 24, 6, device=DEV), torch.zeros(4, 10, device=DEV), torch.zeros(4, 17, 3, device=DEV))
+
+
+@pytest.mark.parametrize('B,pose_d', [(96, False), (130, True)])
+def test_folded_mode_matches_dense_and_oracle(eng_mod, dmodel, smpl_model_np, j_h36m_np, B, pose_d):
+    """the folded regressor (H = Jn.W.D contracted once per J) is the same function of (theta, beta, J) up to
+    fp32 rounding: 5 fused iterations vs the dense HIP path and vs the oracle"""
+    n = 5
+    batch = _batch(smpl_model_np, j_h36m_np, B, 23)
+    x6d, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0) if pose_d else None
+    res = {}
+    for mode in ('dense', 'folded'):
+        flags = (eng_mod.FLAG_POSE_DISC if pose_d else 0) | (eng_mod.FLAG_FOLDED if mode == 'folded' else 0)
+        eng = eng_mod.RefineEngine(dmodel, B, flags=flags)
+        if mode == 'folded':
+            eng.set_folded(True)
+        eng.set_j_regressor(T(j_h36m_np))
+        if pose_d:
+            eng.set_pose_disc(eng_mod.flatten_state_dict(dsd, eng_mod.DISC_KEYS))
+        xd, bd = x6d.clone().to(DEV), betas.clone().to(DEV)
+        m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+        step = torch.zeros(1, dtype=torch.int32, device=DEV)
+        sq = torch.zeros(B, device=DEV)
+        eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, n, sqerr=sq)
+        res[mode] = (xd.cpu(), bd.cpu(), sq.cpu())
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    o, p, b, hist = oracle.refine_poses(smpl, T(j_h36m_np), x6d[:, :1], x6d[:, 1:], betas, gt_c, n, disc_sd=dsd)
+    ref = torch.cat([o, p], 1)
+    for mode in ('dense', 'folded'):
+        assert (res[mode][0] - ref).abs().max().item() < 3e-4, mode
+        assert (res[mode][1] - b).abs().max().item() < 3e-4, mode
+        np.testing.assert_allclose(float(res[mode][2].sum()) / (B * 51), hist[-1]['joint_loss'], rtol=2e-3)
+    assert (res['dense'][0] - res['folded'][0]).abs().max().item() < 3e-4
