@@ -727,11 +727,8 @@ int launch_rot6d_bwd(const float* x, const float* dR, float* dx, int n, hipStrea
   return 0;
 }
 
-static void ensure_attrs() {}
-
 int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT,
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s) {
-  ensure_attrs();
   hipLaunchKernelGGL(k_prep_fwd, dim3(BP / PP), dim3(PP * NJ), 0, s, x6d, Rin, betas, m.Jt, m.JS, m.parents, FT, AT, R0T,
                      B, BP, step_inc);
   return 0;
@@ -766,7 +763,6 @@ int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale
 }
 
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
-  ensure_attrs();
   hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + PP - 1) / PP), dim3(PP * NJ), 0, s, L.FT, L.R0T, L.AT, m.Jt, m.JS, m.parents,
                      L.dATp, L.dFTp, L.dRT, L.dbT, L.B, L.BP);
   if (L.wait_before_update) (void)hipStreamWaitEvent(s, L.wait_before_update, 0);
