@@ -33,39 +33,65 @@ _REST_JOINTS = np.array([
     [0.68, 0.23, -0.03], [-0.68, 0.23, -0.03], [0.76, 0.22, -0.03], [-0.76, 0.22, -0.03]], dtype=np.float64)
 
 
+N_RINGS, N_SEGS = 84, 82          # 84*82 + 2 poles = 6890 vertices; 2*84*82 = 13776 faces (SMPL's counts)
+
+
+def _body_surface():
+    """A closed, star-shaped (about the vertical axis) body-scale surface sampled on a ring/segment grid in
+    ring-major order, with T-pose "arm" fins at shoulder height: gives the synthetic model a genuine
+    genus-0 triangle mesh with SMPL's vertex and face counts (V - E + F = 2  =>  F = 2V - 4 = 13776)."""
+    y_top, y_bot = 0.52, -1.18
+    yc, H = 0.5 * (y_top + y_bot), 0.5 * (y_top - y_bot)
+    verts = [np.array([0.0, y_top, 0.0])]
+    for u in range(N_RINGS):
+        th = np.pi * (u + 1) / (N_RINGS + 1)
+        y = yc + H * np.cos(th)
+        girth = np.sin(th) ** 0.6 * (0.75 + 0.25 * np.cos(2.2 * th))      # shoulders wider than ankles
+        for w in range(N_SEGS):
+            ph = 2 * np.pi * w / N_SEGS
+            arm = 2.6 * np.exp(-((y - 0.22) / 0.055) ** 2) * np.abs(np.cos(ph)) ** 10
+            verts.append(np.array([0.21 * girth * (1 + arm) * np.cos(ph), y, 0.12 * girth * np.sin(ph)]))
+    verts.append(np.array([0.0, y_bot, 0.0]))
+    verts = np.stack(verts)
+    faces = []
+    ring = lambda u, w: 1 + u * N_SEGS + (w % N_SEGS)
+    for w in range(N_SEGS):
+        faces.append((0, ring(0, w), ring(0, w + 1)))
+    for u in range(N_RINGS - 1):
+        for w in range(N_SEGS):
+            faces.append((ring(u, w), ring(u + 1, w), ring(u + 1, w + 1)))
+            faces.append((ring(u, w), ring(u + 1, w + 1), ring(u, w + 1)))
+    last = 1 + N_RINGS * N_SEGS
+    for w in range(N_SEGS):
+        faces.append((last, ring(N_RINGS - 1, w + 1), ring(N_RINGS - 1, w)))
+    return verts, np.asarray(faces, dtype=np.int32)
+
+
 def synthetic_smpl(seed: int = 1234, max_influences: int = 4) -> Dict[str, np.ndarray]:
-    """Seeded synthetic body model with SMPL's shapes and structural properties:
-    body-scale template, shapedirs ~ N(0, 0.01^2), posedirs ~ N(0, 0.002^2), sparse
-    non-negative J_regressor rows summing to 1, <= `max_influences` skinning weights per
-    vertex summing to 1, canonical SMPL parents."""
+    """Seeded synthetic body model with SMPL's shapes and structural properties: a closed body-scale
+    triangle mesh (6890 vertices / 13776 faces, vertex order spatially coherent), shapedirs ~ N(0, 0.01^2),
+    posedirs ~ N(0, 0.002^2), sparse non-negative J_regressor rows summing to 1, <= `max_influences`
+    smooth skinning weights per vertex summing to 1, canonical SMPL parents."""
     rng = np.random.RandomState(seed)
     V = NUM_VERTS
-    # each vertex is attached to a "home" joint and scattered around it
-    home = rng.randint(0, NUM_JOINTS, size=V)
-    v_template = _REST_JOINTS[home] + rng.normal(0.0, 0.06, size=(V, 3))
+    v_template, faces = _body_surface()
+    assert v_template.shape == (V, 3) and faces.shape == (13776, 3)
+    v_template = v_template + rng.normal(0.0, 0.002, size=(V, 3))       # break the exact symmetry
     shapedirs = rng.normal(0.0, 0.01, size=(V, 3, NUM_BETAS))
     posedirs = rng.normal(0.0, 0.002, size=(207, V * 3))
-    # skinning weights: home joint + up to 3 kinematic neighbours
+    # skinning weights: the nearest rest joints, Gaussian fall-off
+    d2 = ((v_template[:, None, :] - _REST_JOINTS[None]) ** 2).sum(-1)           # (V, 24)
     W = np.zeros((V, NUM_JOINTS))
+    near = np.argsort(d2, axis=1)[:, :max_influences]
     for v in range(V):
-        j = home[v]
-        cand = [j]
-        if SMPL_PARENTS[j] >= 0:
-            cand.append(int(SMPL_PARENTS[j]))
-        cand += [int(c) for c in np.where(SMPL_PARENTS == j)[0]]
-        cand = cand[:max_influences]
-        w = rng.uniform(0.05, 1.0, size=len(cand))
-        w[0] += 1.0
-        W[v, cand] = w / w.sum()
-    # rest-joint regressor: each joint regresses from 12 vertices homed at it
+        w = np.exp(-d2[v, near[v]] / (2 * 0.12 ** 2)) + 1e-3
+        W[v, near[v]] = w / w.sum()
+    # rest-joint regressor: each joint regresses from its 12 nearest vertices
     J_regressor = np.zeros((NUM_JOINTS, V))
     for j in range(NUM_JOINTS):
-        idx = np.where(home == j)[0]
-        pick = rng.choice(idx, size=min(12, len(idx)), replace=False)
+        pick = np.argsort(d2[:, j])[:12]
         w = rng.uniform(0.2, 1.0, size=len(pick))
         J_regressor[j, pick] = w / w.sum()
-    faces = np.stack([np.arange(0, 13776) % V, (np.arange(0, 13776) * 7 + 1) % V,
-                      (np.arange(0, 13776) * 13 + 2) % V], axis=1).astype(np.int32)
     return dict(v_template=v_template.astype(np.float32), shapedirs=shapedirs.astype(np.float32),
                 posedirs=posedirs.astype(np.float32), J_regressor=J_regressor.astype(np.float32),
                 lbs_weights=W.astype(np.float32), parents=SMPL_PARENTS.copy(), faces=faces)
