@@ -51,7 +51,8 @@ enum {
   JRR_FLAG_POSE_DISC = 1,   /* allocate / run the pose-discriminator term (optimize.py:241-247) */
   JRR_FLAG_SHAPE_DISC = 2,  /* shape-discriminator term (optimize.py:244,249-250) */
   JRR_FLAG_KEEP_VERTS = 4,  /* reserve a (B,6890,3) vertex buffer for return_verts / J step */
-  JRR_FLAG_FOLDED = 8       /* reserve the folded-regressor tables (jrr_engine_set_folded) */
+  JRR_FLAG_FOLDED = 8,      /* reserve the folded-regressor tables (jrr_engine_set_folded) */
+  JRR_FLAG_SILHOUETTE = 16  /* reserve the soft-silhouette buffers (needs JRR_FLAG_KEEP_VERTS and model faces) */
 };
 
 typedef struct jrr_model jrr_model_t;   /* device-resident, re-laid-out SMPL constants */
@@ -72,6 +73,9 @@ int jrr_model_create(const float* v_template_host, const float* shapedirs_host,
                      const float* lbs_weights_host, const int32_t* parents_host,
                      jrr_model_t** out);
 void jrr_model_destroy(jrr_model_t* m);
+/* triangle list of the mesh (SMPL `f`, 13776 x 3 int32; the reference reads it from data/body_model/smpl_uv.obj,
+ * scripts/mesh_renderer.py:40-41); needed by the silhouette renderer only.  Synchronous.                  */
+int jrr_model_set_faces(jrr_model_t* m, const int32_t* faces_host, int n_faces);
 
 /* ---- engine -------------------------------------------------------------------------------
  * `batch` = poses on this device; `batch_norm` = divisor batch of the MSE means
@@ -181,6 +185,21 @@ int jrr_engine_set_reprojection(jrr_engine_t* e, const float* gt_j2d_dev, float*
 int jrr_camera_prefit(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev, const float* gt_j2d_dev,
                       float* cam_dev, int n_steps, float lr, float* sq2d_dev, void* stream);
 
+/* ---- soft silhouette (BASELINE configs[4]) ---------------------------
+ * render_mesh(...) = Mesh_Renderer(224)(batch, verts*[-2,-2,2])[:, 3], scripts/optimize.py:77-85 +
+ * scripts/mesh_renderer.py:23-79 (pytorch3d 0.3.0 rasteriser, blur_radius 0, 1 face per pixel,
+ * SoftSilhouetteShader sigma 1e-4).  verts (B,6890,3), cam (B,3) -> alpha (B,224,224).              */
+int jrr_silhouette_forward(jrr_engine_t* e, const float* verts_dev, const float* cam_dev, float* alpha_dev,
+                           void* stream);
+/* adjoint for the SAME inputs (must follow the forward): galpha (B,224,224) -> dverts (B,6890,3), dcam (B,3);
+ * float atomics: summation order (last bits) varies between runs.                                    */
+int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha_dev, float* dverts_dev, float* dcam_dev,
+                            void* stream);
+/* Enable (mask_dev != NULL, (B,224,224)) / disable the term 100 * mean((silhouette - mask)^2) of the inner
+ * loop (scripts/optimize.py:234-237,252); shares the camera parameter with jrr_engine_set_reprojection.  */
+int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask_dev, float* cam_dev, float* cam_m_dev,
+                              float* cam_v_dev);
+
 /* ---- fused inner loop ---------------------------------------------------------------------
  * n_iters iterations of scripts/optimize.py:220-265 restricted to the engine's loss terms:
  * rot6d->R, SMPL, J-regress, pelvis-centre, MSE x10000 [+ pose-D x10] [+ shape-D x10],
@@ -206,8 +225,8 @@ int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n);
  * milliseconds per launch of each class into ms_host[JRR_PROF_CLASSES] and the number of samples
  * into counts_host, then clears the recorded events.  Classes:
  *   0 k_prep_fwd  1 k_lbs_fwd  2 k_joints_loss  3 k_lbs_bwd  4 k_gemm_tn (blend adjoint)
- *   5 pose discriminator (7 launches)  6 k_shape_disc  7 k_prep_bwd (+Adam)                  */
-enum { JRR_PROF_CLASSES = 8 };
+ *   5 pose discriminator (7 launches)  6 k_shape_disc  7 k_prep_bwd (+Adam)  8 silhouette (fwd+bwd) */
+enum { JRR_PROF_CLASSES = 9 };
 int jrr_engine_set_profiling(jrr_engine_t* e, int enabled);
 int jrr_engine_profile_read(jrr_engine_t* e, float* ms_host, int32_t* counts_host);
 

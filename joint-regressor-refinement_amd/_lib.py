@@ -22,6 +22,7 @@ SIGNATURES = {
     'jrr_version': (c_int, []),
     'jrr_model_create': (c_int, [_P, _P, _P, _P, _P, _P, POINTER(_P)]),
     'jrr_model_destroy': (None, [_P]),
+    'jrr_model_set_faces': (c_int, [_P, _P, c_int]),
     'jrr_engine_workspace_bytes': (c_size_t, [c_int, c_int]),
     'jrr_engine_create': (c_int, [_P, c_int, c_int, _P, c_size_t, c_int, POINTER(_P)]),
     'jrr_engine_destroy': (None, [_P]),
@@ -47,6 +48,9 @@ SIGNATURES = {
     'jrr_project_joints': (c_int, [_P, _P, _P, c_int, _P]),
     'jrr_engine_set_reprojection': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_camera_prefit': (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P]),
+    'jrr_silhouette_forward': (c_int, [_P, _P, _P, _P, _P]),
+    'jrr_silhouette_backward': (c_int, [_P, _P, _P, _P, _P]),
+    'jrr_engine_set_silhouette': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_refine_run': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),
     'jrr_j_regressor_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     'jrr_engine_info': (c_int, [_P, POINTER(c_int32), c_int]),

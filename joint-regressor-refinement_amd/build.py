@@ -17,7 +17,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libjrr_hip.so')
-SOURCES = ['api.hip', 'prep.hip', 'lbs.hip', 'gemm.hip', 'disc.hip', 'eval.hip', 'fold.hip']
+SOURCES = ['api.hip', 'prep.hip', 'lbs.hip', 'gemm.hip', 'disc.hip', 'eval.hip', 'fold.hip', 'sil.hip']
 HEADERS = ['jrr_common.h', 'kernels.h', os.path.join('..', '..', 'include', 'jrr.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 
@@ -88,7 +88,7 @@ def build(force: bool = False, report: bool = False, verbose: bool = True) -> st
         return src, p.returncode, p.stdout + p.stderr
 
     if jobs:
-        with ThreadPoolExecutor(max_workers=min(len(jobs), 7)) as ex:
+        with ThreadPoolExecutor(max_workers=min(len(jobs), 8)) as ex:
             for src, rc, out in ex.map(run, jobs):
                 if rc != 0:
                     sys.stderr.write(out)

@@ -92,6 +92,8 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   m->d.Jt = m->d.Wvj + nWvj;
   m->d.JS = m->d.Jt + nJt;
   m->d.parents.maxd = 0;
+  m->d.faces = nullptr;
+  m->d.nfaces = 0;
   for (int j = 0; j < NJ; ++j) {
     m->d.parents.p[j] = parents[j];
     m->d.parents.depth[j] = (j == 0) ? 0 : m->d.parents.depth[parents[j]] + 1;
@@ -101,8 +103,20 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   return JRR_OK;
 }
 
+extern "C" int jrr_model_set_faces(jrr_model_t* m, const int32_t* faces, int n_faces) {
+  if (!m || !faces || n_faces <= 0) return JRR_ERR_ARG;
+  for (int i = 0; i < n_faces * 3; ++i)
+    if (faces[i] < 0 || faces[i] >= V) { jrr_set_error("face index %d out of range", faces[i]); return JRR_ERR_ARG; }
+  if (m->d.faces) (void)hipFree(m->d.faces);
+  JRR_HIP(hipMalloc((void**)&m->d.faces, (size_t)n_faces * 3 * sizeof(int)));
+  JRR_HIP(hipMemcpy(m->d.faces, faces, (size_t)n_faces * 3 * sizeof(int), hipMemcpyHostToDevice));
+  m->d.nfaces = n_faces;
+  return JRR_OK;
+}
+
 extern "C" void jrr_model_destroy(jrr_model_t* m) {
   if (!m) return;
+  if (m->d.faces) (void)hipFree(m->d.faces);
   if (m->base) (void)hipFree(m->base);
   delete m;
 }
@@ -120,6 +134,8 @@ struct jrr_engine {
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
   float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc;
   float *Ps, *gb;
+  float *ndc, *dvpm, *sqsil_strips, *sqsil; int* p2f;   // soft silhouette (JRR_FLAG_SILHOUETTE)
+  const float* sil_mask;
   float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
   bool folded, fold_valid;
   float *verts, *djpad, *dJnp, *dJn, *dj;
@@ -224,6 +240,13 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   if (flags & JRR_FLAG_SHAPE_DISC) {
     t->Ps = c.take(256);
     t->gb = c.take((size_t)BP * NB);
+  }
+  if (flags & JRR_FLAG_SILHOUETTE) {
+    t->ndc = c.take((size_t)BP * V * 4);
+    t->dvpm = c.take((size_t)BP * VP * 3);
+    t->p2f = (int*)c.take((size_t)BP * 224 * 224);
+    t->sqsil_strips = c.take((size_t)BP * 4);
+    t->sqsil = c.take((size_t)BP);
   }
   if (flags & JRR_FLAG_FOLDED) {
     t->JW = c.take((size_t)VP * FOLD_MJ);
@@ -527,7 +550,7 @@ extern "C" int jrr_smpl_vertices_backward(jrr_engine_t* e, const float* x6d, con
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   // the padded vertex buffer is reused as the transposed adjoint [3][VP][BP] (same size)
-  launch_dverts_transpose(dverts, e->verts, e->B, e->BP, s);
+  launch_dverts_transpose(dverts, V * 3, e->verts, e->B, e->BP, s);
   e->verts_zeroed = false;
   launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, nullptr, e->verts, e->DVP, e->dATp, e->BP, e->nvcb, s);
   int rc = blend_adjoint_gemm(e, s);
@@ -722,6 +745,51 @@ extern "C" int jrr_camera_prefit(jrr_engine_t* e, const float* x6d, const float*
 }
 
 // =============================================================================================
+// soft silhouette (row f2)
+// =============================================================================================
+static int sil_check(jrr_engine* e) {
+  if (!(e->flags & JRR_FLAG_SILHOUETTE)) { jrr_set_error("engine created without JRR_FLAG_SILHOUETTE"); return JRR_ERR_STATE; }
+  if (!e->m.faces) { jrr_set_error("model has no faces (jrr_model_set_faces)"); return JRR_ERR_STATE; }
+  return 0;
+}
+
+extern "C" int jrr_silhouette_forward(jrr_engine_t* e, const float* verts, const float* cam, float* alpha, void* stream) {
+  if (!e || !verts || !cam || !alpha) return JRR_ERR_ARG;
+  int rc = sil_check(e);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  launch_sil_project(verts, V * 3, cam, e->ndc, e->B, s);
+  launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, nullptr, e->p2f, alpha, nullptr, nullptr, e->B, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha, float* dverts, float* dcam, void* stream) {
+  if (!e || !galpha || !dverts || !dcam) return JRR_ERR_ARG;
+  int rc = sil_check(e);
+  if (rc) return rc;
+  hipStream_t s = (hipStream_t)stream;
+  JRR_HIP(hipMemsetAsync(dverts, 0, (size_t)e->B * V * 3 * 4, s));
+  JRR_HIP(hipMemsetAsync(dcam, 0, (size_t)e->B * 3 * 4, s));
+  launch_sil_bwd(e->ndc, e->m.faces, e->p2f, nullptr, galpha, 0.f, dverts, V * 3, dcam, e->B, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask, float* cam, float* cam_m, float* cam_v) {
+  if (!e) return JRR_ERR_ARG;
+  if (mask) {
+    int rc = sil_check(e);
+    if (rc) return rc;
+    if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("the silhouette term needs JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
+    if (!cam || !cam_m || !cam_v) { jrr_set_error("set_silhouette: cam / cam_m / cam_v required"); return JRR_ERR_ARG; }
+    e->cam = cam; e->cam_m = cam_m; e->cam_v = cam_v;
+  }
+  e->sil_mask = mask;
+  return JRR_OK;
+}
+
+// =============================================================================================
 // fused inner loop (scripts/optimize.py:220-265)
 // =============================================================================================
 extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const float* gt_mm, float* adam_m,
@@ -765,7 +833,9 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
       if (rcf) return rcf;
       launch_fold_fwd(e->MT, e->AT, e->G0, e->Jsum, e->BP, s);
     } else {
-      launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, nullptr, 0, e->B, e->BP, e->nvc, s);
+      const bool silf = e->sil_mask != nullptr;      // the silhouette term needs the vertices
+      launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, silf ? e->verts : nullptr, VP * 3, e->B, e->BP, e->nvc, s);
+      if (silf) e->verts_zeroed = false;
     }
     prof_mark(e, 1, s);
     prof_mark(e, 2, s);
@@ -775,9 +845,21 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
                        e->gt_j2d ? &rl : nullptr);
     prof_mark(e, 2, s);
     int rc = 0;
+    const bool sil = e->sil_mask != nullptr && !folded;
+    if (sil) {   // 100 * mean((silhouette - mask)^2), optimize.py:234-237,252
+      prof_mark(e, 8, s);
+      const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * 224.0 * 224.0));
+      launch_sil_project(e->verts, VP * 3, e->cam, e->ndc, e->B, s);
+      launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, e->sil_mask, e->p2f, nullptr, e->sqsil_strips, e->sqsil, e->B, s);
+      JRR_HIP(hipMemsetAsync(e->dvpm, 0, (size_t)e->BP * VP * 3 * 4, s));
+      if (!e->gt_j2d) JRR_HIP(hipMemsetAsync(e->gcam, 0, (size_t)e->B * 3 * 4, s));
+      launch_sil_bwd(e->ndc, e->m.faces, e->p2f, e->sil_mask, nullptr, silscale, e->dvpm, VP * 3, e->gcam, e->B, s);
+      launch_dverts_transpose(e->dvpm, VP * 3, e->verts, e->B, e->BP, s);     // verts buffer becomes the transposed adjoint
+      prof_mark(e, 8, s);
+    }
     prof_mark(e, 3, s);
     if (folded) launch_fold_bwd(e->dJT, e->AT, e->MT, e->G0, e->dMT, e->dA, e->BP, s);
-    else launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
+    else launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, sil ? e->verts : nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
     prof_mark(e, 3, s);
     prof_mark(e, 4, s);
     if (folded) {
@@ -813,7 +895,7 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step;
     L.lr = lr; L.B = e->B; L.BP = e->BP;
     L.wait_before_update = fork ? e->ev_join : nullptr;
-    if (e->gt_j2d) { L.gcam = e->gcam; L.cam_io = e->cam; L.cam_m = e->cam_m; L.cam_v = e->cam_v; }
+    if (e->gt_j2d || sil) { L.gcam = e->gcam; L.cam_io = e->cam; L.cam_m = e->cam_m; L.cam_v = e->cam_v; }
     launch_prep_bwd(L, e->m, s);
     prof_mark(e, 7, s);
   }

@@ -72,6 +72,8 @@ struct Model {
   float* Jt;    // [24][3]           rest joints of the template
   float* JS;    // [24][3][10]       rest-joint shape directions
   Parents parents;
+  int* faces;   // [nfaces][3] (device) or NULL
+  int nfaces;
 };
 
 inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }

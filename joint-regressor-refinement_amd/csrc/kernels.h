@@ -62,7 +62,7 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s);
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s);
-int launch_dverts_transpose(const float* dverts, float* dVT, int B, int BP, hipStream_t s);
+int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s);
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv,
                           hipStream_t s);
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
@@ -75,6 +75,13 @@ int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+
+// sil.hip
+int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s);
+int launch_sil_raster(const float* ndc, const int* faces, int nfaces, const float* mask, int* p2f, float* alpha,
+                      float* sqsil_strips, float* sqsil, int B, hipStream_t s);
+int launch_sil_bwd(const float* ndc, const int* faces, const int* p2f, const float* mask, const float* galpha, float scale,
+                   float* dverts, int ldv, float* gcam, int B, hipStream_t s);
 
 // fold.hip
 int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, hipStream_t s);

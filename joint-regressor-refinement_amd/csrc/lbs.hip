@@ -205,7 +205,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
 //   v_posed tile is register-prefetched one tile ahead.
 //   outputs: DVP, dATp [nvc][12][24][BP] partials.
 // ------------------------------------------------------------------------------------------
-template <bool DVERTS_MEM>
+// DV: 0 = vertex adjoint from the joint adjoint dJT (Jn^T dj), 1 = loaded from dVT, 2 = both (sum)
+template <int DV>
 __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb, const float* __restrict__ AT,
                                                     const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                     const float* __restrict__ dVT, float* __restrict__ DVP,
@@ -246,7 +247,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
       ldsA[(r * 12 + jp) * 64 + lane] = AT[(size_t)((r * 4 + c) * NJ + 2 * jp + half) * BP + bcol];
 
   float dj[3][9];
-  if (!DVERTS_MEM) {
+  if (DV != 1) {
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -269,13 +270,15 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
     const float* tab = ring + ((vt - t_begin) & 1) * TB_FLOATS;
 
     f32x16 dv[3];
-    if (DVERTS_MEM) {
+    if (DV != 0) {
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
         for (int q = 0; q < 16; ++q) dv[r][q] = dVT[((size_t)r * VP + vt * 32 + acc_row(q, half)) * BP + bcol];
     } else {
       dv[0] = zero16(); dv[1] = zero16(); dv[2] = zero16();
+    }
+    if (DV != 1) {
       const float* jp_ = tab + TB_JN + half * 32 + l31;
 #pragma unroll
       for (int ip = 0; ip < 9; ++ip) {
@@ -332,14 +335,14 @@ __global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __r
 }
 
 // (B,6890,3) -> [3][VP][BP] transpose of an external vertex adjoint (operator-level SMPL backward)
-__global__ void k_dverts_transpose(const float* __restrict__ dverts, float* __restrict__ dVT, int B, int BP) {
+__global__ void k_dverts_transpose(const float* __restrict__ dverts, int ldv, float* __restrict__ dVT, int B, int BP) {
   __shared__ float tile[32][97];
   const int v0 = blockIdx.x * 32, bb0 = blockIdx.y * 32;
   for (int idx = threadIdx.x; idx < 32 * 96; idx += blockDim.x) {
     int bl = idx / 96, rem = idx % 96;   // rem = vv*3 + r
     int b = bb0 + bl, v = v0 + rem / 3;
     float val = 0.f;
-    if (b < B && v < V) val = dverts[((size_t)b * V + v0) * 3 + rem];
+    if (b < B && v < V) val = dverts[(size_t)b * ldv + v0 * 3 + rem];
     tile[bl][rem] = val;
   }
   __syncthreads();
@@ -434,15 +437,17 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
   (void)m;
   const int wg_per_vc = (BP / BT) * 3 / 4;     // BP is a multiple of 128, so 3*BP/32 is a multiple of 4
   dim3 grid(wg_per_vc * nvc), block(256);
-  if (dVT)
-    hipLaunchKernelGGL((k_lbs_bwd<true>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, wg_per_vc);
+  if (dVT && dJT)
+    hipLaunchKernelGGL((k_lbs_bwd<2>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, wg_per_vc);
+  else if (dVT)
+    hipLaunchKernelGGL((k_lbs_bwd<1>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, wg_per_vc);
   else
-    hipLaunchKernelGGL((k_lbs_bwd<false>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, wg_per_vc);
+    hipLaunchKernelGGL((k_lbs_bwd<0>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, wg_per_vc);
   return 0;
 }
 
-int launch_dverts_transpose(const float* dverts, float* dVT, int B, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_dverts_transpose, dim3(VT, BP / 32), dim3(256), 0, s, dverts, dVT, B, BP);
+int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s) {
+  hipLaunchKernelGGL(k_dverts_transpose, dim3(VT, BP / 32), dim3(256), 0, s, dverts, ldv, dVT, B, BP);
   return 0;
 }
 

@@ -19,6 +19,8 @@ FLAG_POSE_DISC = 1
 FLAG_SHAPE_DISC = 2
 FLAG_KEEP_VERTS = 4
 FLAG_FOLDED = 8
+FLAG_SILHOUETTE = 16
+SIL = 224
 
 NUM_VERTS, NUM_JOINTS, NUM_H36M, NUM_BETAS = 6890, 24, 17, 10
 DISC_PARAMS = 1840153
@@ -67,6 +69,9 @@ class DeviceModel:
             check(self.lib.jrr_model_create(vt.ctypes.data, sd.ctypes.data, pd.ctypes.data, jr.ctypes.data,
                                             w.ctypes.data, par.ctypes.data, byref(h)), 'jrr_model_create')
         self.handle = h
+        if self.faces is not None:
+            f = np.ascontiguousarray(np.asarray(self.faces, dtype=np.int32))
+            check(self.lib.jrr_model_set_faces(self.handle, f.ctypes.data, int(f.shape[0])), 'jrr_model_set_faces')
 
     def __del__(self):
         try:
@@ -228,6 +233,30 @@ class RefineEngine:
                                          ptr(sq), self._s()), 'camera_prefit')
         return sq
 
+    def silhouette_forward(self, verts, cam):
+        """render_mesh alpha channel: verts (B,6890,3), cam (B,3) -> (B,224,224)"""
+        self._chk(verts, (self.batch, NUM_VERTS, 3), 'verts')
+        self._chk(cam, (self.batch, 3), 'cam')
+        alpha = torch.empty(self.batch, SIL, SIL, device=self.device)
+        check(self.lib.jrr_silhouette_forward(self.handle, ptr(verts), ptr(cam), ptr(alpha), self._s()), 'silhouette_forward')
+        return alpha
+
+    def silhouette_backward(self, galpha):
+        self._chk(galpha, (self.batch, SIL, SIL), 'galpha')
+        dverts = torch.empty(self.batch, NUM_VERTS, 3, device=self.device)
+        dcam = torch.empty(self.batch, 3, device=self.device)
+        check(self.lib.jrr_silhouette_backward(self.handle, ptr(galpha), ptr(dverts), ptr(dcam), self._s()), 'silhouette_backward')
+        return dverts, dcam
+
+    def set_silhouette(self, mask=None, cam=None, cam_m=None, cam_v=None):
+        """enable (tensors) / disable (None) the silhouette term of refine_run"""
+        if mask is not None:
+            self._chk(mask, (self.batch, SIL, SIL), 'mask')
+            for t, n in ((cam, 'cam'), (cam_m, 'cam_m'), (cam_v, 'cam_v')):
+                self._chk(t, (self.batch, 3), n)
+        self._sil_refs = (mask, cam, cam_m, cam_v)
+        check(self.lib.jrr_engine_set_silhouette(self.handle, ptr(mask), ptr(cam), ptr(cam_m), ptr(cam_v)), 'set_silhouette')
+
     def refine_run(self, x6d, betas, gt_centred_mm, adam_m, adam_v, step, lr: float, n_iters: int, sqerr=None):
         B = self.batch
         self._chk(x6d, (B, NUM_JOINTS, 6), 'x6d')
@@ -240,15 +269,15 @@ class RefineEngine:
                                       ptr(step), float(lr), int(n_iters), ptr(sqerr), self._s()), 'refine_run')
 
     PROF_CLASSES = ['k_prep_fwd', 'k_lbs_fwd', 'k_joints_loss', 'k_lbs_bwd', 'k_gemm_tn_blend_adjoint', 'pose_disc_7_launches',
-                    'k_shape_disc', 'k_prep_bwd']
+                    'k_shape_disc', 'k_prep_bwd', 'silhouette_fwd_bwd']
 
     def set_profiling(self, on: bool):
         check(self.lib.jrr_engine_set_profiling(self.handle, int(bool(on))), 'set_profiling')
 
     def profile_read(self):
         """mean ms per launch (HIP events on the launch stream) and sample counts per kernel class"""
-        ms = (ctypes.c_float * 8)()
-        n = (c_int32 * 8)()
+        ms = (ctypes.c_float * 9)()
+        n = (c_int32 * 9)()
         check(self.lib.jrr_engine_profile_read(self.handle, ms, n), 'profile_read')
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.PROF_CLASSES)}
 

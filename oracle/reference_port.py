@@ -325,11 +325,12 @@ W_SHAPE_D = 10.0    # scripts/optimize.py:253
 
 
 W_J2D = 0.01       # scripts/optimize.py:252  (loss_j2d/100)
+W_SIL = 100.0      # scripts/optimize.py:252  (silhouette_loss*100)
 
 
 def inner_losses(smpl, J_regressor, mask, orient6d, pose6d, betas, gt_j3d_mm_centred,
                  disc_sd=None, shape_disc_sd=None, batch_norm: Optional[int] = None, smpl_evals: int = 1,
-                 gt_j2d=None, cam=None):
+                 gt_j2d=None, cam=None, sil_mask=None, faces=None):
     """One evaluation of the inner-loop objective (scripts/optimize.py:222-253) without the
     2-D and silhouette terms (BASELINE configs 2-4).  Returns (opt_loss, dict of terms, joints).
 
@@ -342,7 +343,7 @@ def inner_losses(smpl, J_regressor, mask, orient6d, pose6d, betas, gt_j3d_mm_cen
     nb = B if batch_norm is None else batch_norm
     R_orient = rot6d_to_rotmat(orient6d.reshape(-1, 6)).view(-1, 1, 3, 3)     # :222-223
     R_pose = rot6d_to_rotmat(pose6d.reshape(-1, 6)).view(-1, 23, 3, 3)        # :225-226
-    pred_joints = find_joints(smpl, betas, R_orient, R_pose, J_regressor, mask=mask)   # :228-229
+    pred_joints, pred_verts = find_joints(smpl, betas, R_orient, R_pose, J_regressor, mask=mask, return_verts=True)   # :228-229
     for _ in range(smpl_evals - 1):     # the reference's 2nd/3rd SMPL forward on identical inputs
         _ = find_joints(smpl, betas, R_orient, R_pose, J_regressor)
     diff = move_pelvis(pred_joints) - gt_j3d_mm_centred / 1000                # :238-239
@@ -353,6 +354,11 @@ def inner_losses(smpl, J_regressor, mask, orient6d, pose6d, betas, gt_j3d_mm_cen
         loss_j2d = ((gt_j2d - project_joints(pred_joints, cam)) ** 2).sum() / (nb * NUM_H36M * 2)
         terms['loss_j2d'] = loss_j2d
         opt_loss = opt_loss + loss_j2d * W_J2D
+    if sil_mask is not None:                                                  # :234-237 render_mesh + MSE, weight 100
+        from . import silhouette_port
+        sil_loss, _ = silhouette_port.silhouette_loss(pred_verts, faces, cam, sil_mask, batch_norm=nb)
+        terms['silhouette_loss'] = sil_loss
+        opt_loss = opt_loss + sil_loss * W_SIL
     if disc_sd is not None:
         pred_disc = discriminator_forward(disc_sd, torch.cat([orient6d, pose6d], dim=1))   # :241-242
         pose_d = ((pred_disc - 1) ** 2).sum() / (nb * 25)                     # :246-247
@@ -368,7 +374,8 @@ def inner_losses(smpl, J_regressor, mask, orient6d, pose6d, betas, gt_j3d_mm_cen
 
 def refine_poses(smpl, J_regressor, orient6d, pose6d, betas, gt_j3d_mm_centred, n_iters: int,
                  disc_sd=None, shape_disc_sd=None, lr: float = 1e-2, mask=None,
-                 batch_norm: Optional[int] = None, smpl_evals: int = 1, record=None, gt_j2d=None, cam=None):
+                 batch_norm: Optional[int] = None, smpl_evals: int = 1, record=None, gt_j2d=None, cam=None,
+                 sil_mask=None, faces=None):
     """scripts/optimize.py:201-202,220-265: fresh torch Adam over [pose, orient, betas] (cam has
     no gradient in configs 2-4 and is skipped by torch Adam), n_iters inner iterations.
     Inputs are cloned; returns the refined (orient6d, pose6d, betas) and the loss history."""
@@ -379,14 +386,14 @@ def refine_poses(smpl, J_regressor, orient6d, pose6d, betas, gt_j3d_mm_centred, 
         mask = find_j_reg_mask(J_regressor)
     params = [pose, orient, b]
     c = None
-    if gt_j2d is not None:
+    if gt_j2d is not None or sil_mask is not None:
         c = cam.clone().detach().requires_grad_(True)
         params.append(c)                                                      # :180-181,201-202
     opt = torch.optim.Adam(params, lr=lr)
     hist = []
     for it in range(n_iters):
         loss, terms, joints = inner_losses(smpl, J_regressor.detach(), mask, orient, pose, b, gt_j3d_mm_centred,
-                                           disc_sd, shape_disc_sd, batch_norm, smpl_evals, gt_j2d, c)
+                                           disc_sd, shape_disc_sd, batch_norm, smpl_evals, gt_j2d, c, sil_mask, faces)
         opt.zero_grad()
         loss.backward()
         if record is not None:

@@ -251,3 +251,71 @@ def test_refine_run_with_2d_term_matches_oracle(smpl_hip, smpl_model_np, j_h36m_
     assert (bd.cpu() - b).abs().max().item() < 3e-4
     assert (cd.cpu() - c).abs().max().item() < 3e-4
     assert (cd.cpu() - cam0).abs().max().item() > 1e-2           # the camera really moved
+
+
+def _sil_setup(smpl_model_np, j_h36m_np, B, seed):
+    from oracle import silhouette_port as sp
+    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, j_h36m_np, B, seed=seed)
+    x6, betas, cam = T(batch['pose6d']), T(batch['betas']), T(batch['cam'])
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(B, 24, 3, 3)
+    verts = smpl(R[:, :1], R[:, 1:], betas).vertices
+    # target mask: the silhouette of a slightly shifted camera, binarised (stand-in for Mask-RCNN output)
+    img = sp.soft_silhouette(verts, smpl_model_np['faces'], cam + torch.tensor([0.15, -0.1, 1.0]))
+    mask = (img[:, 0] > 0).float()
+    return sp, batch, x6, betas, cam, verts, mask
+
+
+def test_silhouette_forward_backward(smpl_hip, smpl_model_np, j_h36m_np):
+    """row f2: rasteriser + soft silhouette vs the oracle's brute-force restatement of pytorch3d 0.3.0"""
+    eng_mod = _mod('engine')
+    B = 3
+    sp, batch, x6, betas, cam, verts, mask = _sil_setup(smpl_model_np, j_h36m_np, B, 51)
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_SILHOUETTE)
+    alpha = eng.silhouette_forward(verts.to(DEV).contiguous(), cam.to(DEV))
+    vr, cr = verts.clone().requires_grad_(True), cam.clone().requires_grad_(True)
+    ref = sp.soft_silhouette(vr, smpl_model_np['faces'], cr)[:, 0]
+    cov_ref, cov = ref.detach() > 0, alpha.cpu() > 0
+    assert cov_ref.sum() > 3000 * B
+    # coverage may differ only on pixels whose centre sits on an edge to within fp32 rounding
+    assert (cov_ref != cov).float().mean().item() < 2e-4
+    both = cov_ref & cov
+    # alpha = sigmoid(d/1e-4) amplifies fp32 noise in d (d ~ 1e-5): compare where both rasterisers agree
+    assert (alpha.cpu()[both] - ref.detach()[both]).abs().mean().item() < 2e-3
+    g = (ref.detach() - mask) * 2 / (B * 224 * 224)
+    (ref * g).sum().backward()
+    dv, dc = eng.silhouette_backward(g.to(DEV).contiguous())
+    assert relerr(dc, cr.grad) < 2e-2
+    num = (dv.cpu().double() - vr.grad.double()).norm() / vr.grad.double().norm()
+    assert num.item() < 2e-2
+    # module-level interface (scripts/mesh_renderer.py): (B,4,H,W), alpha in channel 3
+    mr = _mod('mesh_renderer')
+    out = mr.Mesh_Renderer(224, smpl_hip)({'cam': cam.to(DEV)}, verts.to(DEV))
+    assert out.shape == (B, 4, 224, 224) and torch.equal(out[:, 3], alpha)
+
+
+def test_refine_run_with_silhouette_term(smpl_hip, smpl_model_np, j_h36m_np):
+    """BASELINE configs[4]: joint loss + silhouette loss (x100) in the fused loop vs the oracle"""
+    eng_mod = _mod('engine')
+    B, n = 3, 3
+    sp, batch, x6, betas, cam0, verts, mask = _sil_setup(smpl_model_np, j_h36m_np, B, 52)
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    o, p, b, hist, c = oracle.refine_poses(smpl, T(j_h36m_np), x6[:, :1], x6[:, 1:], betas, gt_c, n, cam=cam0,
+                                           sil_mask=mask[:, None], faces=smpl_model_np['faces'])
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_SILHOUETTE | eng_mod.FLAG_KEEP_VERTS)
+    eng.set_j_regressor(T(j_h36m_np))
+    xd, bd, cd = x6.clone().to(DEV), betas.clone().to(DEV), cam0.clone().to(DEV)
+    cm, cv = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV)
+    eng.set_silhouette(mask.to(DEV).contiguous(), cd, cm, cv)
+    m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, n)
+    eng.set_silhouette(None)
+    # Adam normalises the update: agreement to a fraction of lr unless a near-zero gradient flips sign
+    dx = (xd.cpu() - torch.cat([o, p], 1)).abs()
+    assert dx.max().item() < 2e-3 and dx.mean().item() < 1e-4
+    assert (bd.cpu() - b).abs().max().item() < 2e-3
+    assert (cd.cpu() - c).abs().max().item() < 2e-3
+    assert (cd.cpu() - cam0).abs().max().item() > 5e-3
+    assert 'silhouette_loss' in hist[0]
