@@ -47,8 +47,8 @@ def parse():
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=4096, help='poses per GPU (BASELINE metric: 4096)')
-    ap.add_argument('--config', type=int, default=3, choices=[2, 3],
-                    help='BASELINE config: 2 = joint loss only, 3 = + pose discriminator (headline)')
+    ap.add_argument('--config', type=int, default=3, choices=[2, 3, 5],
+                    help='BASELINE config: 2 = joint loss only, 3 = + pose discriminator (headline), 5 = + soft silhouette')
     ap.add_argument('--j_step_every', type=int, default=100, help='inner iterations per J_regressor step')
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_batch', type=int, default=512, help='cpu_baseline sample batch (scaled to batch-4096 units)')
@@ -121,12 +121,13 @@ def main():
     sm = importlib.import_module(PKG + '.smpl_model')
     eng_mod = importlib.import_module(PKG + '.engine')
     B = a.batch
-    use_disc = a.config == 3
+    use_disc = a.config in (3, 5)
+    use_sil = a.config == 5
     model_np = sm.synthetic_smpl(1234)
     J_np = sm.default_h36m_regressor()
     batch_np = sm.synthetic_batch(model_np, J_np, B, seed=1000 + rank)
     dmodel = eng_mod.DeviceModel(model_np, dev)
-    flags = eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0)
+    flags = eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0) | (eng_mod.FLAG_SILHOUETTE if use_sil else 0)
     eng = eng_mod.RefineEngine(dmodel, B, batch_norm=B * world, flags=flags)
     J = torch.from_numpy(J_np).to(dev)
     eng.set_j_regressor(J)
@@ -142,6 +143,14 @@ def main():
     v = torch.zeros(B, 154, device=dev)
     step = torch.zeros(1, dtype=torch.int32, device=dev)
     sq = torch.zeros(B, device=dev)
+    if use_sil:     # BASELINE configs[4]: silhouette target = the initial mesh through a perturbed camera, binarised
+        cam = torch.from_numpy(batch_np['cam']).to(dev).contiguous()
+        cam_m, cam_v = torch.zeros_like(cam), torch.zeros_like(cam)
+        _, verts0 = eng.find_joints_forward(betas, x6d=x6d, return_verts=True)
+        shift = torch.tensor([0.15, -0.1, 1.0], device=dev)
+        sil_mask = (eng.silhouette_forward(verts0, (cam + shift).contiguous()) > 0).float().contiguous()
+        del verts0
+        eng.set_silhouette(sil_mask, cam, cam_m, cam_v)
     Jm, Jv = torch.zeros_like(J), torch.zeros_like(J)
     Jstep = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -203,7 +212,7 @@ def main():
     # ---- folded-regressor mode (a different algorithm with its own denominator): timed
     #      separately on a fresh copy of the same batch, never part of `value` ----
     folded = None
-    if not a.no_folded:
+    if not a.no_folded and not use_sil:
         feng = eng_mod.RefineEngine(dmodel, B, batch_norm=B * world,
                                     flags=eng_mod.FLAG_FOLDED | (eng_mod.FLAG_POSE_DISC if use_disc else 0))
         feng.set_folded(True)
@@ -252,7 +261,8 @@ def main():
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'BASELINE configs[{a.config - 1}]: batch={B}/GPU inner loop, 3D-joint loss'
-                               + (' + pose-discriminator adversarial term' if use_disc else ''),
+                               + (' + pose-discriminator adversarial term' if use_disc else '')
+                               + (' + soft-silhouette loss (224x224 rasteriser)' if use_sil else ''),
                    'global_batch': B * world, 'poses_per_sec': round(it_s * world * B, 1),
                    'j_step_every': a.j_step_every, 'parallelism': f'dp{world}', 'joint_loss_last': loss_joint,
                    'geometry': eng.info},

@@ -44,6 +44,8 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument('--shape_disc', action='store_true', help='add the shape-discriminator term (optimize.py:244,249-250)')
     parser.add_argument('--reprojection', action='store_true',
                         help='camera pre-fit (optimize.py:187-199) + 2-D joint term (optimize.py:231-233) on synthetic gt_j2d')
+    parser.add_argument('--silhouette', action='store_true',
+                        help='soft-silhouette term (optimize.py:234-237, x100) against synthetic masks (BASELINE configs[4])')
     parser.add_argument('--camera_iters', type=int, default=1000, help='camera pre-fit Adam steps (optimize.py:190)')
     parser.add_argument('--save_j_regressor', type=str, default=None,
                         help='write the trained regressor in the models/retrained_J_Regressor.pt format')

@@ -245,7 +245,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->ndc = c.take((size_t)BP * V * 4);
     t->dvpm = c.take((size_t)BP * VP * 3);
     t->p2f = (int*)c.take((size_t)BP * 224 * 224);
-    t->sqsil_strips = c.take((size_t)BP * 4);
+    t->sqsil_strips = c.take((size_t)BP * 4);   // >= 3 strips per pose
     t->sqsil = c.take((size_t)BP);
   }
   if (flags & JRR_FLAG_FOLDED) {
@@ -769,9 +769,7 @@ extern "C" int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha, flo
   int rc = sil_check(e);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  JRR_HIP(hipMemsetAsync(dverts, 0, (size_t)e->B * V * 3 * 4, s));
-  JRR_HIP(hipMemsetAsync(dcam, 0, (size_t)e->B * 3 * 4, s));
-  launch_sil_bwd(e->ndc, e->m.faces, e->p2f, nullptr, galpha, 0.f, dverts, V * 3, dcam, e->B, s);
+  launch_sil_bwd(e->ndc, e->m.faces, e->p2f, nullptr, galpha, 0.f, dverts, V * 3, dcam, 0, e->B, s);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -851,9 +849,8 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
       const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * 224.0 * 224.0));
       launch_sil_project(e->verts, VP * 3, e->cam, e->ndc, e->B, s);
       launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, e->sil_mask, e->p2f, nullptr, e->sqsil_strips, e->sqsil, e->B, s);
-      JRR_HIP(hipMemsetAsync(e->dvpm, 0, (size_t)e->BP * VP * 3 * 4, s));
-      if (!e->gt_j2d) JRR_HIP(hipMemsetAsync(e->gcam, 0, (size_t)e->B * 3 * 4, s));
-      launch_sil_bwd(e->ndc, e->m.faces, e->p2f, e->sil_mask, nullptr, silscale, e->dvpm, VP * 3, e->gcam, e->B, s);
+      launch_sil_bwd(e->ndc, e->m.faces, e->p2f, e->sil_mask, nullptr, silscale, e->dvpm, VP * 3, e->gcam,
+                     e->gt_j2d ? 1 : 0, e->B, s);
       launch_dverts_transpose(e->dvpm, VP * 3, e->verts, e->B, e->BP, s);     // verts buffer becomes the transposed adjoint
       prof_mark(e, 8, s);
     }

@@ -81,7 +81,7 @@ int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc
 int launch_sil_raster(const float* ndc, const int* faces, int nfaces, const float* mask, int* p2f, float* alpha,
                       float* sqsil_strips, float* sqsil, int B, hipStream_t s);
 int launch_sil_bwd(const float* ndc, const int* faces, const int* p2f, const float* mask, const float* galpha, float scale,
-                   float* dverts, int ldv, float* gcam, int B, hipStream_t s);
+                   float* dverts, int ldv, float* gcam, int accumulate_cam, int B, hipStream_t s);
 
 // fold.hip
 int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, hipStream_t s);

@@ -68,7 +68,8 @@ def optimize_pose_refiner(log=print) -> Dict:
     B_global = args.batch_size
     lo, hi = jdist.shard_bounds(B_global, rank, world)
     B = hi - lo
-    flags = _engine.FLAG_KEEP_VERTS | (_engine.FLAG_POSE_DISC if use_pd else 0) | (_engine.FLAG_SHAPE_DISC if use_sd else 0)
+    flags = _engine.FLAG_KEEP_VERTS | (_engine.FLAG_POSE_DISC if use_pd else 0) | (_engine.FLAG_SHAPE_DISC if use_sd else 0) \
+        | (_engine.FLAG_SILHOUETTE if args.silhouette else 0)
     eng = _engine.RefineEngine(smpl.device_model, B, batch_norm=B_global, flags=flags)
     eng.set_j_regressor(J_regressor, j_reg_mask)
     if use_pd:
@@ -90,13 +91,15 @@ def optimize_pose_refiner(log=print) -> Dict:
         sq = torch.zeros(B, device=device)
 
         # ---- camera pre-fit + 2-D term (:170-173,187-199,231-233; row f1) on synthetic 2-D targets ----
-        loss_j2d = None
+        cam = torch.from_numpy(full['cam'][lo:hi]).to(device).contiguous()               # :170-172 pred_cam_t
+        cam_m, cam_v = torch.zeros_like(cam), torch.zeros_like(cam)
         if args.reprojection:
-            cam = torch.from_numpy(full['cam'][lo:hi]).to(device).contiguous()           # :170-172 pred_cam_t
             gt_j2d = _synthetic_gt_j2d(eng, x6d, betas, cam, args.seed * 1000 + it)
             eng.camera_prefit(x6d, betas, gt_j2d, cam, n_steps=args.camera_iters, lr=1e-2)   # :187-199
-            cam_m, cam_v = torch.zeros_like(cam), torch.zeros_like(cam)
             eng.set_reprojection(gt_j2d, cam, cam_m, cam_v)
+        if args.silhouette:                                                                # :234-237 (row f2)
+            sil_mask = _synthetic_mask(eng, x6d, betas, cam, args.seed * 1000 + it)
+            eng.set_silhouette(sil_mask, cam, cam_m, cam_v)
 
         t0 = time.perf_counter()
         done = 0
@@ -109,6 +112,8 @@ def optimize_pose_refiner(log=print) -> Dict:
         joint_loss = _global_mean(sq, B_global * 51)
         if args.reprojection:
             eng.set_reprojection(None)
+        if args.silhouette:
+            eng.set_silhouette(None)
 
         # ---- pose-discriminator update (:276-284) ----
         pose_d_loss = None
@@ -168,6 +173,15 @@ def _synthetic_gt_j2d(eng, x6d, betas, cam, seed):
     cam_true = cam + (torch.randn(B, 3, generator=g) * torch.tensor([0.3, 0.3, 3.0])).to(cam.device)
     p = renderer.project_points(joints, cam_true)[..., :2]
     return (p + (torch.randn(B, 17, 2, generator=g) * 2.0).to(cam.device)).contiguous()
+
+
+def _synthetic_mask(eng, x6d, betas, cam, seed):
+    """Target silhouettes (stand-in for batch['mask_rcnn'], scripts/data.py): the current mesh seen through a
+    perturbed camera, binarised."""
+    g = torch.Generator().manual_seed(seed + 7)
+    _, verts = eng.find_joints_forward(betas, x6d=x6d, return_verts=True)
+    cam_true = (cam + (torch.randn(cam.shape[0], 3, generator=g) * torch.tensor([0.2, 0.2, 2.0])).to(cam.device)).contiguous()
+    return (eng.silhouette_forward(verts, cam_true) > 0).float().contiguous()
 
 
 def _global_mean(local_sum_tensor: torch.Tensor, denom: int) -> float:

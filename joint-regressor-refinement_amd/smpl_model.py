@@ -67,6 +67,21 @@ def _body_surface():
     return verts, np.asarray(faces, dtype=np.int32)
 
 
+def _smooth_fields(rng, n: int) -> np.ndarray:
+    """n smooth scalar fields over the surface, (n, 6890), unit RMS: sums of 3 low-order harmonics in the ring
+    angle theta and the segment angle phi with random amplitudes and phases."""
+    th = np.concatenate([[0.0], np.repeat(np.pi * (np.arange(N_RINGS) + 1) / (N_RINGS + 1), N_SEGS), [np.pi]])
+    ph = np.concatenate([[0.0], np.tile(2 * np.pi * np.arange(N_SEGS) / N_SEGS, N_RINGS), [0.0]])
+    out = np.zeros((n, NUM_VERTS))
+    for _ in range(3):
+        p = rng.randint(0, 4, size=(n, 1))
+        q = rng.randint(0, 4, size=(n, 1))
+        a = rng.normal(0.0, 1.0, size=(n, 1))
+        out += a * np.cos(p * th[None] * 2 + rng.uniform(0, 2 * np.pi, size=(n, 1))) * \
+            np.cos(q * ph[None] + rng.uniform(0, 2 * np.pi, size=(n, 1))) * np.sin(th[None]) ** (q > 0)
+    return out / np.sqrt((out ** 2).mean(axis=1, keepdims=True) + 1e-12)
+
+
 def synthetic_smpl(seed: int = 1234, max_influences: int = 4) -> Dict[str, np.ndarray]:
     """Seeded synthetic body model with SMPL's shapes and structural properties: a closed body-scale
     triangle mesh (6890 vertices / 13776 faces, vertex order spatially coherent), shapedirs ~ N(0, 0.01^2),
@@ -77,8 +92,10 @@ def synthetic_smpl(seed: int = 1234, max_influences: int = 4) -> Dict[str, np.nd
     v_template, faces = _body_surface()
     assert v_template.shape == (V, 3) and faces.shape == (13776, 3)
     v_template = v_template + rng.normal(0.0, 0.002, size=(V, 3))       # break the exact symmetry
-    shapedirs = rng.normal(0.0, 0.01, size=(V, 3, NUM_BETAS))
-    posedirs = rng.normal(0.0, 0.002, size=(207, V * 3))
+    # blend shapes: spatially SMOOTH displacement fields (low-order harmonics over the surface
+    # parametrisation), like real SMPL's -- independent per-vertex noise would crumple the mesh
+    shapedirs = _smooth_fields(rng, 3 * NUM_BETAS).T.reshape(V, 3, NUM_BETAS) * 0.01
+    posedirs = _smooth_fields(rng, 207 * 3).reshape(207, 3, V).transpose(0, 2, 1).reshape(207, V * 3) * 0.002
     # skinning weights: the nearest rest joints, Gaussian fall-off
     d2 = ((v_template[:, None, :] - _REST_JOINTS[None]) ** 2).sum(-1)           # (V, 24)
     W = np.zeros((V, NUM_JOINTS))
