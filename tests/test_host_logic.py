@@ -149,3 +149,34 @@ def test_data_parallel_j_step_equals_single_process(tmp_path, smpl_model_np, j_h
     oracle.adam_step(J, gJ, torch.zeros_like(J), torch.zeros_like(J), 1, 1e-2)
     np.testing.assert_allclose(got['o'], o[int(got['lo']):int(got['hi'])].numpy(), rtol=0, atol=1e-6)
     np.testing.assert_allclose(got['J'], J.numpy(), rtol=0, atol=1e-6)
+
+
+def test_dataset_tensor_layout(tmp_path):
+    """row f4: the reference's precomputed-tensor directory layout and the crop re-positioning of gt_j2d
+    (scripts/data.py:49-86,134-158,220-247) on synthetic files."""
+    d = _mod('data')
+    loc = tmp_path / 'precomputed_val'
+    loc.mkdir()
+    g = torch.Generator().manual_seed(0)
+    n = 5
+    bb = torch.tensor([[100., 200., 700., 600.], [0., 0., 1000., 1000.], [300., 100., 500., 900.],
+                       [50., 60., 950., 940.], [400., 400., 600., 600.]])
+    files = dict(bboxes=bb, betas=torch.randn(n, 10, generator=g), estimated_translation=torch.randn(n, 3, generator=g),
+                 gt_j2d=torch.rand(n, 17, 2, generator=g) * 1000, gt_j3d=torch.randn(n, 17, 3, generator=g) * 300,
+                 intrinsics=torch.eye(3).repeat(n, 1, 1), orient=torch.randn(n, 1, 6, generator=g),
+                 pose=torch.randn(n, 23, 6, generator=g))
+    for k, v in files.items():
+        torch.save(v, str(loc / f'{k}.pt'))
+    ds = d.data_set('validation', root=str(tmp_path))
+    assert len(ds) == n
+    s = ds[0]
+    assert set(s) == {'bboxes', 'betas', 'cam', 'gt_j2d', 'gt_j3d', 'intrinsics', 'orient', 'pose', 'inc_gt'}
+    # sample 0: bbox y 100..700, x 200..600 -> square crop of side 600 centred at (400, 400): min (100, 100); scale is
+    # the half side in units of 500 px (0.6), so (j - min)/scale spans 0..1000 and /(1000/224) spans 0..224
+    min_x, min_y, scale = d.crop_params(bb)
+    assert abs(float(min_x[0]) - 100) < 1e-3 and abs(float(min_y[0]) - 100) < 1e-3 and abs(float(scale[0]) - 0.6) < 1e-6
+    np.testing.assert_allclose(s['gt_j2d'].numpy(), ((files['gt_j2d'][0] - 100) / 0.6 / (1000 / 224)).numpy(), rtol=1e-5, atol=1e-3)
+    # full-frame bbox: identity crop up to the 1000 -> 224 resolution change
+    np.testing.assert_allclose(ds[1]['gt_j2d'].numpy(), (files['gt_j2d'][1] / (1000 / 224)).numpy(), rtol=1e-5, atol=1e-3)
+    with pytest.raises(FileNotFoundError):
+        d.data_set('train', root=str(tmp_path))
