@@ -116,7 +116,8 @@ int jrr_rot6d_backward(const float* x6d_dev, const float* dR_dev, float* dx6d_de
 
 /* find_joints, scripts/utils.py:85-103 (SMPL forward + J_regressor contraction).
  * Exactly one of x6d_dev (B,24,6) / R_dev (B,24,3,3) is non-NULL.  joints_dev (B,17,3).
- * verts_dev (B,6890,3) may be NULL (return_verts=False).                                      */
+ * verts_dev (B,6890,3) may be NULL (return_verts=False); non-NULL needs JRR_FLAG_KEEP_VERTS (or _SILHOUETTE):
+ * the kernel stores the vertices coordinate-major and a transposing pass produces the reference's layout.  */
 int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d_dev, const float* R_dev,
                             const float* betas_dev, float* joints_dev, float* verts_dev, void* stream);
 /* Adjoint of the call above for the SAME inputs (must follow it): djoints (B,17,3) ->

@@ -138,8 +138,8 @@ struct jrr_engine {
   const float* sil_mask;
   float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
   bool folded, fold_valid;
+  float *VTb;       // [3][VP][BP] vertices / transposed vertex adjoint (KEEP_VERTS or SILHOUETTE)
   float *verts, *djpad, *dJnp, *dJn, *dj;
-  bool verts_zeroed;
   int32_t* step_scratch;
   bool profiling;
   std::vector<hipEvent_t>* ev[JRR_PROF_CLASSES];
@@ -241,6 +241,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->Ps = c.take(256);
     t->gb = c.take((size_t)BP * NB);
   }
+  if (flags & (JRR_FLAG_SILHOUETTE | JRR_FLAG_KEEP_VERTS)) t->VTb = c.take((size_t)3 * VP * BP);
   if (flags & JRR_FLAG_SILHOUETTE) {
     t->ndc = c.take((size_t)BP * V * 4);
     t->dvpm = c.take((size_t)BP * VP * 3);
@@ -467,18 +468,11 @@ static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s) {
 }
 
 static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,
-                        float* verts, int ldv, int32_t* step_inc, hipStream_t s) {
+                        bool keep_verts, int32_t* step_inc, hipStream_t s) {
   launch_prep_fwd(e->m, x6d, R, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step_inc, s);
-  launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, keep_vp ? e->VPb : nullptr, e->JP, verts, ldv, e->B, e->BP, e->nvc, s);
+  launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, keep_vp ? e->VPb : nullptr, e->JP, keep_verts ? e->VTb : nullptr, e->B, e->BP,
+                 e->nvc, s);
   return 0;
-}
-
-// the padded internal vertex buffer (row stride VP*3) must hold zeros outside [0,B) x [0,6890*3)
-static int ensure_verts_zeroed(jrr_engine* e, hipStream_t s) {
-  if (e->verts_zeroed) return JRR_OK;
-  JRR_HIP(hipMemsetAsync(e->verts, 0, (size_t)e->BP * VP * 3 * 4, s));
-  e->verts_zeroed = true;
-  return JRR_OK;
 }
 
 extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const float* R, const float* betas,
@@ -486,17 +480,12 @@ extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const 
   if (!e || !betas || !joints || ((x6d == nullptr) == (R == nullptr))) { jrr_set_error("find_joints_forward: bad argument"); return JRR_ERR_ARG; }
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
-  if (e->flags & JRR_FLAG_KEEP_VERTS) {
-    // keep a padded copy for the J-regressor adjoint; hand the caller a compact copy if asked
-    int rc = ensure_verts_zeroed(e, s);
-    if (rc) return rc;
-    smpl_forward(e, x6d, R, betas, true, e->verts, VP * 3, nullptr, s);
-    if (verts)
-      JRR_HIP(hipMemcpy2DAsync(verts, (size_t)V * 3 * 4, e->verts, (size_t)VP * 3 * 4, (size_t)V * 3 * 4, e->B,
-                               hipMemcpyDeviceToDevice, s));
-  } else {
-    smpl_forward(e, x6d, R, betas, true, verts, V * 3, nullptr, s);
-  }
+  const bool kv = (e->flags & JRR_FLAG_KEEP_VERTS) != 0;
+  if (verts && !e->VTb) { jrr_set_error("return_verts needs an engine created with JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
+  smpl_forward(e, x6d, R, betas, true, kv || verts, nullptr, s);
+  if (kv)      // padded pose-major copy (row stride VP*3, zeros in the padding) for the J_regressor adjoint
+    launch_verts_untranspose(e->VTb, e->verts, VP * 3, VP, nullptr, nullptr, e->BP, e->BP, s);
+  if (verts) launch_verts_untranspose(e->VTb, verts, V * 3, V, nullptr, nullptr, e->B, e->BP, s);
   reduce_joint_partials(e, s);
   launch_joints_loss(e->Jsum, 1, nullptr, nullptr, 0.f, joints, nullptr, nullptr, e->B, e->BP, s);
   CHECK_LAUNCH();
@@ -550,9 +539,8 @@ extern "C" int jrr_smpl_vertices_backward(jrr_engine_t* e, const float* x6d, con
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   // the padded vertex buffer is reused as the transposed adjoint [3][VP][BP] (same size)
-  launch_dverts_transpose(dverts, V * 3, e->verts, e->B, e->BP, s);
-  e->verts_zeroed = false;
-  launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, nullptr, e->verts, e->DVP, e->dATp, e->BP, e->nvcb, s);
+  launch_dverts_transpose(dverts, V * 3, e->VTb, e->B, e->BP, s);      // the vertex buffer doubles as the transposed adjoint
+  launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, nullptr, e->VTb, e->DVP, e->dATp, e->BP, e->nvcb, s);
   int rc = blend_adjoint_gemm(e, s);
   if (rc) return rc;
   reduce_adjoint_partials(e, s);
@@ -735,7 +723,7 @@ extern "C" int jrr_camera_prefit(jrr_engine_t* e, const float* x6d, const float*
   if (!e || !x6d || !betas || !gt_j2d || !cam || n_steps < 0) return JRR_ERR_ARG;
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
-  smpl_forward(e, x6d, nullptr, betas, false, nullptr, 0, nullptr, s);
+  smpl_forward(e, x6d, nullptr, betas, false, false, nullptr, s);
   reduce_joint_partials(e, s);
   launch_joints_loss(e->Jsum, 1, nullptr, nullptr, 0.f, e->joints, nullptr, nullptr, e->B, e->BP, s);
   const float scale2d = (float)(2.0 / ((double)e->bnorm * 34.0));     // optimize.py:193 unweighted MSE
@@ -779,7 +767,6 @@ extern "C" int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask, flo
   if (mask) {
     int rc = sil_check(e);
     if (rc) return rc;
-    if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("the silhouette term needs JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
     if (!cam || !cam_m || !cam_v) { jrr_set_error("set_silhouette: cam / cam_m / cam_v required"); return JRR_ERR_ARG; }
     e->cam = cam; e->cam_m = cam_m; e->cam_v = cam_v;
   }
@@ -832,8 +819,7 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
       launch_fold_fwd(e->MT, e->AT, e->G0, e->Jsum, e->BP, s);
     } else {
       const bool silf = e->sil_mask != nullptr;      // the silhouette term needs the vertices
-      launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, silf ? e->verts : nullptr, VP * 3, e->B, e->BP, e->nvc, s);
-      if (silf) e->verts_zeroed = false;
+      launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, silf ? e->VTb : nullptr, e->B, e->BP, e->nvc, s);
     }
     prof_mark(e, 1, s);
     prof_mark(e, 2, s);
@@ -847,16 +833,16 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     if (sil) {   // 100 * mean((silhouette - mask)^2), optimize.py:234-237,252
       prof_mark(e, 8, s);
       const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * 224.0 * 224.0));
-      launch_sil_project(e->verts, VP * 3, e->cam, e->ndc, e->B, s);
+      launch_verts_untranspose(e->VTb, nullptr, 0, 0, e->cam, e->ndc, e->B, e->BP, s);   // project straight from the tiles
       launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, e->sil_mask, e->p2f, nullptr, e->sqsil_strips, e->sqsil, e->B, s);
       launch_sil_bwd(e->ndc, e->m.faces, e->p2f, e->sil_mask, nullptr, silscale, e->dvpm, VP * 3, e->gcam,
                      e->gt_j2d ? 1 : 0, e->B, s);
-      launch_dverts_transpose(e->dvpm, VP * 3, e->verts, e->B, e->BP, s);     // verts buffer becomes the transposed adjoint
+      launch_dverts_transpose(e->dvpm, VP * 3, e->VTb, e->B, e->BP, s);     // the vertex buffer becomes the transposed adjoint
       prof_mark(e, 8, s);
     }
     prof_mark(e, 3, s);
     if (folded) launch_fold_bwd(e->dJT, e->AT, e->MT, e->G0, e->dMT, e->dA, e->BP, s);
-    else launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, sil ? e->verts : nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
+    else launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, sil ? e->VTb : nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
     prof_mark(e, 3, s);
     prof_mark(e, 4, s);
     if (folded) {
@@ -947,9 +933,8 @@ extern "C" int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d, const flo
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("J step requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
-  int rc = ensure_verts_zeroed(e, s);
-  if (rc) return rc;
-  smpl_forward(e, x6d, nullptr, betas, false, e->verts, VP * 3, nullptr, s);
+  smpl_forward(e, x6d, nullptr, betas, false, true, nullptr, s);
+  launch_verts_untranspose(e->VTb, e->verts, VP * 3, VP, nullptr, nullptr, e->BP, e->BP, s);
   const float scale = (float)(2.0 * 1.0 / ((double)e->bnorm * 51.0));   // optimize.py:307 unweighted MSE
   reduce_joint_partials(e, s);
   launch_joints_loss(e->Jsum, 1, gt_mm, nullptr, scale, e->joints, sqerr ? sqerr : e->sqerr, nullptr, e->B, e->BP, s);

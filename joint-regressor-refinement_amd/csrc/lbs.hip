@@ -33,7 +33,8 @@ namespace jrr {
 //                regressor product  joints^T += Jn . verts_r                 24 (+16) MFMA / wave
 //   The skinning-weight / regressor tiles (W^T, Jn) ride with stage 0 into a per-tile-parity
 //   region.  outputs: JP [nvc][3][17][BP] joint partials; optional VPb [3][VP][BP] (v_posed,
-//   kept for the backward pass) and verts (B,6890,3).
+//   kept for the backward pass) and VTb [3][VP][BP] (the vertices, same layout; k_verts_untranspose turns
+//   them into the reference's (B,6890,3) and/or projects them for the silhouette renderer).
 // ------------------------------------------------------------------------------------------
 constexpr int W_FLOATS = NJ * 32;             // 768
 constexpr int JN_FLOATS = 32 * 32;            // 1024
@@ -59,8 +60,8 @@ template <bool STORE_VP, bool STORE_VERTS>
 __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk, const float* __restrict__ Wjv,
                                                     const float* __restrict__ Jn_vi, const float* __restrict__ FT,
                                                     const float* __restrict__ AT, float* __restrict__ VPb,
-                                                    float* __restrict__ JP, float* __restrict__ verts, int ldv, int B,
-                                                    int BP, int nvc) {
+                                                    float* __restrict__ JP, float* __restrict__ VTb, int B, int BP,
+                                                    int nvc) {
   __shared__ float lds[2 * STG_FLOATS + 2 * WJ_FLOATS];
   float* const ring = lds;
   float* const wj = lds + 2 * STG_FLOATS;
@@ -167,12 +168,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
 #pragma unroll
           for (int jp = 0; jp < 12; ++jp) T = mfma(wp[(2 * jp) * 32], a1[(2 * jp) * BG], T);     // T_{r,2}
           vr += T * vp[2];
-          if (STORE_VERTS) {
+          if (STORE_VERTS) {      // vertices, coordinate-major and pose-contiguous like v_posed (coalesced)
 #pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              const int v = vt * 32 + acc_row(q, half);
-              if (v < V && b0 + l31 < B) verts[(size_t)(b0 + l31) * ldv + v * 3 + r] = vr[q];
-            }
+            for (int q = 0; q < 16; ++q)
+              VTb[((size_t)r * VP + vt * 32 + acc_row(q, half)) * BP + bcol] = vr[q];
           }
           // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b]
 #pragma unroll
@@ -334,6 +333,47 @@ __global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __r
   else if (k - W_FLOATS - 1024 < TB_FLOATS - TB_WVJ - 1024) dst[TB_WVJ + 1024 + (k - W_FLOATS - 1024)] = 0.f;
 }
 
+// [3][VP][BP] vertices -> pose-major (B, ldv) rows of (v, xyz) and/or projected (x_ndc, y_ndc, Z, 0) records for
+// the silhouette renderer (scripts/optimize.py:80-82 flip/scale + scripts/mesh_renderer.py:52-57 camera).
+// One 32-vertex x 32-pose tile per block through LDS; every global access is contiguous.
+__global__ void k_verts_untranspose(const float* __restrict__ VTb, float* __restrict__ verts, int ldv, int vlimit,
+                                    const float* __restrict__ cam, f32x4* __restrict__ ndc, float focal, int B, int BP) {
+  __shared__ float tile[32][97];
+  const int v0 = blockIdx.x * 32, bb0 = blockIdx.y * 32;
+  for (int idx = threadIdx.x; idx < 96 * 32; idx += blockDim.x) {
+    const int rem = idx / 32, bl = idx % 32;       // rem = r*32 + vv
+    const int r = rem / 32, vv = rem % 32;
+    tile[bl][vv * 3 + r] = VTb[((size_t)r * VP + v0 + vv) * BP + bb0 + bl];
+  }
+  __syncthreads();
+  if (verts) {
+    for (int idx = threadIdx.x; idx < 32 * 96; idx += blockDim.x) {
+      const int bl = idx / 96, rem = idx % 96;
+      const int b = bb0 + bl, v = v0 + rem / 3;
+      if (b < B && v < vlimit) verts[(size_t)b * ldv + v0 * 3 + rem] = tile[bl][rem];
+    }
+  }
+  if (ndc) {
+    for (int idx = threadIdx.x; idx < 32 * 32; idx += blockDim.x) {
+      const int bl = idx / 32, vv = idx % 32;
+      const int b = bb0 + bl, v = v0 + vv;
+      if (b < B && v < V) {
+        const float X = -2.f * tile[bl][vv * 3] + cam[(size_t)b * 3], Y = -2.f * tile[bl][vv * 3 + 1] + cam[(size_t)b * 3 + 1];
+        const float Z = 2.f * tile[bl][vv * 3 + 2] + cam[(size_t)b * 3 + 2];
+        f32x4 o = {focal * X / Z, focal * Y / Z, Z, 0.f};
+        ndc[(size_t)b * V + v] = o;
+      }
+    }
+  }
+}
+
+int launch_verts_untranspose(const float* VTb, float* verts, int ldv, int vlimit, const float* cam, float* ndc, int B, int BP,
+                             hipStream_t s) {
+  hipLaunchKernelGGL(k_verts_untranspose, dim3(VT, BP / 32), dim3(256), 0, s, VTb, verts, ldv, vlimit, cam, (f32x4*)ndc,
+                     5000.f / 224.f, B, BP);
+  return 0;
+}
+
 // (B,6890,3) -> [3][VP][BP] transpose of an external vertex adjoint (operator-level SMPL backward)
 __global__ void k_dverts_transpose(const float* __restrict__ dverts, int ldv, float* __restrict__ dVT, int B, int BP) {
   __shared__ float tile[32][97];
@@ -419,16 +459,16 @@ __global__ void k_jreg_bwd(const float* __restrict__ J, const float* __restrict_
 // launchers
 // ------------------------------------------------------------------------------------------
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
-                   float* verts, int ldv, int B, int BP, int nvc, hipStream_t s) {
+                   float* verts, int B, int BP, int nvc, hipStream_t s) {
   dim3 grid((BP / BG) * nvc), block(256);
   if (VPb && verts)
-    hipLaunchKernelGGL((k_lbs_fwd<true, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, ldv, B, BP, nvc);
+    hipLaunchKernelGGL((k_lbs_fwd<true, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc);
   else if (VPb)
-    hipLaunchKernelGGL((k_lbs_fwd<true, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, ldv, B, BP, nvc);
+    hipLaunchKernelGGL((k_lbs_fwd<true, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc);
   else if (verts)
-    hipLaunchKernelGGL((k_lbs_fwd<false, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, ldv, B, BP, nvc);
+    hipLaunchKernelGGL((k_lbs_fwd<false, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc);
   else
-    hipLaunchKernelGGL((k_lbs_fwd<false, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, ldv, B, BP, nvc);
+    hipLaunchKernelGGL((k_lbs_fwd<false, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc);
   return 0;
 }
 

@@ -56,7 +56,7 @@ def test_rot6d_forward_backward(eng_mod):
 def test_find_joints_forward_and_verts(eng_mod, dmodel, smpl_model_np, j_h36m_np, B):
     batch = _batch(smpl_model_np, j_h36m_np, B, seed=11)
     x6d, betas = T(batch['pose6d']), T(batch['betas'])
-    eng = eng_mod.RefineEngine(dmodel, B)
+    eng = eng_mod.RefineEngine(dmodel, B, flags=eng_mod.FLAG_KEEP_VERTS)
     eng.set_j_regressor(T(j_h36m_np))
     joints, verts = eng.find_joints_forward(betas.to(DEV), x6d=x6d.to(DEV), return_verts=True)
     ref_j, ref_v = _oracle_joints(smpl_model_np, T(j_h36m_np), x6d, betas, return_verts=True)
