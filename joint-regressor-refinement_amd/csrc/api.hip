@@ -134,7 +134,7 @@ struct jrr_engine {
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
   float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc;
   float *Ps, *gb;
-  float *ndc, *dvpm, *sqsil_strips, *sqsil; int* p2f;   // soft silhouette (JRR_FLAG_SILHOUETTE)
+  float *ndc, *dvpm, *sqsil; unsigned* cover; int* ncover;   // soft silhouette (JRR_FLAG_SILHOUETTE)
   const float* sil_mask;
   float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
   bool folded, fold_valid;
@@ -245,8 +245,8 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   if (flags & JRR_FLAG_SILHOUETTE) {
     t->ndc = c.take((size_t)BP * V * 4);
     t->dvpm = c.take((size_t)BP * VP * 3);
-    t->p2f = (int*)c.take((size_t)BP * 224 * 224);
-    t->sqsil_strips = c.take((size_t)BP * 4);   // >= 3 strips per pose
+    t->cover = (unsigned*)c.take((size_t)BP * 224 * 224);
+    t->ncover = (int*)c.take((size_t)BP);
     t->sqsil = c.take((size_t)BP);
   }
   if (flags & JRR_FLAG_FOLDED) {
@@ -747,7 +747,7 @@ extern "C" int jrr_silhouette_forward(jrr_engine_t* e, const float* verts, const
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   launch_sil_project(verts, V * 3, cam, e->ndc, e->B, s);
-  launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, nullptr, e->p2f, alpha, nullptr, nullptr, e->B, s);
+  launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, nullptr, e->cover, e->ncover, alpha, nullptr, e->B, s);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -757,7 +757,7 @@ extern "C" int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha, flo
   int rc = sil_check(e);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
-  launch_sil_bwd(e->ndc, e->m.faces, e->p2f, nullptr, galpha, 0.f, dverts, V * 3, dcam, 0, e->B, s);
+  launch_sil_bwd(e->ndc, e->m.faces, e->cover, e->ncover, nullptr, galpha, 0.f, dverts, V * 3, dcam, 0, e->B, s);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -834,9 +834,8 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
       prof_mark(e, 8, s);
       const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * 224.0 * 224.0));
       launch_verts_untranspose(e->VTb, nullptr, 0, 0, e->cam, e->ndc, e->B, e->BP, s);   // project straight from the tiles
-      launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, e->sil_mask, e->p2f, nullptr, e->sqsil_strips, e->sqsil, e->B, s);
-      launch_sil_bwd(e->ndc, e->m.faces, e->p2f, e->sil_mask, nullptr, silscale, e->dvpm, VP * 3, e->gcam,
-                     e->gt_j2d ? 1 : 0, e->B, s);
+      launch_sil_raster_adj(e->ndc, e->m.faces, e->m.nfaces, e->sil_mask, e->cover, e->ncover, e->sqsil, silscale, e->dvpm,
+                            VP * 3, e->gcam, e->gt_j2d ? 1 : 0, e->B, s);   // forward, loss and adjoint in one kernel
       launch_dverts_transpose(e->dvpm, VP * 3, e->VTb, e->B, e->BP, s);     // the vertex buffer becomes the transposed adjoint
       prof_mark(e, 8, s);
     }

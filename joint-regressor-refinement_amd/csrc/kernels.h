@@ -80,10 +80,16 @@ int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 
 // sil.hip
 int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s);
-int launch_sil_raster(const float* ndc, const int* faces, int nfaces, const float* mask, int* p2f, float* alpha,
-                      float* sqsil_strips, float* sqsil, int B, hipStream_t s);
-int launch_sil_bwd(const float* ndc, const int* faces, const int* p2f, const float* mask, const float* galpha, float scale,
-                   float* dverts, int ldv, float* gcam, int accumulate_cam, int B, hipStream_t s);
+// cover [B][224*224] / ncover [B]: the covered pixels of each pose (pixel << 14 | winning face), written by the
+// rasteriser and consumed by the adjoint
+int launch_sil_raster(const float* ndc, const int* faces, int nfaces, const float* mask, unsigned* cover, int* ncover,
+                      float* alpha, float* sqsil, int B, hipStream_t s);
+int launch_sil_raster_adj(const float* ndc, const int* faces, int nfaces, const float* mask, unsigned* cover, int* ncover,
+                          float* sqsil, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
+                          hipStream_t s);
+int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, const int* ncover, const float* mask,
+                   const float* galpha, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
+                   hipStream_t s);
 
 // fold.hip
 int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, hipStream_t s);

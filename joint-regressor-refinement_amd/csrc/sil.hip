@@ -9,24 +9,34 @@
 //
 // Kernels (one mesh = 6890 vertices / 13776 faces of ~1 pixel each at 224x224):
 //   k_sil_project  per (pose, vertex): world -> (x_ndc, y_ndc, view depth Z)
-//   k_sil_raster   per (pose, 75-row strip): every thread walks faces (4 fetched together), tests the <= few
-//                  pixels of each face's bounding box and keeps the nearest face per pixel with a 64-bit
-//                  atomicMin on an LDS z-buffer keyed (depth bits << 32 | face index); then resolves alpha,
-//                  writes pix_to_face, and reduces the squared error against the target mask
-//   k_sil_bwd      per pose: adjoint of alpha -> the two end points of the nearest edge (NDC) -> world
-//                  vertices, accumulated in LDS (81 KB per mesh) and written once, and the camera translation
+//   k_sil_raster   per pose (one 1024-thread workgroup, ~155 KB LDS): projected vertices resident in LDS, face
+//                  indices in registers; the image is swept in 40-row strips: each thread tests the pixel centres
+//                  inside its faces' bounding boxes and keeps the nearest face per pixel with a 64-bit atomicMin on
+//                  an LDS z-buffer keyed (depth bits << 32 | face index).  Background pixels are finished per
+//                  strip; covered pixels (8-9 %) go to a per-pose list (pixel << 14 | face) and are resolved densely
+//                  at the end: alpha, squared error against the target mask and -- <true>, the fused inner loop --
+//                  the adjoint of the loss term, accumulated per vertex in NDC space in the z-buffer's LDS
+//   k_sil_bwd      per pose: the same adjoint for an arbitrary upstream gradient (standalone API), from the list
+// Measured costs that shaped this (MI355X): LDS float atomics retire ~1 lane per 2.5 clocks (so: 4 per covered
+// pixel, NDC space, not 6 in world space); the face sweep is VALU-bound (max-over-lanes bounding box trips).
 #include "jrr_common.h"
 #include "kernels.h"
 
 namespace jrr {
 
 constexpr int SIL = 224;                 // image size (scripts/optimize.py:110 Mesh_Renderer(image_size=224))
-constexpr int SIL_STRIP = 75;            // rows per LDS z-buffer strip (75*224*8 B = 131 KB; 3 strips: 75+75+74)
-constexpr int SIL_NSTRIP = 3;
-constexpr int SIL_RT = 1024;             // threads of the raster workgroup (one workgroup per CU: LDS-bound)
-constexpr int SIL_FB = 4;                // faces fetched together per thread (gather latency amortised)
+constexpr int SIL_STRIP = 40;            // rows per LDS z-buffer strip (40*224*8 B = 70 KB; 6 strips, the last of 24 rows)
+constexpr int SIL_RT = 1024;             // threads of the raster workgroup (one workgroup per pose and per CU: LDS-bound)
+constexpr int SIL_FPT = 14;              // faces per thread, kept in registers (14 * 1024 >= 13776)
+constexpr int SIL_FBITS = 14;             // covered-pixel list entry = pixel << 14 | face (faces < 16384, pixels < 65536)
+constexpr int SIL_PPT = (40 * 224 + 1023) / 1024;   // pixels per thread and strip
+constexpr int SIL_EB = 6;                 // list entries fetched together per thread in the resolve
+static_assert((3 * V + 2) % 2 == 0, "z-buffer alignment");
+static_assert(V * 2 * 4 <= 40 * 224 * 8, "adjoint accumulators must fit the z-buffer");
+constexpr int SIL_VPAD = 3 * V + 2;      // floats of the LDS vertex arrays, padded so the u64 z-buffer is 8-byte aligned
 constexpr float SIL_F = 5000.f / 224.f;  // NDC focal length
-constexpr float SIL_SIGMA = 1e-4f;
+// BlendParams sigma = 1e-4 (mesh_renderer.py:28); only its reciprocal is used
+constexpr float SIL_ISIGMA = 1e4f;
 constexpr float SIL_EPS = 1e-8f;
 
 struct alignas(16) NdcV { float x, y, z, pad; };
@@ -47,7 +57,10 @@ __global__ void k_sil_project(const float* __restrict__ verts, int ldv, const fl
 __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay, float bx, float by) {
   return (px - ax) * (by - ay) - (py - ay) * (bx - ax);
 }
-__device__ __forceinline__ float pix_x(int xi) { return 1.f - (2.f * xi + 1.f) / SIL; }
+// pixel centre 1 - fl32((2 xi + 1)/224).  The fp32 quotient is formed as a rounded f64 product: (2 xi + 1)/224 is
+// never within 2^-53 (relative) of an fp32 rounding boundary, so this equals the IEEE fp32 division bit for bit
+// (checked for all 224 indices in tests/test_host_logic.py) at 3 instructions instead of 12.
+__device__ __forceinline__ float pix_x(int xi) { return 1.f - (float)((double)(2 * xi + 1) * (1.0 / SIL)); }
 
 // squared distance from p to segment a-b, and the clamped parameter t
 __device__ __forceinline__ float seg_dist2(float px, float py, float ax, float ay, float bx, float by, float& t) {
@@ -58,87 +71,232 @@ __device__ __forceinline__ float seg_dist2(float px, float py, float ax, float a
   return (px - qx) * (px - qx) + (py - qy) * (py - qy);
 }
 
+// nearest edge (first minimum) of the triangle (x[k], y[k]): returns the squared distance; the edge runs from
+// corner ka to corner (ka + 1) % 3 and tt is the clamped parameter of the closest point on it
+__device__ __forceinline__ float sil_nearest_edge(float px, float py, const float x[3], const float y[3], int& ka, float& tt) {
+  float t1, t2;
+  float dist = seg_dist2(px, py, x[0], y[0], x[1], y[1], tt);
+  const float d1 = seg_dist2(px, py, x[1], y[1], x[2], y[2], t1);
+  const float d2 = seg_dist2(px, py, x[2], y[2], x[0], y[0], t2);
+  ka = 0;
+  if (d1 < dist) { dist = d1; tt = t1; ka = 1; }
+  if (d2 < dist) { dist = d2; tt = t2; ka = 2; }
+  return dist;
+}
+// alpha = sigmoid(dist / sigma) (sigma = 1e-4: 1/sigma = 1e4 is exact in fp32)
+__device__ __forceinline__ float sil_alpha(float dist) { return 1.f / (1.f + expf(-dist * SIL_ISIGMA)); }
+
+// One workgroup per pose.  The pose's projected vertices (3 x 6890 floats = 81 KB) are loaded ONCE into LDS and
+// each thread keeps the vertex indices of its <= 14 faces (and their pixel-row ranges) in registers, so the only
+// global traffic of the face passes is zero: the image is swept in 6 strips of 40 rows (LDS z-buffer 70 KB), and a
+// face is only touched in the strip(s) its rows fall into.
+//
+// ADJ (the fused inner loop): the adjoint of scale * sum((alpha - mask)^2)/2... i.e. g_alpha = scale * (alpha - mask)
+// is taken in the same kernel: after the last strip the z-buffer's LDS holds the vertex-adjoint accumulators,
+// written out pose-major.
+template <bool ADJ>
 __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ ndc, const int* __restrict__ faces,
                                                        int nfaces, const float* __restrict__ mask,
-                                                       int* __restrict__ p2f, float* __restrict__ alpha_out,
-                                                       float* __restrict__ sqsil) {
-  extern __shared__ unsigned long long zb[];     // [SIL_STRIP][SIL]
+                                                       unsigned* __restrict__ cover, int* __restrict__ ncover,
+                                                       float* __restrict__ alpha_out, float* __restrict__ sqsil,
+                                                       float scale, float* __restrict__ dverts, int ldv,
+                                                       float* __restrict__ gcam, int accumulate_cam) {
+  extern __shared__ unsigned long long smem64[];      // 8-byte aligned whatever static LDS precedes it
+  float* vx = reinterpret_cast<float*>(smem64);       // [V]; the vertex arrays first: ds offsets stay < 64 KB
+  unsigned long long* zb = smem64 + SIL_VPAD / 2;     // [SIL_STRIP][SIL]
+  float* vy = vx + V;
+  float* vz = vx + 2 * V;
   __shared__ float red[SIL_RT];
-  const int b = blockIdx.x / SIL_NSTRIP, strip = blockIdx.x % SIL_NSTRIP;
-  const int y0 = strip * SIL_STRIP, y1 = min(y0 + SIL_STRIP, SIL);   // rows [y0, y1)
+  __shared__ float gcs[3];
+  __shared__ float pxt[SIL];          // pixel centres
+  __shared__ int ncov;
+  const int b = blockIdx.x;
   const NdcV* vb = ndc + (size_t)b * V;
-  for (int i = threadIdx.x; i < SIL_STRIP * SIL; i += SIL_RT) zb[i] = ~0ull;
+  unsigned* lst = cover + (size_t)b * SIL * SIL;
+  if (threadIdx.x == 0) ncov = 0;
+  if (threadIdx.x < SIL) pxt[threadIdx.x] = pix_x(threadIdx.x);
+  for (int v = threadIdx.x; v < V; v += SIL_RT) {
+    const NdcV p = vb[v];
+    vx[v] = p.x; vy[v] = p.y; vz[v] = p.z;
+  }
+  // this thread's faces: vertex indices now, pixel-row range after the vertices have landed
+  int fi[SIL_FPT][3];
+  int frow[SIL_FPT];                  // first row | last row << 16
+#pragma unroll
+  for (int u = 0; u < SIL_FPT; ++u) {
+    const int f = threadIdx.x + u * SIL_RT;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fi[u][k] = (f < nfaces) ? faces[f * 3 + k] : 0;
+  }
   __syncthreads();
-  for (int f0 = threadIdx.x; f0 < nfaces; f0 += SIL_RT * SIL_FB) {
-    // fetch SIL_FB faces at once: all index loads, then all vertex gathers, are in flight together
-    int fi[SIL_FB][3];
-    NdcV fv[SIL_FB][3];
 #pragma unroll
-    for (int u = 0; u < SIL_FB; ++u) {
-      const int f = min(f0 + u * SIL_RT, nfaces - 1);
+  for (int u = 0; u < SIL_FPT; ++u) {
+    const int f = threadIdx.x + u * SIL_RT;
+    const float y0v = vy[fi[u][0]], y1v = vy[fi[u][1]], y2v = vy[fi[u][2]];
+    const float ymax = fmaxf(y0v, fmaxf(y1v, y2v)), ymin = fminf(y0v, fminf(y1v, y2v));
+    // pixel centres inside the bounding box: yf = 1 - (2 yi + 1)/H in [ymin, ymax]  <=>
+    // yi in [ceil((H (1 - ymax) - 1)/2), floor((H (1 - ymin) - 1)/2)]; 1e-3 px of slack, the inside test is exact.
+    int ylo = (int)ceilf((SIL * (1.f - ymax) - 1.f) * 0.5f - 1e-3f), yhi = (int)floorf((SIL * (1.f - ymin) - 1.f) * 0.5f + 1e-3f);
+    ylo = max(ylo, 0); yhi = min(yhi, SIL - 1);
+    if (f >= nfaces || !(ymax == ymax) || !(ymin == ymin)) { ylo = 1; yhi = 0; }     // empty range
+    frow[u] = ylo | (yhi << 16);
+  }
+  float err = 0.f;
+  for (int y0 = 0; y0 < SIL; y0 += SIL_STRIP) {
+    const int y1 = min(y0 + SIL_STRIP, SIL);                           // rows [y0, y1)
+    for (int i = threadIdx.x; i < SIL_STRIP * SIL; i += SIL_RT) zb[i] = ~0ull;
+    __syncthreads();
 #pragma unroll
-      for (int k = 0; k < 3; ++k) fi[u][k] = faces[f * 3 + k];
-    }
-#pragma unroll
-    for (int u = 0; u < SIL_FB; ++u)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) fv[u][k] = vb[fi[u][k]];
-#pragma unroll
-    for (int u = 0; u < SIL_FB; ++u) {
-      const int f = f0 + u * SIL_RT;
-      if (f >= nfaces) continue;
-      const NdcV a = fv[u][0], bb = fv[u][1], c = fv[u][2];
-      const float ymax = fmaxf(a.y, fmaxf(bb.y, c.y)), ymin = fminf(a.y, fminf(bb.y, c.y));
-      // pixel centres inside the bounding box: yf = 1 - (2 yi + 1)/H in [ymin, ymax]  <=>
-      // yi in [ceil((H (1 - ymax) - 1)/2), floor((H (1 - ymin) - 1)/2)]; 1e-3 px of slack, the inside test is exact.
-      // Most faces are smaller than a pixel and contain no centre at all.
-      int ylo = (int)ceilf((SIL * (1.f - ymax) - 1.f) * 0.5f - 1e-3f), yhi = (int)floorf((SIL * (1.f - ymin) - 1.f) * 0.5f + 1e-3f);
-      ylo = max(ylo, y0); yhi = min(yhi, y1 - 1);
-      if (ylo > yhi) continue;                                     // not in this strip / no pixel centre
-      const float xmax = fmaxf(a.x, fmaxf(bb.x, c.x)), xmin = fminf(a.x, fminf(bb.x, c.x));
+    for (int u = 0; u < SIL_FPT; ++u) {
+      const int ylo = max(frow[u] & 0xffff, y0), yhi = min(frow[u] >> 16, y1 - 1);
+      if (ylo > yhi) continue;                                         // no pixel centre of this face in the strip
+      const int f = threadIdx.x + u * SIL_RT;
+      const float ax = vx[fi[u][0]], ay = vy[fi[u][0]], az = vz[fi[u][0]];
+      const float bx = vx[fi[u][1]], by = vy[fi[u][1]], bz = vz[fi[u][1]];
+      const float cx = vx[fi[u][2]], cy = vy[fi[u][2]], cz = vz[fi[u][2]];
+      const float xmax = fmaxf(ax, fmaxf(bx, cx)), xmin = fminf(ax, fminf(bx, cx));
       int xlo = (int)ceilf((SIL * (1.f - xmax) - 1.f) * 0.5f - 1e-3f), xhi = (int)floorf((SIL * (1.f - xmin) - 1.f) * 0.5f + 1e-3f);
       xlo = max(xlo, 0); xhi = min(xhi, SIL - 1);
       if (xlo > xhi) continue;
-      const float area = edge_fn(c.x, c.y, a.x, a.y, bb.x, bb.y);
+      const float area = edge_fn(cx, cy, ax, ay, bx, by);
       if (!(fabsf(area) > SIL_EPS)) continue;                    // also rejects NaN
-      if (fmaxf(a.z, fmaxf(bb.z, c.z)) < 0.f) continue;          // behind the camera
+      if (fmaxf(az, fmaxf(bz, cz)) < 0.f) continue;              // behind the camera
       const float inv = 1.f / area;
-      for (int yi = ylo; yi <= yhi; ++yi) {
-        const float py = pix_x(yi);
-        for (int xi = xlo; xi <= xhi; ++xi) {
-          const float px = pix_x(xi);
-          const float w0 = edge_fn(px, py, bb.x, bb.y, c.x, c.y) * inv;
-          const float w1 = edge_fn(px, py, c.x, c.y, a.x, a.y) * inv;
-          const float w2 = edge_fn(px, py, a.x, a.y, bb.x, bb.y) * inv;
-          if (!(w0 > 0.f && w1 > 0.f && w2 > 0.f)) continue;
-          const float pz = w0 * a.z + w1 * bb.z + w2 * c.z;
-          if (!(pz >= 0.f)) continue;
+      // one flat loop over the bounding box (xi fastest): a wave runs max-over-lanes(nx * ny) trips, not
+      // sum-over-rows(max nx)
+      for (int xi = xlo, yi = ylo; yi <= yhi;) {
+        const float px = pxt[xi], py = pxt[yi];
+        const float w0 = edge_fn(px, py, bx, by, cx, cy) * inv;
+        const float w1 = edge_fn(px, py, cx, cy, ax, ay) * inv;
+        const float w2 = edge_fn(px, py, ax, ay, bx, by) * inv;
+        const float pz = w0 * az + w1 * bz + w2 * cz;
+        if (w0 > 0.f && w1 > 0.f && w2 > 0.f && pz >= 0.f) {
           const unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
           atomicMin(&zb[(yi - y0) * SIL + xi], key);
         }
+        const bool wrap = xi >= xhi;
+        xi = wrap ? xlo : xi + 1;
+        yi += wrap ? 1 : 0;
+      }
+    }
+    __syncthreads();
+    // resolve, pass 1: background pixels are finished here; covered pixels are appended to the pose's list
+    // (pixel << 14 | face) -- 8-9 % of the image, handled densely in pass 2 instead of under divergence here.
+    // The thread's <= 9 pixels are fetched together; one LDS atomic per wave reserves the list slots.
+    {
+      unsigned long long key[SIL_PPT];
+      float mk[SIL_PPT];
+      const int npx = (y1 - y0) * SIL;
+#pragma unroll
+      for (int k = 0; k < SIL_PPT; ++k) {
+        const int i = threadIdx.x + k * SIL_RT;
+        key[k] = (i < npx) ? zb[i] : ~0ull;
+        mk[k] = (mask && i < npx) ? mask[(size_t)b * SIL * SIL + y0 * SIL + i] : 0.f;
+      }
+#pragma unroll
+      for (int k = 0; k < SIL_PPT; ++k) {
+        const int i = threadIdx.x + k * SIL_RT;
+        const bool cov = key[k] != ~0ull;
+        const unsigned long long bal = __ballot(cov);
+        if (bal) {                                                       // wave-uniform
+          const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
+          int base = 0;
+          if (lane == leader) base = atomicAdd(&ncov, __popcll(bal));
+          base = __shfl(base, leader);
+          if (cov) lst[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned)(y0 * SIL + i) << SIL_FBITS) | (unsigned)(key[k] & 0xffffffffu);
+        }
+        if (!cov && i < npx) {
+          if (alpha_out) alpha_out[(size_t)b * SIL * SIL + y0 * SIL + i] = 0.f;
+          err += mk[k] * mk[k];
+        }
+      }
+    }
+    __syncthreads();                                                   // strip resolved before the z-buffer is reused
+  }
+  // resolve, pass 2: alpha of the covered pixels from the edge distances of their winning faces
+  const int n = ncov;
+  if (threadIdx.x == 0) ncover[b] = n;
+  // ADJ: the adjoint is accumulated per vertex in NDC space, (G_x, G_y) = sum of d loss / d (x_ndc, y_ndc), in the
+  // z-buffer's LDS (2 x 6890 floats); the chain through x_ndc = f X / Z, y_ndc = f Y / Z is linear in (G_x, G_y)
+  // with per-VERTEX coefficients and is applied once per vertex at write-out:
+  //   gX = f G_x / Z, gY = f G_y / Z, gZ = -(x G_x + y G_y) / Z;  d/d verts = (-2 gX, -2 gY, 2 gZ), d/d cam = (gX, gY, gZ)
+  // (LDS float atomics retire one lane at a time: 4 per covered pixel instead of 6, and one sweep.)
+  float* acc = reinterpret_cast<float*>(zb);
+  if (ADJ) {
+    for (int i = threadIdx.x; i < V * 2; i += SIL_RT) acc[i] = 0.f;
+    __syncthreads();
+  }
+  for (int e0 = threadIdx.x; e0 < n; e0 += SIL_RT * SIL_EB) {
+    unsigned ent[SIL_EB];
+    int id[SIL_EB][3];
+    float tg[SIL_EB];
+#pragma unroll
+    for (int u = 0; u < SIL_EB; ++u) ent[u] = (e0 + u * SIL_RT < n) ? lst[e0 + u * SIL_RT] : 0u;
+#pragma unroll
+    for (int u = 0; u < SIL_EB; ++u) {
+      const int f = (int)(ent[u] & ((1u << SIL_FBITS) - 1));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) id[u][k] = faces[f * 3 + k];
+      tg[u] = mask ? mask[(size_t)b * SIL * SIL + (ent[u] >> SIL_FBITS)] : 0.f;
+    }
+#pragma unroll
+    for (int u = 0; u < SIL_EB; ++u) {
+      if (e0 + u * SIL_RT >= n) continue;
+      const int pix = (int)(ent[u] >> SIL_FBITS);
+      const float px = pxt[pix % SIL], py = pxt[pix / SIL];
+      const float x[3] = {vx[id[u][0]], vx[id[u][1]], vx[id[u][2]]}, y[3] = {vy[id[u][0]], vy[id[u][1]], vy[id[u][2]]};
+      int ka;
+      float tt;
+      const float dist = sil_nearest_edge(px, py, x, y, ka, tt);
+      const float al = sil_alpha(dist);
+      if (alpha_out) alpha_out[(size_t)b * SIL * SIL + pix] = al;
+      if (mask) { const float dm = al - tg[u]; err += dm * dm; }
+      if (ADJ) {
+        const float gd = scale * (al - tg[u]) * al * (1.f - al) * SIL_ISIGMA;          // d loss / d dist
+        if (gd == 0.f) continue;
+        // end points of edge ka (selects, not indexed registers)
+        const int ida = ka == 0 ? id[u][0] : ka == 1 ? id[u][1] : id[u][2], idb = ka == 0 ? id[u][1] : ka == 1 ? id[u][2] : id[u][0];
+        const float xa = ka == 0 ? x[0] : ka == 1 ? x[1] : x[2], xb = ka == 0 ? x[1] : ka == 1 ? x[2] : x[0];
+        const float ya = ka == 0 ? y[0] : ka == 1 ? y[1] : y[2], yb = ka == 0 ? y[1] : ka == 1 ? y[2] : y[0];
+        // dist = |p - q|^2, q = a + t (b - a): d/da = -2 (1-t) r, d/db = -2 t r (t clamped: the same formulas)
+        const float rx = px - (xa + tt * (xb - xa)), ry = py - (ya + tt * (yb - ya));
+        const float ca = -2.f * (1.f - tt) * gd, cb = -2.f * tt * gd;
+        if (ca != 0.f) { atomicAdd(&acc[ida * 2], ca * rx); atomicAdd(&acc[ida * 2 + 1], ca * ry); }
+        if (cb != 0.f) { atomicAdd(&acc[idb * 2], cb * rx); atomicAdd(&acc[idb * 2 + 1], cb * ry); }
       }
     }
   }
-  __syncthreads();
-  float err = 0.f;
-  for (int i = threadIdx.x; i < (y1 - y0) * SIL; i += SIL_RT) {
-    const int yi = y0 + i / SIL, xi = i % SIL;
-    const unsigned long long key = zb[i];
-    float al = 0.f;
-    int f = -1;
-    if (key != ~0ull) {
-      f = (int)(key & 0xffffffffu);
-      const NdcV a = vb[faces[f * 3]], bb = vb[faces[f * 3 + 1]], c = vb[faces[f * 3 + 2]];
-      const float px = pix_x(xi), py = pix_x(yi);
-      float t;
-      const float d = fminf(fminf(seg_dist2(px, py, a.x, a.y, bb.x, bb.y, t), seg_dist2(px, py, bb.x, bb.y, c.x, c.y, t)),
-                            seg_dist2(px, py, c.x, c.y, a.x, a.y, t));
-      al = 1.f / (1.f + expf(-d / SIL_SIGMA));
+  if (ADJ) {
+    __syncthreads();
+    float* dv = dverts + (size_t)b * ldv;
+    float gc[3] = {0.f, 0.f, 0.f};
+    for (int v = threadIdx.x; v < V; v += SIL_RT) {
+      const float Gx = acc[v * 2], Gy = acc[v * 2 + 1];
+      float g[3] = {0.f, 0.f, 0.f};
+      if (Gx != 0.f || Gy != 0.f) {
+        const float iz = 1.f / vz[v];
+        g[0] = SIL_F * iz * Gx; g[1] = SIL_F * iz * Gy; g[2] = -(vx[v] * Gx + vy[v] * Gy) * iz;
+      }
+      dv[v * 3] = -2.f * g[0]; dv[v * 3 + 1] = -2.f * g[1]; dv[v * 3 + 2] = 2.f * g[2];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) gc[c] += g[c];
     }
-    const size_t o = ((size_t)b * SIL + yi) * SIL + xi;
-    p2f[o] = f;
-    if (alpha_out) alpha_out[o] = al;
-    if (mask) { const float dm = al - mask[o]; err += dm * dm; }
+    if (gcam) {                                                          // wave sums, then 16 LDS atomics per component
+      if (threadIdx.x < 3) gcs[threadIdx.x] = 0.f;
+      __syncthreads();
+#pragma unroll
+      for (int c = 0; c < 3; ++c) {
+        float w = gc[c];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
+        if ((threadIdx.x & 63) == 0) atomicAdd(&gcs[c], w);
+      }
+      __syncthreads();
+      if (threadIdx.x < 3) {
+        if (accumulate_cam) gcam[(size_t)b * 3 + threadIdx.x] += gcs[threadIdx.x];
+        else gcam[(size_t)b * 3 + threadIdx.x] = gcs[threadIdx.x];
+      }
+    }
   }
   if (sqsil) {
     red[threadIdx.x] = err;
@@ -147,112 +305,145 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
       if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
       __syncthreads();
     }
-    if (threadIdx.x == 0) sqsil[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) sqsil[b] = red[0];
   }
 }
 
-// adjoint: g_alpha = galpha[pixel] if given, else scale * (alpha - mask[pixel]).
-// One workgroup per pose: the vertex adjoints of the whole mesh (6890 x 3 floats = 81 KB) are accumulated in
-// LDS (ds_add_f32) and written out once, pose-major, with plain coalesced stores -- no global atomics, no
-// zero-fill of the output.  (LDS float adds: the summation order, hence the last bits, varies between runs.)
+// adjoint for an arbitrary upstream gradient: g_alpha = galpha[pixel] if given, else scale * (alpha - mask[pixel]).
+// One workgroup per pose walks the pose's covered-pixel list (dense lanes) and accumulates the NDC-space vertex
+// adjoints (G_x, G_y) in LDS (2 x 6890 floats, ds_add_f32), exactly as k_sil_raster<true> does; the projection's
+// chain rule is applied per vertex at write-out (plain coalesced stores of all 6890 x 3 floats: no global
+// atomics, no zero-fill of the output).  LDS float adds and the list order: the summation order, hence the last
+// bits, varies between runs.
 constexpr int SIL_BT = 1024;
+constexpr int SIL_PB = 3;                // list entries fetched together per thread
 __global__ __launch_bounds__(SIL_BT) void k_sil_bwd(const NdcV* __restrict__ ndc, const int* __restrict__ faces,
-                                                    const int* __restrict__ p2f, const float* __restrict__ mask,
+                                                    const unsigned* __restrict__ cover, const int* __restrict__ ncover,
+                                                    const float* __restrict__ mask,
                                                     const float* __restrict__ galpha, float scale,
                                                     float* __restrict__ dverts, int ldv, float* __restrict__ gcam,
                                                     int accumulate_cam) {
-  extern __shared__ float acc[];                 // [V*3] + 3 camera sums
+  extern __shared__ float acc[];                 // [V*2]
+  __shared__ float gcs[3];
   const int b = blockIdx.x;
   const NdcV* vb = ndc + (size_t)b * V;
-  for (int i = threadIdx.x; i < V * 3 + 3; i += SIL_BT) acc[i] = 0.f;
+  const unsigned* lst = cover + (size_t)b * SIL * SIL;
+  const int n = ncover[b];
+  for (int i = threadIdx.x; i < V * 2; i += SIL_BT) acc[i] = 0.f;
+  if (threadIdx.x < 3) gcs[threadIdx.x] = 0.f;
   __syncthreads();
-  float gc[3] = {0.f, 0.f, 0.f};
-  for (int pix = threadIdx.x; pix < SIL * SIL; pix += SIL_BT) {
-    const size_t o = (size_t)b * SIL * SIL + pix;
-    const int f = p2f[o];
-    if (f < 0) continue;
-    const int yi = pix / SIL, xi = pix % SIL;
-    const int id[3] = {faces[f * 3], faces[f * 3 + 1], faces[f * 3 + 2]};
-    const NdcV vv[3] = {vb[id[0]], vb[id[1]], vb[id[2]]};
-    const float px = pix_x(xi), py = pix_x(yi);
-    float t0, t1, t2;
-    const float d0 = seg_dist2(px, py, vv[0].x, vv[0].y, vv[1].x, vv[1].y, t0);
-    const float d1 = seg_dist2(px, py, vv[1].x, vv[1].y, vv[2].x, vv[2].y, t1);
-    const float d2 = seg_dist2(px, py, vv[2].x, vv[2].y, vv[0].x, vv[0].y, t2);
-    // nearest edge (first minimum), its end points A -> B
-    NdcV A = vv[0], Bv = vv[1];
-    int ida = id[0], idb = id[1];
-    float dist = d0, tt = t0;
-    if (d1 < dist) { dist = d1; tt = t1; A = vv[1]; Bv = vv[2]; ida = id[1]; idb = id[2]; }
-    if (d2 < dist) { dist = d2; tt = t2; A = vv[2]; Bv = vv[0]; ida = id[2]; idb = id[0]; }
-    const float al = 1.f / (1.f + expf(-dist / SIL_SIGMA));
-    const float ga = galpha ? galpha[o] : scale * (al - mask[o]);
-    const float gd = ga * al * (1.f - al) / SIL_SIGMA;          // d loss / d dist
-    if (gd == 0.f) continue;
-    const float rx = px - (A.x + tt * (Bv.x - A.x)), ry = py - (A.y + tt * (Bv.y - A.y));
-    // dist = |p - q|^2, q = a + t (b - a): d/da = -2 (1-t) r, d/db = -2 t r (t clamped: the same formulas)
-    const float ca = -2.f * (1.f - tt) * gd, cb = -2.f * tt * gd;
-    {   // end point A
-      const float gx = ca * rx, gy = ca * ry;
-      const float Z = A.z, X = A.x * Z / SIL_F, Y = A.y * Z / SIL_F;
-      const float gX = SIL_F / Z * gx, gY = SIL_F / Z * gy, gZ = -SIL_F * (X * gx + Y * gy) / (Z * Z);
-      atomicAdd(&acc[ida * 3], -2.f * gX); atomicAdd(&acc[ida * 3 + 1], -2.f * gY); atomicAdd(&acc[ida * 3 + 2], 2.f * gZ);
-      gc[0] += gX; gc[1] += gY; gc[2] += gZ;
+  // SIL_PB entries per thread are fetched together: the dependent chain entry -> face indices -> vertices costs
+  // three memory round trips per BATCH rather than per pixel.
+  for (int e0 = threadIdx.x; e0 < n; e0 += SIL_BT * SIL_PB) {
+    unsigned ent[SIL_PB];
+    int id[SIL_PB][3];
+    float tgt[SIL_PB];
+    NdcV vv[SIL_PB][3];
+#pragma unroll
+    for (int u = 0; u < SIL_PB; ++u) ent[u] = (e0 + u * SIL_BT < n) ? lst[e0 + u * SIL_BT] : 0u;
+#pragma unroll
+    for (int u = 0; u < SIL_PB; ++u) {
+      const int fc = (int)(ent[u] & ((1u << SIL_FBITS) - 1));
+#pragma unroll
+      for (int k = 0; k < 3; ++k) id[u][k] = faces[fc * 3 + k];
+      const size_t o = (size_t)b * SIL * SIL + (ent[u] >> SIL_FBITS);
+      tgt[u] = galpha ? galpha[o] : mask[o];
     }
-    {   // end point B
-      const float gx = cb * rx, gy = cb * ry;
-      const float Z = Bv.z, X = Bv.x * Z / SIL_F, Y = Bv.y * Z / SIL_F;
-      const float gX = SIL_F / Z * gx, gY = SIL_F / Z * gy, gZ = -SIL_F * (X * gx + Y * gy) / (Z * Z);
-      atomicAdd(&acc[idb * 3], -2.f * gX); atomicAdd(&acc[idb * 3 + 1], -2.f * gY); atomicAdd(&acc[idb * 3 + 2], 2.f * gZ);
-      gc[0] += gX; gc[1] += gY; gc[2] += gZ;
+#pragma unroll
+    for (int u = 0; u < SIL_PB; ++u)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) vv[u][k] = vb[id[u][k]];
+#pragma unroll
+    for (int u = 0; u < SIL_PB; ++u) {
+      if (e0 + u * SIL_BT >= n) continue;
+      const int pix = (int)(ent[u] >> SIL_FBITS);
+      const float px = pix_x(pix % SIL), py = pix_x(pix / SIL);
+      const float x[3] = {vv[u][0].x, vv[u][1].x, vv[u][2].x}, y[3] = {vv[u][0].y, vv[u][1].y, vv[u][2].y};
+      int ka;
+      float tt;
+      const float dist = sil_nearest_edge(px, py, x, y, ka, tt);
+      const float al = sil_alpha(dist);
+      const float ga = galpha ? tgt[u] : scale * (al - tgt[u]);
+      const float gd = ga * al * (1.f - al) * SIL_ISIGMA;          // d loss / d dist
+      if (gd == 0.f) continue;
+      const int ida = ka == 0 ? id[u][0] : ka == 1 ? id[u][1] : id[u][2], idb = ka == 0 ? id[u][1] : ka == 1 ? id[u][2] : id[u][0];
+      const float xa = ka == 0 ? x[0] : ka == 1 ? x[1] : x[2], xb = ka == 0 ? x[1] : ka == 1 ? x[2] : x[0];
+      const float ya = ka == 0 ? y[0] : ka == 1 ? y[1] : y[2], yb = ka == 0 ? y[1] : ka == 1 ? y[2] : y[0];
+      const float rx = px - (xa + tt * (xb - xa)), ry = py - (ya + tt * (yb - ya));
+      const float ca = -2.f * (1.f - tt) * gd, cb = -2.f * tt * gd;
+      if (ca != 0.f) { atomicAdd(&acc[ida * 2], ca * rx); atomicAdd(&acc[ida * 2 + 1], ca * ry); }
+      if (cb != 0.f) { atomicAdd(&acc[idb * 2], cb * rx); atomicAdd(&acc[idb * 2 + 1], cb * ry); }
     }
   }
-#pragma unroll
-  for (int c = 0; c < 3; ++c)
-    if (gc[c] != 0.f) atomicAdd(&acc[V * 3 + c], gc[c]);
   __syncthreads();
   float* dv = dverts + (size_t)b * ldv;
-  for (int i = threadIdx.x; i < V * 3; i += SIL_BT) dv[i] = acc[i];
-  if (gcam && threadIdx.x < 3) {
-    if (accumulate_cam) gcam[(size_t)b * 3 + threadIdx.x] += acc[V * 3 + threadIdx.x];
-    else gcam[(size_t)b * 3 + threadIdx.x] = acc[V * 3 + threadIdx.x];
+  float gc[3] = {0.f, 0.f, 0.f};
+  for (int v = threadIdx.x; v < V; v += SIL_BT) {
+    const float Gx = acc[v * 2], Gy = acc[v * 2 + 1];
+    float g[3] = {0.f, 0.f, 0.f};
+    if (Gx != 0.f || Gy != 0.f) {
+      const NdcV p = vb[v];
+      const float iz = 1.f / p.z;
+      g[0] = SIL_F * iz * Gx; g[1] = SIL_F * iz * Gy; g[2] = -(p.x * Gx + p.y * Gy) * iz;
+    }
+    dv[v * 3] = -2.f * g[0]; dv[v * 3 + 1] = -2.f * g[1]; dv[v * 3 + 2] = 2.f * g[2];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) gc[c] += g[c];
   }
-}
-
-// per-pose sum of the strip partials
-__global__ void k_sil_sum(const float* __restrict__ sqsil, float* __restrict__ out, int B) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= B) return;
-  float acc = 0.f;
-  for (int s = 0; s < SIL_NSTRIP; ++s) acc += sqsil[(size_t)b * SIL_NSTRIP + s];
-  out[b] = acc;
+  if (gcam) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float w = gc[c];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
+      if ((threadIdx.x & 63) == 0) atomicAdd(&gcs[c], w);
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+      if (accumulate_cam) gcam[(size_t)b * 3 + threadIdx.x] += gcs[threadIdx.x];
+      else gcam[(size_t)b * 3 + threadIdx.x] = gcs[threadIdx.x];
+    }
+  }
 }
 
 static bool g_sil_attr = false;
 static void sil_attrs() {
   if (g_sil_attr) return;
-  (void)hipFuncSetAttribute((const void*)k_sil_raster, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_STRIP * SIL * 8);
-  (void)hipFuncSetAttribute((const void*)k_sil_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (V * 3 + 3) * 4);
+  (void)hipFuncSetAttribute((const void*)k_sil_raster<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_VPAD * 4 + SIL_STRIP * SIL * 8);
+  (void)hipFuncSetAttribute((const void*)k_sil_raster<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_VPAD * 4 + SIL_STRIP * SIL * 8);
+  (void)hipFuncSetAttribute((const void*)k_sil_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, V * 2 * 4);
   g_sil_attr = true;
 }
 int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s) {
   hipLaunchKernelGGL(k_sil_project, dim3((B * V + 255) / 256), dim3(256), 0, s, verts, ldv, cam, (NdcV*)ndc, B);
   return 0;
 }
-int launch_sil_raster(const float* ndc, const int* faces, int nfaces, const float* mask, int* p2f, float* alpha,
-                      float* sqsil_strips, float* sqsil, int B, hipStream_t s) {
+int launch_sil_raster(const float* ndc, const int* faces, int nfaces, const float* mask, unsigned* cover, int* ncover,
+                      float* alpha, float* sqsil, int B, hipStream_t s) {
   sil_attrs();
-  hipLaunchKernelGGL(k_sil_raster, dim3(B * SIL_NSTRIP), dim3(SIL_RT), SIL_STRIP * SIL * 8, s, (const NdcV*)ndc, faces, nfaces,
-                     mask, p2f, alpha, sqsil_strips);
-  if (sqsil && sqsil_strips) hipLaunchKernelGGL(k_sil_sum, dim3((B + 255) / 256), dim3(256), 0, s, sqsil_strips, sqsil, B);
+  if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
+  hipLaunchKernelGGL(k_sil_raster<false>, dim3(B), dim3(SIL_RT), SIL_VPAD * 4 + SIL_STRIP * SIL * 8, s, (const NdcV*)ndc, faces,
+                     nfaces, mask, cover, ncover, alpha, sqsil, 0.f, nullptr, 0, nullptr, 0);
+  return 0;
+}
+// rasterise + squared error against mask + the adjoint of scale/2 * sum((alpha - mask)^2) in one kernel;
+// writes ALL of dverts[b][0 .. 6890*3); gcam: overwrite or accumulate
+int launch_sil_raster_adj(const float* ndc, const int* faces, int nfaces, const float* mask, unsigned* cover, int* ncover,
+                          float* sqsil, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
+                          hipStream_t s) {
+  sil_attrs();
+  if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
+  hipLaunchKernelGGL(k_sil_raster<true>, dim3(B), dim3(SIL_RT), SIL_VPAD * 4 + SIL_STRIP * SIL * 8, s, (const NdcV*)ndc, faces,
+                     nfaces, mask, cover, ncover, nullptr, sqsil, scale, dverts, ldv, gcam, accumulate_cam);
   return 0;
 }
 // writes ALL of dverts[b][0 .. 6890*3) (no zero-fill needed); gcam: overwrite or accumulate
-int launch_sil_bwd(const float* ndc, const int* faces, const int* p2f, const float* mask, const float* galpha, float scale,
-                   float* dverts, int ldv, float* gcam, int accumulate_cam, int B, hipStream_t s) {
+int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, const int* ncover, const float* mask,
+                   const float* galpha, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
+                   hipStream_t s) {
   sil_attrs();
-  hipLaunchKernelGGL(k_sil_bwd, dim3(B), dim3(SIL_BT), (V * 3 + 3) * 4, s, (const NdcV*)ndc, faces, p2f, mask, galpha, scale,
-                     dverts, ldv, gcam, accumulate_cam);
+  hipLaunchKernelGGL(k_sil_bwd, dim3(B), dim3(SIL_BT), V * 2 * 4, s, (const NdcV*)ndc, faces, cover, ncover, mask, galpha,
+                     scale, dverts, ldv, gcam, accumulate_cam);
   return 0;
 }
 
