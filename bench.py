@@ -209,6 +209,35 @@ def main():
     torch.cuda.synchronize(); barrier()
     j_ms = (time.perf_counter() - tj) / nj * 1e3
 
+    # ---- pose-discriminator update (scripts/optimize.py:276-284; one per outer batch in the reference): two D
+    #      forward + weight-gradient passes, all-reduce of the 1.84 M-float gradient, Adam(lr 1e-3), re-upload.
+    #      Timed separately, never part of `value`. ----
+    d_ms = None
+    if use_disc:
+        dflat = disc_flat.to(dev).clone()
+        dm_, dv_ = torch.zeros_like(dflat), torch.zeros_like(dflat)
+        dstep = torch.zeros(1, dtype=torch.int32, device=dev)
+        spin_pose = torch.from_numpy(batch_np['pose6d']).to(dev).contiguous()
+
+        def d_step():
+            g = torch.zeros_like(dflat)
+            eng.pose_disc_backward_params(x6d, 0.0, g)
+            eng.pose_disc_backward_params(spin_pose, 1.0, g)
+            if dist is not None:
+                dist.all_reduce(g)
+            dstep.add_(1)
+            eng_mod.adam_step(dflat, g, dm_, dv_, dstep, 1e-3)
+            eng.set_pose_disc(dflat)
+
+        d_step()
+        torch.cuda.synchronize(); barrier()
+        td = time.perf_counter()
+        for _ in range(nj):
+            d_step()
+        torch.cuda.synchronize(); barrier()
+        d_ms = (time.perf_counter() - td) / nj * 1e3
+        eng.set_pose_disc(disc_flat.to(dev))
+
     # ---- folded-regressor mode (a different algorithm with its own denominator): timed
     #      separately on a fresh copy of the same batch, never part of `value` ----
     folded = None
@@ -274,6 +303,13 @@ def main():
         'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
                    'allreduce_bytes': 17 * 6890 * 4},
     }
+    # outer-step work amortised over the inner loop: reference cadence = one D update and
+    # one J step per 100 inner iterations; cadence 1 = both after every inner iteration
+    outer_ms = j_ms + (d_ms or 0.0)
+    out['outer_step'] = {'j_step_ms': round(j_ms, 3), 'pose_d_update_ms': None if d_ms is None else round(d_ms, 3),
+                         'it_s_amortised_cadence_100': round(world / ((ms_per_step + outer_ms / 100.0) * 1e-3), 3),
+                         'it_s_amortised_cadence_1': round(world / ((ms_per_step + outer_ms) * 1e-3), 3),
+                         'pose_d_allreduce_bytes': 1840153 * 4 if use_disc else 0}
     if folded is not None:
         out['folded_mode'] = folded
     if not a.no_cpu_baseline:

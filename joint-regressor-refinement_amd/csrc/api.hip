@@ -132,7 +132,7 @@ struct jrr_engine {
   // workspace sections
   float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv;
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
-  float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc;
+  float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc, *wgs;
   float *Ps, *gb;
   float *ndc, *dvpm, *sqsil; unsigned* cover; int* ncover;   // soft silhouette (JRR_FLAG_SILHOUETTE)
   const float* sil_mask;
@@ -234,6 +234,10 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->gx = c.take((size_t)BP * JRR_POSE6D);
     t->TrA = c.take((size_t)BP * 1024);
     t->TrB = c.take((size_t)BP * 1024);
+    {   // weight-gradient partial slabs: 8 pose-splits of a 1024x1024 layer, or one conv/head slab per wave
+      const size_t conv = (size_t)(BP / 64) * (4 * 1280 + 792), fc = (size_t)8 * 1024 * 1024;
+      t->wgs = c.take(conv > fc ? conv : fc);
+    }
     t->dz0 = c.take((size_t)BP);
     t->dsc = c.take((size_t)BP * 25);
   }
@@ -650,9 +654,15 @@ extern "C" int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d, 
   launch_transpose(e->A1T, e->TrB, 1024, e->BP, s);
   GemmArgs g;
   g.bias = nullptr; g.mask = nullptr; g.split_stride = 0;
-  g.A = e->TrA; g.lda = 1024; g.Bm = e->TrB; g.ldb = 1024; g.Out = dP + DP_FC2_W; g.ldo = 1024; g.M = 1024; g.N = 1024; g.K = e->BP;
-  rc = launch_gemm_128(g, EPI_ACCUM, 1, s);
+  // the pose dimension is the reduction: split it so that the 64 output tiles become >= 512 workgroups; partial
+  // slabs, then a wide accumulate-reduce into the flat gradient (deterministic, no atomics)
+  const int wsplit = e->BP >= 4096 ? 8 : e->BP >= 1024 ? 4 : e->BP >= 256 ? 2 : 1;
+  g.A = e->TrA; g.lda = 1024; g.Bm = e->TrB; g.ldb = 1024; g.Out = e->wgs; g.ldo = 1024; g.M = 1024; g.N = 1024; g.K = e->BP;
+  g.split_stride = (size_t)1024 * 1024;
+  rc = launch_gemm_128(g, EPI_STORE, wsplit, s);
   if (rc) return rc;
+  launch_reduce_slabs(e->wgs, wsplit, (size_t)1024 * 1024, dP + DP_FC2_W, (size_t)1024 * 1024, s, 1);
+  g.split_stride = 0;
   launch_rowdot_accum(e->dA2T, e->BP, nullptr, dP + DP_FC2_B, 1024, e->BP, s);
   // back through fc2
   g.A = e->Pd + DP_FC2_W; g.lda = 1024; g.Bm = e->dA2T; g.ldb = e->BP; g.Out = e->dA1T; g.ldo = e->BP; g.mask = e->A1T;
@@ -663,14 +673,23 @@ extern "C" int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d, 
   launch_transpose(e->dA1T, e->TrA, 1024, e->BP, s);
   launch_transpose(e->H2T, e->TrB, 768, e->BP, s);
   g.mask = nullptr;
-  g.A = e->TrA; g.lda = 1024; g.Bm = e->TrB; g.ldb = 768; g.Out = dP + DP_FC0_W; g.ldo = 768; g.M = 1024; g.N = 768; g.K = e->BP;
-  rc = launch_gemm_128(g, EPI_ACCUM, 1, s);
+  g.A = e->TrA; g.lda = 1024; g.Bm = e->TrB; g.ldb = 768; g.Out = e->wgs; g.ldo = 768; g.M = 1024; g.N = 768; g.K = e->BP;
+  g.split_stride = (size_t)1024 * 768;
+  rc = launch_gemm_128(g, EPI_STORE, wsplit, s);
   if (rc) return rc;
+  launch_reduce_slabs(e->wgs, wsplit, (size_t)1024 * 768, dP + DP_FC0_W, (size_t)1024 * 768, s, 1);
+  g.split_stride = 0;
   launch_rowdot_accum(e->dA1T, e->BP, nullptr, dP + DP_FC0_B, 1024, e->BP, s);
   g.A = e->Pd + DP_FC0_W; g.lda = 768; g.Bm = e->dA1T; g.ldb = e->BP; g.Out = e->dH2T; g.ldo = e->BP; g.M = 768; g.N = e->BP; g.K = 1024;
   rc = launch_gemm_128x64(g, EPI_STORE, 1, s);
   if (rc) return rc;
-  launch_disc_conv_bwd_params(e->Pd, x6d, e->dH2T, scale, target, dP, e->B, e->BP, s);
+  {   // conv / head weight gradients: one slab per wave, reduced into the flat gradient
+    float* slab_shared = e->wgs;
+    float* slab_heads = e->wgs + (size_t)4 * (e->BP / 64) * 1280;
+    launch_disc_conv_bwd_params(e->Pd, x6d, e->dH2T, scale, target, slab_shared, slab_heads, e->B, e->BP, s);
+    launch_reduce_slabs(slab_shared, 4 * (e->BP / 64), 1280, dP + DP_CONV0_W, 1280, s, 1);
+    launch_reduce_slabs(slab_heads, e->BP / 64, 792, dP + DP_HEADS, 792, s, 1);
+  }
   CHECK_LAUNCH();
   return JRR_OK;
 }

@@ -214,49 +214,98 @@ __global__ void k_rowdot_accum(const float* __restrict__ M, int ld, const float*
   if (threadIdx.x == 0) out[r] += red[0];
 }
 
-// per-joint MLP + head weight gradients: lane = pose, blockIdx.y = joint; wave-reduce then one atomic
-// per parameter per wave.  dH2T = gradient arriving from fc0.
+// per-joint MLP + head weight gradients.  One wave per (64 poses, 6 joints): lane = pose runs the joint MLP forward
+// and backward in registers; the outer products over the 64 poses (dW2 = dh2^T h1, dW0 = dh1^T x, the bias and head
+// sums) are taken from LDS-staged copies with lane = (output row o, half of the columns), accumulated in registers
+// over the wave's joints and written as ONE partial slab per wave -- no atomics; the caller reduces the slabs.
+// dH2T = gradient arriving from fc0.
+constexpr int CW_LD = 36;                      // LDS row stride in floats (16-byte aligned rows)
 __global__ __launch_bounds__(64) void k_disc_conv_bwd_params(const float* __restrict__ P, const float* __restrict__ x6d,
                                                              const float* __restrict__ dH2T, float scale, float target,
-                                                             float* __restrict__ dP, int B, int BP) {
-  const int lane = threadIdx.x, b = blockIdx.x * 64 + lane, j = blockIdx.y;
+                                                             float* __restrict__ slab_shared,
+                                                             float* __restrict__ slab_heads, int B, int BP) {
+  __shared__ __attribute__((aligned(16))) float Sa[64 * CW_LD];
+  __shared__ __attribute__((aligned(16))) float Sb[64 * CW_LD];
+  const int lane = threadIdx.x, b = blockIdx.x * 64 + lane, q = blockIdx.y;
+  const int o_ = lane & 31, hf = lane >> 5;
   const bool ok = b < B;
-  float x[6], h1[32], h2[32];
+  float aW2[16], aW0[3] = {0.f, 0.f, 0.f}, ab2 = 0.f, ab0 = 0.f;
 #pragma unroll
-  for (int c = 0; c < 6; ++c) x[c] = ok ? x6d[((size_t)b * NJ + j) * 6 + c] : 0.f;
-  joint_mlp(P, x, h1, h2);
-  const float* wh = P + DP_HEADS + 33 * j;
-  float z = wh[32];
+  for (int k = 0; k < 16; ++k) aW2[k] = 0.f;
+  for (int jj = 0; jj < 6; ++jj) {
+    const int j = q * 6 + jj;
+    float x[6], h1[32], h2[32];
 #pragma unroll
-  for (int o = 0; o < 32; ++o) z = fmaf(wh[o], h2[o], z);
-  const float s = sigmoidf(z);
-  const float dz = ok ? scale * (s - target) * s * (1.f - s) : 0.f;
-  float dh2[32], dh1[32];
+    for (int c = 0; c < 6; ++c) x[c] = ok ? x6d[((size_t)b * NJ + j) * 6 + c] : 0.f;
+    joint_mlp(P, x, h1, h2);
+    const float* wh = P + DP_HEADS + 33 * j;
+    float z = wh[32];
 #pragma unroll
-  for (int o = 0; o < 32; ++o) {
-    float g = dz * wh[o];
-    if (ok) g += dH2T[(size_t)(j * 32 + o) * BP + b];
-    dh2[o] = (ok && h2[o] > 0.f) ? g : 0.f;
-    wave_atomic_add(dz * h2[o], dP + DP_HEADS + 33 * j + o, lane);
-    wave_atomic_add(dh2[o], dP + DP_CONV2_B + o, lane);
-  }
-  wave_atomic_add(dz, dP + DP_HEADS + 33 * j + 32, lane);
-  const float* w2 = P + DP_CONV2_W;
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    float acc = 0.f;
+    for (int o = 0; o < 32; ++o) z = fmaf(wh[o], h2[o], z);
+    const float s = sigmoidf(z);
+    const float dz = ok ? scale * (s - target) * s * (1.f - s) : 0.f;
+    float dh2[32], dh1[32];
 #pragma unroll
     for (int o = 0; o < 32; ++o) {
-      acc = fmaf(w2[o * 32 + c], dh2[o], acc);
-      wave_atomic_add(dh2[o] * h1[c], dP + DP_CONV2_W + o * 32 + c, lane);
+      float g = dz * wh[o];
+      if (ok) g += dH2T[(size_t)(j * 32 + o) * BP + b];
+      dh2[o] = (ok && h2[o] > 0.f) ? g : 0.f;
     }
-    dh1[c] = (h1[c] > 0.f) ? acc : 0.f;
-    wave_atomic_add(dh1[c], dP + DP_CONV0_B + c, lane);
+    const float* w2 = P + DP_CONV2_W;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+      float acc = 0.f;
+#pragma unroll
+      for (int o = 0; o < 32; ++o) acc = fmaf(w2[o * 32 + c], dh2[o], acc);
+      dh1[c] = (h1[c] > 0.f) ? acc : 0.f;
+    }
+    // ---- head of joint j: dW[o] = sum_b dz h2[o], db = sum_b dz
+#pragma unroll
+    for (int o = 0; o < 32; ++o) Sa[lane * CW_LD + o] = dz * h2[o];
+    Sa[lane * CW_LD + 32] = dz;
+    __syncthreads();
+    if (lane < 33) {
+      float acc = 0.f;
+      for (int bb = 0; bb < 64; ++bb) acc += Sa[bb * CW_LD + lane];
+      slab_heads[(size_t)blockIdx.x * 792 + 33 * j + lane] = acc;
+    }
+    __syncthreads();
+    // ---- conv2: dW2[o][c] += sum_b dh2[b][o] h1[b][c]; db2[o] += sum_b dh2[b][o]
+#pragma unroll
+    for (int o = 0; o < 32; ++o) { Sa[lane * CW_LD + o] = dh2[o]; Sb[lane * CW_LD + o] = h1[o]; }
+    __syncthreads();
+    for (int bb = 0; bb < 64; ++bb) {
+      const float a = Sa[bb * CW_LD + o_];
+      const f32x4* hr = reinterpret_cast<const f32x4*>(&Sb[bb * CW_LD + hf * 16]);
+#pragma unroll
+      for (int k4 = 0; k4 < 4; ++k4) {
+        const f32x4 r = hr[k4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) aW2[k4 * 4 + k] = fmaf(a, r[k], aW2[k4 * 4 + k]);
+      }
+      ab2 += a;
+    }
+    __syncthreads();
+    // ---- conv0: dW0[o][c] += sum_b dh1[b][o] x[b][c]; db0[o] += sum_b dh1[b][o]
+#pragma unroll
+    for (int o = 0; o < 32; ++o) Sa[lane * CW_LD + o] = dh1[o];
+#pragma unroll
+    for (int c = 0; c < 6; ++c) Sb[lane * CW_LD + c] = x[c];
+    __syncthreads();
+    for (int bb = 0; bb < 64; ++bb) {
+      const float a = Sa[bb * CW_LD + o_];
+#pragma unroll
+      for (int k = 0; k < 3; ++k) aW0[k] = fmaf(a, Sb[bb * CW_LD + hf * 3 + k], aW0[k]);
+      ab0 += a;
+    }
+    __syncthreads();
   }
+  float* slab = slab_shared + ((size_t)blockIdx.x * 4 + q) * 1280;
 #pragma unroll
-  for (int o = 0; o < 32; ++o)
+  for (int k = 0; k < 16; ++k) slab[DP_CONV2_W + o_ * 32 + hf * 16 + k] = aW2[k];
 #pragma unroll
-    for (int c = 0; c < 6; ++c) wave_atomic_add(dh1[o] * x[c], dP + DP_CONV0_W + o * 6 + c, lane);
+  for (int k = 0; k < 3; ++k) slab[DP_CONV0_W + o_ * 6 + hf * 3 + k] = aW0[k];
+  if (hf == 0) { slab[DP_CONV2_B + o_] = ab2; slab[DP_CONV0_B + o_] = ab0; }
 }
 
 // shape discriminator: forward, weight gradients of mean((s-target)^2), per-pose squared error
@@ -327,8 +376,9 @@ int launch_rowdot_accum(const float* M, int ld, const float* vec, float* out, in
   return 0;
 }
 int launch_disc_conv_bwd_params(const float* P, const float* x6d, const float* dH2T, float scale, float target,
-                                float* dparams, int B, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_disc_conv_bwd_params, dim3((B + 63) / 64, NJ), dim3(64), 0, s, P, x6d, dH2T, scale, target, dparams, B, BP);
+                                float* slab_shared, float* slab_heads, int B, int BP, hipStream_t s) {
+  hipLaunchKernelGGL(k_disc_conv_bwd_params, dim3(BP / 64, 4), dim3(64), 0, s, P, x6d, dH2T, scale, target, slab_shared,
+                     slab_heads, B, BP);
   return 0;
 }
 int launch_shape_disc_bwd_params(const float* P, const float* betas, float scale, float target, float* dparams,

@@ -52,7 +52,7 @@ int launch_camera_fit(const float* joints, const float* gt_j2d, float* cam, floa
 int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale, float* sqerr, float* djoints, int B,
                             hipStream_t s);
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s);
-int launch_reduce_slabs(const float* P, int nslab, size_t stride, float* out, size_t n, hipStream_t s);
+int launch_reduce_slabs(const float* P, int nslab, size_t stride, float* out, size_t n, hipStream_t s, int accumulate = 0);
 int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr, float b1,
                      float b2, float eps, hipStream_t s);
 
@@ -106,8 +106,10 @@ int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* ou
 int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
                     float target, int B, int BP, hipStream_t s, float* dz0 = nullptr);
 int launch_rowdot_accum(const float* M, int ld, const float* vec, float* out, int rows, int cols, hipStream_t s);
+// conv / per-joint-head weight gradients as partial slabs: shared [4 * BP/64][1280] (conv0 W,b | conv2 W,b in the
+// DP_* order) and heads [BP/64][792]; the caller reduces them into the flat gradient
 int launch_disc_conv_bwd_params(const float* P, const float* x6d, const float* dH2T, float scale, float target,
-                                float* dparams, int B, int BP, hipStream_t s);
+                                float* slab_shared, float* slab_heads, int B, int BP, hipStream_t s);
 int launch_shape_disc_bwd_params(const float* P, const float* betas, float scale, float target, float* dparams,
                                  float* sqerr, int B, hipStream_t s);
 int launch_sqerr_rows(const float* out, int ncol, float target, float* sqerr, int B, hipStream_t s);

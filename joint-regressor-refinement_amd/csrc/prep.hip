@@ -697,21 +697,23 @@ __global__ __launch_bounds__(64) void k_pose_update(PoseUpdateArgs a) {
   }
 }
 
-// out[i] = sum_s P[s*stride + i]  (split-K / vertex-chunk partial slabs), float4-wide
+// out[i] (+)= sum_s P[s*stride + i]  (split-K / vertex-chunk partial slabs), float4-wide
 __global__ void k_reduce_slabs(const f32x4* __restrict__ P, int nslab, size_t stride4, f32x4* __restrict__ out,
-                               size_t n4) {
+                               size_t n4, int accumulate) {
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
     f32x4 acc = P[i];
     for (int s = 1; s < nslab; ++s) acc += P[(size_t)s * stride4 + i];
+    if (accumulate) acc += out[i];
     out[i] = acc;
   }
 }
 
-int launch_reduce_slabs(const float* P, int nslab, size_t stride, float* out, size_t n, hipStream_t s) {
+int launch_reduce_slabs(const float* P, int nslab, size_t stride, float* out, size_t n, hipStream_t s, int accumulate) {
   size_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
   if (blocks > 4096) blocks = 4096;
-  hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, (const f32x4*)P, nslab, stride / 4, (f32x4*)out, n4);
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, (const f32x4*)P, nslab, stride / 4, (f32x4*)out, n4,
+                     accumulate);
   return 0;
 }
 
