@@ -197,6 +197,7 @@ def main():
     eng.set_profiling(True)
     eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, max(2, min(a.steps, 20)), sqerr=sq)
     prof = eng.profile_read()
+    probe = eng.probe_read()
     eng.set_profiling(False)
 
     # ---- J step at cadence 1 (BASELINE configs[3]): timed separately, never part of `value` ----
@@ -298,7 +299,13 @@ def main():
         'roofline': {'bound': 'mfma', 'kernel': 'k_lbs_fwd<true,false>', 'achieved': round(achieved, 2),
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                      'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'launches_timed': dom_n,
-                     'algorithmic_flop_per_launch': FLOP_LBS_FWD_PER_POSE * B},
+                     'algorithmic_flop_per_launch': FLOP_LBS_FWD_PER_POSE * B,
+                     # in-kernel shader-clock probe (s_memtime, workgroup 0 / wave 0): how busy the MFMA pipe is and
+                     # at what clock the chip sustains this kernel; `peak` above assumes the 2.4 GHz boost clock
+                     'mfma_pipe_occupancy': round(probe[1] * probe[2] * probe[3] / probe[0], 4) if probe[0] else None,
+                     'sustained_clock_ghz': round(probe[0] / probe[4], 3) if probe[4] else None,
+                     'frac_of_peak_at_sustained_clock': round(achieved / (PEAK_F32_MFMA_TFLOPS * (probe[0] / probe[4] / 2.4)), 4)
+                     if probe[4] else None},
         'kernels_ms': {k: round(t, 4) for k, (t, n) in prof.items() if n},
         'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
                    'allreduce_bytes': 17 * 6890 * 4},

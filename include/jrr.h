@@ -230,6 +230,12 @@ int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n);
 enum { JRR_PROF_CLASSES = 9 };
 int jrr_engine_set_profiling(jrr_engine_t* e, int enabled);
 int jrr_engine_profile_read(jrr_engine_t* e, float* ms_host, int32_t* counts_host);
+/* Shader-clock probe of the dominant kernel (k_lbs_fwd), recorded while profiling is on by workgroup 0 / wave 0
+ * of the last launch inside jrr_refine_run: out[0] = shader clocks the wave was resident (s_memtime),
+ * out[1] = MFMA instructions it issued, out[2] = waves resident per SIMD, out[3] = issue clocks per MFMA,
+ * out[4] = the same interval in ns (s_memrealtime).  MFMA-pipe occupancy = out[1]*out[2]*out[3]/out[0];
+ * sustained shader clock = out[0]/out[4] GHz.  out_host holds 5 values.  Synchronous (device -> host copy). */
+int jrr_engine_probe_read(jrr_engine_t* e, int64_t* out_host);
 
 #ifdef __cplusplus
 }

@@ -56,6 +56,7 @@ SIGNATURES = {
     'jrr_engine_info': (c_int, [_P, POINTER(c_int32), c_int]),
     'jrr_engine_set_profiling': (c_int, [_P, c_int]),
     'jrr_engine_profile_read': (c_int, [_P, POINTER(c_float), POINTER(c_int32)]),
+    'jrr_engine_probe_read': (c_int, [_P, POINTER(ctypes.c_int64)]),
 }
 
 _lib = None

@@ -134,6 +134,7 @@ struct jrr_engine {
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
   float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc, *wgs;
   float *Ps, *gb;
+  long long* probe;                                  // shader-clock probe of k_lbs_fwd (profiling)
   float *ndc, *dvpm, *sqsil; unsigned* cover; int* ncover;   // soft silhouette (JRR_FLAG_SILHOUETTE)
   const float* sil_mask;
   float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
@@ -178,6 +179,8 @@ static void plan_geometry(int BP, int& nvc, int& nvcb, int& nsplit, int& nsplitJ
   if (nsplit < 1) nsplit = 1;
   nsplitJ = 8;
   if (BP / 16 < nsplitJ) nsplitJ = BP / 16;
+  if (getenv("JRR_NVC")) nvc = atoi(getenv("JRR_NVC"));
+  if (getenv("JRR_NVCB")) nvcb = atoi(getenv("JRR_NVCB"));
 }
 
 struct Carver {
@@ -197,6 +200,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   jrr_engine tmp;
   jrr_engine* t = e ? e : &tmp;
   t->rowsum = c.take(32);
+  t->probe = (long long*)c.take(16);   // 3 x int64 used
   t->Jraw = c.take((size_t)NH * V);
   t->Jmask = c.take((size_t)NH * V);
   t->Jn = c.take((size_t)NH * V);
@@ -330,6 +334,17 @@ extern "C" int jrr_engine_set_profiling(jrr_engine_t* e, int enabled) {
   for (int c = 0; c < JRR_PROF_CLASSES; ++c)
     if (!e->ev[c]) e->ev[c] = new std::vector<hipEvent_t>();
   if (!e->profiling) clear_events(e);
+  return JRR_OK;
+}
+
+extern "C" int jrr_engine_probe_read(jrr_engine_t* e, int64_t* out_host) {
+  if (!e || !out_host) return JRR_ERR_ARG;
+  long long v[3] = {0, 0, 0};
+  JRR_HIP(hipMemcpy(v, e->probe, sizeof(v), hipMemcpyDeviceToHost));
+  out_host[0] = v[0]; out_host[1] = v[1];
+  out_host[2] = 2;          // waves resident per SIMD (2 workgroups of 4 waves per CU: launch bounds + 70 KB LDS)
+  out_host[3] = 16 * 4;     // issue clocks per v_mfma_f32_32x32x2_f32 (16 passes of 4 clocks)
+  out_host[4] = v[2] * 10;  // the interval of out[0] in ns (s_memrealtime, 100 MHz)
   return JRR_OK;
 }
 
@@ -838,7 +853,8 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
       launch_fold_fwd(e->MT, e->AT, e->G0, e->Jsum, e->BP, s);
     } else {
       const bool silf = e->sil_mask != nullptr;      // the silhouette term needs the vertices
-      launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, silf ? e->VTb : nullptr, e->B, e->BP, e->nvc, s);
+      launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, silf ? e->VTb : nullptr, e->B, e->BP, e->nvc, s,
+                     e->profiling ? e->probe : nullptr);
     }
     prof_mark(e, 1, s);
     prof_mark(e, 2, s);

@@ -80,17 +80,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
     if (ch + 1 < c_end) issue(ch + 1, (ch - c_begin + 1) & 1);
     const float* ap = lds + ((ch - c_begin) & 1) * SLOT + half * BM + wm * WM * 32 + l31;
     const float* bp = lds + ((ch - c_begin) & 1) * SLOT + GK * BM + half * BN + wn * WN * 32 + l31;
+    // The operands of K-pair kk+1 are requested right after the first MFMA of pair kk has issued, so the reads
+    // complete under this pair's MFMAs (the compiler's own schedule reads right before use and exposes the LDS
+    // latency once per pair).
+    float a[WM], b[WN];
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a[i] = ap[i * 32];
+#pragma unroll
+    for (int j = 0; j < WN; ++j) b[j] = bp[j * 32];
 #pragma unroll
     for (int kk = 0; kk < GK / 2; ++kk) {
-      float a[WM], b[WN];
+      float ca[WM], cb[WN];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[i] = ap[(2 * kk) * BM + i * 32];
+      for (int i = 0; i < WM; ++i) ca[i] = a[i];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) b[j] = bp[(2 * kk) * BN + j * 32];
+      for (int j = 0; j < WN; ++j) cb[j] = b[j];
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0][0] = mfma(ca[0], cb[0], acc[0][0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (kk + 1 < GK / 2) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[i] = ap[(2 * kk + 2) * BM + i * 32];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[j] = bp[(2 * kk + 2) * BN + j * 32];
+      }
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int i = 0; i < WM; ++i)
 #pragma unroll
-        for (int j = 0; j < WN; ++j) acc[i][j] = mfma(a[i], b[j], acc[i][j]);
+        for (int j = 0; j < WN; ++j)
+          if (i + j > 0) acc[i][j] = mfma(ca[i], cb[j], acc[i][j]);
     }
   }
 

@@ -58,7 +58,7 @@ int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, con
 
 // lbs.hip
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
-                   float* VTb, int B, int BP, int nvc, hipStream_t s);
+                   float* VTb, int B, int BP, int nvc, hipStream_t s, long long* probe = nullptr);
 int launch_verts_untranspose(const float* VTb, float* verts, int ldv, int vlimit, const float* cam, float* ndc, int B, int BP,
                              hipStream_t s);
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s);

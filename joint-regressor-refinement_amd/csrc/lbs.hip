@@ -41,6 +41,8 @@ constexpr int JN_FLOATS = 32 * 32;            // 1024
 constexpr int STG_FLOATS = KCH * 96 + KCH * BG;   // 3072 (D chunk) + 4096 (F chunk) = 7168
 constexpr int WJ_FLOATS = W_FLOATS + JN_FLOATS;   // 1792
 constexpr int NSTAGE = NKCH + 6;                  // 13
+// v_mfma_f32_32x32x2_f32 instructions per wave and vertex tile: 109 K-pairs x 3 planes + 12 x 24 / 2 + 3 x 16
+constexpr int LBS_FWD_MFMA_PER_TILE = (KF / 2) * 3 + 6 * 24 + 3 * 16;
 // per-tile operand record of the backward kernel: [Jn 18x32 | W^T 24x32 | W 32x32(j) | pad] = 10 KB
 constexpr int TB_JN = 0, TB_WJV = NHP * 32, TB_WVJ = TB_WJV + W_FLOATS, TB_FLOATS = 2560;
 
@@ -61,8 +63,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
                                                     const float* __restrict__ Jn_vi, const float* __restrict__ FT,
                                                     const float* __restrict__ AT, float* __restrict__ VPb,
                                                     float* __restrict__ JP, float* __restrict__ VTb, int B, int BP,
-                                                    int nvc) {
+                                                    int nvc, long long* __restrict__ probe) {
   __shared__ float lds[2 * STG_FLOATS + 2 * WJ_FLOATS];
+  // shader-clock probe (profiling only), see jrr_engine_probe_read
+  const long long probe_t0 = probe ? clock64() : 0, probe_w0 = probe ? wall_clock64() : 0;
   float* const ring = lds;
   float* const wj = lds + 2 * STG_FLOATS;
 
@@ -132,13 +136,24 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         const int npairs = (s == NKCH - 1) ? (KF - (NKCH - 1) * KCH) / 2 : KCH / 2;   // 13 : 16
         const float* dp = buf + half * 96 + l31;
         const float* fp = buf + KCH * 96 + half * BG + wave * BT + l31;
+        // The operands of K-pair kk+1 are requested right after the FIRST MFMA of pair kk has issued: the reads
+        // complete under the 192 clocks of this pair's MFMAs, so the wait before the next pair costs nothing.
+        // (The compiler's own schedule reads right before use and exposes the LDS latency after every third MFMA.)
+        float f = fp[0], d0 = dp[0], d1 = dp[32], d2 = dp[64];
 #pragma unroll
-        for (int kk = 0; kk < npairs; ++kk) {
-          const float f = fp[(2 * kk) * BG];
-          const float d0 = dp[(2 * kk) * 96], d1 = dp[(2 * kk) * 96 + 32], d2 = dp[(2 * kk) * 96 + 64];
-          vp[0] = mfma(d0, f, vp[0]);
-          vp[1] = mfma(d1, f, vp[1]);
-          vp[2] = mfma(d2, f, vp[2]);
+        for (int kk = 0; kk < KCH / 2; ++kk) {
+          if (kk >= npairs) break;          // constant trip count for the unroller; folds once `s` is unrolled
+          const float fc = f, c0 = d0, c1 = d1, c2 = d2;
+          __builtin_amdgcn_sched_barrier(0);
+          vp[0] = mfma(c0, fc, vp[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (kk + 1 < npairs) {
+            f = fp[(2 * kk + 2) * BG];
+            d0 = dp[(2 * kk + 2) * 96]; d1 = dp[(2 * kk + 2) * 96 + 32]; d2 = dp[(2 * kk + 2) * 96 + 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          vp[1] = mfma(c1, fc, vp[1]);
+          vp[2] = mfma(c2, fc, vp[2]);
         }
       } else {
         const int h = s - NKCH, r = h >> 1;
@@ -151,31 +166,46 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         const float* wp = ldsW + half * 32 + l31;
         const float* a0 = buf + half * BG + wave * BT + l31;
         const float* a1 = a0 + NJ * BG;
+        // two accumulator chains per half-stage, interleaved (a back-to-back MFMA on the SAME accumulator issues
+        // every 112 clocks instead of 64: tools/probe/clock_probe.hip), operands of joint pair jp+1 requested
+        // right after the first MFMA of pair jp
+        f32x16 T = zero16();
+        f32x16 U = zero16();
+        {
+          float w = wp[0], x0 = a0[0], x1 = a1[0];
+#pragma unroll
+          for (int jp = 0; jp < 12; ++jp) {
+            const float wc = w, c0 = x0, c1 = x1;
+            __builtin_amdgcn_sched_barrier(0);
+            T = mfma(wc, c0, T);
+            __builtin_amdgcn_sched_barrier(0);
+            if (jp + 1 < 12) { w = wp[(2 * jp + 2) * 32]; x0 = a0[(2 * jp + 2) * BG]; x1 = a1[(2 * jp + 2) * BG]; }
+            __builtin_amdgcn_sched_barrier(0);
+            U = mfma(wc, c1, U);
+          }
+        }
         if ((h & 1) == 0) {
-          vr = zero16();
-#pragma unroll
-          for (int jp = 0; jp < 12; ++jp) vr = mfma(wp[(2 * jp) * 32], a0[(2 * jp) * BG], vr);   // T_{r,3}
-          f32x16 T = zero16();
-#pragma unroll
-          for (int jp = 0; jp < 12; ++jp) T = mfma(wp[(2 * jp) * 32], a1[(2 * jp) * BG], T);     // T_{r,0}
-          vr += T * vp[0];
+          vr = T + U * vp[0];                    // T_{r,3} + T_{r,0} v_x
         } else {
-          f32x16 T = zero16();
-#pragma unroll
-          for (int jp = 0; jp < 12; ++jp) T = mfma(wp[(2 * jp) * 32], a0[(2 * jp) * BG], T);     // T_{r,1}
-          vr += T * vp[1];
-          T = zero16();
-#pragma unroll
-          for (int jp = 0; jp < 12; ++jp) T = mfma(wp[(2 * jp) * 32], a1[(2 * jp) * BG], T);     // T_{r,2}
-          vr += T * vp[2];
+          vr += T * vp[1];                       // T_{r,1} v_y
+          vr += U * vp[2];                       // T_{r,2} v_z
           if (STORE_VERTS) {      // vertices, coordinate-major and pose-contiguous like v_posed (coalesced)
 #pragma unroll
             for (int q = 0; q < 16; ++q)
               VTb[((size_t)r * VP + vt * 32 + acc_row(q, half)) * BP + bcol] = vr[q];
           }
           // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b]
+          {
+            float jn = ldsJ[acc_row(0, half) * 32 + l31];
 #pragma unroll
-          for (int q = 0; q < 16; ++q) jacc[r] = mfma(ldsJ[acc_row(q, half) * 32 + l31], vr[q], jacc[r]);
+            for (int q = 0; q < 16; ++q) {
+              const float jc = jn;
+              __builtin_amdgcn_sched_barrier(0);
+              jacc[r] = mfma(jc, vr[q], jacc[r]);
+              __builtin_amdgcn_sched_barrier(0);
+              if (q + 1 < 16) jn = ldsJ[acc_row(q + 1, half) * 32 + l31];
+            }
+          }
         }
       }
     }
@@ -187,6 +217,11 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
       const int i = acc_row(q, half);
       if (i < NH) JP[((size_t)(vc * 3 + r) * NH + i) * BP + bcol] = jacc[r][q];
     }
+  if (probe && blockIdx.x == 0 && tid == 0) {
+    probe[0] = clock64() - probe_t0;                 // shader clocks this wave was resident
+    probe[1] = (long long)(t_end - t_begin) * LBS_FWD_MFMA_PER_TILE;   // MFMA instructions it issued
+    probe[2] = wall_clock64() - probe_w0;            // the same interval on the constant 100 MHz counter
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -459,16 +494,16 @@ __global__ void k_jreg_bwd(const float* __restrict__ J, const float* __restrict_
 // launchers
 // ------------------------------------------------------------------------------------------
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
-                   float* verts, int B, int BP, int nvc, hipStream_t s) {
+                   float* verts, int B, int BP, int nvc, hipStream_t s, long long* probe) {
   dim3 grid((BP / BG) * nvc), block(256);
   if (VPb && verts)
-    hipLaunchKernelGGL((k_lbs_fwd<true, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc);
+    hipLaunchKernelGGL((k_lbs_fwd<true, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe);
   else if (VPb)
-    hipLaunchKernelGGL((k_lbs_fwd<true, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc);
+    hipLaunchKernelGGL((k_lbs_fwd<true, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe);
   else if (verts)
-    hipLaunchKernelGGL((k_lbs_fwd<false, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc);
+    hipLaunchKernelGGL((k_lbs_fwd<false, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe);
   else
-    hipLaunchKernelGGL((k_lbs_fwd<false, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc);
+    hipLaunchKernelGGL((k_lbs_fwd<false, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe);
   return 0;
 }
 

@@ -281,6 +281,14 @@ class RefineEngine:
         check(self.lib.jrr_engine_profile_read(self.handle, ms, n), 'profile_read')
         return {k: (float(ms[i]), int(n[i])) for i, k in enumerate(self.PROF_CLASSES)}
 
+    def probe_read(self):
+        """shader-clock probe of the last profiled k_lbs_fwd launch (include/jrr.h jrr_engine_probe_read):
+        (resident shader clocks of workgroup 0 / wave 0, MFMA instructions it issued, waves per SIMD, clocks per MFMA,
+        the interval in ns)"""
+        out = (ctypes.c_int64 * 5)()
+        check(self.lib.jrr_engine_probe_read(self.handle, out), 'probe_read')
+        return tuple(int(x) for x in out)
+
     def j_regressor_grad(self, x6d, betas, gt_centred_mm, sqerr=None):
         dJ = torch.empty(NUM_H36M, NUM_VERTS, device=self.device)
         check(self.lib.jrr_j_regressor_grad(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(dJ), ptr(sqerr),
