@@ -300,12 +300,14 @@ def main():
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                      'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'launches_timed': dom_n,
                      'algorithmic_flop_per_launch': FLOP_LBS_FWD_PER_POSE * B,
-                     # in-kernel shader-clock probe (s_memtime, workgroup 0 / wave 0): how busy the MFMA pipe is and
-                     # at what clock the chip sustains this kernel; `peak` above assumes the 2.4 GHz boost clock
-                     'mfma_pipe_occupancy': round(probe[1] * probe[2] * probe[3] / probe[0], 4) if probe[0] else None,
+                     # in-kernel probe (s_memtime / s_memrealtime, workgroup 0 / wave 0): the clock the chip holds on
+                     # this kernel (`peak` assumes 2.4 GHz), hence the MFMA-pipe utilisation of the whole launch, and
+                     # how much of the launch the FIRST-dispatched workgroup is resident (the two workgroups of a CU
+                     # do not progress evenly: the older one finishes early)
                      'sustained_clock_ghz': round(probe[0] / probe[4], 3) if probe[4] else None,
-                     'frac_of_peak_at_sustained_clock': round(achieved / (PEAK_F32_MFMA_TFLOPS * (probe[0] / probe[4] / 2.4)), 4)
-                     if probe[4] else None},
+                     'mfma_pipe_utilisation': round(achieved / (PEAK_F32_MFMA_TFLOPS * (probe[0] / probe[4] / 2.4)), 4)
+                     if probe[4] else None,
+                     'first_workgroup_resident_frac': round(probe[4] * 1e-6 / dom_ms, 3) if probe[4] and dom_ms > 0 else None},
         'kernels_ms': {k: round(t, 4) for k, (t, n) in prof.items() if n},
         'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
                    'allreduce_bytes': 17 * 6890 * 4},
