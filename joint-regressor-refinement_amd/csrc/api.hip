@@ -179,8 +179,6 @@ static void plan_geometry(int BP, int& nvc, int& nvcb, int& nsplit, int& nsplitJ
   if (nsplit < 1) nsplit = 1;
   nsplitJ = 8;
   if (BP / 16 < nsplitJ) nsplitJ = BP / 16;
-  if (getenv("JRR_NVC")) nvc = atoi(getenv("JRR_NVC"));
-  if (getenv("JRR_NVCB")) nvcb = atoi(getenv("JRR_NVCB"));
 }
 
 struct Carver {
@@ -583,14 +581,9 @@ extern "C" int jrr_joint_loss(const float* joints, const float* gt_mm, float wei
 }
 
 // ---- pose discriminator --------------------------------------------------------------------
-// tile choice for the four discriminator GEMMs (A/B switch for tuning: JRR_DISC_TILE=0|1|2)
-static int disc_gemm(const GemmArgs& g, int epi, int nsplit, hipStream_t s) {
-  static int mode = -1;
-  if (mode < 0) { const char* v = getenv("JRR_DISC_TILE"); mode = v ? atoi(v) : 0; }
-  if (mode == 1) return launch_gemm_128(g, epi, nsplit, s);
-  if (mode == 2) return launch_gemm_128w8(g, epi, nsplit, s);
-  return launch_gemm_128x64(g, epi, nsplit, s);
-}
+// the four discriminator GEMMs use the 128x64 tile: 512 workgroups at N = 4096 (128x128 and the 8-wave 128x128
+// tile measured the same)
+static int disc_gemm(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_gemm_128x64(g, epi, nsplit, s); }
 
 static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t s) {
   launch_disc_conv_fwd(e->Pd, x6d, e->H2T, out, e->B, e->BP, s);

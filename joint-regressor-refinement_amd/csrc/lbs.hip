@@ -58,6 +58,23 @@ __device__ __forceinline__ void dma16u(const float* base_uniform, unsigned lane_
   __builtin_amdgcn_global_load_lds(JRR_GLB(base_uniform + lane_off), JRR_LDS(lds_dst_wave), 16, 0, 0);
 }
 
+// Row pointer of a [rows][BP] array for a WAVE-UNIFORM row, kept in an SGPR pair: the access is then
+// `global_* v_lane_offset, v_data, s[row]` (scalar address arithmetic) instead of five VALU instructions, two of
+// them quarter-rate 64-bit multiplies, per element.  The per-lane part (4 * half rows + pose column) is a
+// loop-invariant 32-bit offset.
+__device__ __forceinline__ float* urow(float* base, size_t row, int BP) {
+  float* p = base + row * (size_t)BP;
+  asm volatile("" : "+s"(p));
+  return p;
+}
+__device__ __forceinline__ const float* urow(const float* base, size_t row, int BP) {
+  const float* p = base + row * (size_t)BP;
+  asm volatile("" : "+s"(p));
+  return p;
+}
+// uniform part of acc_row(q, half) = (q & 3) + 8 (q >> 2) + 4 half
+__device__ __forceinline__ constexpr int acc_row_u(int q) { return (q & 3) + 8 * (q >> 2); }
+
 template <bool STORE_VP, bool STORE_VERTS>
 __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk, const float* __restrict__ Wjv,
                                                     const float* __restrict__ Jn_vi, const float* __restrict__ FT,
@@ -77,6 +94,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   const int b0 = bg * BG + wave * BT;
   const int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
   const size_t bcol = (size_t)b0 + l31;
+  const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)bcol;   // lane part of a (row, pose) address
   // DMA addressing = wave-uniform base pointer (SGPR pair) + one 32-bit per-lane offset (VGPR), so
   // the 78 copies per tile cost scalar address arithmetic only.  Row-pair pattern: lanes 0-31
   // fetch row 2o, lanes 32-63 row 2o+1, 16 B per lane.
@@ -161,7 +179,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
           const int c = h >> 1, q0 = (h & 1) * 8;
 #pragma unroll
           for (int q = q0; q < q0 + 8; ++q)
-            VPb[((size_t)c * VP + vt * 32 + acc_row(q, half)) * BP + bcol] = vp[c][q];
+            urow(VPb, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff] = vp[c][q];
         }
         const float* wp = ldsW + half * 32 + l31;
         const float* a0 = buf + half * BG + wave * BT + l31;
@@ -192,7 +210,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
           if (STORE_VERTS) {      // vertices, coordinate-major and pose-contiguous like v_posed (coalesced)
 #pragma unroll
             for (int q = 0; q < 16; ++q)
-              VTb[((size_t)r * VP + vt * 32 + acc_row(q, half)) * BP + bcol] = vr[q];
+              urow(VTb, (size_t)r * VP + vt * 32 + acc_row_u(q), BP)[voff] = vr[q];
           }
           // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b]
           {
@@ -256,6 +274,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
   const int c = item % 3, bt = item / 3;
   const int b0 = bt * BT;
   const size_t bcol = (size_t)b0 + l31;
+  const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)bcol;   // lane part of a (row, pose) address
   const int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
   const unsigned lane_ln = (unsigned)lane * 4u;
 
@@ -270,7 +289,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
   };
   auto load_vp = [&](int vt, f32x16& dstv) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) dstv[q] = VPb[((size_t)c * VP + vt * 32 + acc_row(q, half)) * BP + bcol];
+    for (int q = 0; q < 16; ++q) dstv[q] = urow(VPb, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff];
   };
 
   // this wave's A^T operand vectors (r, j-pair) -> LDS, once
@@ -308,7 +327,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) dv[r][q] = dVT[((size_t)r * VP + vt * 32 + acc_row(q, half)) * BP + bcol];
+        for (int q = 0; q < 16; ++q) dv[r][q] = urow(dVT, (size_t)r * VP + vt * 32 + acc_row_u(q), BP)[voff];
     } else {
       dv[0] = zero16(); dv[1] = zero16(); dv[2] = zero16();
     }
@@ -334,7 +353,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
       }
     }
 #pragma unroll
-    for (int q = 0; q < 16; ++q) DVP[((size_t)c * VP + vt * 32 + acc_row(q, half)) * BP + bcol] = dvp[q];
+    for (int q = 0; q < 16; ++q) urow(DVP, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff] = dvp[q];
 
     const float* wvp = tab + TB_WVJ + l31;
 #pragma unroll
