@@ -132,6 +132,27 @@ def test_pose_disc_weight_gradients(smpl_hip):
         assert relerr(got[k], ref[k]) < 1e-3, k
 
 
+@pytest.mark.parametrize('B', [300, 1030])
+def test_pose_disc_weight_gradients_pose_split(smpl_hip, B):
+    """the weight-gradient GEMMs split the pose (reduction) dimension into partial slabs from BP = 256 on
+    (2 splits at B = 300, 4 at B = 1030) and the conv/head gradients use one slab per wave: same gradients"""
+    eng_mod = _mod('engine')
+    sd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+    flat = eng_mod.flatten_state_dict(sd, eng_mod.DISC_KEYS)
+    gen = torch.Generator().manual_seed(11)
+    xo, xs = torch.randn(B, 24, 6, generator=gen) * 0.6, torch.randn(B, 24, 6, generator=gen) * 0.6
+    loss, ref = oracle.discriminator_update_loss_and_grads(sd, xo, xs)
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_POSE_DISC)
+    eng.set_pose_disc(flat)
+    dP = torch.zeros(eng_mod.DISC_PARAMS, device=DEV)
+    l0 = eng.pose_disc_backward_params(xo.to(DEV), 0.0, dP)
+    l1 = eng.pose_disc_backward_params(xs.to(DEV), 1.0, dP)
+    np.testing.assert_allclose(float((l0 + l1).sum()) / (B * 25), float(loss), rtol=1e-5)
+    got = eng_mod.unflatten_state_dict(dP.cpu(), sd, eng_mod.DISC_KEYS)
+    for k in eng_mod.DISC_KEYS:
+        assert relerr(got[k], ref[k]) < 1e-3, k
+
+
 def test_shape_disc_weight_gradients(smpl_hip):
     eng_mod = _mod('engine')
     sd = oracle.formula_state_dict(oracle.SHAPE_DISC_PARAM_SHAPES, seed=1)

@@ -302,6 +302,33 @@ def test_refine_run_is_deterministic(eng_mod, dmodel, smpl_model_np, j_h36m_np):
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
 
 
+def test_profiling_probe(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    """jrr_engine_set_profiling / _profile_read / _probe_read: per-kernel HIP-event times and the in-kernel
+    shader-clock probe of k_lbs_fwd are populated by a profiled jrr_refine_run and do not change its results"""
+    import importlib as _il
+    sm = _il.import_module(PKG_NAME + '.smpl_model')
+    B = 256
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=5)
+    outs = []
+    for prof in (False, True):
+        eng = eng_mod.RefineEngine(dmodel, B)
+        eng.set_j_regressor(torch.from_numpy(j_h36m_np).to(DEV))
+        x = torch.from_numpy(batch['pose6d']).to(DEV).contiguous(); b = torch.from_numpy(batch['betas']).to(DEV).contiguous()
+        gt = torch.from_numpy(batch['gt_j3d']); gt = (gt - gt[:, :1]).to(DEV).contiguous()
+        m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+        step = torch.zeros(1, dtype=torch.int32, device=DEV)
+        eng.set_profiling(prof)
+        eng.refine_run(x, b, gt, m, v, step, 1e-2, 3)
+        if prof:
+            times = eng.profile_read()
+            clocks, mfmas, waves, clk_per_mfma, ns = eng.probe_read()
+            assert times['k_lbs_fwd'][1] == 3 and times['k_lbs_fwd'][0] > 0
+            assert clocks > 0 and ns > 0 and mfmas > 0 and waves == 2 and clk_per_mfma == 64
+            assert 0.5 < clocks / ns < 3.0            # GHz
+        outs.append((x.clone(), b.clone()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+
+
 def test_error_behaviour(eng_mod, dmodel):
     """errors come back as status codes + message and surface as JrrError (nothing crashes the process)"""
     lib_mod = importlib.import_module(PKG_NAME + '._lib')
