@@ -306,6 +306,9 @@ def main():
         'roofline': {'bound': 'mfma', 'kernel': 'k_lbs_fwd<true,false>', 'achieved': round(achieved, 2),
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                      'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'launches_timed': dom_n,
+                     # HBM side of the same kernel (PMC bytes per launch / live duration) against the 8 TB/s spec
+                     'hbm_gb_s': round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms > 0 else None,
+                     'hbm_frac_of_8tb_s': round(traffic / (dom_ms * 1e-3) / 8e12, 4) if traffic and dom_ms > 0 else None,
                      'algorithmic_flop_per_launch': FLOP_LBS_FWD_PER_POSE * B,
                      # in-kernel probe (s_memtime / s_memrealtime, workgroup 0 / wave 0): the clock the chip holds on
                      # this kernel (`peak` assumes 2.4 GHz), hence the MFMA-pipe utilisation of the whole launch, and
