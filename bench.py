@@ -333,7 +333,7 @@ def main():
                          'j_allreduce_bytes': 17 * 6890 * 4, 'pose_d_allreduce_bytes': 1840153 * 4 if use_disc else 0}
     if folded is not None:
         out['folded_mode'] = folded
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:   # the CPU baseline leg runs at N = 1 only
         cb = min(a.cpu_batch or B, B)
         its, dt, nthreads = cpu_baseline(model_np, J_np, batch_np, disc_sd, cb, a.cpu_iters, use_disc)
         out['cpu_baseline'] = {'value': round(its * cb / B, 5), 'unit': f'it/s (x{B} poses)', 'cores': nthreads,
