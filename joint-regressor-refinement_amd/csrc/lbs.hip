@@ -80,7 +80,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
                                                     const float* __restrict__ Jn_vi, const float* __restrict__ FT,
                                                     const float* __restrict__ AT, float* __restrict__ VPb,
                                                     float* __restrict__ JP, float* __restrict__ VTb, int B, int BP,
-                                                    int nvc, long long* __restrict__ probe) {
+                                                    int nvc, long long* __restrict__ probe, int paired) {
   __shared__ float lds[2 * STG_FLOATS + 2 * WJ_FLOATS];
   // shader-clock probe (profiling only), see jrr_engine_probe_read
   const long long probe_t0 = probe ? clock64() : 0, probe_w0 = probe ? wall_clock64() : 0;
@@ -90,9 +90,27 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int bg = L / nvc, vc = L % nvc;
+  int bg = L / nvc, vc = L % nvc;
+  int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
+  if (paired) {
+    // One full round of 512 workgroups = two per CU, and the two do NOT progress evenly: the first-dispatched one
+    // wins the issue arbitration and would finish ~20 % earlier, leaving its partner alone (one wave per SIMD) for
+    // the tail (measured with per-workgroup s_memrealtime stamps).  So the two workgroups of a CU
+    // -- dispatch slots j and j + per_xcd/2 of an XCD -- share one PAIR of vertex chunks of the same pose group and
+    // the first one takes 5/9 of the pair's tiles (15 : 12 at B = 4096).  Static, hence still bitwise reproducible;
+    // if the hardware paired differently the split would merely be uneven.
+    const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int p = j % (per_xcd / 2), slot = j / (per_xcd / 2);
+    const int npair = nvc / 2, bg_per_xcd = (per_xcd / 2) / npair;
+    bg = xcd * bg_per_xcd + p / npair;
+    const int vcp = p % npair;
+    vc = 2 * vcp + slot;
+    const int P0 = (int)((long)VT * vcp / npair), P1 = (int)((long)VT * (vcp + 1) / npair);
+    const int mid = P0 + ((P1 - P0) * 5 + 4) / 9;
+    t_begin = slot ? mid : P0;
+    t_end = slot ? P1 : mid;
+  }
   const int b0 = bg * BG + wave * BT;
-  const int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
   const size_t bcol = (size_t)b0 + l31;
   const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)bcol;   // lane part of a (row, pose) address
   // DMA addressing = wave-uniform base pointer (SGPR pair) + one 32-bit per-lane offset (VGPR), so
@@ -515,14 +533,16 @@ __global__ void k_jreg_bwd(const float* __restrict__ J, const float* __restrict_
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
                    float* verts, int B, int BP, int nvc, hipStream_t s, long long* probe) {
   dim3 grid((BP / BG) * nvc), block(256);
+  // exactly one round of two workgroups per CU, an even number of chunks and whole pose groups per XCD
+  const int paired = (grid.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? 1 : 0;
   if (VPb && verts)
-    hipLaunchKernelGGL((k_lbs_fwd<true, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe);
+    hipLaunchKernelGGL((k_lbs_fwd<true, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe, paired);
   else if (VPb)
-    hipLaunchKernelGGL((k_lbs_fwd<true, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe);
+    hipLaunchKernelGGL((k_lbs_fwd<true, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe, paired);
   else if (verts)
-    hipLaunchKernelGGL((k_lbs_fwd<false, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe);
+    hipLaunchKernelGGL((k_lbs_fwd<false, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe, paired);
   else
-    hipLaunchKernelGGL((k_lbs_fwd<false, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe);
+    hipLaunchKernelGGL((k_lbs_fwd<false, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe, paired);
   return 0;
 }
 

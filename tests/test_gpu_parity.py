@@ -257,6 +257,47 @@ def test_full_size_properties(eng_mod, dmodel, smpl_model_np, j_h36m_np):
     assert (j2 - rigid).abs().max().item() < 2e-5
 
 
+def test_full_size_matches_small_engines_and_oracle(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    """B = 4096 runs the single-round launch geometry (two workgroups per CU sharing a chunk pair 15 : 12); smaller
+    engines run the even split.  Random poses / shapes: joints AND vertices of the 4096 engine must match 8 engines
+    of 512 poses, and the oracle on a strided subset, to fp32 rounding; 3 refine iterations must match too."""
+    import importlib as _il
+    sm = _il.import_module(PKG_NAME + '.smpl_model')
+    B, Bs = 4096, 512
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=77)
+    x = torch.from_numpy(batch['pose6d']).to(DEV).contiguous(); b = torch.from_numpy(batch['betas']).to(DEV).contiguous()
+    gt = torch.from_numpy(batch['gt_j3d']); gt = (gt - gt[:, :1]).to(DEV).contiguous()
+    big = eng_mod.RefineEngine(dmodel, B, flags=eng_mod.FLAG_KEEP_VERTS)
+    big.set_j_regressor(T(j_h36m_np))
+    jb, vb = big.find_joints_forward(b, x6d=x, return_verts=True)
+    small = eng_mod.RefineEngine(dmodel, Bs, batch_norm=B, flags=eng_mod.FLAG_KEEP_VERTS)
+    small.set_j_regressor(T(j_h36m_np))
+    for k in range(B // Bs):
+        sl = slice(k * Bs, (k + 1) * Bs)
+        js, vs = small.find_joints_forward(b[sl].contiguous(), x6d=x[sl].contiguous(), return_verts=True)
+        assert (jb[sl] - js).abs().max().item() < 2e-6
+        assert (vb[sl] - vs).abs().max().item() < 2e-6
+    idx = torch.arange(0, B, 257)
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    R = oracle.rot6d_to_rotmat(x[idx].cpu().reshape(-1, 6)).view(-1, 24, 3, 3)
+    jo, vo = oracle.find_joints(smpl, b[idx].cpu(), R[:, :1], R[:, 1:], T(j_h36m_np), return_verts=True)
+    assert (jb[idx].cpu() - jo).abs().max().item() < 5e-6
+    assert (vb[idx].cpu() - vo).abs().max().item() < 5e-6
+    # the fused loop: same updates from the big engine and from the shards (batch_norm = global batch)
+    xb, bb = x.clone(), b.clone()
+    m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    big.refine_run(xb, bb, gt, m, v, step, 1e-2, 3)
+    for k in (0, 5):
+        sl = slice(k * Bs, (k + 1) * Bs)
+        xs, bs_ = x[sl].clone().contiguous(), b[sl].clone().contiguous()
+        ms, vs_ = torch.zeros(Bs, 154, device=DEV), torch.zeros(Bs, 154, device=DEV)
+        st = torch.zeros(1, dtype=torch.int32, device=DEV)
+        small.refine_run(xs, bs_, gt[sl].contiguous(), ms, vs_, st, 1e-2, 3)
+        assert (xb[sl] - xs).abs().max().item() < 2e-4      # Adam amplifies last-bit gradient differences in step 1
+        assert (bb[sl] - bs_).abs().max().item() < 2e-4
+
+
 def test_evaluate_on_device(eng_mod):
     """row f3: MPJPE / PA-MPJPE kernel vs the golden vector captured from the reference's evaluate()"""
     g = load_golden('g6_evaluate.npz')
