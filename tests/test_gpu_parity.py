@@ -257,13 +257,16 @@ def test_full_size_properties(eng_mod, dmodel, smpl_model_np, j_h36m_np):
     assert (j2 - rigid).abs().max().item() < 2e-5
 
 
-def test_full_size_matches_small_engines_and_oracle(eng_mod, dmodel, smpl_model_np, j_h36m_np):
-    """B = 4096 runs the single-round launch geometry (two workgroups per CU sharing a chunk pair 15 : 12); smaller
-    engines run the even split.  Random poses / shapes: joints AND vertices of the 4096 engine must match 8 engines
-    of 512 poses, and the oracle on a strided subset, to fp32 rounding; 3 refine iterations must match too."""
+@pytest.mark.parametrize('B', [4096, 8192])
+def test_full_size_matches_small_engines_and_oracle(eng_mod, dmodel, smpl_model_np, j_h36m_np, B):
+    """B = 4096 / 8192 run the single-round launch geometry (512 workgroups, two per CU sharing a chunk pair
+    5 : 4, with 16 / 8 vertex chunks); smaller engines run the even split.  Random poses / shapes: joints AND
+    vertices of the big engine must match engines of 512 poses, and the oracle on a strided subset, to fp32
+    rounding; 3 refine iterations must match too."""
     import importlib as _il
     sm = _il.import_module(PKG_NAME + '.smpl_model')
-    B, Bs = 4096, 512
+    Bs = 512
+    assert eng_mod.RefineEngine(dmodel, B).info['nvc'] * (B // 128) == 512
     batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=77)
     x = torch.from_numpy(batch['pose6d']).to(DEV).contiguous(); b = torch.from_numpy(batch['betas']).to(DEV).contiguous()
     gt = torch.from_numpy(batch['gt_j3d']); gt = (gt - gt[:, :1]).to(DEV).contiguous()
@@ -288,7 +291,7 @@ def test_full_size_matches_small_engines_and_oracle(eng_mod, dmodel, smpl_model_
     m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
     step = torch.zeros(1, dtype=torch.int32, device=DEV)
     big.refine_run(xb, bb, gt, m, v, step, 1e-2, 3)
-    for k in (0, 5):
+    for k in (0, B // Bs - 1):
         sl = slice(k * Bs, (k + 1) * Bs)
         xs, bs_ = x[sl].clone().contiguous(), b[sl].clone().contiguous()
         ms, vs_ = torch.zeros(Bs, 154, device=DEV), torch.zeros(Bs, 154, device=DEV)
