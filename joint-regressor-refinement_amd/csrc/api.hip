@@ -237,7 +237,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->TrA = c.take((size_t)BP * 1024);
     t->TrB = c.take((size_t)BP * 1024);
     {   // weight-gradient partial slabs: 8 pose-splits of a 1024x1024 layer, or one conv/head slab per wave
-      const size_t conv = (size_t)(BP / 64) * (4 * 1280 + 792), fc = (size_t)8 * 1024 * 1024;
+      const size_t conv = (size_t)(BP / 64) * (NJ * 1280 + 792) + (size_t)NJ * 1280, fc = (size_t)8 * 1024 * 1024;
       t->wgs = c.take(conv > fc ? conv : fc);
     }
     t->dz0 = c.take((size_t)BP);
@@ -691,12 +691,16 @@ extern "C" int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d, 
   g.A = e->Pd + DP_FC0_W; g.lda = 768; g.Bm = e->dA1T; g.ldb = e->BP; g.Out = e->dH2T; g.ldo = e->BP; g.M = 768; g.N = e->BP; g.K = 1024;
   rc = launch_gemm_128x64(g, EPI_STORE, 1, s);
   if (rc) return rc;
-  {   // conv / head weight gradients: one slab per wave, reduced into the flat gradient
+  {   // conv / head weight gradients: one slab per wave [pose group][joint][1280], reduced in two wide steps
+      // (over the pose groups, then over the joints) into the flat gradient
+    const int ng = e->BP / 64;
     float* slab_shared = e->wgs;
-    float* slab_heads = e->wgs + (size_t)4 * (e->BP / 64) * 1280;
+    float* slab_heads = slab_shared + (size_t)NJ * ng * 1280;
+    float* tmp = slab_heads + (size_t)ng * 792;
     launch_disc_conv_bwd_params(e->Pd, x6d, e->dH2T, scale, target, slab_shared, slab_heads, e->B, e->BP, s);
-    launch_reduce_slabs(slab_shared, 4 * (e->BP / 64), 1280, dP + DP_CONV0_W, 1280, s, 1);
-    launch_reduce_slabs(slab_heads, e->BP / 64, 792, dP + DP_HEADS, 792, s, 1);
+    launch_reduce_slabs(slab_shared, ng, (size_t)NJ * 1280, tmp, (size_t)NJ * 1280, s, 0);
+    launch_reduce_slabs(tmp, NJ, 1280, dP + DP_CONV0_W, 1280, s, 1);
+    launch_reduce_slabs(slab_heads, ng, 792, dP + DP_HEADS, 792, s, 1);
   }
   CHECK_LAUNCH();
   return JRR_OK;

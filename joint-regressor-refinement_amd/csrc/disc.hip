@@ -214,10 +214,10 @@ __global__ void k_rowdot_accum(const float* __restrict__ M, int ld, const float*
   if (threadIdx.x == 0) out[r] += red[0];
 }
 
-// per-joint MLP + head weight gradients.  One wave per (64 poses, 6 joints): lane = pose runs the joint MLP forward
+// per-joint MLP + head weight gradients.  One wave per (64 poses, joint): lane = pose runs the joint MLP forward
 // and backward in registers; the outer products over the 64 poses (dW2 = dh2^T h1, dW0 = dh1^T x, the bias and head
-// sums) are taken from LDS-staged copies with lane = (output row o, half of the columns), accumulated in registers
-// over the wave's joints and written as ONE partial slab per wave -- no atomics; the caller reduces the slabs.
+// sums) are taken from LDS-staged copies with lane = (output row o, half of the columns) and written as ONE partial
+// slab per wave -- no atomics; the caller reduces the slabs.
 // dH2T = gradient arriving from fc0.
 constexpr int CW_LD = 36;                      // LDS row stride in floats (16-byte aligned rows)
 __global__ __launch_bounds__(64) void k_disc_conv_bwd_params(const float* __restrict__ P, const float* __restrict__ x6d,
@@ -226,14 +226,13 @@ __global__ __launch_bounds__(64) void k_disc_conv_bwd_params(const float* __rest
                                                              float* __restrict__ slab_heads, int B, int BP) {
   __shared__ __attribute__((aligned(16))) float Sa[64 * CW_LD];
   __shared__ __attribute__((aligned(16))) float Sb[64 * CW_LD];
-  const int lane = threadIdx.x, b = blockIdx.x * 64 + lane, q = blockIdx.y;
+  const int lane = threadIdx.x, b = blockIdx.x * 64 + lane, j = blockIdx.y;
   const int o_ = lane & 31, hf = lane >> 5;
   const bool ok = b < B;
   float aW2[16], aW0[3] = {0.f, 0.f, 0.f}, ab2 = 0.f, ab0 = 0.f;
 #pragma unroll
   for (int k = 0; k < 16; ++k) aW2[k] = 0.f;
-  for (int jj = 0; jj < 6; ++jj) {
-    const int j = q * 6 + jj;
+  {
     float x[6], h1[32], h2[32];
 #pragma unroll
     for (int c = 0; c < 6; ++c) x[c] = ok ? x6d[((size_t)b * NJ + j) * 6 + c] : 0.f;
@@ -300,7 +299,7 @@ __global__ __launch_bounds__(64) void k_disc_conv_bwd_params(const float* __rest
     }
     __syncthreads();
   }
-  float* slab = slab_shared + ((size_t)blockIdx.x * 4 + q) * 1280;
+  float* slab = slab_shared + ((size_t)blockIdx.x * NJ + j) * 1280;
 #pragma unroll
   for (int k = 0; k < 16; ++k) slab[DP_CONV2_W + o_ * 32 + hf * 16 + k] = aW2[k];
 #pragma unroll
@@ -377,7 +376,7 @@ int launch_rowdot_accum(const float* M, int ld, const float* vec, float* out, in
 }
 int launch_disc_conv_bwd_params(const float* P, const float* x6d, const float* dH2T, float scale, float target,
                                 float* slab_shared, float* slab_heads, int B, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_disc_conv_bwd_params, dim3(BP / 64, 4), dim3(64), 0, s, P, x6d, dH2T, scale, target, slab_shared,
+  hipLaunchKernelGGL(k_disc_conv_bwd_params, dim3(BP / 64, NJ), dim3(64), 0, s, P, x6d, dH2T, scale, target, slab_shared,
                      slab_heads, B, BP);
   return 0;
 }

@@ -106,7 +106,7 @@ int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* ou
 int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
                     float target, int B, int BP, hipStream_t s, float* dz0 = nullptr);
 int launch_rowdot_accum(const float* M, int ld, const float* vec, float* out, int rows, int cols, hipStream_t s);
-// conv / per-joint-head weight gradients as partial slabs: shared [4 * BP/64][1280] (conv0 W,b | conv2 W,b in the
+// conv / per-joint-head weight gradients as partial slabs: shared [24 * BP/64][1280] (conv0 W,b | conv2 W,b in the
 // DP_* order) and heads [BP/64][792]; the caller reduces them into the flat gradient
 int launch_disc_conv_bwd_params(const float* P, const float* x6d, const float* dH2T, float scale, float target,
                                 float* slab_shared, float* slab_heads, int B, int BP, hipStream_t s);
