@@ -113,24 +113,32 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
     }
   }
 
+  // epilogue: the row part of every address is wave-uniform (kept in SGPRs), the lane part (4 * half rows + column)
+  // is one 32-bit offset -- one store per element instead of five VALU instructions of address arithmetic
   float* out = g.Out + (size_t)split * g.split_stride;
+  const unsigned lane_off = (unsigned)(4 * half) * (unsigned)g.ldo + (unsigned)(n0 + l31);
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const int m = m0 + (wm * WM + i) * 32 + acc_row(q, half);
+      const int mu = m0 + (wm * WM + i) * 32 + (q & 3) + 8 * (q >> 2);   // acc_row(q, half) = mu-part + 4 half
+      const int m = mu + 4 * half;
       if (m >= g.M) continue;
       float bias = 0.f;
       if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS) bias = g.bias[m];
+      float* orow = out + (size_t)mu * g.ldo;
+      asm volatile("" : "+s"(orow));
+      const float* mrow = (EPI == EPI_MASK) ? g.mask + (size_t)mu * g.ldo : nullptr;
+      if (EPI == EPI_MASK) asm volatile("" : "+s"(mrow));
 #pragma unroll
       for (int j = 0; j < WN; ++j) {
-        const int n = n0 + (wn * WN + j) * 32 + l31;
+        const unsigned off = lane_off + (unsigned)((wn * WN + j) * 32);
         float v = acc[i][j][q];
         if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
         if (EPI == EPI_BIAS) v = v + bias;
-        if (EPI == EPI_MASK) v = (g.mask[(size_t)m * g.ldo + n] > 0.f) ? v : 0.f;
-        if (EPI == EPI_ACCUM) v += out[(size_t)m * g.ldo + n];
-        out[(size_t)m * g.ldo + n] = v;
+        if (EPI == EPI_MASK) v = (mrow[off] > 0.f) ? v : 0.f;
+        if (EPI == EPI_ACCUM) v += orow[off];
+        orow[off] = v;
       }
     }
 }

@@ -17,10 +17,10 @@ x = torch.from_numpy(batch['pose6d']).to(dev).contiguous(); b = torch.from_numpy
 gt = torch.from_numpy(batch['gt_j3d']); gt_c = (gt - gt[:, :1]).to(dev).contiguous()
 m = torch.zeros(B, 154, device=dev); v = torch.zeros(B, 154, device=dev); st = torch.zeros(1, dtype=torch.int32, device=dev)
 e.refine_run(x, b, gt_c, m, v, st, 1e-2, 5); torch.cuda.synchronize()
-for rnd in range(4):
+for rnd in range(12):
     for ns in (1, 2):
         e.set_concurrency(ns)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        e.refine_run(x, b, gt_c, m, v, st, 1e-2, 30)
+        e.refine_run(x, b, gt_c, m, v, st, 1e-2, 100)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print(f'round {rnd} streams={ns}: {dt / 30 * 1e3:.3f} ms/iter', flush=True)
+        print(f'round {rnd} streams={ns}: {dt / 100 * 1e3:.3f} ms/iter', flush=True)
