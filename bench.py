@@ -293,7 +293,7 @@ def main():
         except Exception:
             traffic = None
     out = {
-        'metric': 'pose-refinement iters/sec, batch 4096 per GPU',
+        'metric': 'pose-refinement iters/sec, batch 4096, at 1/2/4/8 MI355X',   # BASELINE.json's metric string; batch = poses per GPU (weak scaling)
         'value': round(it_s * world, 3), 'unit': f'it/s (x{B} poses)', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
         'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
