@@ -80,7 +80,9 @@ int jrr_model_set_faces(jrr_model_t* m, const int32_t* faces_host, int n_faces);
 /* ---- engine -------------------------------------------------------------------------------
  * `batch` = poses on this device; `batch_norm` = divisor batch of the MSE means
  * (== batch single-GPU; == global batch under data parallelism so that a sharded run equals
- * the single-process run).  The caller owns `workspace_dev`.         */
+ * the single-process run).  The caller owns `workspace_dev`.
+ * `model` may be NULL for an engine that serves the discriminators only (flags within
+ * JRR_FLAG_POSE_DISC | JRR_FLAG_SHAPE_DISC): Discriminator / Shape_Discriminator modules need no body model. */
 size_t jrr_engine_workspace_bytes(int batch, int flags);
 int jrr_engine_create(const jrr_model_t* model, int batch, int batch_norm, void* workspace_dev,
                       size_t workspace_bytes, int flags, jrr_engine_t** out);
@@ -91,12 +93,6 @@ int jrr_engine_set_batch_norm(jrr_engine_t* e, int batch_norm);
  * joints = A . (H F) instead of skinning 6890 vertices -- the same function of (theta, beta, J) up to fp32
  * rounding, ~25x fewer FLOP, no vertices.  A separate mode with its own denominator; never the default.   */
 int jrr_engine_set_folded(jrr_engine_t* e, int enabled, void* stream);
-/* 1 (default) = every launch of jrr_refine_run on the caller's stream; 2 = the discriminator branch of
- * each iteration runs on an engine-owned second stream, forked from / joined back into the caller's
- * stream with events (the two branches only meet in the Adam update).  Measured gain at batch 4096:
- * 1.5-3.6 % (tools/exp/ab_streams.py), with one unexplained 20 % slower outlier run, hence opt-in.  */
-int jrr_engine_set_concurrency(jrr_engine_t* e, int streams);
-
 /* J*mask -> ReLU -> row-normalise (scripts/utils.py:87-92), into the engine's tile-major
  * copies.  J_dev: (17,6890) row-major raw parameter; mask_dev may be NULL.                   */
 int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J_dev, const float* mask_dev, void* stream);
@@ -113,6 +109,13 @@ int jrr_engine_set_shape_disc(jrr_engine_t* e, const float* params_dev, void* st
 /* rot6d_to_rotmat, scripts/utils.py:190-204: x (n,6) -> R (n,3,3); and its adjoint.          */
 int jrr_rot6d_forward(const float* x6d_dev, float* R_dev, int n, void* stream);
 int jrr_rot6d_backward(const float* x6d_dev, const float* dR_dev, float* dx6d_dev, int n, void* stream);
+
+/* Axis-angle -> rotation matrix, smplx 0.1.26 lbs.batch_rodrigues: the pose2rot=True branch of the SMPL operator
+ * (smplx.SMPL.forward default; the reference's wrapper inherits it, scripts/smpl.py:61-85, base class :7-9).
+ * aa (n,3) -> R (n,3,3) with theta = |aa + 1e-8|, R = I + sin(theta) K + (1-cos(theta)) K^2; and its adjoint
+ * dR (n,3,3) -> daa (n,3), finite at aa = 0.                                                               */
+int jrr_rodrigues_forward(const float* aa_dev, float* R_dev, int n, void* stream);
+int jrr_rodrigues_backward(const float* aa_dev, const float* dR_dev, float* daa_dev, int n, void* stream);
 
 /* find_joints, scripts/utils.py:85-103 (SMPL forward + J_regressor contraction).
  * Exactly one of x6d_dev (B,24,6) / R_dev (B,24,3,3) is non-NULL.  joints_dev (B,17,3).
@@ -156,9 +159,24 @@ int jrr_pose_disc_vjp_input(jrr_engine_t* e, const float* x6d_dev, const float* 
  * sqerr_dev (B, nullable) receives sum_k (D(x)[b,k]-target)^2.                                   */
 int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d_dev, float target,
                                   float* dparams_dev, float* sqerr_dev, void* stream);
+/* vector-Jacobian product of Discriminator.forward w.r.t. the WEIGHTS for an arbitrary upstream gradient gout (B,25),
+ * accumulated (+=) into a flat vector laid out like the parameter vector: what `loss.backward()` leaves in the
+ * module's .grad for any loss of the discriminator output (scripts/optimize.py:276-284 through the nn.Module).  */
+int jrr_pose_disc_vjp_params(jrr_engine_t* e, const float* x6d_dev, const float* gout_dev, float* dparams_dev,
+                             void* stream);
+/* the same for Shape_Discriminator: gout (B), 171 parameters (float atomics) */
+int jrr_shape_disc_vjp_params(jrr_engine_t* e, const float* betas_dev, const float* gout_dev, float* dparams_dev,
+                              void* stream);
 /* the same for Shape_Discriminator (scripts/optimize.py:286-293): betas (B,10), 171 parameters */
 int jrr_shape_disc_backward_params(jrr_engine_t* e, const float* betas_dev, float target,
                                    float* dparams_dev, float* sqerr_dev, void* stream);
+
+/* Shape_Discriminator.forward, scripts/discriminator.py:70-74: betas (B,10) -> out (B) sigmoid scores; and the
+ * vector-Jacobian product w.r.t. the input for an upstream gradient gout (B) (autograd backward of the module).
+ * Stateless apart from the parameters (jrr_engine_set_shape_disc): the vjp recomputes the 171-parameter forward. */
+int jrr_shape_disc_forward(jrr_engine_t* e, const float* betas_dev, float* out_dev, void* stream);
+int jrr_shape_disc_vjp_input(jrr_engine_t* e, const float* betas_dev, const float* gout_dev, float* dbetas_dev,
+                             void* stream);
 
 /* torch.optim.Adam single-tensor update (defaults used at scripts/optimize.py:116-126,201):
  * step_dev holds the 1-based step count of THIS update.                                        */
@@ -211,6 +229,12 @@ int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask_dev, float* cam
 int jrr_refine_run(jrr_engine_t* e, float* x6d_dev, float* betas_dev, const float* gt_centred_mm_dev,
                    float* adam_m_dev, float* adam_v_dev, int32_t* step_dev, float lr, int n_iters,
                    float* sqerr_dev, void* stream);
+
+/* Adversarial loss values of the LAST iteration of the last jrr_refine_run, for the reference's log record
+ * (scripts/optimize.py:246-250,323-337 `pose_discriminated_loss`, `shape_discriminated_loss`):
+ * pose_disc_sq_dev[b] = sum_k (D(x_b)[k] - 1)^2 over the 25 outputs, shape_disc_sq_dev[b] = (SD(beta_b) - 1)^2.
+ * Either pointer may be NULL; a non-NULL one needs its term active in the engine.                           */
+int jrr_refine_aux_losses(jrr_engine_t* e, float* pose_disc_sq_dev, float* shape_disc_sq_dev, void* stream);
 
 /* J step, scripts/optimize.py:300-312: gradient of mean((move_pelvis(joints)-gt/1000)^2) w.r.t.
  * the raw J_regressor for the current (detached) poses; dJ_dev (17,6890).                      */

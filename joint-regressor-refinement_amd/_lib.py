@@ -27,13 +27,14 @@ SIGNATURES = {
     'jrr_engine_create': (c_int, [_P, c_int, c_int, _P, c_size_t, c_int, POINTER(_P)]),
     'jrr_engine_destroy': (None, [_P]),
     'jrr_engine_set_batch_norm': (c_int, [_P, c_int]),
-    'jrr_engine_set_concurrency': (c_int, [_P, c_int]),
     'jrr_engine_set_folded': (c_int, [_P, c_int, _P]),
     'jrr_engine_set_j_regressor': (c_int, [_P, _P, _P, _P]),
     'jrr_engine_set_pose_disc': (c_int, [_P, _P, _P]),
     'jrr_engine_set_shape_disc': (c_int, [_P, _P, _P]),
     'jrr_rot6d_forward': (c_int, [_P, _P, c_int, _P]),
     'jrr_rot6d_backward': (c_int, [_P, _P, _P, c_int, _P]),
+    'jrr_rodrigues_forward': (c_int, [_P, _P, c_int, _P]),
+    'jrr_rodrigues_backward': (c_int, [_P, _P, _P, c_int, _P]),
     'jrr_find_joints_forward': (c_int, [_P, _P, _P, _P, _P, _P, _P]),
     'jrr_find_joints_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_smpl_vertices_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
@@ -43,6 +44,11 @@ SIGNATURES = {
     'jrr_pose_disc_backward_input': (c_int, [_P, _P, c_float, c_float, _P, _P]),
     'jrr_pose_disc_backward_params': (c_int, [_P, _P, c_float, _P, _P, _P]),
     'jrr_shape_disc_backward_params': (c_int, [_P, _P, c_float, _P, _P, _P]),
+    'jrr_pose_disc_vjp_params': (c_int, [_P, _P, _P, _P, _P]),
+    'jrr_shape_disc_vjp_params': (c_int, [_P, _P, _P, _P, _P]),
+    'jrr_shape_disc_forward': (c_int, [_P, _P, _P, _P]),
+    'jrr_shape_disc_vjp_input': (c_int, [_P, _P, _P, _P, _P]),
+    'jrr_refine_aux_losses': (c_int, [_P, _P, _P, _P]),
     'jrr_adam_step': (c_int, [_P, _P, _P, _P, c_size_t, _P, c_float, c_float, c_float, c_float, _P]),
     'jrr_evaluate': (c_int, [_P, _P, _P, _P, c_int, _P]),
     'jrr_project_joints': (c_int, [_P, _P, _P, c_int, _P]),

@@ -50,6 +50,16 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument('--save_j_regressor', type=str, default=None,
                         help='write the trained regressor in the models/retrained_J_Regressor.pt format')
     parser.add_argument('--seed', type=int, default=0)
+    parser.add_argument('--dist_backend', type=str, default=None,
+                        help='torch.distributed backend under torchrun (default: nccl = RCCL on GPUs); gloo for debugging')
+    parser.add_argument('--single_device', action='store_true',
+                        help='debug: every rank uses --device (exercises the N > 1 path on a 1-GPU box; use with --dist_backend gloo)')
+    parser.add_argument('--data_root', type=str, default=None,
+                        help='directory holding precomputed_{train,val}/ in the reference layout (scripts/data.py:49-86); '
+                             'synthetic batches if not given')
+    parser.add_argument('--synthetic', action='store_true',
+                        help='accept the synthetic body model / regressor when --smpl_dir / --j_regressor_init do not exist '
+                             '(otherwise a missing explicit path is an error)')
     return parser
 
 

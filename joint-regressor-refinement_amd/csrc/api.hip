@@ -128,12 +128,13 @@ struct jrr_engine {
   Model m;
   int B, BP, bnorm, flags;
   int nvc, nvcb, nsplit, nsplitJ;
-  bool have_J, have_mask, have_pd, have_sd;
+  bool have_J, have_mask, have_pd, have_sd, has_model;
   // workspace sections
   float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv;
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
   float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc, *wgs;
   float *Ps, *gb;
+  float *dsq, *ssq;                                  // per-pose squared adversarial errors of the last iteration [25][BP], [BP]
   long long* probe;                                  // shader-clock probe of k_lbs_fwd (profiling)
   float *ndc, *dvpm, *sqsil; unsigned* cover; int* ncover;   // soft silhouette (JRR_FLAG_SILHOUETTE)
   const float* sil_mask;
@@ -146,9 +147,6 @@ struct jrr_engine {
   std::vector<hipEvent_t>* ev[JRR_PROF_CLASSES];
   const float* gt_j2d; float* cam; float* cam_m; float* cam_v;   // 2-D reprojection term (nullable)
   float *gcam, *sq2d;
-  int streams;                 // 1 or 2
-  hipStream_t s2;              // discriminator branch
-  hipEvent_t ev_fork, ev_join;
 };
 
 // number of vertex chunks such that the grid fills whole "rounds" of the chip's resident
@@ -242,10 +240,12 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     }
     t->dz0 = c.take((size_t)BP);
     t->dsc = c.take((size_t)BP * 25);
+    t->dsq = c.take((size_t)BP * 25);
   }
   if (flags & JRR_FLAG_SHAPE_DISC) {
     t->Ps = c.take(256);
     t->gb = c.take((size_t)BP * NB);
+    t->ssq = c.take((size_t)BP);
   }
   if (flags & (JRR_FLAG_SILHOUETTE | JRR_FLAG_KEEP_VERTS)) t->VTb = c.take((size_t)3 * VP * BP);
   if (flags & JRR_FLAG_SILHOUETTE) {
@@ -283,18 +283,22 @@ extern "C" size_t jrr_engine_workspace_bytes(int batch, int flags) {
 
 extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_norm, void* ws, size_t ws_bytes,
                                  int flags, jrr_engine_t** out) {
-  if (!model || !ws || !out || batch <= 0) { jrr_set_error("jrr_engine_create: bad argument"); return JRR_ERR_ARG; }
+  if (!ws || !out || batch <= 0) { jrr_set_error("jrr_engine_create: bad argument"); return JRR_ERR_ARG; }
+  if (!model && (flags & ~(JRR_FLAG_POSE_DISC | JRR_FLAG_SHAPE_DISC))) {
+    jrr_set_error("jrr_engine_create: a model-less engine serves the discriminators only");
+    return JRR_ERR_ARG;
+  }
   if (((uintptr_t)ws & 255) != 0) { jrr_set_error("workspace must be 256-byte aligned"); return JRR_ERR_ARG; }
   const size_t need = jrr_engine_workspace_bytes(batch, flags);
   if (ws_bytes < need) { jrr_set_error("workspace too small: %zu < %zu", ws_bytes, need); return JRR_ERR_WORKSPACE; }
   jrr_engine* e = new jrr_engine();
   memset((void*)e, 0, sizeof(*e));
-  e->m = model->d;
+  if (model) e->m = model->d;
+  e->has_model = model != nullptr;
   e->B = batch;
   e->bnorm = batch_norm > 0 ? batch_norm : batch;
   e->flags = flags;
   carve(e, ws, batch, flags);
-  e->streams = 1;
   *out = e;
   return JRR_OK;
 }
@@ -311,19 +315,7 @@ extern "C" void jrr_engine_destroy(jrr_engine_t* e) {
   if (!e) return;
   clear_events(e);
   for (int c = 0; c < JRR_PROF_CLASSES; ++c) delete e->ev[c];
-  if (e->s2) {
-    (void)hipStreamSynchronize(e->s2);
-    (void)hipStreamDestroy(e->s2);
-    (void)hipEventDestroy(e->ev_fork);
-    (void)hipEventDestroy(e->ev_join);
-  }
   delete e;
-}
-
-extern "C" int jrr_engine_set_concurrency(jrr_engine_t* e, int streams) {
-  if (!e || streams < 1 || streams > 2) return JRR_ERR_ARG;
-  e->streams = streams;
-  return JRR_OK;
 }
 
 extern "C" int jrr_engine_set_profiling(jrr_engine_t* e, int enabled) {
@@ -421,6 +413,7 @@ extern "C" int jrr_engine_set_folded(jrr_engine_t* e, int enabled, void* stream)
 
 extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const float* mask, void* stream) {
   if (!e || !J) { jrr_set_error("set_j_regressor: null"); return JRR_ERR_ARG; }
+  if (!e->has_model) { jrr_set_error("engine was created without an SMPL model (discriminators only)"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
@@ -471,6 +464,22 @@ extern "C" int jrr_rot6d_backward(const float* x, const float* dR, float* dx, in
   if (!x || !dR || !dx || n < 0) return JRR_ERR_ARG;
   if (n == 0) return JRR_OK;
   launch_rot6d_bwd(x, dR, dx, n, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+/* smplx batch_rodrigues (pose2rot=True branch of the SMPL operator) */
+extern "C" int jrr_rodrigues_forward(const float* aa, float* R, int n, void* stream) {
+  if (!aa || !R || n < 0) return JRR_ERR_ARG;
+  if (n == 0) return JRR_OK;
+  launch_rodrigues_fwd(aa, R, n, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+extern "C" int jrr_rodrigues_backward(const float* aa, const float* dR, float* daa, int n, void* stream) {
+  if (!aa || !dR || !daa || n < 0) return JRR_ERR_ARG;
+  if (n == 0) return JRR_OK;
+  launch_rodrigues_bwd(aa, dR, daa, n, (hipStream_t)stream);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -597,8 +606,8 @@ static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t
 }
 
 static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, const float* gout, float scale,
-                               float target, float* gx, hipStream_t s) {
-  launch_disc_out(e->Pd, e->A2T, out, e->dA2T, gout, scale, target, e->B, e->BP, s);
+                               float target, float* gx, hipStream_t s, float* sq = nullptr) {
+  launch_disc_out(e->Pd, e->A2T, out, e->dA2T, gout, scale, target, e->B, e->BP, s, nullptr, sq);
   GemmArgs g;
   g.bias = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   // dA1T[k][b] = relu'(A1T) * sum_n fc2.w[n][k] dA2T[n][b]
@@ -609,7 +618,7 @@ static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, cons
   g.A = e->Pd + DP_FC0_W; g.lda = 768; g.Bm = e->dA1T; g.Out = e->dH2T; g.mask = nullptr; g.M = 768; g.K = 1024;
   rc = disc_gemm(g, EPI_STORE, 1, s);
   if (rc) return rc;
-  launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s);
+  launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s, sq);
   return 0;
 }
 
@@ -644,15 +653,13 @@ extern "C" int jrr_pose_disc_vjp_input(jrr_engine_t* e, const float* x6d, const 
   return JRR_OK;
 }
 
-extern "C" int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d, float target, float* dP, float* sqerr,
-                                             void* stream) {
-  if (!e || !x6d || !dP) return JRR_ERR_ARG;
-  if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
-  hipStream_t s = (hipStream_t)stream;
-  const float scale = (float)(2.0 / ((double)e->bnorm * 25.0));
+// weight gradients of the pose discriminator: either of the MSE against `target` (gout == NULL; scale = 2/(bnorm*25))
+// or the vector-Jacobian product for an arbitrary upstream gradient gout (B,25)
+static int disc_backward_params(jrr_engine* e, const float* x6d, const float* gout, float scale, float target, float* dP,
+                                float* sqerr, hipStream_t s) {
   int rc = disc_forward(e, x6d, e->dsc, s);
   if (rc) return rc;
-  launch_disc_out(e->Pd, e->A2T, e->dsc, e->dA2T, nullptr, scale, target, e->B, e->BP, s, e->dz0);
+  launch_disc_out(e->Pd, e->A2T, e->dsc, e->dA2T, gout, scale, target, e->B, e->BP, s, e->dz0);
   if (sqerr) launch_sqerr_rows(e->dsc, 25, target, sqerr, e->B, s);
   // fc4: dw[n] += sum_b A2T[n][b] dz0[b] ; db += sum_b dz0[b]
   launch_rowdot_accum(e->A2T, e->BP, e->dz0, dP + DP_FC4_W, 1024, e->BP, s);
@@ -697,11 +704,32 @@ extern "C" int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d, 
     float* slab_shared = e->wgs;
     float* slab_heads = slab_shared + (size_t)NJ * ng * 1280;
     float* tmp = slab_heads + (size_t)ng * 792;
-    launch_disc_conv_bwd_params(e->Pd, x6d, e->dH2T, scale, target, slab_shared, slab_heads, e->B, e->BP, s);
+    launch_disc_conv_bwd_params(e->Pd, x6d, e->dH2T, gout, scale, target, slab_shared, slab_heads, e->B, e->BP, s);
     launch_reduce_slabs(slab_shared, ng, (size_t)NJ * 1280, tmp, (size_t)NJ * 1280, s, 0);
     launch_reduce_slabs(tmp, NJ, 1280, dP + DP_CONV0_W, 1280, s, 1);
     launch_reduce_slabs(slab_heads, ng, 792, dP + DP_HEADS, 792, s, 1);
   }
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d, float target, float* dP, float* sqerr,
+                                             void* stream) {
+  if (!e || !x6d || !dP) return JRR_ERR_ARG;
+  if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
+  return disc_backward_params(e, x6d, nullptr, (float)(2.0 / ((double)e->bnorm * 25.0)), target, dP, sqerr, (hipStream_t)stream);
+}
+
+extern "C" int jrr_pose_disc_vjp_params(jrr_engine_t* e, const float* x6d, const float* gout, float* dP, void* stream) {
+  if (!e || !x6d || !gout || !dP) return JRR_ERR_ARG;
+  if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
+  return disc_backward_params(e, x6d, gout, 0.f, 0.f, dP, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int jrr_shape_disc_vjp_params(jrr_engine_t* e, const float* betas, const float* gout, float* dP, void* stream) {
+  if (!e || !betas || !gout || !dP) return JRR_ERR_ARG;
+  if (!e->have_sd) { jrr_set_error("shape discriminator not set"); return JRR_ERR_STATE; }
+  launch_shape_disc_bwd_params(e->Ps, betas, gout, 0.f, 0.f, dP, nullptr, e->B, (hipStream_t)stream);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -711,7 +739,38 @@ extern "C" int jrr_shape_disc_backward_params(jrr_engine_t* e, const float* beta
   if (!e || !betas || !dP) return JRR_ERR_ARG;
   if (!e->have_sd) { jrr_set_error("shape discriminator not set"); return JRR_ERR_STATE; }
   const float scale = (float)(2.0 / ((double)e->bnorm * 1.0));
-  launch_shape_disc_bwd_params(e->Ps, betas, scale, target, dP, sqerr, e->B, (hipStream_t)stream);
+  launch_shape_disc_bwd_params(e->Ps, betas, nullptr, scale, target, dP, sqerr, e->B, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_shape_disc_forward(jrr_engine_t* e, const float* betas, float* out, void* stream) {
+  if (!e || !betas || !out) return JRR_ERR_ARG;
+  if (!e->have_sd) { jrr_set_error("shape discriminator not set"); return JRR_ERR_STATE; }
+  launch_shape_disc(e->Ps, betas, out, nullptr, 0.f, 0.f, e->B, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_shape_disc_vjp_input(jrr_engine_t* e, const float* betas, const float* gout, float* dbetas, void* stream) {
+  if (!e || !betas || !gout || !dbetas) return JRR_ERR_ARG;
+  if (!e->have_sd) { jrr_set_error("shape discriminator not set"); return JRR_ERR_STATE; }
+  launch_shape_disc(e->Ps, betas, nullptr, dbetas, 0.f, 0.f, e->B, (hipStream_t)stream, gout);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_refine_aux_losses(jrr_engine_t* e, float* pose_disc_sq, float* shape_disc_sq, void* stream) {
+  if (!e) return JRR_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  if (pose_disc_sq) {
+    if (!((e->flags & JRR_FLAG_POSE_DISC) && e->have_pd)) { jrr_set_error("pose discriminator term not active"); return JRR_ERR_STATE; }
+    launch_colsum(e->dsq, 25, e->BP, pose_disc_sq, e->B, s);
+  }
+  if (shape_disc_sq) {
+    if (!((e->flags & JRR_FLAG_SHAPE_DISC) && e->have_sd)) { jrr_set_error("shape discriminator term not active"); return JRR_ERR_STATE; }
+    JRR_HIP(hipMemcpyAsync(shape_disc_sq, e->ssq, (size_t)e->B * 4, hipMemcpyDeviceToDevice, s));
+  }
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -818,24 +877,7 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
   const float jscale = (float)(2.0 * 10000.0 / ((double)e->bnorm * 51.0));   // optimize.py:252 weight 10000
   const float dscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 25.0));      // optimize.py:253 weight 10
   const float sscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 1.0));
-  // The discriminator branch (7 launches) only meets the SMPL branch in the Adam update: run it
-  // on a second stream so its latency-bound kernels fill the gaps of the MFMA-bound ones.
-  const bool fork = pd && e->streams == 2 && !e->profiling;
-  if (fork && !e->s2) {
-    JRR_HIP(hipStreamCreateWithFlags(&e->s2, hipStreamNonBlocking));
-    JRR_HIP(hipEventCreateWithFlags(&e->ev_fork, hipEventDisableTiming));
-    JRR_HIP(hipEventCreateWithFlags(&e->ev_join, hipEventDisableTiming));
-  }
   for (int it = 0; it < n_iters; ++it) {
-    if (fork) {
-      JRR_HIP(hipEventRecord(e->ev_fork, s));
-      JRR_HIP(hipStreamWaitEvent(e->s2, e->ev_fork, 0));
-      int rcd = disc_forward(e, x6d, nullptr, e->s2);
-      if (rcd) return rcd;
-      rcd = disc_backward_input(e, x6d, nullptr, nullptr, dscale, 1.f, e->gx, e->s2);
-      if (rcd) return rcd;
-      JRR_HIP(hipEventRecord(e->ev_join, e->s2));
-    }
     prof_mark(e, 0, s);
     launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, s);
     prof_mark(e, 0, s);
@@ -886,17 +928,17 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     }
     prof_mark(e, 4, s);
     if (rc) return rc;
-    if (pd && !fork) {
+    if (pd) {
       prof_mark(e, 5, s);
       rc = disc_forward(e, x6d, nullptr, s);
       if (rc) return rc;
-      rc = disc_backward_input(e, x6d, nullptr, nullptr, dscale, 1.f, e->gx, s);
+      rc = disc_backward_input(e, x6d, nullptr, nullptr, dscale, 1.f, e->gx, s, e->dsq);
       prof_mark(e, 5, s);
       if (rc) return rc;
     }
     if (sd) {
       prof_mark(e, 6, s);
-      launch_shape_disc(e->Ps, betas, nullptr, e->gb, sscale, 1.f, e->B, s);
+      launch_shape_disc(e->Ps, betas, nullptr, e->gb, sscale, 1.f, e->B, s, nullptr, e->ssq);
       prof_mark(e, 6, s);
     }
     prof_mark(e, 7, s);
@@ -908,7 +950,6 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     L.gx_extra = pd ? e->gx : nullptr; L.gb_extra = sd ? e->gb : nullptr;
     L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step;
     L.lr = lr; L.B = e->B; L.BP = e->BP;
-    L.wait_before_update = fork ? e->ev_join : nullptr;
     if (e->gt_j2d || sil) { L.gcam = e->gcam; L.cam_io = e->cam; L.cam_m = e->cam_m; L.cam_v = e->cam_v; }
     launch_prep_bwd(L, e->m, s);
     prof_mark(e, 7, s);

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(64) void k_disc_conv_fwd(const float* __restrict__ 
 __global__ __launch_bounds__(1024) void k_disc_out(const float* __restrict__ P, const float* __restrict__ A2T,
                                                    float* __restrict__ out, float* __restrict__ dA2T,
                                                    const float* __restrict__ gout, float scale, float target, int B,
-                                                   int BP, float* __restrict__ dz0) {
+                                                   int BP, float* __restrict__ dz0, float* __restrict__ sq0) {
   __shared__ float red[16][64];
   __shared__ float dzs[64];
   const int lane = threadIdx.x & 63, q = threadIdx.x >> 6;
@@ -82,6 +82,7 @@ __global__ __launch_bounds__(1024) void k_disc_out(const float* __restrict__ P, 
     for (int i = 0; i < 16; ++i) z += red[i][lane];
     float s = sigmoidf(z);
     if (out && b < B) out[(size_t)b * 25] = s;
+    if (sq0) sq0[b] = (b < B) ? (s - target) * (s - target) : 0.f;
     const float up = gout ? ((b < B) ? gout[(size_t)b * 25] : 0.f) : scale * (s - target);
     dzs[lane] = (b < B) ? up * s * (1.f - s) : 0.f;
     if (dz0) dz0[b] = dzs[lane];
@@ -99,7 +100,8 @@ __global__ __launch_bounds__(1024) void k_disc_out(const float* __restrict__ P, 
 // input gradient of the per-joint MLP + heads; dH2T is the gradient arriving from fc0 (may be NULL)
 __global__ __launch_bounds__(64) void k_disc_conv_bwd(const float* __restrict__ P, const float* __restrict__ x6d,
                                                       const float* __restrict__ dH2T, const float* __restrict__ gout,
-                                                      float scale, float target, float* __restrict__ gx, int B, int BP) {
+                                                      float scale, float target, float* __restrict__ gx, int B, int BP,
+                                                      float* __restrict__ sqj) {
   const int b = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y;
   if (b >= B) return;
   float x[6], h1[32], h2[32];
@@ -111,6 +113,7 @@ __global__ __launch_bounds__(64) void k_disc_conv_bwd(const float* __restrict__ 
 #pragma unroll
   for (int o = 0; o < 32; ++o) z = fmaf(wh[o], h2[o], z);
   const float s = sigmoidf(z);
+  if (sqj) sqj[(size_t)(1 + j) * BP + b] = (s - target) * (s - target);
   const float dz = (gout ? gout[(size_t)b * 25 + 1 + j] : scale * (s - target)) * s * (1.f - s);
   float dh2[32];
 #pragma unroll
@@ -141,7 +144,8 @@ __global__ __launch_bounds__(64) void k_disc_conv_bwd(const float* __restrict__ 
 // shape discriminator 10 -> 10 -> 5 -> 1 (discriminator.py:57-74): forward + input gradient of
 // weight*mean((s-target)^2).  Params: w0 0 (10x10) b0 100 w2 110 (5x10) b2 160 w4 165 (1x5) b4 170
 __global__ void k_shape_disc(const float* __restrict__ P, const float* __restrict__ betas, float* __restrict__ out,
-                             float* __restrict__ gb, float scale, float target, int B) {
+                             float* __restrict__ gb, float scale, float target, int B, const float* __restrict__ gout,
+                             float* __restrict__ sq) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
   float x[10], h1[10], h2[5];
@@ -166,8 +170,9 @@ __global__ void k_shape_disc(const float* __restrict__ P, const float* __restric
   for (int i = 0; i < 5; ++i) z = fmaf(P[165 + i], h2[i], z);
   const float s = sigmoidf(z);
   if (out) out[b] = s;
+  if (sq) sq[b] = (s - target) * (s - target);
   if (!gb) return;
-  const float dz = scale * (s - target) * s * (1.f - s);
+  const float dz = (gout ? gout[b] : scale * (s - target)) * s * (1.f - s);
   float dh2[5], dh1[10];
 #pragma unroll
   for (int i = 0; i < 5; ++i) dh2[i] = (h2[i] > 0.f) ? dz * P[165 + i] : 0.f;
@@ -221,8 +226,8 @@ __global__ void k_rowdot_accum(const float* __restrict__ M, int ld, const float*
 // dH2T = gradient arriving from fc0.
 constexpr int CW_LD = 36;                      // LDS row stride in floats (16-byte aligned rows)
 __global__ __launch_bounds__(64) void k_disc_conv_bwd_params(const float* __restrict__ P, const float* __restrict__ x6d,
-                                                             const float* __restrict__ dH2T, float scale, float target,
-                                                             float* __restrict__ slab_shared,
+                                                             const float* __restrict__ dH2T, const float* __restrict__ gout,
+                                                             float scale, float target, float* __restrict__ slab_shared,
                                                              float* __restrict__ slab_heads, int B, int BP) {
   __shared__ __attribute__((aligned(16))) float Sa[64 * CW_LD];
   __shared__ __attribute__((aligned(16))) float Sb[64 * CW_LD];
@@ -242,7 +247,7 @@ __global__ __launch_bounds__(64) void k_disc_conv_bwd_params(const float* __rest
 #pragma unroll
     for (int o = 0; o < 32; ++o) z = fmaf(wh[o], h2[o], z);
     const float s = sigmoidf(z);
-    const float dz = ok ? scale * (s - target) * s * (1.f - s) : 0.f;
+    const float dz = ok ? (gout ? gout[(size_t)b * 25 + 1 + j] : scale * (s - target)) * s * (1.f - s) : 0.f;
     float dh2[32], dh1[32];
 #pragma unroll
     for (int o = 0; o < 32; ++o) {
@@ -309,7 +314,8 @@ __global__ __launch_bounds__(64) void k_disc_conv_bwd_params(const float* __rest
 
 // shape discriminator: forward, weight gradients of mean((s-target)^2), per-pose squared error
 __global__ __launch_bounds__(64) void k_shape_disc_bwd_params(const float* __restrict__ P, const float* __restrict__ betas,
-                                                              float scale, float target, float* __restrict__ dP,
+                                                              const float* __restrict__ gout, float scale, float target,
+                                                              float* __restrict__ dP,
                                                               float* __restrict__ sqerr, int B) {
   const int lane = threadIdx.x, b = blockIdx.x * 64 + lane;
   const bool ok = b < B;
@@ -335,7 +341,7 @@ __global__ __launch_bounds__(64) void k_shape_disc_bwd_params(const float* __res
   for (int i = 0; i < 5; ++i) z = fmaf(P[165 + i], h2[i], z);
   const float s = sigmoidf(z);
   if (ok && sqerr) sqerr[b] = (s - target) * (s - target);
-  const float dz = ok ? scale * (s - target) * s * (1.f - s) : 0.f;
+  const float dz = ok ? (gout ? gout[b] : scale * (s - target)) * s * (1.f - s) : 0.f;
   float dh2[5], dh1[10];
   wave_atomic_add(dz, dP + 170, lane);
 #pragma unroll
@@ -370,19 +376,32 @@ __global__ void k_sqerr_rows(const float* __restrict__ out, int ncol, float targ
   sqerr[b] = acc;
 }
 
+// out[b] = sum_r M[r][b]   (rows of a [rows][ld] pose-contiguous array)
+__global__ void k_colsum(const float* __restrict__ M, int rows, int ld, float* __restrict__ out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float acc = 0.f;
+  for (int r = 0; r < rows; ++r) acc += M[(size_t)r * ld + b];
+  out[b] = acc;
+}
+int launch_colsum(const float* M, int rows, int ld, float* out, int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_colsum, dim3((B + 255) / 256), dim3(256), 0, s, M, rows, ld, out, B);
+  return 0;
+}
+
 int launch_rowdot_accum(const float* M, int ld, const float* vec, float* out, int rows, int cols, hipStream_t s) {
   hipLaunchKernelGGL(k_rowdot_accum, dim3(rows), dim3(256), 0, s, M, ld, vec, out, cols);
   return 0;
 }
-int launch_disc_conv_bwd_params(const float* P, const float* x6d, const float* dH2T, float scale, float target,
-                                float* slab_shared, float* slab_heads, int B, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_disc_conv_bwd_params, dim3(BP / 64, NJ), dim3(64), 0, s, P, x6d, dH2T, scale, target, slab_shared,
+int launch_disc_conv_bwd_params(const float* P, const float* x6d, const float* dH2T, const float* gout, float scale,
+                                float target, float* slab_shared, float* slab_heads, int B, int BP, hipStream_t s) {
+  hipLaunchKernelGGL(k_disc_conv_bwd_params, dim3(BP / 64, NJ), dim3(64), 0, s, P, x6d, dH2T, gout, scale, target, slab_shared,
                      slab_heads, B, BP);
   return 0;
 }
-int launch_shape_disc_bwd_params(const float* P, const float* betas, float scale, float target, float* dparams,
-                                 float* sqerr, int B, hipStream_t s) {
-  hipLaunchKernelGGL(k_shape_disc_bwd_params, dim3((B + 63) / 64), dim3(64), 0, s, P, betas, scale, target, dparams, sqerr, B);
+int launch_shape_disc_bwd_params(const float* P, const float* betas, const float* gout, float scale, float target,
+                                 float* dparams, float* sqerr, int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_shape_disc_bwd_params, dim3((B + 63) / 64), dim3(64), 0, s, P, betas, gout, scale, target, dparams, sqerr, B);
   return 0;
 }
 int launch_sqerr_rows(const float* out, int ncol, float target, float* sqerr, int B, hipStream_t s) {
@@ -413,18 +432,18 @@ int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* ou
   return 0;
 }
 int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
-                    float target, int B, int BP, hipStream_t s, float* dz0) {
-  hipLaunchKernelGGL(k_disc_out, dim3(BP / 64), dim3(1024), 0, s, P, A2T, out, dA2T, gout, scale, target, B, BP, dz0);
+                    float target, int B, int BP, hipStream_t s, float* dz0, float* sq0) {
+  hipLaunchKernelGGL(k_disc_out, dim3(BP / 64), dim3(1024), 0, s, P, A2T, out, dA2T, gout, scale, target, B, BP, dz0, sq0);
   return 0;
 }
 int launch_disc_conv_bwd(const float* P, const float* x6d, const float* dH2T, const float* gout, float scale,
-                         float target, float* gx, int B, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_disc_conv_bwd, dim3((B + 63) / 64, NJ), dim3(64), 0, s, P, x6d, dH2T, gout, scale, target, gx, B, BP);
+                         float target, float* gx, int B, int BP, hipStream_t s, float* sqj) {
+  hipLaunchKernelGGL(k_disc_conv_bwd, dim3((B + 63) / 64, NJ), dim3(64), 0, s, P, x6d, dH2T, gout, scale, target, gx, B, BP, sqj);
   return 0;
 }
 int launch_shape_disc(const float* P, const float* betas, float* out, float* gb, float scale, float target, int B,
-                      hipStream_t s) {
-  hipLaunchKernelGGL(k_shape_disc, dim3((B + 63) / 64), dim3(64), 0, s, P, betas, out, gb, scale, target, B);
+                      hipStream_t s, const float* gout, float* sq) {
+  hipLaunchKernelGGL(k_shape_disc, dim3((B + 63) / 64), dim3(64), 0, s, P, betas, out, gb, scale, target, B, gout, sq);
   return 0;
 }
 

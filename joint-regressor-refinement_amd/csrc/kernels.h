@@ -33,7 +33,6 @@ struct PrepBwdLaunch {
   float lr = 0, beta1 = 0.9f, beta2 = 0.999f, eps = 1e-8f;
   int B = 0, BP = 0;
   const float* gcam = nullptr; float* cam_io = nullptr; float* cam_m = nullptr; float* cam_v = nullptr;
-  hipEvent_t wait_before_update = nullptr;   // the update kernel also needs the discriminator branch's gx
 };
 
 struct ReprojLaunch { const float* gt_j2d; const float* cam; float* gcam; float* sq2d; float scale2d; };
@@ -41,6 +40,8 @@ struct ReprojLaunch { const float* gt_j2d; const float* cam; float* gcam; float*
 // prep.hip
 int launch_rot6d_fwd(const float* x, float* R, int n, hipStream_t s);
 int launch_rot6d_bwd(const float* x, const float* dR, float* dx, int n, hipStream_t s);
+int launch_rodrigues_fwd(const float* aa, float* R, int n, hipStream_t s);
+int launch_rodrigues_bwd(const float* aa, const float* dR, float* daa, int n, hipStream_t s);
 int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT,
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s);
 int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float* djoints_in, float scale,
@@ -104,18 +105,19 @@ int launch_evaluate(const float* pred, const float* target_mm, float* err, float
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s, int ldin = 0, int ldout = 0);
 int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s);
 int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
-                    float target, int B, int BP, hipStream_t s, float* dz0 = nullptr);
+                    float target, int B, int BP, hipStream_t s, float* dz0 = nullptr, float* sq0 = nullptr);
+int launch_colsum(const float* M, int rows, int ld, float* out, int B, hipStream_t s);
 int launch_rowdot_accum(const float* M, int ld, const float* vec, float* out, int rows, int cols, hipStream_t s);
 // conv / per-joint-head weight gradients as partial slabs: shared [24 * BP/64][1280] (conv0 W,b | conv2 W,b in the
 // DP_* order) and heads [BP/64][792]; the caller reduces them into the flat gradient
-int launch_disc_conv_bwd_params(const float* P, const float* x6d, const float* dH2T, float scale, float target,
-                                float* slab_shared, float* slab_heads, int B, int BP, hipStream_t s);
-int launch_shape_disc_bwd_params(const float* P, const float* betas, float scale, float target, float* dparams,
-                                 float* sqerr, int B, hipStream_t s);
+int launch_disc_conv_bwd_params(const float* P, const float* x6d, const float* dH2T, const float* gout, float scale,
+                                float target, float* slab_shared, float* slab_heads, int B, int BP, hipStream_t s);
+int launch_shape_disc_bwd_params(const float* P, const float* betas, const float* gout, float scale, float target,
+                                 float* dparams, float* sqerr, int B, hipStream_t s);
 int launch_sqerr_rows(const float* out, int ncol, float target, float* sqerr, int B, hipStream_t s);
 int launch_disc_conv_bwd(const float* P, const float* x6d, const float* dH2T, const float* gout, float scale,
-                         float target, float* gx, int B, int BP, hipStream_t s);
+                         float target, float* gx, int B, int BP, hipStream_t s, float* sqj = nullptr);
 int launch_shape_disc(const float* P, const float* betas, float* out, float* gb, float scale, float target, int B,
-                      hipStream_t s);
+                      hipStream_t s, const float* gout = nullptr, float* sq = nullptr);
 
 }  // namespace jrr

@@ -117,6 +117,74 @@ __global__ void k_rot6d_bwd(const float* __restrict__ x, const float* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// Rodrigues: axis-angle -> R (smplx 0.1.26 lbs.batch_rodrigues, the pose2rot=True branch of the SMPL
+// operator: /root/reference/scripts/smpl.py:61-85 inherits smplx.SMPL.forward's default):
+//   theta = |aa + 1e-8| ; r = aa / theta ; K = skew(r) ; R = I + sin(theta) K + (1 - cos(theta)) K^2
+// (1 - cos(theta) is evaluated as 2 sin^2(theta/2): the same value without fp32 cancellation at small angles)
+// and its adjoint (finite at aa = 0: sin(theta)/theta -> 1).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void skew(const float r[3], float K[9]) {
+  K[0] = 0.f;   K[1] = -r[2]; K[2] = r[1];
+  K[3] = r[2];  K[4] = 0.f;   K[5] = -r[0];
+  K[6] = -r[1]; K[7] = r[0];  K[8] = 0.f;
+}
+__device__ __forceinline__ void mat3_mul(const float A[9], const float Bm[9], float C[9]) {
+#pragma unroll
+  for (int i = 0; i < 3; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) C[i * 3 + j] = A[i * 3] * Bm[j] + A[i * 3 + 1] * Bm[3 + j] + A[i * 3 + 2] * Bm[6 + j];
+}
+
+__global__ void k_rodrigues_fwd(const float* __restrict__ aa, float* __restrict__ R, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a[3] = {aa[(size_t)i * 3], aa[(size_t)i * 3 + 1], aa[(size_t)i * 3 + 2]};
+  const float e0 = a[0] + 1e-8f, e1 = a[1] + 1e-8f, e2 = a[2] + 1e-8f;
+  const float th = sqrtf(e0 * e0 + e1 * e1 + e2 * e2);
+  const float r[3] = {a[0] / th, a[1] / th, a[2] / th};
+  const float s = sinf(th), sh = sinf(0.5f * th), omc = 2.f * sh * sh;   // 1 - cos(theta) without cancellation at small theta
+  float K[9], K2[9];
+  skew(r, K);
+  mat3_mul(K, K, K2);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) R[(size_t)i * 9 + k] = ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f) + s * K[k] + omc * K2[k];
+}
+
+__global__ void k_rodrigues_bwd(const float* __restrict__ aa, const float* __restrict__ dR, float* __restrict__ daa, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const float a[3] = {aa[(size_t)i * 3], aa[(size_t)i * 3 + 1], aa[(size_t)i * 3 + 2]};
+  const float e[3] = {a[0] + 1e-8f, a[1] + 1e-8f, a[2] + 1e-8f};
+  const float th = sqrtf(e[0] * e[0] + e[1] * e[1] + e[2] * e[2]);
+  const float r[3] = {a[0] / th, a[1] / th, a[2] / th};
+  const float s = sinf(th), c = cosf(th), sh = sinf(0.5f * th), omc = 2.f * sh * sh;
+  float K[9], K2[9], g[9];
+  skew(r, K);
+  mat3_mul(K, K, K2);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) g[k] = dR[(size_t)i * 9 + k];
+  // through sin / cos
+  float dth = 0.f;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dth += g[k] * (c * K[k] + s * K2[k]);
+  // through K (linear in r): dL/dK = s g + (1-c) (g K^T + K^T g)
+  float Kt[9], gKt[9], Ktg[9], dK[9];
+#pragma unroll
+  for (int p = 0; p < 3; ++p)
+#pragma unroll
+    for (int q = 0; q < 3; ++q) Kt[p * 3 + q] = K[q * 3 + p];
+  mat3_mul(g, Kt, gKt);
+  mat3_mul(Kt, g, Ktg);
+#pragma unroll
+  for (int k = 0; k < 9; ++k) dK[k] = s * g[k] + omc * (gKt[k] + Ktg[k]);
+  const float dr[3] = {dK[7] - dK[5], dK[2] - dK[6], dK[3] - dK[1]};
+  // r = a / theta ; theta = |a + 1e-8|
+  dth -= (dr[0] * a[0] + dr[1] * a[1] + dr[2] * a[2]) / (th * th);
+#pragma unroll
+  for (int k = 0; k < 3; ++k) daa[(size_t)i * 3 + k] = dr[k] / th + dth * e[k] / th;
+}
+
+// ------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ void load_rot(const float* __restrict__ x6d, const float* __restrict__ Rin, int b, int j,
@@ -729,6 +797,15 @@ int launch_rot6d_bwd(const float* x, const float* dR, float* dx, int n, hipStrea
   return 0;
 }
 
+int launch_rodrigues_fwd(const float* aa, float* R, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_rodrigues_fwd, dim3((n + 255) / 256), dim3(256), 0, s, aa, R, n);
+  return 0;
+}
+int launch_rodrigues_bwd(const float* aa, const float* dR, float* daa, int n, hipStream_t s) {
+  hipLaunchKernelGGL(k_rodrigues_bwd, dim3((n + 255) / 256), dim3(256), 0, s, aa, dR, daa, n);
+  return 0;
+}
+
 int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT,
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s) {
   hipLaunchKernelGGL(k_prep_fwd, dim3(BP / PP), dim3(PP * NJ), 0, s, x6d, Rin, betas, m.Jt, m.JS, m.parents, FT, AT, R0T,
@@ -767,7 +844,6 @@ int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
   hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + PP - 1) / PP), dim3(PP * NJ), 0, s, L.FT, L.R0T, L.AT, m.Jt, m.JS, m.parents,
                      L.dATp, L.dFTp, L.dRT, L.dbT, L.B, L.BP);
-  if (L.wait_before_update) (void)hipStreamWaitEvent(s, L.wait_before_update, 0);
   PoseUpdateArgs a;
   a.x6d_in = L.x6d_in; a.dRT = L.dRT; a.dbT = L.dbT; a.gx_extra = L.gx_extra; a.gb_extra = L.gb_extra;
   a.dx6d = L.dx6d; a.dR = L.dR; a.dbetas = L.dbetas;

@@ -3,9 +3,12 @@
 
 `Discriminator()` and `Shape_Discriminator()` are nn.Modules whose parameters use torch's default
 initialisation (same constructors, same order => same values under the same seed as the
-reference).  forward() runs the C-ABI path (jrr_pose_disc_forward / _backward_input) through an
-autograd.Function; gradients w.r.t. the INPUT are provided (that is what the inner loop uses,
-scripts/optimize.py:241-253).
+reference).  `forward()` runs the C-ABI path through an autograd.Function that returns gradients
+w.r.t. the INPUT (what the inner loop uses, scripts/optimize.py:241-253) AND w.r.t. the module's
+parameters (what `loss.backward(); disc_optimizer.step()` needs, scripts/optimize.py:276-293), so the
+modules train exactly like the reference's.  They own a model-less engine per (batch, device): no SMPL
+model is needed to evaluate a discriminator.  The fused driver (optimize.py) does not go through the
+modules; it uses the flat-parameter entry points (jrr_pose_disc_backward_params, jrr_adam_step).
 """
 from __future__ import annotations
 
@@ -17,6 +20,53 @@ from torch import nn
 from . import engine as _engine
 
 
+class _ModuleEngines:
+    """(batch, device) -> model-less RefineEngine holding this module's parameters; the 7.4 MB upload (and the two
+    weight transposes behind it) is repeated only when a parameter has changed (torch's per-tensor version counter)."""
+
+    def __init__(self, flag: int):
+        self.flag = flag
+        self.engines: Dict = {}
+        self.uploaded: Dict = {}
+
+    def get(self, module: nn.Module, batch: int, device, flat: torch.Tensor, setter: str):
+        key = (batch, str(device))
+        if key not in self.engines:
+            self.engines[key] = _engine.RefineEngine(None, batch, flags=self.flag, device=device)
+        eng = self.engines[key]
+        version = tuple((p.data_ptr(), p._version) for p in module.parameters())
+        if self.uploaded.get(key) != version:
+            getattr(eng, setter)(flat.detach())
+            self.uploaded[key] = version
+        return eng
+
+
+class _PoseDiscFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, flat, eng):
+        x = x.detach().contiguous().float()
+        out = eng.pose_disc_forward(x)
+        ctx.eng, ctx.gen = eng, eng.generation
+        ctx.save_for_backward(x, flat.detach())
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        x, flat = ctx.saved_tensors
+        eng = ctx.eng
+        gout = gout.contiguous()
+        if eng.generation != ctx.gen:          # another forward has used the engine since: restore this one's state
+            eng.set_pose_disc(flat)
+            eng.pose_disc_forward(x)
+        dx = eng.pose_disc_vjp_input(x, gout) if ctx.needs_input_grad[0] else None
+        dflat = None
+        if ctx.needs_input_grad[1]:
+            dflat = torch.zeros_like(flat)
+            eng.pose_disc_vjp_params(x, gout, dflat)
+        ctx.gen = eng.generation
+        return dx, dflat, None
+
+
 class Discriminator(nn.Module):
     def __init__(self):
         super().__init__()
@@ -25,47 +75,58 @@ class Discriminator(nn.Module):
         self.linears = nn.ModuleList([nn.Linear(32, 1) for _ in range(self.num_inputs)])
         self.linear_operations = nn.Sequential(nn.Linear(32 * self.num_inputs, 1024), nn.ReLU(), nn.Linear(1024, 1024),
                                                nn.ReLU(), nn.Linear(1024, 1))
-        self._engines: Dict = {}
+        self._jrr = _ModuleEngines(_engine.FLAG_POSE_DISC)
 
     def flat_parameters(self) -> torch.Tensor:
         return _engine.flatten_state_dict(self.state_dict(), _engine.DISC_KEYS)
 
-    def _engine_for(self, batch: int, device, model):
-        key = (batch, str(device))
-        if key not in self._engines:
-            self._engines[key] = _engine.RefineEngine(model, batch, flags=_engine.FLAG_POSE_DISC)
-        eng = self._engines[key]
-        eng.set_pose_disc(self.flat_parameters().to(device))
-        return eng
+    def _flat_with_grad(self) -> torch.Tensor:
+        """the flat parameter vector as a differentiable function of the nn.Parameters (state_dict order)"""
+        named = dict(self.named_parameters())
+        return torch.cat([named[k].reshape(-1) for k in _engine.DISC_KEYS])
 
     def forward(self, rot6d: torch.Tensor, model=None) -> torch.Tensor:
-        """rot6d (B,24,6) -> (B,25,1) sigmoid scores (output 0 global, 1..24 per joint)."""
-        if model is None:
-            model = getattr(self, 'device_model', None)
-        if model is None:
-            raise RuntimeError('Discriminator.forward needs a DeviceModel (set .device_model or pass model=)')
-        eng = self._engine_for(rot6d.shape[0], rot6d.device, model)
-        return _PoseDiscFn.apply(rot6d.contiguous(), eng).unsqueeze(-1)
+        """rot6d (B,24,6) -> (B,25,1) sigmoid scores (output 0 global, 1..24 per joint).  `model` is accepted for
+        backward compatibility and ignored."""
+        flat = self._flat_with_grad().to(rot6d.device)
+        eng = self._jrr.get(self, rot6d.shape[0], rot6d.device, flat, 'set_pose_disc')
+        return _PoseDiscFn.apply(rot6d.contiguous(), flat, eng).unsqueeze(-1)
 
 
-class _PoseDiscFn(torch.autograd.Function):
+class _ShapeDiscFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, eng):
-        x = x.detach().contiguous().float()
+    def forward(ctx, betas, flat, eng):
+        betas = betas.detach().contiguous().float()
         ctx.eng = eng
-        ctx.save_for_backward(x)
-        return eng.pose_disc_forward(x)
+        ctx.save_for_backward(betas, flat.detach())
+        return eng.shape_disc_forward(betas)
 
     @staticmethod
     def backward(ctx, gout):
-        (x,) = ctx.saved_tensors
-        return ctx.eng.pose_disc_vjp_input(x, gout.contiguous()), None
+        betas, flat = ctx.saved_tensors
+        eng = ctx.eng
+        eng.set_shape_disc(flat)               # 684 bytes: the vjp kernels recompute the forward, so this is all the state
+        gout = gout.contiguous()
+        db = eng.shape_disc_vjp_input(betas, gout) if ctx.needs_input_grad[0] else None
+        dflat = None
+        if ctx.needs_input_grad[1]:
+            dflat = torch.zeros_like(flat)
+            eng.shape_disc_vjp_params(betas, gout, dflat)
+        return db, dflat, None
 
 
 class Shape_Discriminator(nn.Module):
     def __init__(self):
         super().__init__()
         self.shape_operations = nn.Sequential(nn.Linear(10, 10), nn.ReLU(), nn.Linear(10, 5), nn.ReLU(), nn.Linear(5, 1))
+        self._jrr = _ModuleEngines(_engine.FLAG_SHAPE_DISC)
 
     def flat_parameters(self) -> torch.Tensor:
         return _engine.flatten_state_dict(self.state_dict(), _engine.SHAPE_DISC_KEYS)
+
+    def forward(self, betas: torch.Tensor) -> torch.Tensor:
+        """scripts/discriminator.py:70-74: betas (B,10) -> (B,1) sigmoid score."""
+        named = dict(self.named_parameters())
+        flat = torch.cat([named[k].reshape(-1) for k in _engine.SHAPE_DISC_KEYS]).to(betas.device)
+        eng = self._jrr.get(self, betas.shape[0], betas.device, flat, 'set_shape_disc')
+        return _ShapeDiscFn.apply(betas.contiguous(), flat, eng).unsqueeze(-1)

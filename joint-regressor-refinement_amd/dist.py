@@ -28,7 +28,7 @@ def init(backend: Optional[str] = None):
         if backend is None:
             backend = 'nccl' if torch.cuda.is_available() else 'gloo'
         kw = {}
-        if backend == 'nccl':
+        if backend == 'nccl':     # RCCL: one rank per GPU
             torch.cuda.set_device(local_rank)
             kw['device_id'] = torch.device('cuda', local_rank)
         dist.init_process_group(backend, **kw)

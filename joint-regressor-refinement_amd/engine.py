@@ -85,19 +85,28 @@ class DeviceModel:
 class RefineEngine:
     """Per-batch plan over a caller-owned (torch) workspace: jrr_engine_*."""
 
-    def __init__(self, model: DeviceModel, batch: int, batch_norm: Optional[int] = None, flags: int = 0):
-        self.lib = model.lib
+    def __init__(self, model: Optional[DeviceModel], batch: int, batch_norm: Optional[int] = None, flags: int = 0,
+                 device=None):
+        """`model` may be None for an engine that serves the discriminators only (flags within POSE_DISC | SHAPE_DISC)"""
+        self.lib = model.lib if model is not None else _lib.load()
         self.model = model
-        self.device = model.device
+        self.device = model.device if model is not None else torch.device(device if device is not None else 'cuda:0')
         self.batch = int(batch)
+        self.batch_norm = int(batch_norm or batch)
         self.flags = int(flags)
+        # Forward-generation counter: the adjoint entry points read the engine's internal state of the MOST RECENT
+        # forward (include/jrr.h: "must follow it"), while autograd defers backward.  Every call that overwrites that
+        # state bumps the counter; the autograd wrappers compare it with the value saved at forward time and re-run
+        # the forward from their saved inputs when it has moved (utils._FindJointsFn, smpl._SMPLVerticesFn,
+        # discriminator._PoseDiscFn).
+        self.generation = 0
         nbytes = self.lib.jrr_engine_workspace_bytes(self.batch, self.flags)
         # zero-filled: padded rows/columns of several sections are read by the GEMM kernels
         self.workspace = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
         base = (self.workspace.data_ptr() + 255) // 256 * 256
         h = c_void_p()
         with torch.cuda.device(self.device):
-            check(self.lib.jrr_engine_create(model.handle, self.batch, int(batch_norm or batch), c_void_p(base), nbytes,
+            check(self.lib.jrr_engine_create(model.handle if model is not None else None, self.batch, int(batch_norm or batch), c_void_p(base), nbytes,
                                              self.flags, byref(h)), 'jrr_engine_create')
         self.handle = h
         info = (c_int32 * 8)()
@@ -124,15 +133,15 @@ class RefineEngine:
     # -- configuration ---------------------------------------------------------------------
     def set_batch_norm(self, n: int):
         check(self.lib.jrr_engine_set_batch_norm(self.handle, int(n)), 'set_batch_norm')
+        self.batch_norm = int(n)
+        self.info['batch_norm'] = int(n)
 
     def set_folded(self, enabled: bool):
         """refine_run through the folded regressor tables (engine must have FLAG_FOLDED)"""
         check(self.lib.jrr_engine_set_folded(self.handle, int(bool(enabled)), self._s()), 'set_folded')
 
-    def set_concurrency(self, streams: int):
-        check(self.lib.jrr_engine_set_concurrency(self.handle, int(streams)), 'set_concurrency')
-
     def set_j_regressor(self, J: torch.Tensor, mask: Optional[torch.Tensor] = None):
+        self.generation += 1
         J = J.detach().to(self.device, torch.float32).contiguous()      # any stride / device tag
         self._chk(J, (NUM_H36M, NUM_VERTS), 'J_regressor')
         if mask is not None:
@@ -140,6 +149,7 @@ class RefineEngine:
         check(self.lib.jrr_engine_set_j_regressor(self.handle, ptr(J), ptr(mask), self._s()), 'set_j_regressor')
 
     def set_pose_disc(self, flat: torch.Tensor):
+        self.generation += 1
         flat = self._chk(flat.detach().to(self.device, torch.float32).contiguous(), (DISC_PARAMS,), 'disc params')
         check(self.lib.jrr_engine_set_pose_disc(self.handle, ptr(flat), self._s()), 'set_pose_disc')
 
@@ -149,6 +159,7 @@ class RefineEngine:
 
     # -- operators --------------------------------------------------------------------------
     def find_joints_forward(self, betas, x6d=None, R=None, return_verts=False):
+        self.generation += 1
         B = self.batch
         self._chk(betas, (B, NUM_BETAS), 'betas')
         if x6d is not None:
@@ -173,6 +184,7 @@ class RefineEngine:
         return (dx if x6d is not None else dR), db, dJ
 
     def pose_disc_forward(self, x6d):
+        self.generation += 1
         self._chk(x6d, (self.batch, NUM_JOINTS, 6), 'x6d')
         out = torch.empty(self.batch, 25, device=self.device)
         check(self.lib.jrr_pose_disc_forward(self.handle, ptr(x6d), ptr(out), self._s()), 'pose_disc_forward')
@@ -186,6 +198,7 @@ class RefineEngine:
 
     def pose_disc_backward_params(self, x6d, target: float, dparams: torch.Tensor):
         """dparams += d mean((D(x)-target)^2)/d weights; returns per-pose sum_k (D-target)^2"""
+        self.generation += 1
         self._chk(x6d, (self.batch, NUM_JOINTS, 6), 'x6d')
         self._chk(dparams, (DISC_PARAMS,), 'dparams')
         sq = torch.empty(self.batch, device=self.device)
@@ -200,6 +213,41 @@ class RefineEngine:
         check(self.lib.jrr_shape_disc_backward_params(self.handle, ptr(betas), float(target), ptr(dparams), ptr(sq), self._s()),
               'shape_disc_backward_params')
         return sq
+
+    def pose_disc_vjp_params(self, x6d, gout, dparams: torch.Tensor):
+        """dparams += (dD/dweights)^T gout for an upstream gradient gout (B,25); runs its own forward"""
+        self.generation += 1
+        self._chk(x6d, (self.batch, NUM_JOINTS, 6), 'x6d')
+        self._chk(gout, (self.batch, 25), 'gout')
+        self._chk(dparams, (DISC_PARAMS,), 'dparams')
+        check(self.lib.jrr_pose_disc_vjp_params(self.handle, ptr(x6d), ptr(gout), ptr(dparams), self._s()), 'pose_disc_vjp_params')
+
+    def shape_disc_vjp_params(self, betas, gout, dparams: torch.Tensor):
+        self._chk(betas, (self.batch, NUM_BETAS), 'betas')
+        self._chk(gout, (self.batch,), 'gout')
+        self._chk(dparams, (SHAPE_DISC_PARAMS,), 'dparams')
+        check(self.lib.jrr_shape_disc_vjp_params(self.handle, ptr(betas), ptr(gout), ptr(dparams), self._s()), 'shape_disc_vjp_params')
+
+    def shape_disc_forward(self, betas):
+        """Shape_Discriminator.forward: betas (B,10) -> (B) sigmoid scores"""
+        self._chk(betas, (self.batch, NUM_BETAS), 'betas')
+        out = torch.empty(self.batch, device=self.device)
+        check(self.lib.jrr_shape_disc_forward(self.handle, ptr(betas), ptr(out), self._s()), 'shape_disc_forward')
+        return out
+
+    def shape_disc_vjp_input(self, betas, gout):
+        self._chk(betas, (self.batch, NUM_BETAS), 'betas')
+        self._chk(gout, (self.batch,), 'gout')
+        db = torch.empty(self.batch, NUM_BETAS, device=self.device)
+        check(self.lib.jrr_shape_disc_vjp_input(self.handle, ptr(betas), ptr(gout), ptr(db), self._s()), 'shape_disc_vjp_input')
+        return db
+
+    def refine_aux_losses(self, pose_disc=True, shape_disc=False):
+        """per-pose squared adversarial errors of the last refine_run iteration (pose: summed over the 25 outputs)"""
+        pd = torch.empty(self.batch, device=self.device) if pose_disc else None
+        sd = torch.empty(self.batch, device=self.device) if shape_disc else None
+        check(self.lib.jrr_refine_aux_losses(self.handle, ptr(pd), ptr(sd), self._s()), 'refine_aux_losses')
+        return pd, sd
 
     def pose_disc_vjp_input(self, x6d, gout):
         """input gradient for an arbitrary upstream gradient gout (B,25); follows pose_disc_forward"""
@@ -228,13 +276,15 @@ class RefineEngine:
         check(self.lib.jrr_engine_set_reprojection(self.handle, ptr(gt_j2d), ptr(cam), ptr(cam_m), ptr(cam_v)), 'set_reprojection')
 
     def camera_prefit(self, x6d, betas, gt_j2d, cam, n_steps: int = 1000, lr: float = 1e-2):
+        self.generation += 1
         sq = torch.empty(self.batch, device=self.device)
         check(self.lib.jrr_camera_prefit(self.handle, ptr(x6d), ptr(betas), ptr(gt_j2d), ptr(cam), int(n_steps), float(lr),
                                          ptr(sq), self._s()), 'camera_prefit')
         return sq
 
     def silhouette_forward(self, verts, cam):
-        """render_mesh alpha channel: verts (B,6890,3), cam (B,3) -> (B,224,224)"""
+        """render_mesh alpha channel: verts (B,6890,3) in SMPL space, cam (B,3) -> (B,224,224)"""
+        self.generation += 1
         self._chk(verts, (self.batch, NUM_VERTS, 3), 'verts')
         self._chk(cam, (self.batch, 3), 'cam')
         alpha = torch.empty(self.batch, SIL, SIL, device=self.device)
@@ -258,6 +308,7 @@ class RefineEngine:
         check(self.lib.jrr_engine_set_silhouette(self.handle, ptr(mask), ptr(cam), ptr(cam_m), ptr(cam_v)), 'set_silhouette')
 
     def refine_run(self, x6d, betas, gt_centred_mm, adam_m, adam_v, step, lr: float, n_iters: int, sqerr=None):
+        self.generation += 1
         B = self.batch
         self._chk(x6d, (B, NUM_JOINTS, 6), 'x6d')
         self._chk(betas, (B, NUM_BETAS), 'betas')
@@ -290,6 +341,7 @@ class RefineEngine:
         return tuple(int(x) for x in out)
 
     def j_regressor_grad(self, x6d, betas, gt_centred_mm, sqerr=None):
+        self.generation += 1
         dJ = torch.empty(NUM_H36M, NUM_VERTS, device=self.device)
         check(self.lib.jrr_j_regressor_grad(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(dJ), ptr(sqerr),
                                             self._s()), 'j_regressor_grad')
@@ -312,6 +364,24 @@ def rot6d_backward(x: torch.Tensor, dR: torch.Tensor) -> torch.Tensor:
     dx = torch.empty_like(x)
     check(lib.jrr_rot6d_backward(ptr(x), ptr(dR), ptr(dx), x.shape[0], stream_ptr(x.device)), 'rot6d_backward')
     return dx
+
+
+def rodrigues_forward(aa: torch.Tensor) -> torch.Tensor:
+    """smplx batch_rodrigues: axis-angle (N,3) -> (N,3,3)"""
+    lib = _lib.load()
+    aa = aa.contiguous().view(-1, 3).float()
+    R = torch.empty(aa.shape[0], 3, 3, device=aa.device)
+    check(lib.jrr_rodrigues_forward(ptr(aa), ptr(R), aa.shape[0], stream_ptr(aa.device)), 'rodrigues_forward')
+    return R
+
+
+def rodrigues_backward(aa: torch.Tensor, dR: torch.Tensor) -> torch.Tensor:
+    lib = _lib.load()
+    aa = aa.contiguous().view(-1, 3).float()
+    dR = dR.contiguous().float()
+    daa = torch.empty_like(aa)
+    check(lib.jrr_rodrigues_backward(ptr(aa), ptr(dR), ptr(daa), aa.shape[0], stream_ptr(aa.device)), 'rodrigues_backward')
+    return daa
 
 
 def project_joints(joints: torch.Tensor, cam: torch.Tensor) -> torch.Tensor:

@@ -13,17 +13,31 @@ from . import engine as _engine
 class _SilhouetteFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, verts, cam, eng):
-        ctx.eng = eng
-        return eng.silhouette_forward(verts.detach().contiguous().float(), cam.detach().contiguous().float())
+        verts, cam = verts.detach().contiguous().float(), cam.detach().contiguous().float()
+        alpha = eng.silhouette_forward(verts, cam)
+        ctx.eng, ctx.gen = eng, eng.generation
+        ctx.save_for_backward(verts, cam)
+        return alpha
 
     @staticmethod
     def backward(ctx, galpha):
-        dverts, dcam = ctx.eng.silhouette_backward(galpha.contiguous())
+        eng = ctx.eng
+        if eng.generation != ctx.gen:      # the rasteriser's per-pose face lists belong to a later forward: redo this one
+            verts, cam = ctx.saved_tensors
+            eng.silhouette_forward(verts, cam)
+            ctx.gen = eng.generation
+        dverts, dcam = eng.silhouette_backward(galpha.contiguous())
         return dverts, dcam, None
 
 
 class Mesh_Renderer(nn.Module):
-    """Mesh_Renderer(image_size)(batch, smpl_verts) -> (B, 4, H, W); channel 3 is the soft silhouette."""
+    """Mesh_Renderer(image_size)(batch, smpl_verts) -> (B, 4, H, W); channel 3 is the soft silhouette.
+
+    As in the reference (scripts/mesh_renderer.py:48-79), `smpl_verts` are the vertices AFTER render_mesh's
+    x/y flip and x2 scale (scripts/optimize.py:80-82): a call site ported from the reference keeps its own flip and
+    scale.  The HIP projection kernel applies that transform itself, so forward() maps the argument back to SMPL
+    space first (an exact sign flip and halving).  Channels 0-2 are 1 as pytorch3d's SoftSilhouetteShader returns
+    them (sigmoid_alpha_blend of all-ones colours), independent of the textures."""
 
     def __init__(self, image_size: int = 224, smpl=None):
         super().__init__()
@@ -39,13 +53,14 @@ class Mesh_Renderer(nn.Module):
         return self._engines[batch]
 
     def forward(self, batch, smpl_verts):
-        alpha = _SilhouetteFn.apply(smpl_verts, batch['cam'], self._engine(smpl_verts.shape[0]))
+        world = smpl_verts * smpl_verts.new_tensor([-0.5, -0.5, 0.5])
+        alpha = _SilhouetteFn.apply(world, batch['cam'], self._engine(smpl_verts.shape[0]))
         ones = torch.ones_like(alpha)
         return torch.stack([ones, ones, ones, alpha], dim=1)
 
 
 def render_mesh(smpl, silhouette_renderer, betas, orient, pose, batch):
-    """scripts/optimize.py:77-85.  The x/y flip and the x2 scale are part of the projection inside the renderer
-    (csrc/sil.hip k_sil_project), so the vertices are passed as SMPL returns them."""
+    """scripts/optimize.py:77-85: SMPL vertices, x/y flip, x2 scale, alpha channel of the renderer."""
     pred_vertices = smpl(global_orient=orient, body_pose=pose, betas=betas, pose2rot=False).vertices
+    pred_vertices = pred_vertices * pred_vertices.new_tensor([-2.0, -2.0, 2.0])
     return silhouette_renderer(batch, pred_vertices)[:, 3].unsqueeze(1)

@@ -2,25 +2,29 @@
 (/root/reference/scripts/optimize.py:88-337) on the HIP path.
 
 Per outer batch (reference line numbers):
+  :132-139  DataLoader over data_set(...)                   -> `--data_root` (precomputed tensors in the reference
+            layout, data.py) or seeded synthetic "SPIN-init" batches
   :158-162  batch to device, ground-truth joints pelvis-centred
-  :164-185  SPIN initial pose (B,24,6) / betas / camera  -> here: seeded synthetic "SPIN-init" batches
-            (the SPIN network, its checkpoint and Human3.6M are absent)
-  :187-199  camera pre-fit on the 2-D loss                 -> "next" row f1 (not in BASELINE configs 1-4)
+  :164-185  SPIN initial pose (B,24,6) / betas / camera     -> the dataset's pose / orient / betas tensors stand in for
+            the SPIN network's prediction (the network and its checkpoint are absent)
+  :187-199  camera pre-fit on the 2-D loss                 -> row f1 (`--reprojection`)
   :201-202  fresh Adam over [pose, orient, betas, cam], lr 1e-2
   :220-265  100 inner iterations                            -> ONE C-ABI call, jrr_refine_run
   :276-284  pose-discriminator update, Adam(lr=args.opt_disc_learning_rate)
   :286-293  shape-discriminator update
   :300-312  J_regressor step, Adam(lr=args.j_reg_lr)        -> + one RCCL all-reduce under data parallelism
-  :314-337  MPJPE / PA-MPJPE before and after the J step, logging
+  :314-337  MPJPE / PA-MPJPE before and after the J step, logging (all ten scalars of the reference's record)
 
 Data parallelism (new): one process per GPU, the batch is sharded contiguously, per-pose state is
 rank-local, the MSE means are normalised by the GLOBAL batch; the only collectives are one
-sum-all-reduce per shared-parameter step (J gradient; discriminator gradients).
+sum-all-reduce per shared-parameter step (J gradient; discriminator gradients) and the scalar sums of
+the log record.  Every rank draws the same global batch (same seed) and keeps rows [lo, hi), so a
+sharded run reproduces the single-process run on the same global batch.
 """
 from __future__ import annotations
 
 import time
-from typing import Dict, Optional
+from typing import Dict, Iterator
 
 import numpy as np
 import torch
@@ -45,15 +49,54 @@ class AdamState:
         _engine.adam_step(param, grad, self.m, self.v, self.step, self.lr)
 
 
+# ---- batch sources -----------------------------------------------------------------------------
+def pose_to_rot6d(orient: torch.Tensor, pose: torch.Tensor) -> torch.Tensor:
+    """Dataset pose tensors -> (B,24,6) 6-D rotations (x[2i+k] = R[i,k], scripts/utils.py:198-204).
+    Accepted: 6-D ((B,1,6)/(B,6) + (B,23,6)/(B,138)), rotation matrices ((B,1,3,3) + (B,23,3,3)) or
+    axis-angle ((B,3)/(B,1,3) + (B,69)/(B,23,3); converted by the HIP Rodrigues kernel)."""
+    B = pose.shape[0]
+    if pose.shape[-1] == 6 or pose.numel() == B * 138:
+        return torch.cat([orient.reshape(B, 1, 6), pose.reshape(B, 23, 6)], 1).float().contiguous()
+    if pose.numel() == B * 23 * 9:
+        R = torch.cat([orient.reshape(B, 1, 3, 3), pose.reshape(B, 23, 3, 3)], 1).float()
+    elif pose.numel() == B * 69:
+        aa = torch.cat([orient.reshape(B, 1, 3), pose.reshape(B, 23, 3)], 1).float().contiguous()
+        R = _engine.rodrigues_forward(aa.reshape(-1, 3)).view(B, 24, 3, 3)
+    else:
+        raise ValueError(f'unrecognised pose tensor shape {tuple(pose.shape)}')
+    return R[..., :, :2].reshape(B, 24, 6).contiguous()
+
+
+def _synthetic_batches(model_np, J_np, B_global: int, n: int, seed: int) -> Iterator[Dict[str, torch.Tensor]]:
+    for it in range(n):
+        full = smpl_model.synthetic_batch(model_np, J_np, B_global, seed=seed * 1000 + it)
+        yield {'pose6d': torch.from_numpy(full['pose6d']), 'betas': torch.from_numpy(full['betas']),
+               'gt_j3d': torch.from_numpy(full['gt_j3d']), 'cam': torch.from_numpy(full['cam']), 'seed': seed * 1000 + it}
+
+
+def _dataset_batches(root: str, B_global: int, seed: int, device) -> Iterator[Dict[str, torch.Tensor]]:
+    """scripts/optimize.py:132-137: DataLoader(data_set("validation"), batch_size, shuffle=True, drop_last=False)."""
+    from . import data as jdata
+    ds = jdata.data_set('validation', root=root)
+    g = torch.Generator().manual_seed(seed)          # every rank shuffles identically
+    loader = torch.utils.data.DataLoader(ds, batch_size=B_global, num_workers=0, shuffle=True, drop_last=False, generator=g)
+    for it, batch in enumerate(loader):
+        x6 = pose_to_rot6d(batch['orient'].to(device), batch['pose'].to(device)).cpu()
+        yield {'pose6d': x6, 'betas': batch['betas'].float(), 'gt_j3d': batch['gt_j3d'].float(), 'cam': batch['cam'].float(),
+               'gt_j2d': batch['gt_j2d'].float(), 'seed': seed * 1000 + it}
+
+
 def optimize_pose_refiner(log=print) -> Dict:
-    dist = jdist.init()
+    dist = jdist.init(args.dist_backend)
     rank, local_rank, world = jdist.env_rank_world()
-    device = torch.device(args.device if world == 1 else f'cuda:{local_rank}')
+    device = torch.device(args.device if (world == 1 or args.single_device) else f'cuda:{local_rank}')
     torch.cuda.set_device(device)
     utils.set_seed(args.seed)
 
-    smpl = SMPL(args.smpl_dir, batch_size=1).to(device)                                   # :96-99
-    J_regressor = torch.from_numpy(smpl_model.default_h36m_regressor(args.j_regressor_init)).float().to(device)   # :105-107
+    smpl = SMPL(args.smpl_dir, batch_size=1, allow_synthetic=args.synthetic or args.smpl_dir == 'SPIN/data/smpl').to(device)   # :96-99
+    J_np = smpl_model.default_h36m_regressor(args.j_regressor_init,
+                                             allow_default=args.synthetic or args.j_regressor_init == 'SPIN/data/J_regressor_h36m.npy')
+    J_regressor = torch.from_numpy(J_np).float().to(device)                                # :105-107
     j_reg_mask = utils.find_j_reg_mask(J_regressor)                                        # :130
 
     use_pd, use_sd = not args.no_pose_disc, bool(args.shape_disc)
@@ -65,24 +108,42 @@ def optimize_pose_refiner(log=print) -> Dict:
     sdisc_opt = AdamState(sdisc_flat, args.opt_disc_learning_rate)                        # :122-123
     J_opt = AdamState(J_regressor, args.j_reg_lr)                                          # :125-126
 
-    B_global = args.batch_size
-    lo, hi = jdist.shard_bounds(B_global, rank, world)
-    B = hi - lo
     flags = _engine.FLAG_KEEP_VERTS | (_engine.FLAG_POSE_DISC if use_pd else 0) | (_engine.FLAG_SHAPE_DISC if use_sd else 0) \
         | (_engine.FLAG_SILHOUETTE if args.silhouette else 0)
-    eng = _engine.RefineEngine(smpl.device_model, B, batch_norm=B_global, flags=flags)
-    eng.set_j_regressor(J_regressor, j_reg_mask)
-    if use_pd:
-        eng.set_pose_disc(disc_flat)
-    if use_sd:
-        eng.set_shape_disc(sdisc_flat)
+    engines: Dict = {}
+
+    def engine_for(B_local: int, B_global: int):
+        """one engine per shard size (the last batch of a dataset may be ragged: drop_last=False)"""
+        if B_local not in engines:
+            engines[B_local] = _engine.RefineEngine(smpl.device_model, B_local, batch_norm=B_global, flags=flags)
+        eng = engines[B_local]
+        eng.set_batch_norm(B_global)
+        eng.set_j_regressor(J_regressor, j_reg_mask)
+        if use_pd:
+            eng.set_pose_disc(disc_flat)
+        if use_sd:
+            eng.set_shape_disc(sdisc_flat)
+        return eng
+
+    if args.data_root:
+        source = _dataset_batches(args.data_root, args.batch_size, args.seed, device)
+    else:
+        source = _synthetic_batches(smpl.model_np, J_np, args.batch_size, args.synthetic_batches, args.seed)
 
     history = []
-    for it in range(args.synthetic_batches):                                               # :144-148
-        full = smpl_model.synthetic_batch(smpl.model_np, J_regressor.detach().cpu().numpy(), B_global, seed=args.seed * 1000 + it)
-        spin_pose = torch.from_numpy(full['pose6d'][lo:hi]).to(device).contiguous()        # :166-168 (synthetic SPIN-init)
-        spin_betas = torch.from_numpy(full['betas'][lo:hi]).to(device).contiguous()
-        gt_j3d = utils.move_pelvis(torch.from_numpy(full['gt_j3d'][lo:hi]).to(device)).contiguous()   # :162
+    x6d = betas = None
+    lo = hi = 0
+    for it, full in enumerate(source):                                                     # :144-148
+        B_global = int(full['pose6d'].shape[0])
+        lo, hi = jdist.shard_bounds(B_global, rank, world)
+        B = hi - lo
+        if B == 0:
+            raise RuntimeError(f'batch of {B_global} poses cannot be sharded over {world} ranks')
+        eng = engine_for(B, B_global)
+        spin_pose = full['pose6d'][lo:hi].to(device).float().contiguous()                   # :166-168,177-178
+        spin_betas = full['betas'][lo:hi].to(device).float().contiguous()
+        gt_mm = full['gt_j3d'][lo:hi].to(device).float().contiguous()
+        gt_j3d = utils.move_pelvis(gt_mm).contiguous()                                     # :162
         x6d = spin_pose.clone()                                                            # :177-179 pose + orient
         betas = spin_betas.clone()
         m = torch.zeros(B, 154, device=device)                                             # :201-202 fresh optimizer
@@ -90,15 +151,18 @@ def optimize_pose_refiner(log=print) -> Dict:
         step = torch.zeros(1, dtype=torch.int32, device=device)
         sq = torch.zeros(B, device=device)
 
-        # ---- camera pre-fit + 2-D term (:170-173,187-199,231-233; row f1) on synthetic 2-D targets ----
-        cam = torch.from_numpy(full['cam'][lo:hi]).to(device).contiguous()               # :170-172 pred_cam_t
+        # ---- camera pre-fit + 2-D term (:170-173,187-199,231-233; row f1) ----
+        cam = full['cam'][lo:hi].to(device).float().contiguous()                            # :170-172 pred_cam_t
         cam_m, cam_v = torch.zeros_like(cam), torch.zeros_like(cam)
         if args.reprojection:
-            gt_j2d = _synthetic_gt_j2d(eng, x6d, betas, cam, args.seed * 1000 + it)
+            if 'gt_j2d' in full:
+                gt_j2d = full['gt_j2d'][lo:hi].to(device).float().contiguous()
+            else:
+                gt_j2d = _synthetic_gt_j2d(eng, x6d, betas, cam, full['seed'], lo, hi, B_global)
             eng.camera_prefit(x6d, betas, gt_j2d, cam, n_steps=args.camera_iters, lr=1e-2)   # :187-199
             eng.set_reprojection(gt_j2d, cam, cam_m, cam_v)
         if args.silhouette:                                                                # :234-237 (row f2)
-            sil_mask = _synthetic_mask(eng, x6d, betas, cam, args.seed * 1000 + it)
+            sil_mask = _synthetic_mask(eng, x6d, betas, cam, full['seed'], lo, hi, B_global)
             eng.set_silhouette(sil_mask, cam, cam_m, cam_v)
 
         t0 = time.perf_counter()
@@ -110,6 +174,9 @@ def optimize_pose_refiner(log=print) -> Dict:
             if done % args.j_step_every == 0 and done < args.inner_iters:
                 _j_step(eng, J_regressor, J_opt, x6d, betas, gt_j3d, j_reg_mask)
         joint_loss = _global_mean(sq, B_global * 51)
+        pose_disc_sq, shape_disc_sq = eng.refine_aux_losses(use_pd, use_sd) if args.inner_iters > 0 else (None, None)
+        pose_discriminated_loss = _global_mean(pose_disc_sq, B_global * 25) if pose_disc_sq is not None else None   # :246-247
+        shape_discriminated_loss = _global_mean(shape_disc_sq, B_global) if shape_disc_sq is not None else None    # :249-250
         if args.reprojection:
             eng.set_reprojection(None)
         if args.silhouette:
@@ -140,14 +207,15 @@ def optimize_pose_refiner(log=print) -> Dict:
         joints_before = eng.find_joints_forward(betas, x6d=x6d)
         j_err = _j_step(eng, J_regressor, J_opt, x6d, betas, gt_j3d, j_reg_mask)
         joints_after = eng.find_joints_forward(betas, x6d=x6d)
-        gt_mm = torch.from_numpy(full['gt_j3d'][lo:hi]).to(device)
-        mpjpe_b, pampjpe_b = utils.evaluate(joints_before, gt_mm)
-        mpjpe_a, pampjpe_a = utils.evaluate(joints_after, gt_mm)
+        mpjpe_b, pampjpe_b = _global_evaluate(joints_before, gt_mm, B_global)
+        mpjpe_a, pampjpe_a = _global_evaluate(joints_after, gt_mm, B_global)
         torch.cuda.synchronize()
-        rec = {'batch': it, 'joint_loss': joint_loss, 'pose_discriminator_loss': pose_d_loss,
-               'shape_discriminator_loss': shape_d_loss, 'j_regressor_error': j_err, 'mpjpe': float(mpjpe_a),
-               'pampjpe': float(pampjpe_a), 'mpjpe difference': float(mpjpe_b - mpjpe_a),
-               'pampjpe difference': float(pampjpe_b - pampjpe_a), 'seconds': time.perf_counter() - t0}
+        rec = {'batch': it, 'joint_loss': joint_loss, 'pose_discriminated_loss': pose_discriminated_loss,
+               'shape_discriminated_loss': shape_discriminated_loss, 'pose_discriminator_loss': pose_d_loss,
+               'shape_discriminator_loss': shape_d_loss, 'j_regressor_error': j_err, 'mpjpe': mpjpe_a,
+               'pampjpe': pampjpe_a, 'mpjpe difference': mpjpe_b - mpjpe_a,
+               'pampjpe difference': pampjpe_b - pampjpe_a, 'seconds': time.perf_counter() - t0,
+               'body_model': smpl.provenance, 'data': 'dataset' if args.data_root else 'synthetic'}
         history.append(rec)
         if rank == 0:
             log(rec)                                                                        # :323-337 (wandb.log analogue)
@@ -160,27 +228,30 @@ def optimize_pose_refiner(log=print) -> Dict:
 
     if args.save_j_regressor and rank == 0:
         checkpoint.save_j_regressor(J_regressor, args.save_j_regressor)
-    return {'history': history, 'J_regressor': J_regressor, 'disc_flat': disc_flat}
+    return {'history': history, 'J_regressor': J_regressor, 'disc_flat': disc_flat, 'sdisc_flat': sdisc_flat,
+            'x6d': x6d, 'betas': betas, 'shard': (lo, hi)}
 
 
-def _synthetic_gt_j2d(eng, x6d, betas, cam, seed):
+def _synthetic_gt_j2d(eng, x6d, betas, cam, seed, lo, hi, B_global):
     """2-D targets in the 224-crop pixel frame (scripts/data.py:134-138): the current joints seen through a
-    perturbed camera, plus pixel noise (stand-in for the H36M annotations)."""
+    perturbed camera, plus pixel noise (stand-in for the H36M annotations).  The noise is drawn for the GLOBAL
+    batch and sliced, so a sharded run sees the same targets as the single-process run."""
     from . import renderer
     g = torch.Generator().manual_seed(seed)
     joints = eng.find_joints_forward(betas, x6d=x6d)
-    B = joints.shape[0]
-    cam_true = cam + (torch.randn(B, 3, generator=g) * torch.tensor([0.3, 0.3, 3.0])).to(cam.device)
-    p = renderer.project_points(joints, cam_true)[..., :2]
-    return (p + (torch.randn(B, 17, 2, generator=g) * 2.0).to(cam.device)).contiguous()
+    dcam = (torch.randn(B_global, 3, generator=g) * torch.tensor([0.3, 0.3, 3.0]))[lo:hi]
+    noise = (torch.randn(B_global, 17, 2, generator=g) * 2.0)[lo:hi]
+    p = renderer.project_points(joints, cam + dcam.to(cam.device))[..., :2]
+    return (p + noise.to(cam.device)).contiguous()
 
 
-def _synthetic_mask(eng, x6d, betas, cam, seed):
+def _synthetic_mask(eng, x6d, betas, cam, seed, lo, hi, B_global):
     """Target silhouettes (stand-in for batch['mask_rcnn'], scripts/data.py): the current mesh seen through a
     perturbed camera, binarised."""
     g = torch.Generator().manual_seed(seed + 7)
     _, verts = eng.find_joints_forward(betas, x6d=x6d, return_verts=True)
-    cam_true = (cam + (torch.randn(cam.shape[0], 3, generator=g) * torch.tensor([0.2, 0.2, 2.0])).to(cam.device)).contiguous()
+    dcam = (torch.randn(B_global, 3, generator=g) * torch.tensor([0.2, 0.2, 2.0]))[lo:hi]
+    cam_true = (cam + dcam.to(cam.device)).contiguous()
     return (eng.silhouette_forward(verts, cam_true) > 0).float().contiguous()
 
 
@@ -188,6 +259,14 @@ def _global_mean(local_sum_tensor: torch.Tensor, denom: int) -> float:
     t = local_sum_tensor.sum().reshape(1).clone()
     jdist.all_reduce_sum_(t)
     return float(t.item()) / denom
+
+
+def _global_evaluate(joints: torch.Tensor, gt_mm: torch.Tensor, B_global: int):
+    """utils.evaluate over the GLOBAL batch: per-pose errors are summed locally, all-reduced, divided by B_global."""
+    e, e_pa = utils.evaluate_sums(joints, gt_mm)
+    t = torch.stack([e, e_pa]).clone()
+    jdist.all_reduce_sum_(t)
+    return float(t[0].item()) * 1000 / B_global, float(t[1].item()) * 1000 / B_global
 
 
 def _j_step(eng, J_regressor, J_opt, x6d, betas, gt_j3d, mask) -> float:
@@ -198,4 +277,4 @@ def _j_step(eng, J_regressor, J_opt, x6d, betas, gt_j3d, mask) -> float:
     jdist.all_reduce_sum_(dJ)
     J_opt.apply(J_regressor, dJ)
     eng.set_j_regressor(J_regressor, mask)
-    return _global_mean(sq, eng.info['batch_norm'] * 51)
+    return _global_mean(sq, eng.batch_norm * 51)

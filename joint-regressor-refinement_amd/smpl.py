@@ -31,22 +31,46 @@ class _SMPLVerticesFn(torch.autograd.Function):
     def forward(ctx, R, betas, eng):
         R, betas = R.detach().contiguous(), betas.detach().contiguous()
         _, verts = eng.find_joints_forward(betas, R=R, return_verts=True)
-        ctx.eng = eng
+        ctx.eng, ctx.gen = eng, eng.generation
         ctx.save_for_backward(R, betas)
         return verts
 
     @staticmethod
     def backward(ctx, dverts):
         R, betas = ctx.saved_tensors
-        dR, db = ctx.eng.smpl_vertices_backward(betas, dverts.contiguous(), R=R)
+        eng = ctx.eng
+        if eng.generation != ctx.gen:          # engine state overwritten by a later forward: re-run this one
+            eng.find_joints_forward(betas, R=R)
+            ctx.gen = eng.generation
+        dR, db = eng.smpl_vertices_backward(betas, dverts.contiguous(), R=R)
         return dR, db, None
+
+
+class _RodriguesFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, aa):
+        aa = aa.detach().contiguous().float()
+        ctx.save_for_backward(aa)
+        return _engine.rodrigues_forward(aa)
+
+    @staticmethod
+    def backward(ctx, dR):
+        (aa,) = ctx.saved_tensors
+        return _engine.rodrigues_backward(aa, dR.contiguous()).view_as(aa)
+
+
+def batch_rodrigues(rot_vecs: torch.Tensor) -> torch.Tensor:
+    """smplx lbs.batch_rodrigues on the HIP kernel: (N,3) axis-angle -> (N,3,3), differentiable."""
+    return _RodriguesFn.apply(rot_vecs.reshape(-1, 3))
 
 
 class SMPL:
     """smpl = SMPL(model_dir, batch_size=1).to(device)"""
 
-    def __init__(self, model_path: Optional[str] = None, batch_size: int = 1, model: Optional[Dict] = None, **_):
-        self.model_np = model if model is not None else _smpl_model.load_smpl_model(model_path)
+    def __init__(self, model_path: Optional[str] = None, batch_size: int = 1, model: Optional[Dict] = None,
+                 allow_synthetic: bool = True, **_):
+        self.model_np = model if model is not None else _smpl_model.load_smpl_model(model_path, allow_synthetic)
+        self.provenance = str(self.model_np.get('provenance', 'caller-supplied arrays'))
         self.faces = self.model_np.get('faces')
         self.device = None
         self.device_model = None
@@ -62,7 +86,7 @@ class SMPL:
             self._engines = {}
         return self
 
-    def engine(self, batch: int, flags: int = 0) -> '_engine.RefineEngine':
+    def engine(self, batch: int, flags: int = _engine.FLAG_KEEP_VERTS) -> '_engine.RefineEngine':
         if self.device_model is None:
             self.to('cuda:0')
         key = (batch, flags)
@@ -72,12 +96,16 @@ class SMPL:
             self._engines[key] = eng
         return self._engines[key]
 
-    def __call__(self, global_orient=None, body_pose=None, betas=None, pose2rot=False, **_):
-        if pose2rot:
-            raise NotImplementedError('the reference passes rotation matrices (pose2rot=False) on this path; '
-                                      'convert 6-D rotations with utils.rot6d_to_rotmat')
+    def __call__(self, global_orient=None, body_pose=None, betas=None, pose2rot=True, **_):
+        """smplx.SMPL.forward's signature and default: pose2rot=True takes axis-angle global_orient (B,3) and
+        body_pose (B,69) and converts them with batch_rodrigues (HIP kernel); the reference's hot path passes
+        rotation matrices with pose2rot=False (scripts/utils.py:94-95)."""
         B = betas.shape[0]
-        R = torch.cat([global_orient.reshape(B, 1, 3, 3), body_pose.reshape(B, 23, 3, 3)], dim=1).float()
-        eng = self.engine(B, _engine.FLAG_KEEP_VERTS)
+        if pose2rot:
+            aa = torch.cat([global_orient.reshape(B, 1, 3), body_pose.reshape(B, 23, 3)], dim=1).float()
+            R = batch_rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3)
+        else:
+            R = torch.cat([global_orient.reshape(B, 1, 3, 3), body_pose.reshape(B, 23, 3, 3)], dim=1).float()
+        eng = self.engine(B)
         verts = _SMPLVerticesFn.apply(R, betas.float(), eng)
         return SMPLOutput(verts, global_orient, body_pose, betas)

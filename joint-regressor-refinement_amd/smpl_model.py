@@ -114,9 +114,12 @@ def synthetic_smpl(seed: int = 1234, max_influences: int = 4) -> Dict[str, np.nd
                 lbs_weights=W.astype(np.float32), parents=SMPL_PARENTS.copy(), faces=faces)
 
 
-def load_smpl_model(model_dir: Optional[str]) -> Dict[str, np.ndarray]:
+def load_smpl_model(model_dir: Optional[str], allow_synthetic: bool = True) -> Dict[str, np.ndarray]:
     """Load a real SMPL model if the user supplies one (`<dir>/SMPL_NEUTRAL.pkl` or `.npz`, the
-    layout smplx expects at scripts/optimize.py:96-99); otherwise return the synthetic model."""
+    layout smplx expects at scripts/optimize.py:96-99).  If no model file is found: the seeded synthetic
+    model WITH a prominent warning when `allow_synthetic`, otherwise FileNotFoundError (a mistyped
+    --smpl_dir must not silently train a regressor on a fake body).  The returned dict carries
+    `provenance` ('file:<path>' or 'synthetic(seed=1234)')."""
     if model_dir:
         for name in ('SMPL_NEUTRAL.npz', 'SMPL_NEUTRAL.pkl', 'smpl_neutral.npz'):
             path = os.path.join(model_dir, name)
@@ -140,8 +143,16 @@ def load_smpl_model(model_dir: Optional[str]) -> Dict[str, np.ndarray]:
             return dict(v_template=np.asarray(d['v_template'], dtype=np.float32), shapedirs=shapedirs,
                         posedirs=np.ascontiguousarray(posedirs), J_regressor=Jr,
                         lbs_weights=np.asarray(d['weights'], dtype=np.float32), parents=parents,
-                        faces=np.asarray(d['f'], dtype=np.int32))
-    return synthetic_smpl()
+                        faces=np.asarray(d['f'], dtype=np.int32), provenance=f'file:{path}')
+        if not allow_synthetic:
+            raise FileNotFoundError(f'no SMPL_NEUTRAL.{{npz,pkl}} under {model_dir!r}; pass --synthetic to run on the '
+                                    f'seeded synthetic body model instead')
+        import warnings
+        warnings.warn(f'SMPL model not found under {model_dir!r}: using the SYNTHETIC body model (seed 1234). '
+                      f'A J_regressor trained on it is not a SMPL regressor.', RuntimeWarning, stacklevel=2)
+    m = synthetic_smpl()
+    m['provenance'] = 'synthetic(seed=1234)'
+    return m
 
 
 # The 107 non-zero entries of the shipped /root/reference/models/retrained_J_Regressor.pt are the
@@ -154,11 +165,18 @@ def j_regressor_from_triplets(rows, cols, vals) -> np.ndarray:
     return J
 
 
-def default_h36m_regressor(path: Optional[str] = None) -> np.ndarray:
+def default_h36m_regressor(path: Optional[str] = None, allow_default: bool = True) -> np.ndarray:
     """H36M regressor initialisation (scripts/optimize.py:105-107): `SPIN/data/J_regressor_h36m.npy`
-    if the user supplies it, else the 107 non-zeros of the shipped checkpoint (assets/)."""
+    if the user supplies it, else (with a warning, or FileNotFoundError when `allow_default` is False)
+    the 107 non-zeros of the shipped checkpoint (assets/)."""
     if path and os.path.exists(path):
         return np.load(path).astype(np.float32)
+    if path:
+        if not allow_default:
+            raise FileNotFoundError(f'{path!r} not found; pass --synthetic to start from the shipped checkpoint\'s support')
+        import warnings
+        warnings.warn(f'{path!r} not found: initialising the H36M regressor from the 107 non-zeros of the shipped checkpoint',
+                      RuntimeWarning, stacklevel=2)
     t = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), 'assets', 'j_regressor_h36m_init.npz'))
     return j_regressor_from_triplets(t['rows'], t['cols'], t['vals'])
 
@@ -198,9 +216,13 @@ def synthetic_batch(model: Dict[str, np.ndarray], J_h36m: np.ndarray, B: int, se
     Jn = np.maximum(J_h36m.astype(np.float64), 0)
     Jn = Jn / Jn.sum(1, keepdims=True)
     gt = np.empty((B, NUM_H36M, 3))
+    cols = np.nonzero(Jn.any(axis=0))[0]          # only the regressor's support vertices need skinning
+    if len(cols) > NUM_VERTS // 2:
+        cols = None
+    Jc = Jn if cols is None else Jn[:, cols]
     for s in range(0, B, 256):
-        verts = _lbs_np(model, R_gt[s:s + 256], betas[s:s + 256])
-        j = np.einsum('iv,bvc->bic', Jn, verts)
+        verts = _lbs_np(model, R_gt[s:s + 256], betas[s:s + 256], cols)
+        j = np.einsum('iv,bvc->bic', Jc, verts)
         gt[s:s + 256] = (j - j[:, :1]) * 1000.0
     gt = gt + rng.normal(0.0, 10.0, size=gt.shape)
     gt = gt - gt[:, :1]
@@ -219,14 +241,21 @@ def _rodrigues_np(aa: np.ndarray) -> np.ndarray:
     return np.eye(3)[None] + s * K + (1 - c) * (K @ K)
 
 
-def _lbs_np(model, R, betas):
-    """float64 numpy LBS used only to synthesise ground-truth joints for benchmark batches."""
+def _lbs_np(model, R, betas, cols=None):
+    """float64 numpy LBS used only to synthesise ground-truth joints for benchmark batches; `cols` restricts the
+    skinned vertices (the rest joints always use every vertex)."""
     B = R.shape[0]
     vt = model['v_template'].astype(np.float64)
     v_shaped = vt[None] + np.einsum('bl,vkl->bvk', betas, model['shapedirs'].astype(np.float64))
     J = np.einsum('jv,bvk->bjk', model['J_regressor'].astype(np.float64), v_shaped)
     pf = (R[:, 1:] - np.eye(3)).reshape(B, -1)
-    v_posed = v_shaped + (pf @ model['posedirs'].astype(np.float64)).reshape(B, -1, 3)
+    pd = model['posedirs'].astype(np.float64)
+    W = model['lbs_weights'].astype(np.float64)
+    if cols is not None:
+        v_shaped = v_shaped[:, cols]
+        pd = pd.reshape(pd.shape[0], -1, 3)[:, cols].reshape(pd.shape[0], -1)
+        W = W[cols]
+    v_posed = v_shaped + (pf @ pd).reshape(B, -1, 3)
     parents = model['parents']
     G_R = np.empty((B, NUM_JOINTS, 3, 3))
     G_t = np.empty((B, NUM_JOINTS, 3))
@@ -236,7 +265,6 @@ def _lbs_np(model, R, betas):
         G_R[:, i] = G_R[:, p] @ R[:, i]
         G_t[:, i] = np.einsum('brc,bc->br', G_R[:, p], J[:, i] - J[:, p]) + G_t[:, p]
     A_t = G_t - np.einsum('bjrc,bjc->bjr', G_R, J)
-    W = model['lbs_weights'].astype(np.float64)
     T_R = np.einsum('vj,bjrc->bvrc', W, G_R)
     T_t = np.einsum('vj,bjr->bvr', W, A_t)
     return np.einsum('bvrc,bvc->bvr', T_R, v_posed) + T_t

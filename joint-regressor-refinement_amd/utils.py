@@ -37,20 +37,33 @@ def rot6d_to_rotmat(x: torch.Tensor) -> torch.Tensor:
 
 
 class _FindJointsFn(torch.autograd.Function):
+    """The adjoint kernels read the engine's state of the most recent forward; autograd defers backward, so the
+    forward generation is saved and, if another call has used the engine since, the forward is re-run from the
+    saved inputs (and the saved J / mask) before the adjoint."""
+
     @staticmethod
     def forward(ctx, R, betas, J, mask, eng):
         R, betas = R.detach().contiguous(), betas.detach().contiguous()
-        eng.set_j_regressor(J.detach(), None if mask is None else mask.detach())
+        Jd = J.detach().clone()
+        md = None if mask is None else mask.detach().clone()
+        eng.set_j_regressor(Jd, md)
         joints = eng.find_joints_forward(betas, R=R)
-        ctx.eng = eng
+        ctx.eng, ctx.gen = eng, eng.generation
         ctx.need_dJ = J.requires_grad
-        ctx.save_for_backward(R, betas)
+        ctx.has_mask = md is not None
+        ctx.save_for_backward(R, betas, Jd, *([md] if md is not None else []))
         return joints
 
     @staticmethod
     def backward(ctx, dj):
-        R, betas = ctx.saved_tensors
-        dR, db, dJ = ctx.eng.find_joints_backward(betas, dj.contiguous(), R=R, want_dJ=ctx.need_dJ)
+        R, betas, Jd = ctx.saved_tensors[:3]
+        md = ctx.saved_tensors[3] if ctx.has_mask else None
+        eng = ctx.eng
+        if eng.generation != ctx.gen:          # the engine has been used since: restore this call's forward state
+            eng.set_j_regressor(Jd, md)
+            eng.find_joints_forward(betas, R=R)
+            ctx.gen = eng.generation
+        dR, db, dJ = eng.find_joints_backward(betas, dj.contiguous(), R=R, want_dJ=ctx.need_dJ)
         return dR, db, dJ, None, None
 
 
@@ -66,8 +79,8 @@ def find_joints(smpl, shape, orient, pose, J_regressor, mask=None, return_verts=
         return torch.matmul(Jn[None].expand(verts.shape[0], -1, -1), verts), verts
     B = shape.shape[0]
     R = torch.cat([orient.reshape(B, 1, 3, 3), pose.reshape(B, 23, 3, 3)], dim=1).float()
-    flags = _engine.FLAG_KEEP_VERTS if J_regressor.requires_grad else 0
-    eng = smpl.engine(B, flags)
+    eng = smpl.engine(B)      # one engine per batch size, shared with smpl(...): the generation counter keeps deferred
+    #                           backward passes correct when several forwards interleave
     return _FindJointsFn.apply(R, shape.float(), J_regressor, mask, eng)
 
 
@@ -88,6 +101,14 @@ def evaluate(pred_j3ds: torch.Tensor, target_j3ds: torch.Tensor):
     with torch.no_grad():
         err, err_pa = _engine.evaluate(pred_j3ds.detach().float(), target_j3ds.detach().float())
         return float(err.mean().item()) * 1000, float(err_pa.mean().item()) * 1000
+
+
+def evaluate_sums(pred_j3ds: torch.Tensor, target_j3ds: torch.Tensor):
+    """Sums over the batch of the per-pose joint error and PA joint error in METRES (device tensors): the pieces a
+    data-parallel run all-reduces before dividing by the global batch."""
+    with torch.no_grad():
+        err, err_pa = _engine.evaluate(pred_j3ds.detach().float(), target_j3ds.detach().float())
+        return err.sum(), err_pa.sum()
 
 
 def set_seed(seed: int):

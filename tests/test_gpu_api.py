@@ -181,7 +181,7 @@ def test_optimize_pose_refiner_outer_step_matches_oracle(smpl_model_np, j_h36m_n
     ckpt = str(tmp_path / 'J.pt')
     argsmod._LazyArgs._ns = argsmod.get_args(['--batch_size', str(B), '--synthetic_batches', '1', '--inner_iters', str(n_inner),
                                                '--shape_disc', '--device', DEV, '--save_j_regressor', ckpt,
-                                               '--smpl_dir', '/nonexistent', '--j_regressor_init', '/nonexistent'])
+                                               '--smpl_dir', '/nonexistent', '--j_regressor_init', '/nonexistent', '--synthetic'])
     opt = _mod('optimize')
     torch.manual_seed(0)
     res = opt.optimize_pose_refiner(log=lambda r: None)
@@ -311,7 +311,7 @@ def test_silhouette_forward_backward(smpl_hip, smpl_model_np, j_h36m_np):
     assert num.item() < 2e-2
     # module-level interface (scripts/mesh_renderer.py): (B,4,H,W), alpha in channel 3
     mr = _mod('mesh_renderer')
-    out = mr.Mesh_Renderer(224, smpl_hip)({'cam': cam.to(DEV)}, verts.to(DEV))
+    out = mr.Mesh_Renderer(224, smpl_hip)({"cam": cam.to(DEV)}, (verts * torch.tensor([-2.0, -2.0, 2.0])).to(DEV))
     assert out.shape == (B, 4, 224, 224) and torch.equal(out[:, 3], alpha)
 
 

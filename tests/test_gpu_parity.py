@@ -420,3 +420,143 @@ def test_folded_mode_matches_dense_and_oracle(eng_mod, dmodel, smpl_model_np, j_
         assert (res[mode][1] - b).abs().max().item() < 3e-4, mode
         np.testing.assert_allclose(float(res[mode][2].sum()) / (B * 51), hist[-1]['joint_loss'], rtol=2e-3)
     assert (res['dense'][0] - res['folded'][0]).abs().max().item() < 3e-4
+
+
+# ---- round 2: the benchmarked configuration at its own size, config 2's geometry, KATs on the kernels ------------
+def test_full_size_pose_disc_parity(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    """BASELINE configs[2] at B = 4096 WITH the pose discriminator (what bench.py times): discriminator GEMMs at
+    N = 4096, k_disc_out / k_disc_conv_* over 64 pose groups, and the fused loop against 512-pose engines and the
+    oracle on a strided subset (scripts/optimize.py:241-253)."""
+    import importlib as _il
+    sm = _il.import_module(PKG_NAME + '.smpl_model')
+    B, Bs = 4096, 512
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=78)
+    x = T(batch['pose6d']).to(DEV).contiguous(); b = T(batch['betas']).to(DEV).contiguous()
+    gt = T(batch['gt_j3d']); gt = (gt - gt[:, :1]).to(DEV).contiguous()
+    dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+    flat = eng_mod.flatten_state_dict(dsd, eng_mod.DISC_KEYS)
+    big = eng_mod.RefineEngine(dmodel, B, flags=eng_mod.FLAG_POSE_DISC)
+    big.set_j_regressor(T(j_h36m_np)); big.set_pose_disc(flat)
+    small = eng_mod.RefineEngine(dmodel, Bs, batch_norm=B, flags=eng_mod.FLAG_POSE_DISC)
+    small.set_j_regressor(T(j_h36m_np)); small.set_pose_disc(flat)
+    # forward + input gradient vs the oracle on every 129th pose (weight 10, target 1, mean over B*25)
+    out = big.pose_disc_forward(x)
+    dx = big.pose_disc_backward_input(x, 10.0, 1.0)
+    idx = torch.arange(0, B, 129)
+    xr = x[idx].cpu().clone().requires_grad_(True)
+    ref = oracle.discriminator_forward(dsd, xr)
+    np.testing.assert_allclose(out[idx].cpu().numpy(), ref.detach().numpy()[:, :, 0], rtol=0, atol=3e-6)
+    (((ref - 1) ** 2).sum() / (B * 25) * 10.0).backward()
+    assert ((dx[idx].cpu() - xr.grad).abs().max() / xr.grad.abs().max()).item() < 5e-4
+    # against the 512-pose engines (different GEMM grid: 8 instead of 64 column tiles)
+    for k in (0, 3, B // Bs - 1):
+        sl = slice(k * Bs, (k + 1) * Bs)
+        outs = small.pose_disc_forward(x[sl].contiguous())
+        dxs = small.pose_disc_backward_input(x[sl].contiguous(), 10.0, 1.0)
+        assert torch.equal(out[sl], outs)                # per-pose columns: identical arithmetic in every geometry
+        assert torch.equal(dx[sl], dxs)
+    # the fused loop with the adversarial term: big engine vs shards, 3 iterations
+    xb, bb = x.clone(), b.clone()
+    m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    sq = torch.zeros(B, device=DEV)
+    big.refine_run(xb, bb, gt, m, v, step, 1e-2, 3, sqerr=sq)
+    for k in (0, B // Bs - 1):
+        sl = slice(k * Bs, (k + 1) * Bs)
+        xs, bs_ = x[sl].clone().contiguous(), b[sl].clone().contiguous()
+        ms, vs_ = torch.zeros(Bs, 154, device=DEV), torch.zeros(Bs, 154, device=DEV)
+        st = torch.zeros(1, dtype=torch.int32, device=DEV)
+        small.refine_run(xs, bs_, gt[sl].contiguous(), ms, vs_, st, 1e-2, 3)
+        assert (xb[sl] - xs).abs().max().item() < 2e-4
+        assert (bb[sl] - bs_).abs().max().item() < 2e-4
+    # and vs the oracle's own 3 iterations on a strided subset (batch_norm = 4096)
+    idx2 = torch.arange(5, B, 341)
+    o, p, bo, hist = oracle.refine_poses(oracle.OracleSMPL(smpl_model_np), T(j_h36m_np), x[idx2, :1].cpu(), x[idx2, 1:].cpu(),
+                                         b[idx2].cpu(), gt[idx2].cpu(), 3, disc_sd=dsd, batch_norm=B)
+    assert (xb[idx2].cpu() - torch.cat([o, p], 1)).abs().max().item() < 3e-4
+    assert (bb[idx2].cpu() - bo).abs().max().item() < 3e-4
+
+
+def test_full_size_pose_disc_weight_gradients(eng_mod, dmodel):
+    """jrr_pose_disc_backward_params at B = 4096: the pose-split weight-gradient GEMMs with wsplit = 8 (only reached at
+    BP >= 4096) and 64 conv slabs, vs the oracle's autograd on the full batch (scripts/optimize.py:276-284)."""
+    B = 4096
+    dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+    flat = eng_mod.flatten_state_dict(dsd, eng_mod.DISC_KEYS)
+    gen = torch.Generator().manual_seed(14)
+    xo, xs = torch.randn(B, 24, 6, generator=gen) * 0.6, torch.randn(B, 24, 6, generator=gen) * 0.6
+    eng = eng_mod.RefineEngine(dmodel, B, flags=eng_mod.FLAG_POSE_DISC)
+    eng.set_pose_disc(flat)
+    dP = torch.zeros(eng_mod.DISC_PARAMS, device=DEV)
+    l0 = eng.pose_disc_backward_params(xo.to(DEV), 0.0, dP)
+    l1 = eng.pose_disc_backward_params(xs.to(DEV), 1.0, dP)
+    loss, ref = oracle.discriminator_update_loss_and_grads(dsd, xo, xs)
+    np.testing.assert_allclose(float((l0 + l1).sum()) / (B * 25), float(loss), rtol=1e-5)
+    got = eng_mod.unflatten_state_dict(dP.cpu(), dsd, eng_mod.DISC_KEYS)
+    for k in eng_mod.DISC_KEYS:
+        err = ((got[k].double() - ref[k].double()).abs().max() / ref[k].abs().max().clamp_min(1e-30)).item()
+        assert err < 1e-3, (k, err)
+
+
+def test_config2_geometry_b1024(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    """BASELINE configs[1]: batch 1024, joint loss only -- its own launch geometry (8 pose groups; pick_chunks(8, 54)),
+    3 iterations vs the oracle on the FULL batch and vs 512-pose engines."""
+    import importlib as _il
+    sm = _il.import_module(PKG_NAME + '.smpl_model')
+    B, n = 1024, 3
+    r = _run_refine(eng_mod, dmodel, smpl_model_np, j_h36m_np, B, 33, n, False, False)
+    o, p, bo, hist = oracle.refine_poses(oracle.OracleSMPL(smpl_model_np), T(j_h36m_np), r['x6d'][:, :1], r['x6d'][:, 1:],
+                                         r['betas'], r['gt_c'], n)
+    assert (r['xd'] - torch.cat([o, p], 1)).abs().max().item() < 3e-4
+    assert (r['bd'] - bo).abs().max().item() < 3e-4
+    np.testing.assert_allclose(float(r['sq'].sum()) / (B * 51), hist[-1]['joint_loss'], rtol=2e-3)
+    eng = eng_mod.RefineEngine(dmodel, B)
+    info = eng.info
+    assert info['BP'] == 1024 and info['nvc'] * (B // 128) >= 256
+    eng.set_j_regressor(T(j_h36m_np))
+    joints = eng.find_joints_forward(r['bd'].to(DEV), x6d=r['xd'].to(DEV).contiguous())
+    ref_j = _oracle_joints(smpl_model_np, T(j_h36m_np), torch.cat([o, p], 1), bo)
+    assert (joints.cpu().double() - ref_j).abs().max().item() < 1e-4          # north_star bar
+
+
+def test_kat_k3_k4_k5_on_the_kernels(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    """The known-answer tests that pin the (parity-unpinned) LBS restatement, asserted on the HIP kernels themselves:
+    K3 shape-only linearity, K4 a child rotation leaves zero-weight vertices untouched, K5 translation equivariance."""
+    B = 130
+    gen = torch.Generator().manual_seed(2)
+    ident6 = torch.tensor([1., 0., 0., 1., 0., 0.]).repeat(B, 24, 1)
+    vt, sd = T(smpl_model_np['v_template']).double(), T(smpl_model_np['shapedirs']).double()
+    eng = eng_mod.RefineEngine(dmodel, B, flags=eng_mod.FLAG_KEEP_VERTS)
+    eng.set_j_regressor(T(j_h36m_np))
+    # K3: identity rotations, random betas -> verts = v_template + S beta ; joints = Jn verts
+    betas = torch.randn(B, 10, generator=gen)
+    joints, verts = eng.find_joints_forward(betas.to(DEV), x6d=ident6.to(DEV).contiguous(), return_verts=True)
+    expect = vt[None] + torch.einsum('bl,vkl->bvk', betas.double(), sd)
+    assert (verts.cpu().double() - expect).abs().max().item() < 3e-6
+    Jn = oracle.normalize_j_regressor(T(j_h36m_np).double())
+    assert (joints.cpu().double() - Jn @ expect).abs().max().item() < 3e-6
+    # K4: posedirs = 0, rotate joint 18 only: vertices with no weight on {18, 20, 22} stay at the template
+    m4 = dict(smpl_model_np); m4['posedirs'] = np.zeros_like(smpl_model_np['posedirs'])
+    dm4 = eng_mod.DeviceModel(m4, DEV)
+    e4 = eng_mod.RefineEngine(dm4, B, flags=eng_mod.FLAG_KEEP_VERTS)
+    e4.set_j_regressor(T(j_h36m_np))
+    x6 = ident6.clone()
+    R18 = oracle.rodrigues(torch.randn(B, 3, generator=gen))
+    x6[:, 18] = R18[:, :, :2].reshape(B, 6)
+    _, v4 = e4.find_joints_forward(torch.zeros(B, 10, device=DEV), x6d=x6.to(DEV).contiguous(), return_verts=True)
+    sub = T(smpl_model_np['lbs_weights'])[:, [18, 20, 22]].sum(1)
+    fixed = sub == 0
+    assert fixed.sum() > 1000 and (~fixed).sum() > 10
+    assert (v4[:, fixed.to(DEV)].cpu().double() - vt[fixed][None]).abs().max().item() < 2e-6
+    assert (v4[:, (~fixed).to(DEV)].cpu().double() - vt[~fixed][None]).abs().max().item() > 1e-3
+    # K5: shifting the template by t shifts every posed vertex by t (rows of W and of J_regressor sum to 1)
+    t = torch.tensor([0.3, -0.2, 0.5])
+    m5 = dict(smpl_model_np); m5['v_template'] = (T(smpl_model_np['v_template']) + t).numpy()
+    dm5 = eng_mod.DeviceModel(m5, DEV)
+    e5 = eng_mod.RefineEngine(dm5, B, flags=eng_mod.FLAG_KEEP_VERTS)
+    e5.set_j_regressor(T(j_h36m_np))
+    batch = _batch(smpl_model_np, j_h36m_np, B, seed=19)
+    xr, zb = T(batch['pose6d']).to(DEV).contiguous(), torch.zeros(B, 10, device=DEV)
+    _, v1 = eng.find_joints_forward(zb, x6d=xr, return_verts=True)
+    _, v2 = e5.find_joints_forward(zb, x6d=xr, return_verts=True)
+    assert (v2 - v1 - t.to(DEV)).abs().max().item() < 5e-6
