@@ -13,9 +13,11 @@ fused Adam -- all through the C ABI (include/jrr.h) on device-resident synthetic
 N > 1 is weak scaling: every rank owns 4096 poses (global batch 4096*N), the MSE means are
 normalised by the GLOBAL batch, and the shared J_regressor is stepped every --j_step_every inner
 iterations (reference cadence 100, scripts/optimize.py:300-312) with ONE RCCL all-reduce on its
-gradient.  After the timed region the J step is also timed at cadence 1 (BASELINE configs[3]
-"all-reduce each step") and reported under "j_step".  `value` = batch-4096 iterations per second
-summed over ranks.
+gradient.  A timed region is EXACTLY --steps iterations between barrier + synchronize pairs; it is
+repeated until >= ~0.3 s of device time has been timed and the MEDIAN region is reported (every
+region's time is listed under `repeat_ms_per_step`).  Reported separately, never part of `value`:
+`cadence1` (J step + all-reduce after EVERY iteration: BASELINE configs[3] "each step"), the
+pose-discriminator update, the folded-regressor mode, BASELINE configs[4] (`config5`), the CPU baseline.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with `roofline` and `cpu_baseline`.
 """
@@ -23,6 +25,7 @@ import argparse
 import importlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,11 +36,14 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 PKG = 'joint-regressor-refinement_amd'
 
-# dense algorithmic FLOP per pose of ONE launch of the dominant kernel
-# (k_lbs_fwd = shape blend + pose blend + skinning blend (12 affine entries) + skinning apply +
-# H36M regressor product).  The rest-joint regression (992 160 FLOP in the survey's table) is
-# folded into a (24x3)x10 table at model upload and is NOT counted.
+# dense algorithmic FLOP per pose of ONE launch of each MFMA kernel.
+# k_lbs_fwd = shape blend + pose blend + skinning blend (12 affine entries) + skinning apply + H36M regressor product;
+# the rest-joint regression (992 160 FLOP in the survey's table) is folded into a (24x3)x10 table at model upload and
+# is NOT counted.
 FLOP_LBS_FWD_PER_POSE = 2 * 20670 * 10 + 2 * 207 * 20670 + 2 * 6890 * 24 * 12 + 2 * 6890 * 3 * 4 + 2 * 17 * 6890 * 3
+FLOP_LBS_BWD_PER_POSE = 2 * 17 * 6890 * 3 + 2 * 6890 * 24 * 9 + 2 * 6890 * 9 + 2 * 6890 * 24 * 12   # dverts, T, dvp, dA
+FLOP_BLEND_ADJ_PER_POSE = 2 * 217 * 20670                                                             # dF = D . dvp
+FLOP_DISC_PER_POSE = 2 * 2 * (24 * (192 + 1024) + 786432 + 1048576 + 1024 + 768)                     # fwd + input-grad
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
 
 
@@ -52,10 +58,13 @@ def parse():
     ap.add_argument('--j_step_every', type=int, default=100,
                     help='inner iterations per J_regressor step (reference: 100); the timed region always contains at least '
                          'one J step with its all-reduce: the effective cadence is min(j_step_every, steps)')
+    ap.add_argument('--min_timed_ms', type=float, default=300.0, help='repeat the K-step timed region until this much is timed')
+    ap.add_argument('--max_repeats', type=int, default=15)
     ap.add_argument('--no_cpu_baseline', action='store_true')
-    ap.add_argument('--cpu_batch', type=int, default=512, help='cpu_baseline sample batch (scaled to batch-4096 units)')
-    ap.add_argument('--cpu_iters', type=int, default=40)
+    ap.add_argument('--cpu_batch', type=int, default=1024, help='cpu_baseline sample batch (scaled to batch-4096 units)')
+    ap.add_argument('--cpu_seconds', type=float, default=8.0, help='time budget per cpu_baseline variant')
     ap.add_argument('--no_folded', action='store_true', help='skip the separately reported folded-regressor mode')
+    ap.add_argument('--no_config5', action='store_true', help='skip the separately reported BASELINE configs[4] block')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL); gloo for debugging')
     ap.add_argument('--single_device', action='store_true',
                     help='debug: every rank uses cuda:0 (exercises the N > 1 code path on a 1-GPU box; use with --backend gloo)')
@@ -70,11 +79,23 @@ def default_disc_flat(seed=0):
     return d.flat_parameters(), d.state_dict()
 
 
-def cpu_baseline(model_np, J_np, batch_np, disc_sd, B, iters, use_disc):
-    """The oracle (oracle/reference_port.py: torch-CPU restatement in the reference's op order,
-    autograd backward, torch.optim.Adam) timed on this box's host cores on the SAME workload.
-    torch's intra-op pool is far from linear on these small ops, so a short sweep picks the thread
-    count (reported as `cores`) before the timed sample."""
+def cpu_model_name():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(model_np, J_np, batch_np, disc_sd, B, budget_s, use_disc):
+    """The oracle (oracle/reference_port.py: torch-CPU restatement in the reference's op order, autograd backward,
+    torch.optim.Adam) timed on this box's host cores on the SAME workload at batch B, three ways:
+      one_eval            1 SMPL evaluation per iteration (the de-duplicated loop the HIP path computes), best thread count
+      reference_3_evals   3 SMPL evaluations per iteration as scripts/optimize.py:228,231,234 does, same thread count
+      single_thread       one_eval on 1 thread
+    torch's intra-op pool is far from linear on these small ops, so a 1-iteration sweep picks the thread count."""
     import oracle
     T = torch.from_numpy
     smpl = oracle.OracleSMPL(model_np)
@@ -83,22 +104,28 @@ def cpu_baseline(model_np, J_np, batch_np, disc_sd, B, iters, use_disc):
     gt_c = oracle.move_pelvis(T(batch_np['gt_j3d'][:B]))
     sd = {k: v.clone() for k, v in disc_sd.items()} if use_disc else None
 
-    def run(n):
+    def run(n, evals=1):
         t0 = time.perf_counter()
-        oracle.refine_poses(smpl, T(J_np), x6[:, :1], x6[:, 1:], betas, gt_c, n, disc_sd=sd)
+        oracle.refine_poses(smpl, T(J_np), x6[:, :1], x6[:, 1:], betas, gt_c, n, disc_sd=sd, smpl_evals=evals)
         return time.perf_counter() - t0
+
+    def timed(evals, threads):
+        torch.set_num_threads(threads)
+        dt1 = run(1, evals)                                  # warm-up + estimate
+        n = max(1, min(40, int(budget_s / max(dt1, 1e-3))))
+        dt = run(n, evals)
+        return {'it_s_at_sample_batch': round(n / dt, 4), 'iterations': n, 'seconds': round(dt, 2), 'threads': threads,
+                'smpl_evals_per_iter': evals}
 
     ncpu = os.cpu_count() or 1
     best_t, best_n = None, 1
     for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
         torch.set_num_threads(nt)
-        run(1)                      # warm-up at this thread count
+        run(1)
         dt = run(1)
         if best_t is None or dt < best_t:
             best_t, best_n = dt, nt
-    torch.set_num_threads(best_n)
-    dt = run(iters)
-    return iters / dt, dt, best_n
+    return {'one_eval': timed(1, best_n), 'reference_3_evals': timed(3, best_n), 'single_thread': timed(1, 1)}, best_n
 
 
 def main():
@@ -145,14 +172,20 @@ def main():
     v = torch.zeros(B, 154, device=dev)
     step = torch.zeros(1, dtype=torch.int32, device=dev)
     sq = torch.zeros(B, device=dev)
-    if use_sil:     # BASELINE configs[4]: silhouette target = the initial mesh through a perturbed camera, binarised
+
+    def silhouette_setup(e, xs, bs):
+        """BASELINE configs[4]: silhouette target = the initial mesh through a perturbed camera, binarised"""
         cam = torch.from_numpy(batch_np['cam']).to(dev).contiguous()
         cam_m, cam_v = torch.zeros_like(cam), torch.zeros_like(cam)
-        _, verts0 = eng.find_joints_forward(betas, x6d=x6d, return_verts=True)
+        _, verts0 = e.find_joints_forward(bs, x6d=xs, return_verts=True)
         shift = torch.tensor([0.15, -0.1, 1.0], device=dev)
-        sil_mask = (eng.silhouette_forward(verts0, (cam + shift).contiguous()) > 0).float().contiguous()
+        sil_mask = (e.silhouette_forward(verts0, (cam + shift).contiguous()) > 0).float().contiguous()
         del verts0
-        eng.set_silhouette(sil_mask, cam, cam_m, cam_v)
+        e.set_silhouette(sil_mask, cam, cam_m, cam_v)
+        return sil_mask, cam, cam_m, cam_v
+
+    if use_sil:
+        sil_refs = silhouette_setup(eng, x6d, betas)   # noqa: F841  (the engine keeps raw pointers)
     Jm, Jv = torch.zeros_like(J), torch.zeros_like(J)
     Jstep = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -168,9 +201,8 @@ def main():
 
     done = [0]
     n_jsteps = [0]
-    cadence = max(1, min(a.j_step_every, a.steps))   # >= 1 J step (SMPL fwd, dJ, RCCL all-reduce, Adam) per timed region
 
-    def run(n):
+    def run(n, cadence):
         """n inner iterations with the J step at its cadence"""
         left = n
         while left > 0:
@@ -186,19 +218,38 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    run(a.warmup)
+    def timed_region(n, cadence):
+        """EXACTLY n steps between barrier + synchronize pairs; max over ranks"""
+        done[0] = 0; n_jsteps[0] = 0   # the cadence counter restarts with the timed region
+        barrier(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(n, cadence)
+        torch.cuda.synchronize(); barrier()
+        el = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([el], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            el = float(t.item())
+        return el, n_jsteps[0]
+
+    cadence = max(1, min(a.j_step_every, a.steps))   # >= 1 J step (SMPL fwd, dJ, RCCL all-reduce, Adam) per timed region
+    run(a.warmup, cadence)
     j_step()                       # untimed: the first J step zero-fills the padded vertex buffer
-    done[0] = 0; n_jsteps[0] = 0   # the cadence counter restarts with the timed region
-    barrier(); torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(a.steps)
-    torch.cuda.synchronize(); barrier()
-    elapsed = time.perf_counter() - t0
-    if dist is not None:
-        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+    regions = []
+    el, nj_region = timed_region(a.steps, cadence)
+    regions.append(el)
+    reps = int(min(a.max_repeats, max(1, np.ceil(a.min_timed_ms * 1e-3 / max(el, 1e-6)))))
+    if dist is not None:           # every rank must run the same number of regions
+        t = torch.tensor([reps], device=dev, dtype=torch.int64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        reps = int(t.item())
+    for _ in range(reps - 1):
+        regions.append(timed_region(a.steps, cadence)[0])
+    elapsed = statistics.median(regions)
     loss_joint = float(sq.sum().item()) / (B * 51)
+
+    # ---- BASELINE configs[3] "all-reduce on the J_regressor gradient EACH step": J step after every iteration ----
+    c1_el, _ = timed_region(a.steps, 1)
 
     # ---- per-kernel timing (HIP events on the launch stream) over the same number of steps ----
     eng.set_profiling(True)
@@ -207,8 +258,8 @@ def main():
     probe = eng.probe_read()
     eng.set_profiling(False)
 
-    # ---- J step at cadence 1 (BASELINE configs[3]): timed separately, never part of `value` ----
-    j_step()                       # untimed: first call zero-fills the padded vertex buffer
+    # ---- J step alone ----
+    j_step()
     torch.cuda.synchronize(); barrier()
     tj = time.perf_counter()
     nj = 10
@@ -246,35 +297,43 @@ def main():
         d_ms = (time.perf_counter() - td) / nj * 1e3
         eng.set_pose_disc(disc_flat.to(dev))
 
-    # ---- folded-regressor mode (a different algorithm with its own denominator): timed
-    #      separately on a fresh copy of the same batch, never part of `value` ----
-    folded = None
-    if not a.no_folded and not use_sil:
-        feng = eng_mod.RefineEngine(dmodel, B, batch_norm=B * world,
-                                    flags=eng_mod.FLAG_FOLDED | (eng_mod.FLAG_POSE_DISC if use_disc else 0))
-        feng.set_folded(True)
-        feng.set_j_regressor(J)
+    def side_run(flags_, setup=None):
+        """a separately reported mode on a fresh copy of the same batch: warm-up, then --steps timed iterations"""
+        e2 = eng_mod.RefineEngine(dmodel, B, batch_norm=B * world, flags=flags_)
+        if flags_ & eng_mod.FLAG_FOLDED:
+            e2.set_folded(True)
+        e2.set_j_regressor(J)
         if use_disc:
-            feng.set_pose_disc(disc_flat.to(dev))
+            e2.set_pose_disc(disc_flat.to(dev))
         fx = torch.from_numpy(batch_np['pose6d']).to(dev).contiguous()
         fb = torch.from_numpy(batch_np['betas']).to(dev).contiguous()
+        refs = setup(e2, fx, fb) if setup else None      # noqa: F841
         fm, fv = torch.zeros(B, 154, device=dev), torch.zeros(B, 154, device=dev)
         fstep = torch.zeros(1, dtype=torch.int32, device=dev)
-        feng.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, a.warmup)
+        e2.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, a.warmup)
         torch.cuda.synchronize(); barrier()
         tf = time.perf_counter()
-        feng.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, a.steps)
+        e2.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, a.steps)
         torch.cuda.synchronize(); barrier()
         fel = time.perf_counter() - tf
         if dist is not None:
             t = torch.tensor([fel], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             fel = float(t.item())
-        folded = {'value': round(a.steps / fel * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(fel / a.steps * 1e3, 4),
-                  'algorithmic_flop_per_pose_iter': 2 * (2 * 1224 * 218) + 4 * (17 * 3 * 24 * 4 * 2),
-                  'note': 'joints = A.(H F) with H = sum_v Jn W D contracted once per J update (exact re-association, '
-                          'same losses/updates; no vertices).  Separate mode, separate denominator: not the headline.'}
-        del feng
+        return {'value': round(a.steps / fel * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(fel / a.steps * 1e3, 4)}
+
+    # ---- folded-regressor mode (DESIGN.md section 3; a different algorithm with its own denominator) ----
+    folded = None
+    if not a.no_folded and not use_sil:
+        folded = side_run(eng_mod.FLAG_FOLDED | (eng_mod.FLAG_POSE_DISC if use_disc else 0))
+        folded.update({'algorithmic_flop_per_pose_iter': 2 * (2 * 1224 * 218) + 4 * (17 * 3 * 24 * 4 * 2),
+                       'note': 'joints = A.(H F) with H = sum_v Jn W D contracted once per J update (exact re-association, '
+                               'same losses/updates; no vertices).  Separate mode, separate denominator: not the headline.'})
+    # ---- BASELINE configs[4]: + soft-silhouette loss inside the inner loop, separately timed ----
+    config5 = None
+    if not a.no_config5 and not use_sil and use_disc:
+        config5 = side_run(eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_POSE_DISC | eng_mod.FLAG_SILHOUETTE, silhouette_setup)
+        config5['workload'] = 'BASELINE configs[4]: configs[2] + soft-silhouette loss (224x224 rasteriser as HIP kernel) in the inner loop'
 
     if rank != 0:
         if dist is not None:
@@ -292,6 +351,8 @@ def main():
             traffic = json.load(open(tpath)).get('k_lbs_fwd_hbm_bytes_per_launch') if B == 4096 else None
         except Exception:
             traffic = None
+    step_flop = FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
+    inner_ms = ms_per_step - nj_region * j_ms / a.steps
     out = {
         'metric': 'pose-refinement iters/sec, batch 4096, at 1/2/4/8 MI355X',   # BASELINE.json's metric string; batch = poses per GPU (weak scaling)
         'value': round(it_s * world, 3), 'unit': f'it/s (x{B} poses)', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -301,15 +362,27 @@ def main():
                                + (' + pose-discriminator adversarial term' if use_disc else '')
                                + (' + soft-silhouette loss (224x224 rasteriser)' if use_sil else ''),
                    'global_batch': B * world, 'poses_per_sec': round(it_s * world * B, 1),
-                   'j_step_every': cadence, 'j_steps_in_timed_region': n_jsteps[0], 'parallelism': f'dp{world}', 'joint_loss_last': loss_joint,
+                   'j_step_every': cadence, 'j_steps_in_timed_region': nj_region, 'parallelism': f'dp{world}', 'joint_loss_last': loss_joint,
+                   'timed_regions': len(regions), 'value_is': 'median region',
+                   'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in regions],
                    'geometry': eng.info},
         'roofline': {'bound': 'mfma', 'kernel': 'k_lbs_fwd<true,false>', 'achieved': round(achieved, 2),
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                     'traffic': traffic, 'avg_launch_ms': round(dom_ms, 4), 'launches_timed': dom_n,
+                     'traffic': traffic,
+                     'traffic_source': 'profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of an earlier '
+                                       'run of this command, gfx950-corrected; NOT measured in this run)' if traffic else None,
+                     'avg_launch_ms': round(dom_ms, 4), 'launches_timed': dom_n,
                      # HBM side of the same kernel (PMC bytes per launch / live duration) against the 8 TB/s spec
                      'hbm_gb_s': round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms > 0 else None,
                      'hbm_frac_of_8tb_s': round(traffic / (dom_ms * 1e-3) / 8e12, 4) if traffic and dom_ms > 0 else None,
                      'algorithmic_flop_per_launch': FLOP_LBS_FWD_PER_POSE * B,
+                     # the WHOLE inner iteration against the same peak: dense algorithmic FLOP of its four MFMA stages
+                     # (k_lbs_fwd + k_lbs_bwd + blend adjoint + discriminator fwd/input-grad) over the measured step time
+                     # without the J step's share
+                     'whole_step': {'flop_per_pose_iter': step_flop,
+                                    'achieved': round(step_flop * B / (inner_ms * 1e-3) / 1e12, 2),
+                                    'frac': round(step_flop * B / (inner_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                    'inner_only_ms_per_step': round(inner_ms, 4)},
                      # in-kernel probe (s_memtime / s_memrealtime, workgroup 0 / wave 0): the clock the chip holds on
                      # this kernel (`peak` assumes 2.4 GHz), hence the MFMA-pipe utilisation of the whole launch, and
                      # how much of the launch the FIRST-dispatched workgroup is resident (the two workgroups of a CU
@@ -320,28 +393,35 @@ def main():
                      'first_workgroup_resident_frac': round(probe[4] * 1e-6 / dom_ms, 3) if probe[4] and dom_ms > 0 else None},
         'kernels_ms': {k: round(t, 4) for k, (t, n) in prof.items() if n},
         'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
-                   'allreduce_bytes': 17 * 6890 * 4, 'in_timed_region': n_jsteps[0]},
+                   'allreduce_bytes': 17 * 6890 * 4, 'in_timed_region': nj_region},
+        'cadence1': {'value': round(a.steps / c1_el * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(c1_el / a.steps * 1e3, 4),
+                     'j_step_every': 1, 'note': 'BASELINE configs[3] / north_star "all-reduce on the J_regressor gradient each step": '
+                                                'the J step (+ its all-reduce) after EVERY inner iteration, timed like `value`'},
     }
     # outer-step work.  `value` already contains the J step (+ all-reduce) at cadence
     # `j_step_every`; the pose-D update is timed separately.  Two derived rates: everything at the measured
     # cadence, and everything after EVERY inner iteration (cadence 1).
-    inner_ms = ms_per_step - n_jsteps[0] * j_ms / a.steps
     out['outer_step'] = {'j_step_ms': round(j_ms, 3), 'pose_d_update_ms': None if d_ms is None else round(d_ms, 3),
                          'inner_only_ms_per_step': round(inner_ms, 4),
                          'it_s_incl_pose_d_update_at_cadence': round(world / ((ms_per_step + (d_ms or 0.0) / cadence) * 1e-3), 3),
-                         'it_s_all_outer_work_every_iteration': round(world / ((inner_ms + j_ms + (d_ms or 0.0)) * 1e-3), 3),
+                         'it_s_all_outer_work_every_iteration': round(world / ((c1_el / a.steps * 1e3 + (d_ms or 0.0)) * 1e-3), 3),
                          'j_allreduce_bytes': 17 * 6890 * 4, 'pose_d_allreduce_bytes': 1840153 * 4 if use_disc else 0}
     if folded is not None:
         out['folded_mode'] = folded
+    if config5 is not None:
+        out['config5'] = config5
     if not a.no_cpu_baseline and world == 1:   # the CPU baseline leg runs at N = 1 only
         cb = min(a.cpu_batch or B, B)
-        its, dt, nthreads = cpu_baseline(model_np, J_np, batch_np, disc_sd, cb, a.cpu_iters, use_disc)
-        out['cpu_baseline'] = {'value': round(its * cb / B, 5), 'unit': f'it/s (x{B} poses)', 'cores': nthreads,
-                               'kind': 'port',
-                               'sample': f'{a.cpu_iters} inner iterations at batch {cb} of the same workload '
-                                         f'(oracle/reference_port.py: torch-CPU ops in the reference order, autograd, '
-                                         f'torch.optim.Adam; 1 SMPL eval/iter), {dt:.1f} s, threads picked from a sweep over 8/16/32/64 '
-                                         f'of {os.cpu_count()} host threads'}
+        variants, nthreads = cpu_baseline(model_np, J_np, batch_np, disc_sd, cb, a.cpu_seconds, use_disc)
+        for vv in variants.values():
+            vv['value_batch4096_units'] = round(vv['it_s_at_sample_batch'] * cb / B, 5)
+        out['cpu_baseline'] = {'value': variants['one_eval']['value_batch4096_units'], 'unit': f'it/s (x{B} poses)', 'cores': nthreads,
+                               'kind': 'port', 'cpu_model': cpu_model_name(), 'host_threads': os.cpu_count(),
+                               'sample': f"{variants['one_eval']['iterations']} inner iterations at batch {cb} of the same workload "
+                                         f'(oracle/reference_port.py: torch-CPU ops in the reference order, autograd, torch.optim.Adam; '
+                                         f"1 SMPL eval/iter), {variants['one_eval']['seconds']} s on {nthreads} threads picked from a "
+                                         f'1-iteration sweep over 8/16/32/64, scaled x{cb}/{B} to batch-{B} units',
+                               'variants': variants}
     print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()

@@ -18,6 +18,7 @@ from . import smpl_model  # noqa: F401  (numpy only)
 
 def __getattr__(name):
     import importlib
-    if name in ('engine', '_lib', 'build', 'smpl', 'utils', 'discriminator', 'optimize', 'args', 'checkpoint', 'dist'):
+    if name in ('engine', '_lib', 'build', 'smpl', 'utils', 'discriminator', 'optimize', 'args', 'checkpoint', 'dist', 'test', 'data', 'renderer',
+                'mesh_renderer'):
         return importlib.import_module(f'{__name__}.{name}')
     raise AttributeError(name)

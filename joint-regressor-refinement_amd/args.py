@@ -50,6 +50,10 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument('--save_j_regressor', type=str, default=None,
                         help='write the trained regressor in the models/retrained_J_Regressor.pt format')
     parser.add_argument('--seed', type=int, default=0)
+    parser.add_argument('--eval_j_regressor', type=str, default=None,
+                        help='retrained regressor read by the evaluation report (default: --save_j_regressor, else '
+                             'models/retrained_J_Regressor.pt as scripts/test.py:46-47)')
+    parser.add_argument('--skip_eval', action='store_true', help='main.py: do not run test_pose_refiner_model() after the optimiser')
     parser.add_argument('--dist_backend', type=str, default=None,
                         help='torch.distributed backend under torchrun (default: nccl = RCCL on GPUs); gloo for debugging')
     parser.add_argument('--single_device', action='store_true',

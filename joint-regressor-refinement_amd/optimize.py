@@ -74,12 +74,13 @@ def _synthetic_batches(model_np, J_np, B_global: int, n: int, seed: int) -> Iter
                'gt_j3d': torch.from_numpy(full['gt_j3d']), 'cam': torch.from_numpy(full['cam']), 'seed': seed * 1000 + it}
 
 
-def _dataset_batches(root: str, B_global: int, seed: int, device) -> Iterator[Dict[str, torch.Tensor]]:
-    """scripts/optimize.py:132-137: DataLoader(data_set("validation"), batch_size, shuffle=True, drop_last=False)."""
+def _dataset_batches(root: str, B_global: int, seed: int, device, drop_last: bool = False) -> Iterator[Dict[str, torch.Tensor]]:
+    """scripts/optimize.py:132-137: DataLoader(data_set("validation"), batch_size, shuffle=True, drop_last=False)
+    (scripts/test.py:59-63 uses drop_last=True)."""
     from . import data as jdata
     ds = jdata.data_set('validation', root=root)
     g = torch.Generator().manual_seed(seed)          # every rank shuffles identically
-    loader = torch.utils.data.DataLoader(ds, batch_size=B_global, num_workers=0, shuffle=True, drop_last=False, generator=g)
+    loader = torch.utils.data.DataLoader(ds, batch_size=B_global, num_workers=0, shuffle=True, drop_last=drop_last, generator=g)
     for it, batch in enumerate(loader):
         x6 = pose_to_rot6d(batch['orient'].to(device), batch['pose'].to(device)).cpu()
         yield {'pose6d': x6, 'betas': batch['betas'].float(), 'gt_j3d': batch['gt_j3d'].float(), 'cam': batch['cam'].float(),

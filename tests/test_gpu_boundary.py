@@ -218,3 +218,80 @@ def test_mesh_renderer_takes_pretransformed_vertices(smpl_hip, smpl_model_np, j_
     # through rotation matrices instead of 6-D input: last-bit vertex differences, amplified by sigmoid(d / 1e-4)
     assert img.shape == (B, 1, 224, 224)
     assert ((img[:, 0] > 0) != (alpha > 0)).float().mean().item() < 1e-4 and (img[:, 0] - alpha).abs().mean().item() < 1e-5
+
+
+def test_config1_eval_report(smpl_model_np, j_h36m_np, tmp_path, capsys):
+    """BASELINE configs[0] / scripts/test.py:33-138: before/after MPJPE & PA-MPJPE of the initial vs a retrained
+    regressor, batch of 4 poses, against the oracle's find_joints + evaluate on the same batches."""
+    B = 4
+    argsmod = _mod('args')
+    ckpt = str(tmp_path / 'retrained_J_Regressor.pt')
+    gen = torch.Generator().manual_seed(8)
+    J_new = T(j_h36m_np) * (1 + 0.2 * torch.rand(17, 6890, generator=gen))       # a "retrained" regressor
+    _mod('checkpoint').save_j_regressor(J_new, ckpt)
+    argsmod._LazyArgs._ns = argsmod.get_args(['--batch_size', str(B), '--synthetic_batches', '3', '--device', DEV, '--synthetic',
+                                               '--eval_j_regressor', ckpt])
+    rep = _mod('test').test_pose_refiner_model()
+    out = capsys.readouterr().out.split()
+    assert out[0] == 'MPJPE' and out[2] == 'PAMPJPE' and out[4] == 'after' and out[5] == 'MPJPE' and out[7] == 'PAMPJPE'
+    assert out[1] == f"{rep['mpjpe_before']:.4f}" and out[8] == f"{rep['pampjpe_after']:.4f}"
+    sm = _mod('smpl_model')
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    acc = {k: [] for k in ('mb', 'pb', 'ma', 'pa')}
+    for it in range(3):
+        full = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=7919 * 1000 + it)
+        x6, betas, gt = T(full['pose6d']), T(full['betas']), oracle.move_pelvis(T(full['gt_j3d']))
+        R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(B, 24, 3, 3)
+        mask = oracle.find_j_reg_mask(T(j_h36m_np))
+        for J, (km, kp) in ((T(j_h36m_np), ('mb', 'pb')), (J_new, ('ma', 'pa'))):
+            j = oracle.find_joints(smpl, betas, R[:, :1], R[:, 1:], J, mask=mask)
+            m_, p_ = oracle.evaluate(j, gt)
+            acc[km].append(float(m_)); acc[kp].append(float(p_))
+    np.testing.assert_allclose(rep['mpjpe_before'], np.mean(acc['mb']), rtol=1e-4)
+    np.testing.assert_allclose(rep['pampjpe_before'], np.mean(acc['pb']), rtol=1e-4)
+    np.testing.assert_allclose(rep['mpjpe_after'], np.mean(acc['ma']), rtol=1e-4)
+    np.testing.assert_allclose(rep['pampjpe_after'], np.mean(acc['pa']), rtol=1e-4)
+    assert abs(rep['mpjpe_after'] - rep['mpjpe_before']) > 1e-3
+
+
+def test_driver_on_dataset_tensors(smpl_model_np, j_h36m_np, tmp_path):
+    """row f4 wired into the driver: `--data_root` makes optimize_pose_refiner iterate data.data_set (the reference's
+    precomputed-tensor layout, scripts/data.py:49-86) -- here on files written from a synthetic batch, with the pose
+    stored as AXIS-ANGLE so that the Rodrigues kernel is on the path -- and reproduces the synthetic-batch run."""
+    sm, argsmod, opt = _mod('smpl_model'), _mod('args'), _mod('optimize')
+    B = 24
+    rng = np.random.RandomState(3)
+    aa = rng.normal(0, 0.3, size=(B, 24, 3)).astype(np.float32)
+    R = oracle.rodrigues(T(aa).reshape(-1, 3)).view(B, 24, 3, 3)
+    x6 = R[..., :, :2].reshape(B, 24, 6)
+    full = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=0)
+    d = tmp_path / 'precomputed_val'
+    d.mkdir()
+    tensors = {'bboxes': torch.tensor([[100., 200., 700., 800.]]).repeat(B, 1), 'betas': T(full['betas']),
+               'estimated_translation': T(full['cam']), 'gt_j2d': torch.rand(B, 17, 2) * 1000, 'gt_j3d': T(full['gt_j3d']),
+               'intrinsics': torch.eye(3).repeat(B, 1, 1), 'orient': T(aa[:, 0]), 'pose': T(aa[:, 1:].reshape(B, 69))}
+    for k, v in tensors.items():
+        torch.save(v, str(d / f'{k}.pt'))
+    argsmod._LazyArgs._ns = argsmod.get_args(['--batch_size', str(B), '--inner_iters', '2', '--device', DEV, '--synthetic',
+                                               '--data_root', str(tmp_path)])
+    res = opt.optimize_pose_refiner(log=lambda r: None)
+    assert res['history'][0]['data'] == 'dataset' and len(res['history']) == 1
+    # the same batch through the oracle (the loader shuffles: compare as sets of refined poses via a sort key)
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    dsd = {k: v.detach() for k, v in _seeded_disc_sd().items()}
+    gt_c = oracle.move_pelvis(T(full['gt_j3d']))
+    o, p, b, hist = oracle.refine_poses(smpl, T(j_h36m_np), x6[:, :1], x6[:, 1:], T(full['betas']), gt_c, 2, disc_sd=dsd)
+    ref = torch.cat([o, p], 1)
+    got = res['x6d'].cpu()
+    # match rows by their (unchanged to 2e-2) first coordinates
+    d2 = ((got[:, None, :, :] - ref[None]) ** 2).sum((-1, -2))
+    match = d2.argmin(1)
+    assert sorted(match.tolist()) == list(range(B))
+    assert (got - ref[match]).abs().max().item() < 3e-4
+    np.testing.assert_allclose(res['history'][0]['joint_loss'], hist[-1]['joint_loss'], rtol=2e-3)
+
+
+def _seeded_disc_sd():
+    """the driver's discriminator: torch default init right after utils.set_seed(args.seed = 0)"""
+    torch.manual_seed(0)
+    return _mod('discriminator').Discriminator().state_dict()
