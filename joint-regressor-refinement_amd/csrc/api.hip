@@ -132,6 +132,7 @@ struct jrr_engine {
   // workspace sections
   float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv;
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
+  float *W2s, *zpart;                                // fc2.w rows scaled by fc4.w; partial fc4 dots [16][BP]
   float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc, *wgs;
   float *Ps, *gb;
   float *dsq, *ssq;                                  // per-pose squared adversarial errors of the last iteration [25][BP], [BP]
@@ -171,7 +172,7 @@ static int pick_chunks(int wg_per_chunk, int max_chunks) {
 static void plan_geometry(int BP, int& nvc, int& nvcb, int& nsplit, int& nsplitJ) {
   const int nbg = BP / BG;
   nvc = pick_chunks(nbg, 54);                       // forward: one workgroup per (128 poses, chunk)
-  nvcb = pick_chunks((BP / BT) * 3 / 4, 36);        // backward: one workgroup per 4 (pose tile, plane) items
+  nvcb = pick_chunks(BP / BT, 36);                  // backward: one workgroup per (32 poses, chunk)
   nsplit = (512 + nbg - 1) / nbg;
   if (nsplit > 32) nsplit = 32;
   if (nsplit < 1) nsplit = 1;
@@ -225,6 +226,8 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->Pd = c.take(DP_TOTAL);
     t->W0T = c.take((size_t)768 * 1024);
     t->W2T = c.take((size_t)1024 * 1024);
+    t->W2s = c.take((size_t)1024 * 1024);
+    t->zpart = c.take((size_t)16 * BP);
     t->H2T = c.take((size_t)768 * BP);
     t->A1T = c.take((size_t)1024 * BP);
     t->A2T = c.take((size_t)1024 * BP);
@@ -437,6 +440,7 @@ extern "C" int jrr_engine_set_pose_disc(jrr_engine_t* e, const float* P, void* s
   JRR_HIP(hipMemcpyAsync(e->Pd, P, (size_t)DP_TOTAL * 4, hipMemcpyDeviceToDevice, s));
   launch_transpose(e->Pd + DP_FC0_W, e->W0T, 1024, 768, s);    // [out][in] -> [in][out]
   launch_transpose(e->Pd + DP_FC2_W, e->W2T, 1024, 1024, s);
+  launch_scale_rows(e->Pd + DP_FC2_W, e->Pd + DP_FC4_W, e->W2s, 1024, 1024, s);   // row n of fc2.w times fc4.w[n]
   CHECK_LAUNCH();
   e->have_pd = true;
   return JRR_OK;
@@ -590,33 +594,39 @@ extern "C" int jrr_joint_loss(const float* joints, const float* gt_mm, float wei
 }
 
 // ---- pose discriminator --------------------------------------------------------------------
-// the four discriminator GEMMs use the 128x64 tile: 512 workgroups at N = 4096 (128x128 and the 8-wave 128x128
-// tile measured the same)
-static int disc_gemm(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_gemm_128x64(g, epi, nsplit, s); }
-
+// Six launches per forward + input gradient (scripts/discriminator.py:32-54 and its adjoint):
+//   k_dconv_fwd (per-joint MLP, MFMA)  ->  fc0 GEMM (+bias, ReLU)  ->  fc2 GEMM (+bias, ReLU, and the fc4 dot product
+//   w4 . a2 as per-column partials in the epilogue)  ->  fc2 adjoint GEMM whose B operand is a2 itself, turned into
+//   relu'(a2) dz on the way to the MFMA (dz from the partial dots in the prologue; fc2.w pre-scaled by w4: the
+//   rank-one output-layer adjoint is never materialised)  ->  fc0 adjoint GEMM  ->  k_dconv_bwd.
+// All four GEMMs: exact 128x64 tiles (512 workgroups at 4096 poses), 3-deep LDS-DMA ring.
 static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t s) {
   launch_disc_conv_fwd(e->Pd, x6d, e->H2T, out, e->B, e->BP, s);
   GemmArgs g;
   g.mask = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   g.A = e->W0T; g.lda = 1024; g.Bm = e->H2T; g.Out = e->A1T; g.bias = e->Pd + DP_FC0_B; g.M = 1024; g.K = 768;
-  int rc = disc_gemm(g, EPI_BIAS_RELU, 1, s);
+  int rc = launch_gemm_disc(g, EPI_BIAS_RELU, 0, s);
   if (rc) return rc;
   g.A = e->W2T; g.lda = 1024; g.Bm = e->A1T; g.Out = e->A2T; g.bias = e->Pd + DP_FC2_B; g.M = 1024; g.K = 1024;
-  return disc_gemm(g, EPI_BIAS_RELU, 1, s);
+  g.dotw = e->Pd + DP_FC4_W; g.dot_out = e->zpart;
+  return launch_gemm_disc(g, EPI_BIAS_RELU_DOT, 0, s);
 }
 
 static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, const float* gout, float scale,
                                float target, float* gx, hipStream_t s, float* sq = nullptr) {
-  launch_disc_out(e->Pd, e->A2T, out, e->dA2T, gout, scale, target, e->B, e->BP, s, nullptr, sq);
   GemmArgs g;
   g.bias = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
-  // dA1T[k][b] = relu'(A1T) * sum_n fc2.w[n][k] dA2T[n][b]
-  g.A = e->Pd + DP_FC2_W; g.lda = 1024; g.Bm = e->dA2T; g.Out = e->dA1T; g.mask = e->A1T; g.M = 1024; g.K = 1024;
-  int rc = disc_gemm(g, EPI_MASK, 1, s);
+  // dA1T[k][b] = relu'(A1T) * sum_n (fc4.w[n] fc2.w[n][k]) relu'(A2T[n][b]) dz[b]
+  g.A = e->W2s; g.lda = 1024; g.Bm = e->A2T; g.Out = e->dA1T; g.mask = e->A1T; g.M = 1024; g.K = 1024;
+  g.zpart = e->zpart; g.nzpart = 16; g.zbias = e->Pd + DP_FC4_B; g.gout = gout; g.gout_ld = 25; g.scale = scale; g.target = target;
+  g.nvalid = e->B; g.sq0 = sq; g.out0 = out; g.out0_ld = 25;
+  int rc = launch_gemm_disc(g, EPI_MASK, 2, s);
   if (rc) return rc;
   // dH2T[k][b] = sum_n fc0.w[n][k] dA1T[n][b]
-  g.A = e->Pd + DP_FC0_W; g.lda = 768; g.Bm = e->dA1T; g.Out = e->dH2T; g.mask = nullptr; g.M = 768; g.K = 1024;
-  rc = disc_gemm(g, EPI_STORE, 1, s);
+  GemmArgs h;
+  h.bias = nullptr; h.split_stride = 0; h.N = e->BP; h.ldb = e->BP; h.ldo = e->BP;
+  h.A = e->Pd + DP_FC0_W; h.lda = 768; h.Bm = e->dA1T; h.Out = e->dH2T; h.mask = nullptr; h.M = 768; h.K = 1024;
+  rc = launch_gemm_disc(h, EPI_STORE, 0, s);
   if (rc) return rc;
   launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s, sq);
   return 0;
@@ -628,7 +638,7 @@ extern "C" int jrr_pose_disc_forward(jrr_engine_t* e, const float* x6d, float* o
   hipStream_t s = (hipStream_t)stream;
   int rc = disc_forward(e, x6d, out, s);
   if (rc) return rc;
-  launch_disc_out(e->Pd, e->A2T, out, nullptr, nullptr, 0.f, 0.f, e->B, e->BP, s);
+  launch_disc_z_finish(e->zpart, 16, e->BP, e->Pd + DP_FC4_B, out, e->B, s);
   CHECK_LAUNCH();
   return JRR_OK;
 }

@@ -37,26 +37,126 @@ __device__ __forceinline__ void joint_mlp(const float* __restrict__ P, const flo
   }
 }
 
-__global__ __launch_bounds__(64) void k_disc_conv_fwd(const float* __restrict__ P, const float* __restrict__ x6d,
-                                                      float* __restrict__ H2T, float* __restrict__ out, int B, int BP) {
-  const int b = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y;
-  if (b >= BP) return;
-  if (b >= B) {
-    for (int o = 0; o < 32; ++o) H2T[(size_t)(j * 32 + o) * BP + b] = 0.f;
-    return;
+// ------------------------------------------------------------------------------------------
+// The per-joint shared MLP (1x1 convs 6 -> 32 -> 32, scripts/discriminator.py:15-18,32-36) and the 24 per-joint heads
+// (:21-23,44-49) on the fp32 matrix cores.  One wave per (32 poses, joint): every layer is a 32 x 32 (channel, pose)
+// tile in the accumulator layout of v_mfma_f32_32x32x2_f32 (rows = channels in registers, columns = poses on lanes), so a
+// layer's output is the next layer's B operand without leaving registers (it sums over the tile's ROW index), forward
+// and adjoint alike.  The weights sit in LDS in the orientation each product reads conflict-free.
+//   forward : h1 = relu(W0 x + b0) [3 MFMA]   h2 = relu(W2 h1 + b2) [16]   z_j = wh_j . h2 + bh_j
+//   adjoint : dh2 = relu'(h2) (dz_j wh_j + dH2)   dh1 = relu'(h1) W2^T dh2 [16]   gx = W0^T dh1 [16]
+// ------------------------------------------------------------------------------------------
+constexpr int CL_W0P = 0;                 // [8][32]   W0p[c][o] = conv0.w[o][c], rows 6,7 zero
+constexpr int CL_B0 = CL_W0P + 256;       // [32]
+constexpr int CL_B2 = CL_B0 + 32;         // [32]
+constexpr int CL_W2T = CL_B2 + 32;        // [32][32]  W2T[c][o] = conv2.w[o][c]
+constexpr int CL_W2 = CL_W2T + 1024;      // [32][32]  conv2.w[o][c]
+constexpr int CL_W0A = CL_W2 + 1024;      // [32][32]  W0a[o][c6] = conv0.w[o][c6], columns 6.. zero
+constexpr int CL_WH = CL_W0A + 1024;      // [24][33]  heads
+constexpr int CL_FLOATS = CL_WH + 24 * 33;
+
+__device__ __forceinline__ void conv_stage_params(const float* __restrict__ P, float* __restrict__ L) {
+  for (int i = threadIdx.x; i < 256; i += blockDim.x) {
+    const int c = i >> 5, o = i & 31;
+    L[CL_W0P + i] = (c < 6) ? P[DP_CONV0_W + o * 6 + c] : 0.f;
   }
-  float x[6], h1[32], h2[32];
+  for (int i = threadIdx.x; i < 32; i += blockDim.x) { L[CL_B0 + i] = P[DP_CONV0_B + i]; L[CL_B2 + i] = P[DP_CONV2_B + i]; }
+  for (int i = threadIdx.x; i < 1024; i += blockDim.x) {
+    const int o = i >> 5, c = i & 31;
+    const float w = P[DP_CONV2_W + i];          // conv2.w[o][c]
+    L[CL_W2 + i] = w;
+    L[CL_W2T + c * 32 + o] = w;
+    L[CL_W0A + i] = (c < 6) ? P[DP_CONV0_W + o * 6 + c] : 0.f;
+  }
+  for (int i = threadIdx.x; i < 24 * 33; i += blockDim.x) L[CL_WH + i] = P[DP_HEADS + i];
+}
+
+// h1, h2 (post-ReLU) of 32 poses x one joint, in accumulator layout
+__device__ __forceinline__ void conv_mlp_tile(const float* __restrict__ L, const float* __restrict__ x6d, int b, bool ok, int j,
+                                              int half, int l31, f32x16& h1, f32x16& h2) {
+  f32x16 acc = zero16();
 #pragma unroll
-  for (int c = 0; c < 6; ++c) x[c] = x6d[((size_t)b * NJ + j) * 6 + c];
-  joint_mlp(P, x, h1, h2);
+  for (int kk = 0; kk < 3; ++kk) {
+    const float xv = ok ? x6d[((size_t)b * NJ + j) * 6 + 2 * kk + half] : 0.f;
+    acc = mfma(L[CL_W0P + (2 * kk + half) * 32 + l31], xv, acc);
+  }
 #pragma unroll
-  for (int o = 0; o < 32; ++o) H2T[(size_t)(j * 32 + o) * BP + b] = h2[o];
+  for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q] + L[CL_B0 + acc_row(q, half)], 0.f);
+  acc = zero16();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) acc = mfma(L[CL_W2T + acc_row(q, half) * 32 + l31], h1[q], acc);
+#pragma unroll
+  for (int q = 0; q < 16; ++q) h2[q] = fmaxf(acc[q] + L[CL_B2 + acc_row(q, half)], 0.f);
+}
+
+// z_j = wh_j . h2 + bh_j for the lane's pose (both lane halves return the full sum)
+__device__ __forceinline__ float conv_head(const float* __restrict__ L, int j, int half, const f32x16& h2) {
+  float part = 0.f;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) part = fmaf(L[CL_WH + j * 33 + acc_row(q, half)], h2[q], part);
+  return part + __shfl_xor(part, 32) + L[CL_WH + j * 33 + 32];
+}
+
+// grid = (BP / 32) * 6 workgroups of 4 waves; wave w of block (bt, jg) owns poses [32 bt, +32) and joint 4 jg + w
+__global__ __launch_bounds__(256) void k_dconv_fwd(const float* __restrict__ P, const float* __restrict__ x6d,
+                                                   float* __restrict__ H2T, float* __restrict__ out, int B, int BP) {
+  __shared__ float L[CL_FLOATS];
+  conv_stage_params(P, L);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  const int bt = blockIdx.x / 6, j = (blockIdx.x % 6) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = bt * 32 + l31;
+  const bool ok = b < B;
+  f32x16 h1, h2;
+  conv_mlp_tile(L, x6d, b, ok, j, half, l31, h1, h2);
+  const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)b;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) urow(H2T, (size_t)(j * 32 + acc_row_u(q)), BP)[voff] = ok ? h2[q] : 0.f;   // padded poses: zeros
   if (out) {
-    const float* wh = P + DP_HEADS + 33 * j;
-    float z = wh[32];
+    const float z = conv_head(L, j, half, h2);
+    if (ok && half == 0) out[(size_t)b * 25 + 1 + j] = sigmoidf(z);
+  }
+}
+
+// input gradient of the per-joint MLP + heads; dH2T = gradient arriving from fc0 (may be NULL), gout (B,25) nullable
+__global__ __launch_bounds__(256) void k_dconv_bwd(const float* __restrict__ P, const float* __restrict__ x6d,
+                                                   const float* __restrict__ dH2T, const float* __restrict__ gout,
+                                                   float scale, float target, float* __restrict__ gx, int B, int BP,
+                                                   float* __restrict__ sqj) {
+  __shared__ float L[CL_FLOATS];
+  conv_stage_params(P, L);
+  __syncthreads();
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  const int bt = blockIdx.x / 6, j = (blockIdx.x % 6) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int b = bt * 32 + l31;
+  const bool ok = b < B;
+  f32x16 h1, h2;
+  conv_mlp_tile(L, x6d, b, ok, j, half, l31, h1, h2);
+  const float z = conv_head(L, j, half, h2);
+  const float sg = sigmoidf(z);
+  if (sqj && ok && half == 0) sqj[(size_t)(1 + j) * BP + b] = (sg - target) * (sg - target);
+  const float up = gout ? (ok ? gout[(size_t)b * 25 + 1 + j] : 0.f) : scale * (sg - target);
+  const float dz = ok ? up * sg * (1.f - sg) : 0.f;
+  const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)b;
+  f32x16 acc = zero16();
 #pragma unroll
-    for (int o = 0; o < 32; ++o) z = fmaf(wh[o], h2[o], z);
-    out[(size_t)b * 25 + 1 + j] = sigmoidf(z);
+  for (int q = 0; q < 16; ++q) {
+    float g = dz * L[CL_WH + j * 33 + acc_row(q, half)];
+    if (dH2T) g += urow(dH2T, (size_t)(j * 32 + acc_row_u(q)), BP)[voff];
+    const float dh2 = (h2[q] > 0.f) ? g : 0.f;
+    acc = mfma(L[CL_W2 + acc_row(q, half) * 32 + l31], dh2, acc);        // dh1[c] += W2[o][c] dh2[o]
+  }
+  f32x16 accx = zero16();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float dh1 = (h1[q] > 0.f) ? acc[q] : 0.f;
+    accx = mfma(L[CL_W0A + acc_row(q, half) * 32 + l31], dh1, accx);     // gx[c6] += W0[o][c6] dh1[o]
+  }
+  if (ok) {      // rows 0..3 live in registers 0..3 of lane half 0, rows 4,5 in registers 0,1 of half 1
+    float* dst = gx + ((size_t)b * NJ + j) * 6 + 4 * half;
+    dst[0] = accx[0];
+    dst[1] = accx[1];
+    if (half == 0) { dst[2] = accx[2]; dst[3] = accx[3]; }
   }
 }
 
@@ -94,50 +194,6 @@ __global__ __launch_bounds__(1024) void k_disc_out(const float* __restrict__ P, 
       float a = A2T[(size_t)n * BP + b];
       dA2T[(size_t)n * BP + b] = (a > 0.f) ? w[n] * dz : 0.f;
     }
-  }
-}
-
-// input gradient of the per-joint MLP + heads; dH2T is the gradient arriving from fc0 (may be NULL)
-__global__ __launch_bounds__(64) void k_disc_conv_bwd(const float* __restrict__ P, const float* __restrict__ x6d,
-                                                      const float* __restrict__ dH2T, const float* __restrict__ gout,
-                                                      float scale, float target, float* __restrict__ gx, int B, int BP,
-                                                      float* __restrict__ sqj) {
-  const int b = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y;
-  if (b >= B) return;
-  float x[6], h1[32], h2[32];
-#pragma unroll
-  for (int c = 0; c < 6; ++c) x[c] = x6d[((size_t)b * NJ + j) * 6 + c];
-  joint_mlp(P, x, h1, h2);
-  const float* wh = P + DP_HEADS + 33 * j;
-  float z = wh[32];
-#pragma unroll
-  for (int o = 0; o < 32; ++o) z = fmaf(wh[o], h2[o], z);
-  const float s = sigmoidf(z);
-  if (sqj) sqj[(size_t)(1 + j) * BP + b] = (s - target) * (s - target);
-  const float dz = (gout ? gout[(size_t)b * 25 + 1 + j] : scale * (s - target)) * s * (1.f - s);
-  float dh2[32];
-#pragma unroll
-  for (int o = 0; o < 32; ++o) {
-    float g = dz * wh[o];
-    if (dH2T) g += dH2T[(size_t)(j * 32 + o) * BP + b];
-    dh2[o] = (h2[o] > 0.f) ? g : 0.f;
-  }
-  const float* w2 = P + DP_CONV2_W;
-  const float* w0 = P + DP_CONV0_W;
-  float dh1[32];
-#pragma unroll
-  for (int c = 0; c < 32; ++c) {
-    float acc = 0.f;
-#pragma unroll
-    for (int o = 0; o < 32; ++o) acc = fmaf(w2[o * 32 + c], dh2[o], acc);
-    dh1[c] = (h1[c] > 0.f) ? acc : 0.f;
-  }
-#pragma unroll
-  for (int c = 0; c < 6; ++c) {
-    float acc = 0.f;
-#pragma unroll
-    for (int o = 0; o < 32; ++o) acc = fmaf(w0[o * 6 + c], dh1[o], acc);
-    gx[((size_t)b * NJ + j) * 6 + c] = acc;
   }
 }
 
@@ -376,6 +432,29 @@ __global__ void k_sqerr_rows(const float* __restrict__ out, int ncol, float targ
   sqerr[b] = acc;
 }
 
+// out[b*25] = sigmoid(fc4.b + sum_t zpart[t][b])   (operator-level forward: the fc4 dot comes from the fc2 epilogue)
+__global__ void k_disc_z_finish(const float* __restrict__ zpart, int nz, int ld, const float* __restrict__ zbias,
+                                float* __restrict__ out, int B) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float z = zbias[0];
+  for (int t = 0; t < nz; ++t) z += zpart[(size_t)t * ld + b];
+  out[(size_t)b * 25] = sigmoidf(z);
+}
+int launch_disc_z_finish(const float* zpart, int nz, int ld, const float* zbias, float* out, int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_disc_z_finish, dim3((B + 255) / 256), dim3(256), 0, s, zpart, nz, ld, zbias, out, B);
+  return 0;
+}
+// out[r][c] = w[r] * in[r][c]
+__global__ void k_scale_rows(const float* __restrict__ in, const float* __restrict__ w, float* __restrict__ out, int rows, int cols) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < (size_t)rows * cols) out[i] = w[i / cols] * in[i];
+}
+int launch_scale_rows(const float* in, const float* w, float* out, int rows, int cols, hipStream_t s) {
+  hipLaunchKernelGGL(k_scale_rows, dim3((unsigned)(((size_t)rows * cols + 255) / 256)), dim3(256), 0, s, in, w, out, rows, cols);
+  return 0;
+}
+
 // out[b] = sum_r M[r][b]   (rows of a [rows][ld] pose-contiguous array)
 __global__ void k_colsum(const float* __restrict__ M, int rows, int ld, float* __restrict__ out, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
@@ -428,7 +507,7 @@ int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_
 }
 
 int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_disc_conv_fwd, dim3(BP / 64, NJ), dim3(64), 0, s, P, x6d, H2T, out, B, BP);
+  hipLaunchKernelGGL(k_dconv_fwd, dim3((BP / 32) * 6), dim3(256), 0, s, P, x6d, H2T, out, B, BP);
   return 0;
 }
 int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
@@ -438,7 +517,7 @@ int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, c
 }
 int launch_disc_conv_bwd(const float* P, const float* x6d, const float* dH2T, const float* gout, float scale,
                          float target, float* gx, int B, int BP, hipStream_t s, float* sqj) {
-  hipLaunchKernelGGL(k_disc_conv_bwd, dim3((B + 63) / 64, NJ), dim3(64), 0, s, P, x6d, dH2T, gout, scale, target, gx, B, BP, sqj);
+  hipLaunchKernelGGL(k_dconv_bwd, dim3((BP / 32) * 6), dim3(256), 0, s, P, x6d, dH2T, gout, scale, target, gx, B, BP, sqj);
   return 0;
 }
 int launch_shape_disc(const float* P, const float* betas, float* out, float* gb, float scale, float target, int B,

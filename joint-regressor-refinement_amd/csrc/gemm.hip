@@ -4,6 +4,8 @@
 // discriminator (scripts/discriminator.py:20-29,32-54), its input-gradient, and the blend-basis
 // adjoint dF = D . dVP is of this form with the pose index on the MFMA column (lane) axis.
 // Optional split-K (blockIdx.z) writes partial slabs that the consumer sums.
+#include <cstdlib>
+
 #include "jrr_common.h"
 #include "kernels.h"
 
@@ -11,8 +13,17 @@ namespace jrr {
 
 
 // Operand chunks ([GK][BM] of A, [GK][BN] of Bm) are staged by LDS-DMA (global_load_lds_dwordx4)
-// into a 2-deep ring, one chunk ahead of the MFMAs, one workgroup barrier per chunk.
-template <int WM, int WN, int WAVES_M, int WAVES_N, int GK, int EPI>
+// into an NSLOT-deep ring, NSLOT-1 chunks ahead of the MFMAs, one workgroup barrier per chunk.
+//   NSLOT = 2: `vmcnt(0)` + barrier per chunk (any shape, partial tiles masked per lane).
+//   NSLOT = 3: needs an EXACT tiling (M % BM == 0, every wave issues the same PA + PB DMA instructions per chunk):
+//              the wait before the barrier is the counted `vmcnt(PA + PB)`, i.e. it leaves the next chunk's copies in
+//              flight (LDS-DMA stays in flight across s_barrier), so a chunk has two chunk-times to land.
+//   BTR = 1:   the B operand is turned into  (x > 0) ? colscale[column] : 0  on its way from LDS to the MFMA
+//              (pose discriminator: B = A2^T, colscale = dz: the rank-one output-layer adjoint relu'(a2) w4 dz
+//              without materialising it; the w4 factor is folded into the A operand by the caller).
+//   EPI_BIAS_RELU_DOT: as EPI_BIAS_RELU, plus the per-column partial dot products  sum_m dotw[m] * out[m][n]  over
+//              this wave's rows, written to dot_out[(m-tile * WAVES_M + wave row)][n]  (fc4 fused into fc2).
+template <int WM, int WN, int WAVES_M, int WAVES_N, int GK, int EPI, int NSLOT = 2, int BTR = 0, int PD = 1>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
@@ -20,7 +31,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
   constexpr int OPA = (A16 + 63) / 64, OPB = (B16 + 63) / 64;   // wave-instructions per chunk
   constexpr int PA = (OPA + NW - 1) / NW, PB = (OPB + NW - 1) / NW;
   constexpr int SLOT = GK * (BM + BN);
-  __shared__ float lds[2 * SLOT];
+  constexpr bool EXACT = NSLOT > 2;
+  static_assert(!EXACT || (A16 % 64 == 0 && B16 % 64 == 0 && OPA % NW == 0 && OPB % NW == 0), "exact tiling required");
+  __shared__ float lds[NSLOT * SLOT];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -40,14 +53,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
   for (int i = 0; i < PA; ++i) {
     const int p = (wave + NW * i) * 64 + lane;
     const int row = p / (BM / 4), col = (p % (BM / 4)) * 4;
-    okA[i] = (wave + NW * i) < OPA && p < A16 && (m0 + col) < g.M;
+    okA[i] = EXACT || ((wave + NW * i) < OPA && p < A16 && (m0 + col) < g.M);
     offA[i] = (unsigned)row * (unsigned)g.lda + (unsigned)col;
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int p = (wave + NW * i) * 64 + lane;
     const int row = p / (BN / 4), col = (p % (BN / 4)) * 4;
-    okB[i] = (wave + NW * i) < OPB && p < B16;
+    okB[i] = EXACT || ((wave + NW * i) < OPB && p < B16);
     offB[i] = (unsigned)row * (unsigned)g.ldb + (unsigned)col;
   }
   const float* const Abase = g.A + m0;
@@ -62,11 +75,36 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
     float* dB = dA + GK * BM;
 #pragma unroll
     for (int i = 0; i < PA; ++i)
-      if (okA[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(a + offA[i]), JRR_LDS(dA + (wave + NW * i) * 256), 16, 0, 0);
+      if (EXACT || okA[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(a + offA[i]), JRR_LDS(dA + (wave + NW * i) * 256), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < PB; ++i)
-      if (okB[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave + NW * i) * 256), 16, 0, 0);
+      if (EXACT || okB[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave + NW * i) * 256), 16, 0, 0);
   };
+
+  // BTR: per-lane column scales (one per 32-column tile of this wave)
+  float cscale[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) cscale[j] = 0.f;
+  if (BTR == 1) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) cscale[j] = g.colscale[n0 + (wn * WN + j) * 32 + l31];
+  }
+  if (BTR == 2) {
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const int n = n0 + (wn * WN + j) * 32 + l31;
+      float z = g.zbias[0];
+      for (int t = 0; t < g.nzpart; ++t) z += g.zpart[(size_t)t * g.ldb + n];
+      const float sg = 1.f / (1.f + expf(-z));
+      const bool ok = n < g.nvalid;
+      const float up = g.gout ? (ok ? g.gout[(size_t)n * g.gout_ld] : 0.f) : g.scale * (sg - g.target);
+      cscale[j] = ok ? up * sg * (1.f - sg) : 0.f;
+      if (mt == 0 && wm == 0 && half == 0 && ok) {
+        if (g.sq0) g.sq0[n] = (sg - g.target) * (sg - g.target);
+        if (g.out0) g.out0[(size_t)n * g.out0_ld] = sg;
+      }
+    }
+  }
 
   f32x16 acc[WM][WN];
 #pragma unroll
@@ -75,34 +113,57 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
     for (int j = 0; j < WN; ++j) acc[i][j] = zero16();
 
   if (c_begin < c_end) issue(c_begin, 0);
+  if (NSLOT > 2 && c_begin + 1 < c_end) issue(c_begin + 1, 1);
+  int slot = 0;     // ring slot of chunk ch
   for (int ch = c_begin; ch < c_end; ++ch) {
-    __syncthreads();   // chunk ch landed (vmcnt(0) + barrier); the other slot is free
-    if (ch + 1 < c_end) issue(ch + 1, (ch - c_begin + 1) & 1);
-    const float* ap = lds + ((ch - c_begin) & 1) * SLOT + half * BM + wm * WM * 32 + l31;
-    const float* bp = lds + ((ch - c_begin) & 1) * SLOT + GK * BM + half * BN + wn * WN * 32 + l31;
-    // The operands of K-pair kk+1 are requested right after the first MFMA of pair kk has issued, so the reads
-    // complete under this pair's MFMAs (the compiler's own schedule reads right before use and exposes the LDS
-    // latency once per pair).
-    float a[WM], b[WN];
+    if (NSLOT == 2) {
+      __syncthreads();   // chunk ch landed (vmcnt(0) + barrier); the other slot is free
+      if (ch + 1 < c_end) issue(ch + 1, slot ^ 1);
+    } else {
+      // this wave's copies of chunk ch have landed once at most the next chunk's PA + PB are outstanding; after the
+      // barrier everybody's have, and everybody has finished reading chunk ch - 1, whose slot is refilled
+      if (ch + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      if (ch + 2 < c_end) issue(ch + 2, slot >= 1 ? slot - 1 : NSLOT - 1);   // (slot + 2) % 3
+    }
+    const float* ap = lds + slot * SLOT + half * BM + wm * WM * 32 + l31;
+    const float* bp = lds + slot * SLOT + GK * BM + half * BN + wn * WN * 32 + l31;
+    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
+    // The operands of K-pair kk + PD are requested right after the first MFMA of pair kk has issued, so the reads
+    // complete under PD pairs' worth of MFMAs (the compiler's own schedule reads right before use and exposes the LDS
+    // latency once per pair).  PD = 1 covers tiles with >= 4 MFMAs per pair; the 2-MFMA pairs of the 64x32 wave tile
+    // (128 clocks) need PD = 2.
+    float a[PD][WM], b[PD][WN];
 #pragma unroll
-    for (int i = 0; i < WM; ++i) a[i] = ap[i * 32];
+    for (int d = 0; d < PD; ++d) {
 #pragma unroll
-    for (int j = 0; j < WN; ++j) b[j] = bp[j * 32];
+      for (int i = 0; i < WM; ++i) a[d][i] = ap[(2 * d) * BM + i * 32];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) b[d][j] = bp[(2 * d) * BN + j * 32];
+    }
 #pragma unroll
     for (int kk = 0; kk < GK / 2; ++kk) {
       float ca[WM], cb[WN];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) ca[i] = a[i];
+      for (int i = 0; i < WM; ++i) ca[i] = a[0][i];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) cb[j] = b[j];
+      for (int j = 0; j < WN; ++j) cb[j] = BTR ? ((b[0][j] > 0.f) ? cscale[j] : 0.f) : b[0][j];
+#pragma unroll
+      for (int d = 0; d + 1 < PD; ++d) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a[d][i] = a[d + 1][i];
+#pragma unroll
+        for (int j = 0; j < WN; ++j) b[d][j] = b[d + 1][j];
+      }
       __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = mfma(ca[0], cb[0], acc[0][0]);
       __builtin_amdgcn_sched_barrier(0);
-      if (kk + 1 < GK / 2) {
+      if (kk + PD < GK / 2) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) a[i] = ap[(2 * kk + 2) * BM + i * 32];
+        for (int i = 0; i < WM; ++i) a[PD - 1][i] = ap[(2 * (kk + PD)) * BM + i * 32];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) b[j] = bp[(2 * kk + 2) * BN + j * 32];
+        for (int j = 0; j < WN; ++j) b[PD - 1][j] = bp[(2 * (kk + PD)) * BN + j * 32];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -117,6 +178,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
   // is one 32-bit offset -- one store per element instead of five VALU instructions of address arithmetic
   float* out = g.Out + (size_t)split * g.split_stride;
   const unsigned lane_off = (unsigned)(4 * half) * (unsigned)g.ldo + (unsigned)(n0 + l31);
+  float dot[WN];
+#pragma unroll
+  for (int j = 0; j < WN; ++j) dot[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -125,7 +189,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
       const int m = mu + 4 * half;
       if (m >= g.M) continue;
       float bias = 0.f;
-      if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS) bias = g.bias[m];
+      if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DOT) bias = g.bias[m];
+      const float dw = (EPI == EPI_BIAS_RELU_DOT) ? g.dotw[m] : 0.f;
       float* orow = out + (size_t)mu * g.ldo;
       asm volatile("" : "+s"(orow));
       const float* mrow = (EPI == EPI_MASK) ? g.mask + (size_t)mu * g.ldo : nullptr;
@@ -134,13 +199,51 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
       for (int j = 0; j < WN; ++j) {
         const unsigned off = lane_off + (unsigned)((wn * WN + j) * 32);
         float v = acc[i][j][q];
-        if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
+        if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RELU_DOT) v = fmaxf(v + bias, 0.f);
+        if (EPI == EPI_BIAS_RELU_DOT) dot[j] = fmaf(dw, v, dot[j]);
         if (EPI == EPI_BIAS) v = v + bias;
         if (EPI == EPI_MASK) v = (mrow[off] > 0.f) ? v : 0.f;
         if (EPI == EPI_ACCUM) v += orow[off];
         orow[off] = v;
       }
     }
+  if (EPI == EPI_BIAS_RELU_DOT) {      // rows of the two lane halves are disjoint: add them, one store per column
+#pragma unroll
+    for (int j = 0; j < WN; ++j) {
+      const float t = dot[j] + __shfl_xor(dot[j], 32);
+      if (half == 0) g.dot_out[(size_t)(mt * WAVES_M + wm) * g.ldo + n0 + (wn * WN + j) * 32 + l31] = t;
+    }
+  }
+}
+
+// the pose discriminator's layers: exact 128x64 tiling, 3-deep ring; epi in {BIAS_RELU, BIAS_RELU_DOT, STORE, MASK},
+// btr = B-operand transform (see k_gemm_tn)
+template <int WM, int WN, int WAVES_M, int WAVES_N>
+static int launch_disc_cfg(const GemmArgs& g, int epi, int btr, hipStream_t s) {
+  constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N, GK = 32;
+  if (g.M % BM != 0 || g.N % BN != 0 || g.K % GK != 0 || g.lda % 4 != 0 || g.ldb % 4 != 0) {
+    jrr_set_error("gemm_disc: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d", g.M, g.N, g.K, g.lda, g.ldb);
+    return JRR_ERR_ARG;
+  }
+  dim3 grid((g.M / BM) * (g.N / BN), 1, 1), block(64 * WAVES_M * WAVES_N);
+  if (epi == EPI_BIAS_RELU && !btr) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_BIAS_RELU, 3, 0, 2>), grid, block, 0, s, g);
+  else if (epi == EPI_BIAS_RELU_DOT && !btr) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_BIAS_RELU_DOT, 3, 0, 2>), grid, block, 0, s, g);
+  else if (epi == EPI_STORE && !btr) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_STORE, 3, 0, 2>), grid, block, 0, s, g);
+  else if (epi == EPI_MASK && !btr) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_MASK, 3, 0, 2>), grid, block, 0, s, g);
+  else if (epi == EPI_MASK && btr == 1) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_MASK, 3, 1, 2>), grid, block, 0, s, g);
+  else if (epi == EPI_MASK && btr == 2) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_MASK, 3, 2, 2>), grid, block, 0, s, g);
+  else { jrr_set_error("gemm_disc: unsupported epilogue %d / transform %d", epi, btr); return JRR_ERR_ARG; }
+  return 0;
+}
+
+// the pose discriminator's layers: exact tiling, 3-deep ring; epi in {BIAS_RELU, BIAS_RELU_DOT, STORE, MASK},
+// btr = B-operand transform (see k_gemm_tn).  Returns the number of partial-dot slabs per column of this tiling
+// through *ndot (EPI_BIAS_RELU_DOT consumers).
+int launch_gemm_disc(const GemmArgs& g, int epi, int btr, hipStream_t s) {
+  static const int tile = getenv("JRR_DISC_TILE") ? atoi(getenv("JRR_DISC_TILE")) : 0;     // experiment switch
+  if (tile == 1) return launch_disc_cfg<2, 1, 2, 4>(g, epi, btr, s);    // 128x128, 8 waves of 64x32
+  if (tile == 2) return launch_disc_cfg<2, 2, 2, 2>(g, epi, btr, s);    // 128x128, 4 waves of 64x64
+  return launch_disc_cfg<2, 1, 2, 2>(g, epi, btr, s);                   // 128x64, 4 waves of 64x32
 }
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int GK>

@@ -57,6 +57,34 @@ __device__ __forceinline__ int xcd_remap(int id, int n) {
 #define JRR_LDS(p) ((__attribute__((address_space(3))) void*)(p))
 #define JRR_GLB(p) ((const __attribute__((address_space(1))) void*)(p))
 
+// Row pointer of a [rows][BP] array for a WAVE-UNIFORM row, kept in an SGPR pair: the access is then
+// `global_* v_lane_offset, v_data, s[row]` (scalar address arithmetic) instead of five VALU instructions, two of
+// them quarter-rate 64-bit multiplies, per element.  The per-lane part (4 * half rows + pose column) is a
+// loop-invariant 32-bit offset.
+__device__ __forceinline__ float* urow(float* base, size_t row, int BP) {
+  float* p = base + row * (size_t)BP;
+  asm volatile("" : "+s"(p));
+  return p;
+}
+__device__ __forceinline__ const float* urow(const float* base, size_t row, int BP) {
+  const float* p = base + row * (size_t)BP;
+  asm volatile("" : "+s"(p));
+  return p;
+}
+// uniform part of acc_row(q, half) = (q & 3) + 8 (q >> 2) + 4 half
+__device__ __forceinline__ constexpr int acc_row_u(int q) { return (q & 3) + 8 * (q >> 2); }
+
+// Workgroup barrier that waits for this wave's LDS operations and for all but its N youngest vector-memory operations.
+// `__syncthreads()` drains vmcnt to 0, i.e. it also waits for every global STORE the wave has issued (write latency
+// 1-2 us under load) and for register prefetches that are not needed yet.  LDS-DMA, loads and stores retire in issue
+// order, so when the copies that must have landed are OLDER than N later operations, waiting for vmcnt(N) is enough;
+// LDS-DMA and stores stay in flight across s_barrier (MI355X_MICROARCH.md, "Co-residence costs").
+template <int N>
+__device__ __forceinline__ void barrier_keep_vm() {
+  static_assert(N >= 0 && N <= 63, "vmcnt is a 6-bit counter");
+  asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
 struct Parents {
   int p[NJ];       // parent joint (p[0] = -1), parents precede children
   int depth[NJ];   // tree depth of each joint (root = 0)

@@ -9,7 +9,7 @@ constexpr int DP_CONV0_W = 0, DP_CONV0_B = 192, DP_CONV2_W = 224, DP_CONV2_B = 1
 constexpr int DP_FC0_W = 2072, DP_FC0_B = 788504, DP_FC2_W = 789528, DP_FC2_B = 1838104;
 constexpr int DP_FC4_W = 1839128, DP_FC4_B = 1840152, DP_TOTAL = 1840153;
 
-enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_BIAS = 3, EPI_ACCUM = 4 };
+enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_BIAS = 3, EPI_ACCUM = 4, EPI_BIAS_RELU_DOT = 5 };
 
 struct GemmArgs {
   const float* A; int lda;      // A[k][m]
@@ -19,6 +19,16 @@ struct GemmArgs {
   const float* mask;            // [m][ldo] (EPI_MASK: keep where mask > 0)
   int M, N, K;
   size_t split_stride;          // floats between split-K partial slabs
+  const float* colscale = nullptr;   // [n]   (BTR = 1: B operand -> (x > 0) ? colscale[n] : 0)
+  // BTR = 2: colscale[n] is the pose discriminator's output-layer adjoint dz[n], computed in the prologue from the
+  // partial dots of the fc2 launch: z = zbias[0] + sum_t zpart[t][n]; s = sigmoid(z);
+  // dz = (gout ? gout[n * gout_ld] : scale * (s - target)) * s * (1 - s), 0 for n >= nvalid.  Workgroups of the first
+  // m-tile also write sq0[n] = (s - target)^2 and out0[n * out0_ld] = s when those pointers are set.
+  const float* zpart = nullptr; int nzpart = 0; const float* zbias = nullptr;
+  const float* gout = nullptr; int gout_ld = 0; float scale = 0.f, target = 0.f; int nvalid = 0;
+  float* sq0 = nullptr; float* out0 = nullptr; int out0_ld = 0;
+  const float* dotw = nullptr;       // [m]   (EPI_BIAS_RELU_DOT)
+  float* dot_out = nullptr;          // [(M/BM) * WAVES_M][ldo] partial column dots (EPI_BIAS_RELU_DOT)
 };
 
 struct PrepBwdLaunch {
@@ -72,6 +82,7 @@ int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const fl
                     float* dJ, hipStream_t s);
 
 // gemm.hip
+int launch_gemm_disc(const GemmArgs& g, int epi, int btr, hipStream_t s);
 int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
@@ -106,6 +117,8 @@ int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_
 int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s);
 int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
                     float target, int B, int BP, hipStream_t s, float* dz0 = nullptr, float* sq0 = nullptr);
+int launch_disc_z_finish(const float* zpart, int nz, int ld, const float* zbias, float* out, int B, hipStream_t s);
+int launch_scale_rows(const float* in, const float* w, float* out, int rows, int cols, hipStream_t s);
 int launch_colsum(const float* M, int rows, int ld, float* out, int B, hipStream_t s);
 int launch_rowdot_accum(const float* M, int ld, const float* vec, float* out, int rows, int cols, hipStream_t s);
 // conv / per-joint-head weight gradients as partial slabs: shared [24 * BP/64][1280] (conv0 W,b | conv2 W,b in the

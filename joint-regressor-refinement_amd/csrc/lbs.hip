@@ -58,23 +58,6 @@ __device__ __forceinline__ void dma16u(const float* base_uniform, unsigned lane_
   __builtin_amdgcn_global_load_lds(JRR_GLB(base_uniform + lane_off), JRR_LDS(lds_dst_wave), 16, 0, 0);
 }
 
-// Row pointer of a [rows][BP] array for a WAVE-UNIFORM row, kept in an SGPR pair: the access is then
-// `global_* v_lane_offset, v_data, s[row]` (scalar address arithmetic) instead of five VALU instructions, two of
-// them quarter-rate 64-bit multiplies, per element.  The per-lane part (4 * half rows + pose column) is a
-// loop-invariant 32-bit offset.
-__device__ __forceinline__ float* urow(float* base, size_t row, int BP) {
-  float* p = base + row * (size_t)BP;
-  asm volatile("" : "+s"(p));
-  return p;
-}
-__device__ __forceinline__ const float* urow(const float* base, size_t row, int BP) {
-  const float* p = base + row * (size_t)BP;
-  asm volatile("" : "+s"(p));
-  return p;
-}
-// uniform part of acc_row(q, half) = (q & 3) + 8 (q >> 2) + 4 half
-__device__ __forceinline__ constexpr int acc_row_u(int q) { return (q & 3) + 8 * (q >> 2); }
-
 template <bool STORE_VP, bool STORE_VERTS>
 __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk, const float* __restrict__ Wjv,
                                                     const float* __restrict__ Jn_vi, const float* __restrict__ FT,
@@ -163,29 +146,45 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     const float* ldsJ = ldsW + W_FLOATS;
 #pragma unroll
     for (int s = 0; s < NSTAGE; ++s, ++g) {
-      __syncthreads();   // stage g landed (vmcnt(0) + barrier); slot (g+1)&1 is free again
+      // Stage g landed; slot (g+1)&1 is free again.  The copies of stage g were issued at the start of the previous
+      // stage, BEFORE that stage's v_posed / vertex stores: exactly those stores are left in flight (they get one more
+      // stage to retire instead of stalling this barrier; barrier_keep_vm).  First stage of the kernel: nothing younger.
+      {
+        const int sp = (s == 0) ? NSTAGE - 1 : s - 1;                     // previous stage
+        const int hp = sp - NKCH;                                          // its skinning half-stage, if any
+        const int nst = (hp < 0) ? 0 : (STORE_VP ? 8 : 0) + ((STORE_VERTS && (hp & 1)) ? 16 : 0);
+        // (`s` is a constant after unrolling: one of these survives per stage)
+        if ((s == 0 && vt == t_begin) || nst == 0) barrier_keep_vm<0>();
+        else if (nst == 8) barrier_keep_vm<8>();
+        else if (nst == 16) barrier_keep_vm<16>();
+        else barrier_keep_vm<24>();
+      }
       if (s + 1 < NSTAGE) issue(vt, s + 1, (g + 1) & 1);
       else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1);
+      __builtin_amdgcn_sched_barrier(0);   // the counted wait above relies on: copies first, this stage's stores after
       const float* buf = ring + (g & 1) * STG_FLOATS;
       if (s < NKCH) {
         if (s == 0) { vp[0] = zero16(); vp[1] = zero16(); vp[2] = zero16(); }
         const int npairs = (s == NKCH - 1) ? (KF - (NKCH - 1) * KCH) / 2 : KCH / 2;   // 13 : 16
         const float* dp = buf + half * 96 + l31;
         const float* fp = buf + KCH * 96 + half * BG + wave * BT + l31;
-        // The operands of K-pair kk+1 are requested right after the FIRST MFMA of pair kk has issued: the reads
-        // complete under the 192 clocks of this pair's MFMAs, so the wait before the next pair costs nothing.
-        // (The compiler's own schedule reads right before use and exposes the LDS latency after every third MFMA.)
-        float f = fp[0], d0 = dp[0], d1 = dp[32], d2 = dp[64];
+        // The operands of K-pair kk+2 are requested right after the FIRST MFMA of pair kk has issued: the reads
+        // complete under two pairs' worth of MFMAs (384 clocks), so the wait before a pair costs nothing even when the
+        // LDS is busy with the other workgroup's DMA.  (The compiler's own schedule reads right before use and exposes
+        // the LDS latency after every third MFMA.)
+        float f0 = fp[0], d00 = dp[0], d01 = dp[32], d02 = dp[64];
+        float f1 = fp[2 * BG], d10 = dp[2 * 96], d11 = dp[2 * 96 + 32], d12 = dp[2 * 96 + 64];
 #pragma unroll
         for (int kk = 0; kk < KCH / 2; ++kk) {
           if (kk >= npairs) break;          // constant trip count for the unroller; folds once `s` is unrolled
-          const float fc = f, c0 = d0, c1 = d1, c2 = d2;
+          const float fc = f0, c0 = d00, c1 = d01, c2 = d02;
+          f0 = f1; d00 = d10; d01 = d11; d02 = d12;
           __builtin_amdgcn_sched_barrier(0);
           vp[0] = mfma(c0, fc, vp[0]);
           __builtin_amdgcn_sched_barrier(0);
-          if (kk + 1 < npairs) {
-            f = fp[(2 * kk + 2) * BG];
-            d0 = dp[(2 * kk + 2) * 96]; d1 = dp[(2 * kk + 2) * 96 + 32]; d2 = dp[(2 * kk + 2) * 96 + 64];
+          if (kk + 2 < npairs) {
+            f1 = fp[(2 * kk + 4) * BG];
+            d10 = dp[(2 * kk + 4) * 96]; d11 = dp[(2 * kk + 4) * 96 + 32]; d12 = dp[(2 * kk + 4) * 96 + 64];
           }
           __builtin_amdgcn_sched_barrier(0);
           vp[1] = mfma(c1, fc, vp[1]);
@@ -207,15 +206,17 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         // right after the first MFMA of pair jp
         f32x16 T = zero16();
         f32x16 U = zero16();
-        {
-          float w = wp[0], x0 = a0[0], x1 = a1[0];
+        {   // operands two joint pairs ahead (a pair is only two MFMAs = 128 clocks)
+          float w0 = wp[0], x00 = a0[0], x01 = a1[0];
+          float w1 = wp[2 * 32], x10 = a0[2 * BG], x11 = a1[2 * BG];
 #pragma unroll
           for (int jp = 0; jp < 12; ++jp) {
-            const float wc = w, c0 = x0, c1 = x1;
+            const float wc = w0, c0 = x00, c1 = x01;
+            w0 = w1; x00 = x10; x01 = x11;
             __builtin_amdgcn_sched_barrier(0);
             T = mfma(wc, c0, T);
             __builtin_amdgcn_sched_barrier(0);
-            if (jp + 1 < 12) { w = wp[(2 * jp + 2) * 32]; x0 = a0[(2 * jp + 2) * BG]; x1 = a1[(2 * jp + 2) * BG]; }
+            if (jp + 2 < 12) { w1 = wp[(2 * jp + 4) * 32]; x10 = a0[(2 * jp + 4) * BG]; x11 = a1[(2 * jp + 4) * BG]; }
             __builtin_amdgcn_sched_barrier(0);
             U = mfma(wc, c1, U);
           }
@@ -231,15 +232,16 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
               urow(VTb, (size_t)r * VP + vt * 32 + acc_row_u(q), BP)[voff] = vr[q];
           }
           // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b]
-          {
-            float jn = ldsJ[acc_row(0, half) * 32 + l31];
+          {   // three steps ahead: one MFMA per step
+            float j0 = ldsJ[acc_row(0, half) * 32 + l31], j1 = ldsJ[acc_row(1, half) * 32 + l31], j2 = ldsJ[acc_row(2, half) * 32 + l31];
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
-              const float jc = jn;
+              const float jc = j0;
+              j0 = j1; j1 = j2;
               __builtin_amdgcn_sched_barrier(0);
               jacc[r] = mfma(jc, vr[q], jacc[r]);
               __builtin_amdgcn_sched_barrier(0);
-              if (q + 1 < 16) jn = ldsJ[acc_row(q + 1, half) * 32 + l31];
+              if (q + 3 < 16) j2 = ldsJ[acc_row(q + 3, half) * 32 + l31];
             }
           }
         }
@@ -262,34 +264,44 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
 
 // ------------------------------------------------------------------------------------------
 // backward (to v_posed and to the skinning transforms)
-//   one wave per (pose tile bt, coordinate plane c in {0,1,2}, vertex chunk vc):
-//     dverts_r[v,b] = sum_i Jn[i,v] dj[b,i,r]                (K = 18)        -- or loaded (DVERTS_MEM)
+//   one workgroup of four waves per (pose tile bt of 32 poses, vertex chunk vc); per vertex tile:
+//     dverts_r[v,b] = sum_i Jn[i,v] dj[b,i,r]                (K = 18)        -- and / or loaded (DV)
 //     T_{r,c}[v,b]  = sum_j W[v,j] A[b,j,r,c]                (K = 24, recomputed)
 //     dvp_c[v,b]    = sum_r T_{r,c} dverts_r                  -> DVP [3][VP][BP]
 //     dA_{r,c}[j,b] += sum_v W[v,j] dverts_r[v,b] vp_c[v,b]   (sums over the tile's ROW index)
 //     dA_{c,3}[j,b] += sum_v W[v,j] dverts_c[v,b]
-//   The four waves of a workgroup walk the same vertex tiles, so the per-tile operand tables
-//   (Jn [18][32], W^T [24][32], W [32][32 j]: one contiguous 10 KB record `Tb` per tile) are
-//   staged once per workgroup by LDS-DMA into a 2-deep ring, one tile ahead, one barrier per
-//   tile.  The wave's slice of A^T (36 operand vectors) lives in LDS for the whole kernel; its
-//   v_posed tile is register-prefetched one tile ahead.
+//   Wave roles.  Waves 0..2 are the PLANE waves c = 0, 1, 2: T_{r,c} for the three r (36 MFMA), dvp_c, dA_{r,c} for the
+//   three r (48 MFMA) -- they need the vertex adjoint dverts_r of all three r.  Wave 3 is the VERTEX-ADJOINT wave: it
+//   computes dverts_r once per tile for the whole workgroup (27 MFMA; each plane wave used to recompute all of it),
+//   hands the three tiles to the plane waves through LDS (48 floats per lane, 16-byte pieces, conflict-free), and
+//   takes the translation column dA_{c,3} of all three c off them (48 MFMA; it only needs dverts).  84 : 84 : 84 : 75
+//   MFMA per tile instead of 4 x 127 per 4/3 tiles.  The vertex-adjoint wave runs ONE TILE AHEAD of the plane waves:
+//   while they work on tile t it computes dverts (and dA_{.,3}) of tile t + 1, so the hand-off costs two short barriers
+//   per tile (tile published / tile consumed) and no waiting on MFMA work.  The per-tile operand records `Tb` = [Jn 18x32 | W^T 24x32 | W 32x32(j) | pad] (10 KB) ride a 3-deep
+//   LDS-DMA ring (tile t for the plane waves, t + 1 for wave 3, t + 2 in flight); each plane wave keeps its slice of
+//   A^T (36 operand vectors) in LDS for the whole kernel and register-prefetches its v_posed tile one tile ahead.
 //   outputs: DVP, dATp [nvc][12][24][BP] partials.
 // ------------------------------------------------------------------------------------------
 // DV: 0 = vertex adjoint from the joint adjoint dJT (Jn^T dj), 1 = loaded from dVT, 2 = both (sum)
+constexpr int BWD_RING = 3;
+constexpr int DVBUF_FLOATS = 3 * 16 * 64;        // three 32x32 tiles as [r][register quad][lane][4]
 template <int DV>
 __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb, const float* __restrict__ AT,
                                                     const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                     const float* __restrict__ dVT, float* __restrict__ DVP,
-                                                    float* __restrict__ dATp, int BP, int nvc, int wg_per_vc) {
-  __shared__ float lds[2 * TB_FLOATS + 4 * 36 * 64];
+                                                    float* __restrict__ dATp, int BP, int nvc, int n_bt) {
+  __shared__ __attribute__((aligned(16))) float lds[BWD_RING * TB_FLOATS + DVBUF_FLOATS + 3 * 36 * 64 + 27 * 64];
   float* const ring = lds;
+  f32x4* const dvbuf = reinterpret_cast<f32x4*>(lds + BWD_RING * TB_FLOATS);
   const int tid = threadIdx.x;
   const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wv = __builtin_amdgcn_readfirstlane(wave);
-  float* const ldsA = lds + 2 * TB_FLOATS + wv * 36 * 64;
+  const bool plane = wv < 3;
+  const int c = wv;                                   // coordinate plane of a plane wave
+  float* const ldsA = lds + BWD_RING * TB_FLOATS + DVBUF_FLOATS + (plane ? wv : 0) * 36 * 64;
+  float* const ldsDj = lds + BWD_RING * TB_FLOATS + DVBUF_FLOATS + 3 * 36 * 64;   // wave 3: dj operands [r * 9 + ip][lane]
   const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int vc = L / wg_per_vc, item = (L % wg_per_vc) * 4 + wv;
-  const int c = item % 3, bt = item / 3;
+  const int vc = L / n_bt, bt = L % n_bt;
   const int b0 = bt * BT;
   const size_t bcol = (size_t)b0 + l31;
   const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)bcol;   // lane part of a (row, pose) address
@@ -305,91 +317,185 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
       if (o < TB_FLOATS / 256) dma16u(src + o * 256, lane_ln, dst + o * 256);
     }
   };
-  auto load_vp = [&](int vt, f32x16& dstv) {
-#pragma unroll
-    for (int q = 0; q < 16; ++q) dstv[q] = urow(VPb, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff];
-  };
+  // The two roles are two separate code paths (each with its own accumulators: the register allocation is the larger
+  // of the two, not their union); both execute the same barrier sequence: one __syncthreads, then two per tile.
+  issue(t_begin, 0);
+  if (t_begin + 1 < t_end) issue(t_begin + 1, 1);
 
-  // this wave's A^T operand vectors (r, j-pair) -> LDS, once
-#pragma unroll
-  for (int r = 0; r < 3; ++r)
-#pragma unroll
-    for (int jp = 0; jp < 12; ++jp)
-      ldsA[(r * 12 + jp) * 64 + lane] = AT[(size_t)((r * 4 + c) * NJ + 2 * jp + half) * BP + bcol];
-
-  float dj[3][9];
-  if (DV != 1) {
+  if (plane) {
+    // ================= plane wave c: T_{r,c}, dvp_c, dA_{r,c} =================
+    f32x16 acc3[3] = {zero16(), zero16(), zero16()};
+    // this wave's A^T operand vectors (r, j-pair) -> LDS, once
 #pragma unroll
     for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int ip = 0; ip < 9; ++ip) dj[r][ip] = dJT[(size_t)(r * NHP + 2 * ip + half) * BP + bcol];
-  }
-
-  f32x16 dA[3] = {zero16(), zero16(), zero16()};
-  f32x16 dA3 = zero16();
-  f32x16 vp_next = zero16();
-  if (t_begin < t_end) {
-    issue(t_begin, 0);
-    load_vp(t_begin, vp_next);
-  }
-
-  for (int vt = t_begin; vt < t_end; ++vt) {
-    __syncthreads();   // tables of tile vt landed; the other ring slot is free
-    if (vt + 1 < t_end) issue(vt + 1, (vt - t_begin + 1) & 1);
-    const f32x16 vp = vp_next;
-    if (vt + 1 < t_end) load_vp(vt + 1, vp_next);
-    const float* tab = ring + ((vt - t_begin) & 1) * TB_FLOATS;
-
-    f32x16 dv[3];
-    if (DV != 0) {
+      for (int jp = 0; jp < 12; ++jp)
+        ldsA[(r * 12 + jp) * 64 + lane] = AT[(size_t)((r * 4 + c) * NJ + 2 * jp + half) * BP + bcol];
+    __syncthreads();                                  // records of the first two tiles landed
+    int slot = 0;                                     // ring slot of tile vt
+    for (int vt = t_begin; vt < t_end; ++vt) {
+      // dverts of tile vt published; record vt + 1 landed; everybody is done with tile vt - 1.  This wave's record
+      // copies are older than its 16 v_posed loads and its 16 dvp stores of the previous tile: the stores stay in
+      // flight across the barrier (the loads have been consumed).
+      barrier_keep_vm<32>();
+      const int slot1 = (slot + 1 == BWD_RING) ? 0 : slot + 1, slot2 = (slot1 + 1 == BWD_RING) ? 0 : slot1 + 1;
+      if (vt + 2 < t_end) issue(vt + 2, slot2);
+      __builtin_amdgcn_sched_barrier(0);     // the counted wait relies on: record copies first, loads / stores after
+      const float* tab = ring + slot * TB_FLOATS;
+      f32x16 dv[3], vpc;
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
-        for (int q = 0; q < 16; ++q) dv[r][q] = urow(dVT, (size_t)r * VP + vt * 32 + acc_row_u(q), BP)[voff];
-    } else {
-      dv[0] = zero16(); dv[1] = zero16(); dv[2] = zero16();
-    }
-    if (DV != 1) {
-      const float* jp_ = tab + TB_JN + half * 32 + l31;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 t = dvbuf[(r * 4 + g) * 64 + lane];
+          dv[r][4 * g] = t[0]; dv[r][4 * g + 1] = t[1]; dv[r][4 * g + 2] = t[2]; dv[r][4 * g + 3] = t[3];
+        }
 #pragma unroll
-      for (int ip = 0; ip < 9; ++ip) {
-        const float jn = jp_[(2 * ip) * 32];
+      for (int q = 0; q < 16; ++q)        // v_posed of this tile: consumed in the second half (dA), after the 36 T products
+        vpc[q] = urow(VPb, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff];
+      // every plane wave holds dverts of tile vt in registers: the buffer may take tile vt + 1 (short barrier: the
+      // plane waves reach it right after their 12 LDS reads, wave 3 at once)
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // T_{r,c} for the three r as three interleaved accumulator chains sharing the W operand; operands of joint pair
+      // jp + 1 are requested right after the first MFMA of pair jp (a wave never parks on lgkmcnt between products)
+      f32x16 T0 = zero16(), T1 = zero16(), T2 = zero16();
+      {
+        const float* wp = tab + TB_WJV + half * 32 + l31;
+        const float* ap = ldsA + lane;
+        float w = wp[0], a0 = ap[0], a1 = ap[12 * 64], a2 = ap[24 * 64];
 #pragma unroll
-        for (int r = 0; r < 3; ++r) dv[r] = mfma(jn, dj[r][ip], dv[r]);
+        for (int jp = 0; jp < 12; ++jp) {
+          const float wc = w, c0 = a0, c1 = a1, c2 = a2;
+          __builtin_amdgcn_sched_barrier(0);
+          T0 = mfma(wc, c0, T0);
+          __builtin_amdgcn_sched_barrier(0);
+          if (jp + 1 < 12) {
+            w = wp[(2 * jp + 2) * 32];
+            a0 = ap[(jp + 1) * 64]; a1 = ap[(12 + jp + 1) * 64]; a2 = ap[(24 + jp + 1) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          T1 = mfma(wc, c1, T1);
+          T2 = mfma(wc, c2, T2);
+        }
       }
-    }
-
-    f32x16 dvp = zero16();
-    {
-      const float* wp = tab + TB_WJV + half * 32 + l31;
 #pragma unroll
-      for (int r = 0; r < 3; ++r) {
-        f32x16 T = zero16();
-#pragma unroll
-        for (int jp = 0; jp < 12; ++jp) T = mfma(wp[(2 * jp) * 32], ldsA[(r * 12 + jp) * 64 + lane], T);
-        dvp += T * dv[r];
+      for (int q = 0; q < 16; ++q) {                     // dvp_c = sum_r T_{r,c} dverts_r
+        const float dvp = fmaf(T2[q], dv[2][q], fmaf(T1[q], dv[1][q], T0[q] * dv[0][q]));
+        urow(DVP, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff] = dvp;
       }
-    }
+      const float* wvp = tab + TB_WVJ + l31;
+      float wn = wvp[acc_row(0, half) * 32];
 #pragma unroll
-    for (int q = 0; q < 16; ++q) urow(DVP, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff] = dvp[q];
-
-    const float* wvp = tab + TB_WVJ + l31;
+      for (int q = 0; q < 16; ++q) {
+        const float wvj = wn;
+        const float p0 = dv[0][q] * vpc[q], p1 = dv[1][q] * vpc[q], p2 = dv[2][q] * vpc[q];
+        __builtin_amdgcn_sched_barrier(0);
+        acc3[0] = mfma(wvj, p0, acc3[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < 16) wn = wvp[acc_row(q + 1, half) * 32];
+        __builtin_amdgcn_sched_barrier(0);
+        acc3[1] = mfma(wvj, p1, acc3[1]);
+        acc3[2] = mfma(wvj, p2, acc3[2]);
+      }
+      slot = slot1;
+    }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
-      const float wvj = wvp[acc_row(q, half) * 32];
+      const int j = acc_row(q, half);
+      if (j < NJ) {
 #pragma unroll
-      for (int r = 0; r < 3; ++r) dA[r] = mfma(wvj, dv[r][q] * vp[q], dA[r]);
-      const float dvc = (c == 0) ? dv[0][q] : (c == 1) ? dv[1][q] : dv[2][q];
-      dA3 = mfma(wvj, dvc, dA3);
+        for (int r = 0; r < 3; ++r) dATp[((size_t)(vc * 12 + r * 4 + c) * NJ + j) * BP + bcol] = acc3[r][q];
+      }
     }
-  }
+  } else {
+    // ================= wave 3: dverts of the next tile for everybody, dA_{r,3} =================
+    f32x16 acc3[3] = {zero16(), zero16(), zero16()};
+    f32x16 dv[3];
+    // vertex adjoint of tile vt: Jn^T dj on the matrix cores and / or the caller's adjoint from memory
+    auto compute_dv = [&](int vt, const float* tab) {
+      if (DV != 0) {
 #pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const int j = acc_row(q, half);
-    if (j < NJ) {
+        for (int r = 0; r < 3; ++r)
 #pragma unroll
-      for (int r = 0; r < 3; ++r) dATp[((size_t)(vc * 12 + r * 4 + c) * NJ + j) * BP + bcol] = dA[r][q];
-      dATp[((size_t)(vc * 12 + c * 4 + 3) * NJ + j) * BP + bcol] = dA3[q];
+          for (int q = 0; q < 16; ++q) dv[r][q] = urow(dVT, (size_t)r * VP + vt * 32 + acc_row_u(q), BP)[voff];
+      } else {
+        dv[0] = zero16(); dv[1] = zero16(); dv[2] = zero16();
+      }
+      if (DV != 1) {
+        const float* jp_ = tab + TB_JN + half * 32 + l31;
+        const float* dp_ = ldsDj + lane;
+        float jn = jp_[0], d0 = dp_[0], d1 = dp_[9 * 64], d2 = dp_[18 * 64];
+#pragma unroll
+        for (int ip = 0; ip < 9; ++ip) {
+          const float jc = jn, c0 = d0, c1 = d1, c2 = d2;
+          __builtin_amdgcn_sched_barrier(0);
+          dv[0] = mfma(jc, c0, dv[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (ip + 1 < 9) {
+            jn = jp_[(2 * ip + 2) * 32];
+            d0 = dp_[(ip + 1) * 64]; d1 = dp_[(9 + ip + 1) * 64]; d2 = dp_[(18 + ip + 1) * 64];
+          }
+          __builtin_amdgcn_sched_barrier(0);
+          dv[1] = mfma(jc, c1, dv[1]);
+          dv[2] = mfma(jc, c2, dv[2]);
+        }
+      }
+    };
+    auto publish_dv = [&]() {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          f32x4 t = {dv[r][4 * g], dv[r][4 * g + 1], dv[r][4 * g + 2], dv[r][4 * g + 3]};
+          dvbuf[(r * 4 + g) * 64 + lane] = t;
+        }
+    };
+    // dA_{r,3}[j,b] += sum_v W[v,j] dverts_r[v,b]
+    auto accumulate_dA3 = [&](const float* tab) {
+      const float* wvp = tab + TB_WVJ + l31;
+      float wn = wvp[acc_row(0, half) * 32];
+#pragma unroll
+      for (int q = 0; q < 16; ++q) {
+        const float wvj = wn;
+        __builtin_amdgcn_sched_barrier(0);
+        acc3[0] = mfma(wvj, dv[0][q], acc3[0]);
+        __builtin_amdgcn_sched_barrier(0);
+        if (q + 1 < 16) wn = wvp[acc_row(q + 1, half) * 32];
+        __builtin_amdgcn_sched_barrier(0);
+        acc3[1] = mfma(wvj, dv[1][q], acc3[1]);
+        acc3[2] = mfma(wvj, dv[2][q], acc3[2]);
+      }
+    };
+    if (DV != 1) {
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int ip = 0; ip < 9; ++ip) ldsDj[(r * 9 + ip) * 64 + lane] = dJT[(size_t)(r * NHP + 2 * ip + half) * BP + bcol];
+    }
+    __syncthreads();                                  // records of the first two tiles landed
+    compute_dv(t_begin, ring);
+    publish_dv();
+    accumulate_dA3(ring);
+    int slot = 0;
+    for (int vt = t_begin; vt < t_end; ++vt) {
+      barrier_keep_vm<0>();                           // nothing younger than this wave's record copies is in flight
+      const int slot1 = (slot + 1 == BWD_RING) ? 0 : slot + 1, slot2 = (slot1 + 1 == BWD_RING) ? 0 : slot1 + 1;
+      if (vt + 2 < t_end) issue(vt + 2, slot2);
+      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (vt + 1 < t_end) {      // this wave's whole tile (27 + 48 MFMA) runs beside the plane waves' 84
+        compute_dv(vt + 1, ring + slot1 * TB_FLOATS);
+        publish_dv();
+        accumulate_dA3(ring + slot1 * TB_FLOATS);
+      }
+      slot = slot1;
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int j = acc_row(q, half);
+      if (j < NJ) {
+#pragma unroll
+        for (int r = 0; r < 3; ++r) dATp[((size_t)(vc * 12 + r * 4 + 3) * NJ + j) * BP + bcol] = acc3[r][q];
+      }
     }
   }
 }
@@ -549,14 +655,14 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s) {
   (void)m;
-  const int wg_per_vc = (BP / BT) * 3 / 4;     // BP is a multiple of 128, so 3*BP/32 is a multiple of 4
-  dim3 grid(wg_per_vc * nvc), block(256);
+  const int n_bt = BP / BT;                     // one workgroup per (pose tile, vertex chunk)
+  dim3 grid(n_bt * nvc), block(256);
   if (dVT && dJT)
-    hipLaunchKernelGGL((k_lbs_bwd<2>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, wg_per_vc);
+    hipLaunchKernelGGL((k_lbs_bwd<2>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt);
   else if (dVT)
-    hipLaunchKernelGGL((k_lbs_bwd<1>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, wg_per_vc);
+    hipLaunchKernelGGL((k_lbs_bwd<1>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt);
   else
-    hipLaunchKernelGGL((k_lbs_bwd<0>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, wg_per_vc);
+    hipLaunchKernelGGL((k_lbs_bwd<0>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt);
   return 0;
 }
 
