@@ -160,6 +160,7 @@ def main():
     eng = eng_mod.RefineEngine(dmodel, B, batch_norm=B * world, flags=flags)
     J = torch.from_numpy(J_np).to(dev)
     eng.set_j_regressor(J)
+    eng.set_forward_reuse(True)     # the iteration after a J step reuses that step's SMPL forward (same poses, new regressor)
     disc_flat, disc_sd = default_disc_flat(0)
     if use_disc:
         eng.set_pose_disc(disc_flat.to(dev))

@@ -241,6 +241,15 @@ int jrr_refine_aux_losses(jrr_engine_t* e, float* pose_disc_sq_dev, float* shape
 int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev,
                          const float* gt_centred_mm_dev, float* dJ_dev, float* sqerr_dev, void* stream);
 
+/* Forward reuse across the J step (needs JRR_FLAG_KEEP_VERTS).  jrr_j_regressor_grad evaluates SMPL on the current
+ * poses; the inner iteration that follows evaluates it on the SAME poses (only the regressor has changed in between,
+ * scripts/optimize.py:300-312 then :220-229).  When enabled, a jrr_refine_run whose x6d / betas POINTERS equal those of the
+ * immediately preceding jrr_j_regressor_grad re-regresses the joints of its first iteration from the stored vertices
+ * with the new regressor instead of repeating the forward -- the same arithmetic up to the summation order of the
+ * regressor product.  The caller guarantees that nothing but jrr_refine_run modifies the pose buffers between the two
+ * calls (any other engine call drops the cached forward).  Default: off.                                            */
+int jrr_engine_set_forward_reuse(jrr_engine_t* e, int enabled);
+
 /* launch geometry: {B, BP, batch_norm, nvc, nvcb, nsplit, nsplitJ, flags} */
 int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n);
 

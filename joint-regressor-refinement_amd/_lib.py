@@ -59,6 +59,7 @@ SIGNATURES = {
     'jrr_engine_set_silhouette': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_refine_run': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),
     'jrr_j_regressor_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P]),
+    'jrr_engine_set_forward_reuse': (c_int, [_P, c_int]),
     'jrr_engine_info': (c_int, [_P, POINTER(c_int32), c_int]),
     'jrr_engine_set_profiling': (c_int, [_P, c_int]),
     'jrr_engine_profile_read': (c_int, [_P, POINTER(c_float), POINTER(c_int32)]),

@@ -141,6 +141,8 @@ struct jrr_engine {
   const float* sil_mask;
   float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
   bool folded, fold_valid;
+  // forward reuse (jrr_engine_set_forward_reuse): state left by jrr_j_regressor_grad's SMPL forward
+  bool reuse_enabled, fwd_cached; const float *fc_x6d, *fc_betas;
   float *VTb;       // [3][VP][BP] vertices / transposed vertex adjoint (KEEP_VERTS or SILHOUETTE)
   float *verts, *djpad, *dJnp, *dJn, *dj;
   int32_t* step_scratch;
@@ -489,12 +491,14 @@ extern "C" int jrr_rodrigues_backward(const float* aa, const float* dR, float* d
 }
 
 // sum the per-vertex-chunk joint partials (wide, memory-bound) so the per-pose kernel reads 51 values
-static void reduce_joint_partials(jrr_engine* e, hipStream_t s) {
-  launch_reduce_slabs(e->JP, e->nvc, (size_t)3 * NH * e->BP, e->Jsum, (size_t)3 * NH * e->BP, s);
-}
+// The per-vertex-chunk joint partials JP [nvc][3][17][BP] and skinning-adjoint partials dATp [nvcb][12][24][BP] are summed
+// by their consumers (k_joints_loss, k_chain_bwd: a few pose-contiguous loads per thread); only the 16 split-K slabs of
+// dF^T (58 MB at 4096 poses) keep a wide reduction kernel of their own.
 static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s) {
-  launch_reduce_slabs(e->dATp, e->nvcb, (size_t)12 * NJ * e->BP, e->dA, (size_t)12 * NJ * e->BP, s);
   launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
+}
+static void set_adjoint_slabs(jrr_engine* e, PrepBwdLaunch& L) {
+  L.dATp = e->dATp; L.nslabA = e->nvcb; L.strideA = (size_t)12 * NJ * e->BP; L.dFTp = e->dF;
 }
 
 static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,
@@ -510,14 +514,14 @@ extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const 
   if (!e || !betas || !joints || ((x6d == nullptr) == (R == nullptr))) { jrr_set_error("find_joints_forward: bad argument"); return JRR_ERR_ARG; }
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
+  e->fwd_cached = false;
   const bool kv = (e->flags & JRR_FLAG_KEEP_VERTS) != 0;
   if (verts && !e->VTb) { jrr_set_error("return_verts needs an engine created with JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
   smpl_forward(e, x6d, R, betas, true, kv || verts, nullptr, s);
   if (kv)      // padded pose-major copy (row stride VP*3, zeros in the padding) for the J_regressor adjoint
     launch_verts_untranspose(e->VTb, e->verts, VP * 3, VP, nullptr, nullptr, e->BP, e->BP, s);
   if (verts) launch_verts_untranspose(e->VTb, verts, V * 3, V, nullptr, nullptr, e->B, e->BP, s);
-  reduce_joint_partials(e, s);
-  launch_joints_loss(e->Jsum, 1, nullptr, nullptr, 0.f, joints, nullptr, nullptr, e->B, e->BP, s);
+  launch_joints_loss(e->JP, e->nvc, nullptr, nullptr, 0.f, joints, nullptr, nullptr, e->B, e->BP, s);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -549,7 +553,7 @@ extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const
     reduce_adjoint_partials(e, s);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.R_in = R; L.betas_in = betas;
-    L.dATp = e->dA; L.dFTp = e->dF; L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
+    set_adjoint_slabs(e, L); L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
     L.dx6d = dx6d; L.dR = dR; L.dbetas = dbetas;
     L.B = e->B; L.BP = e->BP;
     launch_prep_bwd(L, e->m, s);
@@ -568,6 +572,7 @@ extern "C" int jrr_smpl_vertices_backward(jrr_engine_t* e, const float* x6d, con
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("smpl_vertices_backward requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
+  e->fwd_cached = false;
   // the padded vertex buffer is reused as the transposed adjoint [3][VP][BP] (same size)
   launch_dverts_transpose(dverts, V * 3, e->VTb, e->B, e->BP, s);      // the vertex buffer doubles as the transposed adjoint
   launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, nullptr, e->VTb, e->DVP, e->dATp, e->BP, e->nvcb, s);
@@ -576,7 +581,7 @@ extern "C" int jrr_smpl_vertices_backward(jrr_engine_t* e, const float* x6d, con
   reduce_adjoint_partials(e, s);
   PrepBwdLaunch L;
   L.x6d_in = x6d; L.R_in = R; L.betas_in = betas;
-  L.dATp = e->dA; L.dFTp = e->dF; L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
+  set_adjoint_slabs(e, L); L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
   L.dx6d = dx6d; L.dR = dR; L.dbetas = dbetas;
   L.B = e->B; L.BP = e->BP;
   launch_prep_bwd(L, e->m, s);
@@ -823,9 +828,9 @@ extern "C" int jrr_camera_prefit(jrr_engine_t* e, const float* x6d, const float*
   if (!e || !x6d || !betas || !gt_j2d || !cam || n_steps < 0) return JRR_ERR_ARG;
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
+  e->fwd_cached = false;
   smpl_forward(e, x6d, nullptr, betas, false, false, nullptr, s);
-  reduce_joint_partials(e, s);
-  launch_joints_loss(e->Jsum, 1, nullptr, nullptr, 0.f, e->joints, nullptr, nullptr, e->B, e->BP, s);
+  launch_joints_loss(e->JP, e->nvc, nullptr, nullptr, 0.f, e->joints, nullptr, nullptr, e->B, e->BP, s);
   const float scale2d = (float)(2.0 / ((double)e->bnorm * 34.0));     // optimize.py:193 unweighted MSE
   launch_camera_fit(e->joints, gt_j2d, cam, scale2d, n_steps, lr, sq2d, e->B, s);
   CHECK_LAUNCH();
@@ -874,6 +879,24 @@ extern "C" int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask, flo
   return JRR_OK;
 }
 
+extern "C" int jrr_engine_set_forward_reuse(jrr_engine_t* e, int enabled) {
+  if (!e) return JRR_ERR_ARG;
+  e->reuse_enabled = enabled != 0;
+  e->fwd_cached = false;
+  return JRR_OK;
+}
+
+// joints^T partials from the STORED vertices: JPv[split][r][32][BP] = sum_{v in split} Jn[i,v] verts_r[v,b]
+// (one batched split-K product over the three coordinate planes; Jn_vi is [VP][32] = K-major, zero rows i >= 17)
+static int joints_from_stored_verts(jrr_engine* e, hipStream_t s) {
+  GemmArgs g;
+  g.A = e->Jn_vi; g.lda = 32; g.Bm = e->VTb; g.ldb = e->BP; g.Out = e->dFTp; g.ldo = e->BP;
+  g.bias = nullptr; g.mask = nullptr; g.M = 32; g.N = e->BP; g.K = VP;
+  g.batchA = 0; g.batchB = (size_t)VP * e->BP; g.batchO = (size_t)32 * e->BP;
+  g.split_stride = (size_t)3 * 32 * e->BP;
+  return launch_gemm_32x128(g, EPI_STORE, e->nsplit, 3, s);
+}
+
 // =============================================================================================
 // fused inner loop (scripts/optimize.py:220-265)
 // =============================================================================================
@@ -888,12 +911,22 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
   const float dscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 25.0));      // optimize.py:253 weight 10
   const float sscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 1.0));
   for (int it = 0; it < n_iters; ++it) {
-    prof_mark(e, 0, s);
-    launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, s);
-    prof_mark(e, 0, s);
     const bool folded = e->folded && e->fold_valid;
+    // The J step that preceded this call ran the SMPL forward on exactly these poses (jrr_j_regressor_grad keeps
+    // v_posed, the skinning transforms and the vertices): the first iteration re-regresses the joints with the NEW
+    // regressor from the stored vertices instead of repeating the 0.47 ms forward (jrr_engine_set_forward_reuse).
+    const bool reuse = it == 0 && e->reuse_enabled && e->fwd_cached && e->fc_x6d == x6d && e->fc_betas == betas && !folded &&
+                       e->VTb != nullptr && e->sil_mask == nullptr;
+    e->fwd_cached = false;
+    prof_mark(e, 0, s);
+    if (reuse) launch_step_inc(step, s);
+    else launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, s);
+    prof_mark(e, 0, s);
     prof_mark(e, 1, s);
-    if (folded) {
+    if (reuse) {
+      int rcr = joints_from_stored_verts(e, s);
+      if (rcr) return rcr;
+    } else if (folded) {
       GemmArgs g;   // M^T[(i,j,c)][b] = sum_k H[(i,j,c)][k] F^T[k][b]
       g.A = e->Hk; g.lda = FOLD_M; g.Bm = e->FT; g.ldb = e->BP; g.Out = e->MT; g.ldo = e->BP;
       g.bias = nullptr; g.mask = nullptr; g.split_stride = 0; g.M = FOLD_M; g.N = e->BP; g.K = KFP;
@@ -907,10 +940,9 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     }
     prof_mark(e, 1, s);
     prof_mark(e, 2, s);
-    if (!folded) reduce_joint_partials(e, s);
     ReprojLaunch rl{e->gt_j2d, e->cam, e->gcam, e->sq2d, (float)(2.0 * 0.01 / ((double)e->bnorm * 34.0))};   // weight 1/100
-    launch_joints_loss(e->Jsum, 1, gt_mm, nullptr, jscale, e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s,
-                       e->gt_j2d ? &rl : nullptr);
+    launch_joints_loss(reuse ? e->dFTp : folded ? e->Jsum : e->JP, reuse ? e->nsplit : folded ? 1 : e->nvc, gt_mm, nullptr, jscale,
+                       e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s, e->gt_j2d ? &rl : nullptr, reuse ? 32 : NH);
     prof_mark(e, 2, s);
     int rc = 0;
     const bool sil = e->sil_mask != nullptr && !folded;
@@ -956,7 +988,8 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     else reduce_adjoint_partials(e, s);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.betas_in = betas;
-    L.dATp = e->dA; L.dFTp = e->dF; L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
+    if (folded) { L.dATp = e->dA; L.dFTp = e->dF; } else set_adjoint_slabs(e, L);
+    L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
     L.gx_extra = pd ? e->gx : nullptr; L.gb_extra = sd ? e->gb : nullptr;
     L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step;
     L.lr = lr; L.B = e->B; L.BP = e->BP;
@@ -1015,11 +1048,11 @@ extern "C" int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d, const flo
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("J step requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
-  smpl_forward(e, x6d, nullptr, betas, false, true, nullptr, s);
+  smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s);      // v_posed kept: the next inner iteration may reuse this forward
+  e->fwd_cached = true; e->fc_x6d = x6d; e->fc_betas = betas;
   launch_verts_untranspose(e->VTb, e->verts, VP * 3, VP, nullptr, nullptr, e->BP, e->BP, s);
   const float scale = (float)(2.0 * 1.0 / ((double)e->bnorm * 51.0));   // optimize.py:307 unweighted MSE
-  reduce_joint_partials(e, s);
-  launch_joints_loss(e->Jsum, 1, gt_mm, nullptr, scale, e->joints, sqerr ? sqerr : e->sqerr, nullptr, e->B, e->BP, s);
+  launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, scale, e->joints, sqerr ? sqerr : e->sqerr, nullptr, e->B, e->BP, s);
   launch_joint_loss_plain(e->joints, gt_mm, scale, nullptr, e->dj, e->B, s);
   return j_grad_from_verts(e, e->dj, dJ, s);
 }

@@ -63,8 +63,8 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
     okB[i] = EXACT || ((wave + NW * i) < OPB && p < B16);
     offB[i] = (unsigned)row * (unsigned)g.ldb + (unsigned)col;
   }
-  const float* const Abase = g.A + m0;
-  const float* const Bbase = g.Bm + n0;
+  const float* const Abase = g.A + (size_t)blockIdx.y * g.batchA + m0;
+  const float* const Bbase = g.Bm + (size_t)blockIdx.y * g.batchB + n0;
 
   auto issue = [&](int ch, int slot) {
     const float* a = Abase + (size_t)ch * GK * g.lda;
@@ -176,7 +176,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
 
   // epilogue: the row part of every address is wave-uniform (kept in SGPRs), the lane part (4 * half rows + column)
   // is one 32-bit offset -- one store per element instead of five VALU instructions of address arithmetic
-  float* out = g.Out + (size_t)split * g.split_stride;
+  float* out = g.Out + (size_t)split * g.split_stride + (size_t)blockIdx.y * g.batchO;
   const unsigned lane_off = (unsigned)(4 * half) * (unsigned)g.ldo + (unsigned)(n0 + l31);
   float dot[WN];
 #pragma unroll
@@ -247,13 +247,13 @@ int launch_gemm_disc(const GemmArgs& g, int epi, int btr, hipStream_t s) {
 }
 
 template <int WM, int WN, int WAVES_M, int WAVES_N, int GK>
-static int launch_cfg(const GemmArgs& g, int epi, int nsplit, hipStream_t s) {
+static int launch_cfg(const GemmArgs& g, int epi, int nsplit, hipStream_t s, int nbatch = 1) {
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
   if (g.N % BN != 0 || g.K % GK != 0 || g.lda % 4 != 0 || g.ldb % 4 != 0 || g.M % 4 != 0) {
     jrr_set_error("gemm_tn: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d", g.M, g.N, g.K, g.lda, g.ldb);
     return JRR_ERR_ARG;
   }
-  dim3 grid(((g.M + BM - 1) / BM) * (g.N / BN), 1, nsplit), block(64 * WAVES_M * WAVES_N);
+  dim3 grid(((g.M + BM - 1) / BM) * (g.N / BN), nbatch, nsplit), block(64 * WAVES_M * WAVES_N);
   switch (epi) {
     case EPI_STORE: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_STORE>), grid, block, 0, s, g); break;
     case EPI_BIAS_RELU: hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_BIAS_RELU>), grid, block, 0, s, g); break;
@@ -277,5 +277,10 @@ int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { 
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<7, 1, 1, 4, 16>(g, epi, nsplit, s); }
 // 64x128 block tile (4 waves of 64x32): the J-regressor gradient product, M = 51 padded to 64
 int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 1, 4, 16>(g, epi, nsplit, s); }
+
+// 32x128 block tile (4 waves of 32x32 side by side), batched over gridDim.y: joints = Jn . verts from stored vertices
+int launch_gemm_32x128(const GemmArgs& g, int epi, int nsplit, int nbatch, hipStream_t s) {
+  return launch_cfg<1, 1, 1, 4, 16>(g, epi, nsplit, s, nbatch);
+}
 
 }  // namespace jrr

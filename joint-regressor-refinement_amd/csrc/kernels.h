@@ -19,6 +19,7 @@ struct GemmArgs {
   const float* mask;            // [m][ldo] (EPI_MASK: keep where mask > 0)
   int M, N, K;
   size_t split_stride;          // floats between split-K partial slabs
+  size_t batchA = 0, batchB = 0, batchO = 0;   // floats between the operands / outputs of gridDim.y batched products
   const float* colscale = nullptr;   // [n]   (BTR = 1: B operand -> (x > 0) ? colscale[n] : 0)
   // BTR = 2: colscale[n] is the pose discriminator's output-layer adjoint dz[n], computed in the prologue from the
   // partial dots of the fc2 launch: z = zbias[0] + sum_t zpart[t][n]; s = sigmoid(z);
@@ -33,7 +34,8 @@ struct GemmArgs {
 
 struct PrepBwdLaunch {
   const float* x6d_in = nullptr; const float* R_in = nullptr; const float* betas_in = nullptr;
-  const float* dATp = nullptr; const float* dFTp = nullptr;    // REDUCED adjoints dA^T [288][BP], dF^T [224][BP]
+  const float* dATp = nullptr; const float* dFTp = nullptr;    // adjoints dA^T [nslabA][288][BP] (partial slabs, summed
+  int nslabA = 1; size_t strideA = 0;                           // by k_chain_bwd), dF^T [224][BP] (reduced)
   const float* FT = nullptr; const float* R0T = nullptr; const float* AT = nullptr;   // saved by k_prep_fwd
   float* dRT = nullptr; float* dbT = nullptr;                   // scratch [216][BP], [10][BP]
   const float* gx_extra = nullptr; const float* gb_extra = nullptr;
@@ -56,7 +58,8 @@ int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const fl
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s);
 int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float* djoints_in, float scale,
                        float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s,
-                       const ReprojLaunch* r = nullptr);
+                       const ReprojLaunch* r = nullptr, int jp_rows = NH);
+int launch_step_inc(int32_t* step, hipStream_t s);
 int launch_project_joints(const float* joints, const float* cam, float* out, int B, hipStream_t s);
 int launch_camera_fit(const float* joints, const float* gt_j2d, float* cam, float scale2d, int nsteps, float lr, float* sq2d,
                       int B, hipStream_t s);
@@ -89,6 +92,7 @@ int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+int launch_gemm_32x128(const GemmArgs& g, int epi, int nsplit, int nbatch, hipStream_t s);
 
 // sil.hip
 int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s);

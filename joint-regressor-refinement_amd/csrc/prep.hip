@@ -369,7 +369,7 @@ struct Reproj {
 //   scale = 2*weight/(batch_norm*51).  If djoints_in != NULL it is used as the adjoint instead
 //   (operator-level backward), transposed into dJT.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PP * NH) void k_joints_loss(const float* __restrict__ JP, int nvc,
+__global__ __launch_bounds__(PP * NH) void k_joints_loss(const float* __restrict__ JP, int nvc, int jp_rows,
                                                          const float* __restrict__ gt_mm,
                                                          const float* __restrict__ djoints_in, float scale,
                                                          float* __restrict__ joints_out, float* __restrict__ sqerr,
@@ -382,12 +382,22 @@ __global__ __launch_bounds__(PP * NH) void k_joints_loss(const float* __restrict
   const bool ok = b < B;
   float j[3] = {0.f, 0.f, 0.f};
   if (JP) {
+    // per-vertex-chunk partials, summed in chunk order; four chunks' loads (12) in flight together
+    int ch = 0;
+    for (; ch + 4 <= nvc; ch += 4) {
+      float t[4][3];
 #pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float acc = 0.f;
-      for (int ch = 0; ch < nvc; ++ch) acc += JP[(size_t)((ch * 3 + c) * NH + i) * BP + b];
-      j[c] = acc;
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) t[u][c] = JP[(size_t)(((ch + u) * 3 + c) * jp_rows + i) * BP + b];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) j[c] += t[u][c];
     }
+    for (; ch < nvc; ++ch)
+#pragma unroll
+      for (int c = 0; c < 3; ++c) j[c] += JP[(size_t)((ch * 3 + c) * jp_rows + i) * BP + b];
     if (joints_out && ok) {
 #pragma unroll
       for (int c = 0; c < 3; ++c) joints_out[((size_t)b * NH + i) * 3 + c] = j[c];
@@ -563,11 +573,14 @@ __global__ void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, 
 // k_pose_update (one (pose, joint) per thread, joint 24 = betas): 6-D rotation adjoint, extra
 //   (discriminator) gradients, then either the gradient outputs or the fused Adam update.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(PP * NJ) void k_chain_bwd(const float* __restrict__ FT, const float* __restrict__ R0T,
-                                                       const float* __restrict__ AT, const float* __restrict__ Jt,
-                                                       const float* __restrict__ JS, Parents par,
-                                                       const float* __restrict__ dA_, const float* __restrict__ dF_,
-                                                       float* __restrict__ dRT, float* __restrict__ dbT, int B, int BP) {
+constexpr int PPB = 32;   // poses per block of k_chain_bwd (16 halves the coalescing width: measured 1.5x slower)
+__global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict__ FT, const float* __restrict__ R0T,
+                                                        const float* __restrict__ AT, const float* __restrict__ Jt,
+                                                        const float* __restrict__ JS, Parents par,
+                                                        const float* __restrict__ dA_, int nslabA, size_t strideA,
+                                                        const float* __restrict__ dF_, float* __restrict__ dRT,
+                                                        float* __restrict__ dbT, int B, int BP) {
+  constexpr int PP = PPB;
   // one thread per (pose, joint); levels of the kinematic tree are processed deepest first.  Each child
   // leaves its contribution to the parent's dG in its own LDS slot; the parent sums its children in
   // index order (no atomics: bitwise reproducible).
@@ -585,8 +598,16 @@ __global__ __launch_bounds__(PP * NJ) void k_chain_bwd(const float* __restrict__
   rest_joint(Jt, JS, j, beta, Ji);
   // everything this joint needs from global memory, issued up front (independent, pose-contiguous)
   float dA[12], GiR[9], R[9], Gp[9], dFj[9];
+  // dA^T arrives as per-vertex-chunk partial slabs [nslabA][12][24][BP]: summed here, in slab order (deterministic)
 #pragma unroll
   for (int e = 0; e < 12; ++e) dA[e] = dA_[(size_t)(e * NJ + j) * BP + bb];
+  for (int sl = 1; sl < nslabA; ++sl) {        // all 12 loads of a slab in flight together
+    float t[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) t[e] = dA_[(size_t)sl * strideA + (size_t)(e * NJ + j) * BP + bb];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) dA[e] += t[e];
+  }
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -797,6 +818,12 @@ int launch_rot6d_bwd(const float* x, const float* dR, float* dx, int n, hipStrea
   return 0;
 }
 
+__global__ void k_step_inc(int32_t* step) { step[0] += 1; }
+int launch_step_inc(int32_t* step, hipStream_t s) {
+  hipLaunchKernelGGL(k_step_inc, dim3(1), dim3(1), 0, s, step);
+  return 0;
+}
+
 int launch_rodrigues_fwd(const float* aa, float* R, int n, hipStream_t s) {
   hipLaunchKernelGGL(k_rodrigues_fwd, dim3((n + 255) / 256), dim3(256), 0, s, aa, R, n);
   return 0;
@@ -814,11 +841,12 @@ int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const fl
 }
 
 int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float* djoints_in, float scale,
-                       float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s, const ReprojLaunch* r) {
+                       float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s, const ReprojLaunch* r,
+                       int jp_rows) {
   Reproj rp;
   rp.gt_j2d = r ? r->gt_j2d : nullptr; rp.cam = r ? r->cam : nullptr; rp.gcam = r ? r->gcam : nullptr;
   rp.sq2d = r ? r->sq2d : nullptr; rp.scale2d = r ? r->scale2d : 0.f;
-  hipLaunchKernelGGL(k_joints_loss, dim3(BP / PP), dim3(PP * NH), 0, s, JP, nvc, gt_mm, djoints_in, scale, joints_out,
+  hipLaunchKernelGGL(k_joints_loss, dim3(BP / PP), dim3(PP * NH), 0, s, JP, nvc, jp_rows, gt_mm, djoints_in, scale, joints_out,
                      sqerr, dJT, rp, B, BP);
   return 0;
 }
@@ -842,8 +870,8 @@ int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale
 }
 
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
-  hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + PP - 1) / PP), dim3(PP * NJ), 0, s, L.FT, L.R0T, L.AT, m.Jt, m.JS, m.parents,
-                     L.dATp, L.dFTp, L.dRT, L.dbT, L.B, L.BP);
+  hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + PPB - 1) / PPB), dim3(PPB * NJ), 0, s, L.FT, L.R0T, L.AT, m.Jt, m.JS, m.parents,
+                     L.dATp, L.nslabA, L.strideA, L.dFTp, L.dRT, L.dbT, L.B, L.BP);
   PoseUpdateArgs a;
   a.x6d_in = L.x6d_in; a.dRT = L.dRT; a.dbT = L.dbT; a.gx_extra = L.gx_extra; a.gb_extra = L.gb_extra;
   a.dx6d = L.dx6d; a.dR = L.dR; a.dbetas = L.dbetas;

@@ -136,6 +136,10 @@ class RefineEngine:
         self.batch_norm = int(n)
         self.info['batch_norm'] = int(n)
 
+    def set_forward_reuse(self, enabled: bool):
+        """let the inner iteration that follows a J step reuse that step's SMPL forward (include/jrr.h)"""
+        check(self.lib.jrr_engine_set_forward_reuse(self.handle, int(bool(enabled))), 'set_forward_reuse')
+
     def set_folded(self, enabled: bool):
         """refine_run through the folded regressor tables (engine must have FLAG_FOLDED)"""
         check(self.lib.jrr_engine_set_folded(self.handle, int(bool(enabled)), self._s()), 'set_folded')

@@ -118,6 +118,7 @@ def optimize_pose_refiner(log=print) -> Dict:
         if B_local not in engines:
             engines[B_local] = _engine.RefineEngine(smpl.device_model, B_local, batch_norm=B_global, flags=flags)
         eng = engines[B_local]
+        eng.set_forward_reuse(True)       # an inner iteration right after a J step reuses that step's SMPL forward
         eng.set_batch_norm(B_global)
         eng.set_j_regressor(J_regressor, j_reg_mask)
         if use_pd:
