@@ -241,6 +241,9 @@ static int launch_disc_cfg(const GemmArgs& g, int epi, int btr, hipStream_t s) {
 // through *ndot (EPI_BIAS_RELU_DOT consumers).
 int launch_gemm_disc(const GemmArgs& g, int epi, int btr, hipStream_t s) {
   static const int tile = getenv("JRR_DISC_TILE") ? atoi(getenv("JRR_DISC_TILE")) : 0;     // experiment switch
+  // M = 768 (fc0 adjoint) gives only 6 x 64 = 384 workgroups of 128x64: 96x64 tiles of two 96x32 waves fill all 512 slots
+  if (tile == 0 && g.M % 96 == 0 && g.M % 128 == 0 && (g.M / 128) * (g.N / 64) < 512 && (g.M / 96) * (g.N / 64) >= 512)
+    return launch_disc_cfg<3, 1, 1, 2>(g, epi, btr, s);
   if (tile == 1) return launch_disc_cfg<2, 1, 2, 4>(g, epi, btr, s);    // 128x128, 8 waves of 64x32
   if (tile == 2) return launch_disc_cfg<2, 2, 2, 2>(g, epi, btr, s);    // 128x128, 4 waves of 64x64
   return launch_disc_cfg<2, 1, 2, 2>(g, epi, btr, s);                   // 128x64, 4 waves of 64x32

@@ -302,10 +302,11 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
   float* const ldsDj = lds + BWD_RING * TB_FLOATS + DVBUF_FLOATS + 3 * 36 * 64;   // wave 3: dj operands [r * 9 + ip][lane]
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int vc = L / n_bt, bt = L % n_bt;
+  // (a 5 : 4 split of chunk pairs between the two workgroups of a CU, which gains 6 % in k_lbs_fwd, measured equal here)
+  const int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
   const int b0 = bt * BT;
   const size_t bcol = (size_t)b0 + l31;
   const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)bcol;   // lane part of a (row, pose) address
-  const int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
   const unsigned lane_ln = (unsigned)lane * 4u;
 
   auto issue = [&](int vt, int slot) {
@@ -331,18 +332,24 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 #pragma unroll
       for (int jp = 0; jp < 12; ++jp)
         ldsA[(r * 12 + jp) * 64 + lane] = AT[(size_t)((r * 4 + c) * NJ + 2 * jp + half) * BP + bcol];
+    auto load_vp = [&](int vt, f32x16& dstv) {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) dstv[q] = urow(VPb, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff];
+    };
+    f32x16 vpA = zero16(), vpB = zero16();            // v_posed tiles, ping-pong: the next tile's loads fly for a whole tile
+    load_vp(t_begin, vpA);
     __syncthreads();                                  // records of the first two tiles landed
     int slot = 0;                                     // ring slot of tile vt
-    for (int vt = t_begin; vt < t_end; ++vt) {
+    auto tile = [&](int vt, const f32x16& vpc, f32x16& vpn) {
       // dverts of tile vt published; record vt + 1 landed; everybody is done with tile vt - 1.  This wave's record
-      // copies are older than its 16 v_posed loads and its 16 dvp stores of the previous tile: the stores stay in
-      // flight across the barrier (the loads have been consumed).
+      // copies are older than its 16 v_posed prefetch loads and its 16 dvp stores of the previous tile: both stay in
+      // flight across the barrier (the prefetch is consumed in the second half of THIS tile, the stores never).
       barrier_keep_vm<32>();
       const int slot1 = (slot + 1 == BWD_RING) ? 0 : slot + 1, slot2 = (slot1 + 1 == BWD_RING) ? 0 : slot1 + 1;
       if (vt + 2 < t_end) issue(vt + 2, slot2);
       __builtin_amdgcn_sched_barrier(0);     // the counted wait relies on: record copies first, loads / stores after
       const float* tab = ring + slot * TB_FLOATS;
-      f32x16 dv[3], vpc;
+      f32x16 dv[3];
 #pragma unroll
       for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -350,9 +357,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
           const f32x4 t = dvbuf[(r * 4 + g) * 64 + lane];
           dv[r][4 * g] = t[0]; dv[r][4 * g + 1] = t[1]; dv[r][4 * g + 2] = t[2]; dv[r][4 * g + 3] = t[3];
         }
-#pragma unroll
-      for (int q = 0; q < 16; ++q)        // v_posed of this tile: consumed in the second half (dA), after the 36 T products
-        vpc[q] = urow(VPb, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff];
+      if (vt + 1 < t_end) load_vp(vt + 1, vpn);
       // every plane wave holds dverts of tile vt in registers: the buffer may take tile vt + 1 (short barrier: the
       // plane waves reach it right after their 12 LDS reads, wave 3 at once)
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
@@ -398,6 +403,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
         acc3[2] = mfma(wvj, p2, acc3[2]);
       }
       slot = slot1;
+    };
+    for (int vt = t_begin; vt < t_end; vt += 2) {
+      tile(vt, vpA, vpB);
+      if (vt + 1 < t_end) tile(vt + 1, vpB, vpA);
     }
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
