@@ -144,7 +144,7 @@ struct jrr_engine {
   // forward reuse (jrr_engine_set_forward_reuse): state left by jrr_j_regressor_grad's SMPL forward
   bool reuse_enabled, fwd_cached; const float *fc_x6d, *fc_betas;
   float *VTb;       // [3][VP][BP] vertices / transposed vertex adjoint (KEEP_VERTS or SILHOUETTE)
-  float *verts, *djpad, *dJnp, *dJn, *dj;
+  float *dVTb, *dJnp, *dJn;   // transposed external vertex adjoint [3][VP][BP]; J-gradient partial slabs [3*nsplitJ][32][VP]
   int32_t* step_scratch;
   bool profiling;
   std::vector<hipEvent_t>* ev[JRR_PROF_CLASSES];
@@ -178,8 +178,8 @@ static void plan_geometry(int BP, int& nvc, int& nvcb, int& nsplit, int& nsplitJ
   nsplit = (512 + nbg - 1) / nbg;
   if (nsplit > 32) nsplit = 32;
   if (nsplit < 1) nsplit = 1;
-  nsplitJ = 8;
-  if (BP / 16 < nsplitJ) nsplitJ = BP / 16;
+  nsplitJ = 4;                                      // pose splits per coordinate plane of the J-gradient product
+  if (BP / 32 < nsplitJ) nsplitJ = BP / 32;
 }
 
 struct Carver {
@@ -269,11 +269,9 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->dMT = c.take((size_t)FOLD_M * BP);
   }
   if (flags & JRR_FLAG_KEEP_VERTS) {
-    t->verts = c.take((size_t)BP * VP * 3);
-    t->djpad = c.take((size_t)BP * 64);
-    t->dJnp = c.take((size_t)nsplitJ * 64 * VP * 3);
+    t->dVTb = c.take((size_t)3 * VP * BP);
+    t->dJnp = c.take((size_t)3 * nsplitJ * 32 * VP);
     t->dJn = c.take((size_t)NH * VP);
-    t->dj = c.take((size_t)BP * 51);
   }
   if (e) {
     e->BP = BP; e->nvc = nvc; e->nvcb = nvcb; e->nsplit = nsplit; e->nsplitJ = nsplitJ;
@@ -518,8 +516,6 @@ extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const 
   const bool kv = (e->flags & JRR_FLAG_KEEP_VERTS) != 0;
   if (verts && !e->VTb) { jrr_set_error("return_verts needs an engine created with JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
   smpl_forward(e, x6d, R, betas, true, kv || verts, nullptr, s);
-  if (kv)      // padded pose-major copy (row stride VP*3, zeros in the padding) for the J_regressor adjoint
-    launch_verts_untranspose(e->VTb, e->verts, VP * 3, VP, nullptr, nullptr, e->BP, e->BP, s);
   if (verts) launch_verts_untranspose(e->VTb, verts, V * 3, V, nullptr, nullptr, e->B, e->BP, s);
   launch_joints_loss(e->JP, e->nvc, nullptr, nullptr, 0.f, joints, nullptr, nullptr, e->B, e->BP, s);
   CHECK_LAUNCH();
@@ -537,7 +533,7 @@ static int blend_adjoint_gemm(jrr_engine* e, hipStream_t s) {
   return launch_gemm_224(g, EPI_STORE, e->nsplit, s);
 }
 
-static int j_grad_from_verts(jrr_engine* e, const float* djoints_Bx51, float* dJ, hipStream_t s);
+static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s);
 
 extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const float* R, const float* betas,
                                         const float* djoints, float* dx6d, float* dR, float* dbetas, float* dJ,
@@ -545,8 +541,8 @@ extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const
   if (!e || !betas || !djoints || ((x6d == nullptr) == (R == nullptr))) { jrr_set_error("find_joints_backward: bad argument"); return JRR_ERR_ARG; }
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
+  launch_joints_loss(nullptr, 0, nullptr, djoints, 0.f, nullptr, nullptr, e->dJT, e->B, e->BP, s);   // (B,17,3) -> [3][18][BP]
   if (dx6d || dR || dbetas) {
-    launch_joints_loss(nullptr, 0, nullptr, djoints, 0.f, nullptr, nullptr, e->dJT, e->B, e->BP, s);
     launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
     int rc = blend_adjoint_gemm(e, s);
     if (rc) return rc;
@@ -560,7 +556,7 @@ extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const
     CHECK_LAUNCH();
   }
   if (dJ) {
-    int rc = j_grad_from_verts(e, djoints, dJ, s);
+    int rc = j_grad_from_verts(e, dJ, s);
     if (rc) return rc;
   }
   return JRR_OK;
@@ -573,9 +569,9 @@ extern "C" int jrr_smpl_vertices_backward(jrr_engine_t* e, const float* x6d, con
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   e->fwd_cached = false;
-  // the padded vertex buffer is reused as the transposed adjoint [3][VP][BP] (same size)
-  launch_dverts_transpose(dverts, V * 3, e->VTb, e->B, e->BP, s);      // the vertex buffer doubles as the transposed adjoint
-  launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, nullptr, e->VTb, e->DVP, e->dATp, e->BP, e->nvcb, s);
+  // the caller's adjoint, transposed into its own [3][VP][BP] buffer (the stored vertices stay valid for a later dJ)
+  launch_dverts_transpose(dverts, V * 3, e->dVTb, e->B, e->BP, s);
+  launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, nullptr, e->dVTb, e->DVP, e->dATp, e->BP, e->nvcb, s);
   int rc = blend_adjoint_gemm(e, s);
   if (rc) return rc;
   reduce_adjoint_partials(e, s);
@@ -1004,39 +1000,23 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
 // =============================================================================================
 // J step (scripts/optimize.py:300-312)
 // =============================================================================================
-__global__ void k_pad_dj(const float* __restrict__ dj, float* __restrict__ out, int B, int BP) {
-  int idx = blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= BP * 64) return;
-  int b = idx >> 6, k = idx & 63;
-  out[idx] = (b < B && k < 51) ? dj[(size_t)b * 51 + k] : 0.f;
-}
-
-// dJn[i][v] = sum_split sum_c P[split][i*3+c][v*3+c]
-__global__ void k_djn_reduce(const float* __restrict__ P, int nsplit, float* __restrict__ dJn) {
+// dJn[i][v] = sum over the (plane, pose-split) slabs P[s][i][v]
+__global__ void k_djn_reduce(const float* __restrict__ P, int nslab, float* __restrict__ dJn) {
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= NH * VP) return;
   int i = idx / VP, v = idx % VP;
   float acc = 0.f;
-  for (int s = 0; s < nsplit; ++s)
-    for (int c = 0; c < 3; ++c) acc += P[((size_t)s * 64 + i * 3 + c) * (VP * 3) + v * 3 + c];
+  for (int s = 0; s < nslab; ++s) acc += P[((size_t)s * 32 + i) * VP + v];
   dJn[idx] = acc;
 }
 
-namespace jrr { int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s); }
-
-static int j_grad_from_verts(jrr_engine* e, const float* djoints, float* dJ, hipStream_t s) {
+// dJ from the joint adjoint dJT [3][18][BP] (already in the engine) and the stored vertices VTb [3][VP][BP]
+static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s) {
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("dJ requires an engine created with JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
-  hipLaunchKernelGGL(k_pad_dj, dim3((e->BP * 64 + 255) / 256), dim3(256), 0, s, djoints, e->djpad, e->B, e->BP);
-  GemmArgs g;
-  g.A = e->djpad; g.lda = 64;            // A[k=b][m=(i,c)]
-  g.Bm = e->verts; g.ldb = VP * 3;       // Bm[k=b][n=(v,c)]
-  g.Out = e->dJnp; g.ldo = VP * 3;
-  g.bias = nullptr; g.mask = nullptr;
-  g.M = 64; g.N = VP * 3; g.K = e->BP;
-  g.split_stride = (size_t)64 * VP * 3;
-  int rc = jrr::launch_gemm_64(g, EPI_STORE, e->nsplitJ, s);
+  int rc = launch_gemm_nt32(e->dJT, (size_t)NHP * e->BP, e->BP, NHP, e->VTb, (size_t)VP * e->BP, e->BP, e->dJnp, VP,
+                            (size_t)32 * VP, VP, e->BP, 3, e->nsplitJ, s);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_djn_reduce, dim3((NH * VP + 255) / 256), dim3(256), 0, s, e->dJnp, e->nsplitJ, e->dJn);
+  hipLaunchKernelGGL(k_djn_reduce, dim3((NH * VP + 255) / 256), dim3(256), 0, s, e->dJnp, 3 * e->nsplitJ, e->dJn);
   launch_jreg_bwd(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->Jn, e->rowsum, e->dJn, VP, dJ, s);
   CHECK_LAUNCH();
   return JRR_OK;
@@ -1050,9 +1030,7 @@ extern "C" int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d, const flo
   hipStream_t s = (hipStream_t)stream;
   smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s);      // v_posed kept: the next inner iteration may reuse this forward
   e->fwd_cached = true; e->fc_x6d = x6d; e->fc_betas = betas;
-  launch_verts_untranspose(e->VTb, e->verts, VP * 3, VP, nullptr, nullptr, e->BP, e->BP, s);
   const float scale = (float)(2.0 * 1.0 / ((double)e->bnorm * 51.0));   // optimize.py:307 unweighted MSE
-  launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, scale, e->joints, sqerr ? sqerr : e->sqerr, nullptr, e->B, e->BP, s);
-  launch_joint_loss_plain(e->joints, gt_mm, scale, nullptr, e->dj, e->B, s);
-  return j_grad_from_verts(e, e->dj, dJ, s);
+  launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, scale, e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);
+  return j_grad_from_verts(e, dJ, s);
 }

@@ -281,6 +281,89 @@ int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { ret
 // 64x128 block tile (4 waves of 64x32): the J-regressor gradient product, M = 51 padded to 64
 int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 1, 4, 16>(g, epi, nsplit, s); }
 
+// ------------------------------------------------------------------------------------------------------------------
+// "NT" product for operands whose REDUCTION index is the contiguous one (the pose index of the [feature][pose] arrays):
+//     Out[split][m][n] = sum_{k in split} A_c[m][k] * B_c[n][k]        m < 32, c = coordinate plane of the split
+// J-regressor gradient dJn[i][v] = sum_{c,b} dj[c][i][b] verts_c[v][b]  (scripts/optimize.py:300-312) straight from the
+// coordinate-major vertex tiles k_lbs_fwd writes -- no pose-major copy of the 340 MB vertex buffer.
+// The MFMA wants the reduction index on the K axis with one value per lane, the data has it contiguous.  Two facts make
+// that cheap: (1) a K-pair may take ANY two k as long as both operands agree, so step t of an 8-group takes
+// k = 8g + 4*half + t and a lane's four steps are ONE 16-byte piece; (2) an LDS-DMA instruction copies 64 arbitrary
+// 16-byte pieces into 1 KB of LDS, so the gather [row][4 k] -> [k-quad][row] is done by the copy itself, and the
+// ds_read_b128 operand reads are contiguous per half-wave (conflict-free).
+// Tile: 32 (m) x 128 (n), four waves side by side, 32-deep chunks, 2-deep ring.
+// ------------------------------------------------------------------------------------------------------------------
+struct NtArgs {
+  const float* A; size_t planeA; int ldA; int rowsA;   // A_c = A + c*planeA; rows m >= rowsA read row rowsA - 1 (a zero row)
+  const float* Bm; size_t planeB; int ldB;             // B_c = Bm + c*planeB; row n at n*ldB
+  float* Out; int ldo; size_t split_stride;            // Out[split][32][ldo]
+  int K, ksplit;                                        // reduction length per plane, splits per plane
+};
+__global__ __launch_bounds__(256) void k_gemm_nt32(NtArgs g) {
+  constexpr int SA = 8 * 32 * 4, SB = 8 * 128 * 4, SLOT = SA + SB;     // floats: [k-quad 8][row][4]
+  __shared__ __attribute__((aligned(16))) float lds[2 * SLOT];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int n0 = blockIdx.x * 128;
+  const int split = blockIdx.y, c = split / g.ksplit, ks = split % g.ksplit;
+  const int nch = g.K / 32;
+  const int c_begin = (int)((long)nch * ks / g.ksplit), c_end = (int)((long)nch * (ks + 1) / g.ksplit);
+  const float* Ac = g.A + (size_t)c * g.planeA;
+  const float* Bc = g.Bm + (size_t)c * g.planeB;
+  // this wave's copies per chunk: 4 of B (pieces p = (wave*4 + i)*64 + lane: k-quad p / 128, row p % 128), 1 of A
+  unsigned offB[4], offA;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int p = (wave * 4 + i) * 64 + lane;
+    offB[i] = (unsigned)(n0 + (p & 127)) * (unsigned)g.ldB + 4u * (unsigned)(p >> 7);
+  }
+  {
+    const int p = wave * 64 + lane, row = p & 31;
+    offA = (unsigned)(row < g.rowsA ? row : g.rowsA - 1) * (unsigned)g.ldA + 4u * (unsigned)(p >> 5);
+  }
+  auto issue = [&](int ch, int slot) {
+    const float* a = Ac + (size_t)ch * 32;
+    const float* b = Bc + (size_t)ch * 32;
+    asm volatile("" : "+s"(a));
+    asm volatile("" : "+s"(b));
+    float* dA = lds + slot * SLOT;
+    float* dB = dA + SA;
+    __builtin_amdgcn_global_load_lds(JRR_GLB(a + offA), JRR_LDS(dA + wave * 256), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave * 4 + i) * 256), 16, 0, 0);
+  };
+  f32x16 acc = zero16();
+  if (c_begin < c_end) issue(c_begin, 0);
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    __syncthreads();
+    const int slot = (ch - c_begin) & 1;
+    if (ch + 1 < c_end) issue(ch + 1, slot ^ 1);
+    const f32x4* la = reinterpret_cast<const f32x4*>(lds + slot * SLOT);
+    const f32x4* lb = reinterpret_cast<const f32x4*>(lds + slot * SLOT + SA);
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      const f32x4 a4 = la[(gq * 2 + half) * 32 + l31];
+      const f32x4 b4 = lb[(gq * 2 + half) * 128 + wave * 32 + l31];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc = mfma(a4[t], b4[t], acc);
+    }
+  }
+  float* out = g.Out + (size_t)split * g.split_stride;
+#pragma unroll
+  for (int q = 0; q < 16; ++q) out[(size_t)acc_row(q, half) * g.ldo + n0 + wave * 32 + l31] = acc[q];
+}
+
+int launch_gemm_nt32(const float* A, size_t planeA, int ldA, int rowsA, const float* Bm, size_t planeB, int ldB, float* Out,
+                     int ldo, size_t split_stride, int N, int K, int nplanes, int ksplit, hipStream_t s) {
+  if (N % 128 != 0 || K % 32 != 0 || ldA % 4 != 0 || ldB % 4 != 0 || rowsA < 1 || rowsA > 32) {
+    jrr_set_error("gemm_nt32: unsupported shape N=%d K=%d ldA=%d ldB=%d", N, K, ldA, ldB);
+    return JRR_ERR_ARG;
+  }
+  NtArgs g{A, planeA, ldA, rowsA, Bm, planeB, ldB, Out, ldo, split_stride, K, ksplit};
+  hipLaunchKernelGGL(k_gemm_nt32, dim3(N / 128, nplanes * ksplit), dim3(256), 0, s, g);
+  return 0;
+}
+
 // 32x128 block tile (4 waves of 32x32 side by side), batched over gridDim.y: joints = Jn . verts from stored vertices
 int launch_gemm_32x128(const GemmArgs& g, int epi, int nsplit, int nbatch, hipStream_t s) {
   return launch_cfg<1, 1, 1, 4, 16>(g, epi, nsplit, s, nbatch);
