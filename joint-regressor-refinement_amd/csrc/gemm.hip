@@ -81,6 +81,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
       if (EXACT || okB[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave + NW * i) * 256), 16, 0, 0);
   };
 
+  f32x16 acc[WM][WN];
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int j = 0; j < WN; ++j) acc[i][j] = zero16();
+
+  if (c_begin < c_end) issue(c_begin, 0);
+  if (NSLOT > 2 && c_begin + 1 < c_end) issue(c_begin + 1, 1);
+  // (computed while the first chunks are in flight)
   // BTR: per-lane column scales (one per 32-column tile of this wave)
   float cscale[WN];
 #pragma unroll
@@ -106,14 +115,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
     }
   }
 
-  f32x16 acc[WM][WN];
-#pragma unroll
-  for (int i = 0; i < WM; ++i)
-#pragma unroll
-    for (int j = 0; j < WN; ++j) acc[i][j] = zero16();
-
-  if (c_begin < c_end) issue(c_begin, 0);
-  if (NSLOT > 2 && c_begin + 1 < c_end) issue(c_begin + 1, 1);
   int slot = 0;     // ring slot of chunk ch
   for (int ch = c_begin; ch < c_end; ++ch) {
     if (NSLOT == 2) {

@@ -570,17 +570,82 @@ __global__ void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, 
 //   G_j.R from the rotation part of A^T, so nothing of the forward chain is recomputed.  LDS holds
 //   only the dG accumulators (12 floats per joint per lane).
 //
-// k_pose_update (one (pose, joint) per thread, joint 24 = betas): 6-D rotation adjoint, extra
-//   (discriminator) gradients, then either the gradient outputs or the fused Adam update.
+// The same threads then finish the per-pose update (pose_update_*): 6-D rotation adjoint, extra (discriminator)
+//   gradients, then either the gradient outputs or the fused Adam update -- dL/dR never leaves registers.
 // ------------------------------------------------------------------------------------------
+struct PoseUpdateArgs {
+  const float* x6d_in;      // (B,24,6) or NULL (R mode)
+  const float* gx_extra; const float* gb_extra;
+  float* dx6d; float* dR; float* dbetas;                 // gradient outputs (nullable)
+  float* x6d_io; float* betas_io; float* adam_m; float* adam_v; const int32_t* step;   // Adam (x6d_io nullable)
+  float lr, beta1, beta2, eps;
+  const float* gcam; float* cam_io; float* cam_m; float* cam_v;     // camera translation (2-D term), nullable
+};
+
+// joint j of pose b: dL/dR_j (9) -> 6-D rotation adjoint (+ the discriminator's gradient) -> gradient output or Adam
+__device__ __forceinline__ void pose_update_joint(const PoseUpdateArgs& a, int b, int j, const float dRi[9], const AdamScalars& sc) {
+  if (!a.x6d_in) {
+    if (a.dR) {
+#pragma unroll
+      for (int k = 0; k < 9; ++k) a.dR[((size_t)b * NJ + j) * 9 + k] = dRi[k];
+    }
+    return;
+  }
+  float xv[6], R[9], dx[6];
+  Rot6 c;
+#pragma unroll
+  for (int k = 0; k < 6; ++k) xv[k] = a.x6d_in[((size_t)b * NJ + j) * 6 + k];
+  rot6d_fwd(xv, R, c);
+  rot6d_bwd(c, dRi, dx);
+  if (a.gx_extra) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dx[k] += a.gx_extra[((size_t)b * NJ + j) * 6 + k];
+  }
+  if (a.dx6d) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) a.dx6d[((size_t)b * NJ + j) * 6 + k] = dx[k];
+  }
+  if (a.x6d_io) {
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+      const size_t si = (size_t)b * NPARAM + j * 6 + k;
+      float mm = a.adam_m[si], vv = a.adam_v[si];
+      a.x6d_io[((size_t)b * NJ + j) * 6 + k] = adam_update(xv[k], dx[k], mm, vv, sc);
+      a.adam_m[si] = mm;
+      a.adam_v[si] = vv;
+    }
+  }
+}
+// shape coefficient l of pose b
+__device__ __forceinline__ void pose_update_beta(const PoseUpdateArgs& a, int b, int l, float g, const AdamScalars& sc) {
+  if (a.gb_extra) g += a.gb_extra[(size_t)b * NB + l];
+  if (a.dbetas) a.dbetas[(size_t)b * NB + l] = g;
+  if (a.x6d_io) {
+    const size_t si = (size_t)b * NPARAM + JRR_POSE6D + l;
+    float mm = a.adam_m[si], vv = a.adam_v[si];
+    a.betas_io[(size_t)b * NB + l] = adam_update(a.betas_io[(size_t)b * NB + l], g, mm, vv, sc);
+    a.adam_m[si] = mm;
+    a.adam_v[si] = vv;
+  }
+}
+// camera component cc of pose b: Adam over [pose, orient, betas, cam] (optimize.py:201-202)
+__device__ __forceinline__ void pose_update_cam(const PoseUpdateArgs& a, int b, int cc, const AdamScalars& sc) {
+  const size_t si = (size_t)b * 3 + cc;
+  float mm = a.cam_m[si], vv = a.cam_v[si];
+  a.cam_io[si] = adam_update(a.cam_io[si], a.gcam[si], mm, vv, sc);
+  a.cam_m[si] = mm;
+  a.cam_v[si] = vv;
+}
+
 constexpr int PPB = 32;   // poses per block of k_chain_bwd (16 halves the coalescing width: measured 1.5x slower)
 __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict__ FT, const float* __restrict__ R0T,
                                                         const float* __restrict__ AT, const float* __restrict__ Jt,
                                                         const float* __restrict__ JS, Parents par,
                                                         const float* __restrict__ dA_, int nslabA, size_t strideA,
-                                                        const float* __restrict__ dF_, float* __restrict__ dRT,
-                                                        float* __restrict__ dbT, int B, int BP) {
+                                                        const float* __restrict__ dF_, PoseUpdateArgs ua, int B, int BP) {
   constexpr int PP = PPB;
+  __shared__ AdamScalars adam_sc;
+  if (ua.x6d_io && threadIdx.x == 0) adam_sc = adam_scalars(ua.step[0], ua.lr, ua.beta1, ua.beta2, ua.eps);
   // one thread per (pose, joint); levels of the kinematic tree are processed deepest first.  Each child
   // leaves its contribution to the parent's dG in its own LDS slot; the parent sums its children in
   // index order (no atomics: bitwise reproducible).
@@ -690,98 +755,22 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
     }
     __syncthreads();
   }
-  if (ok) {
-#pragma unroll
-    for (int k = 0; k < 9; ++k) dRT[(size_t)(j * 9 + k) * BP + b] = dRi[k];
-  }
   // dL/dbeta: sum the per-joint contributions of each pose (fixed order: deterministic)
 #pragma unroll
   for (int l = 0; l < NB; ++l) dBs[j][l][bl] = dbeta[l];
-  __syncthreads();
-  if (j < NB && ok) {
-    float acc = dF_[(size_t)(207 + j) * BP + b];
+  __syncthreads();           // (also orders thread 0's adam_sc before its readers)
+  // ---- fused per-pose update (formerly a second kernel over the same (pose, joint) threads): 6-D rotation adjoint,
+  //      the discriminators' extra gradients, then either the gradient outputs or torch's Adam in place ----
+  const AdamScalars sc = adam_sc;
+  if (ok) {
+    pose_update_joint(ua, b, j, dRi, sc);
+    if (j < NB) {
+      float acc = dF_[(size_t)(207 + j) * BP + b];
 #pragma unroll
-    for (int q = 0; q < NJ; ++q) acc += dBs[q][j][bl];
-    dbT[(size_t)j * BP + b] = acc;
-  }
-}
-
-struct PoseUpdateArgs {
-  const float* x6d_in;      // (B,24,6) or NULL (R mode)
-  const float* dRT; const float* dbT;
-  const float* gx_extra; const float* gb_extra;
-  float* dx6d; float* dR; float* dbetas;                 // gradient outputs (nullable)
-  float* x6d_io; float* betas_io; float* adam_m; float* adam_v; const int32_t* step;   // Adam (x6d_io nullable)
-  float lr, beta1, beta2, eps;
-  int B, BP;
-  const float* gcam; float* cam_io; float* cam_m; float* cam_v;     // camera translation (2-D term), nullable
-};
-
-__global__ __launch_bounds__(64) void k_pose_update(PoseUpdateArgs a) {
-  const int b = blockIdx.x * 64 + threadIdx.x, j = blockIdx.y;
-  if (b >= a.B) return;
-  const int BP = a.BP;
-  const bool do_adam = a.x6d_io != nullptr;
-  AdamScalars sc;
-  if (do_adam) sc = adam_scalars(a.step[0], a.lr, a.beta1, a.beta2, a.eps);
-  if (j == NJ) {   // betas
-#pragma unroll
-    for (int l = 0; l < NB; ++l) {
-      float g = a.dbT[(size_t)l * BP + b];
-      if (a.gb_extra) g += a.gb_extra[(size_t)b * NB + l];
-      if (a.dbetas) a.dbetas[(size_t)b * NB + l] = g;
-      if (do_adam) {
-        const size_t si = (size_t)b * NPARAM + JRR_POSE6D + l;
-        float mm = a.adam_m[si], vv = a.adam_v[si];
-        a.betas_io[(size_t)b * NB + l] = adam_update(a.betas_io[(size_t)b * NB + l], g, mm, vv, sc);
-        a.adam_m[si] = mm;
-        a.adam_v[si] = vv;
-      }
-    }
-    if (do_adam && a.cam_io) {   // Adam over [pose, orient, betas, cam] (optimize.py:201-202)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        const size_t si = (size_t)b * 3 + c;
-        float mm = a.cam_m[si], vv = a.cam_v[si];
-        a.cam_io[si] = adam_update(a.cam_io[si], a.gcam[si], mm, vv, sc);
-        a.cam_m[si] = mm;
-        a.cam_v[si] = vv;
-      }
-    }
-    return;
-  }
-  float dRi[9];
-#pragma unroll
-  for (int k = 0; k < 9; ++k) dRi[k] = a.dRT[(size_t)(j * 9 + k) * BP + b];
-  if (!a.x6d_in) {
-    if (a.dR) {
-#pragma unroll
-      for (int k = 0; k < 9; ++k) a.dR[((size_t)b * NJ + j) * 9 + k] = dRi[k];
-    }
-    return;
-  }
-  float xv[6], R[9], dx[6];
-  Rot6 c;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) xv[k] = a.x6d_in[((size_t)b * NJ + j) * 6 + k];
-  rot6d_fwd(xv, R, c);
-  rot6d_bwd(c, dRi, dx);
-  if (a.gx_extra) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) dx[k] += a.gx_extra[((size_t)b * NJ + j) * 6 + k];
-  }
-  if (a.dx6d) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) a.dx6d[((size_t)b * NJ + j) * 6 + k] = dx[k];
-  }
-  if (do_adam) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const size_t si = (size_t)b * NPARAM + j * 6 + k;
-      float mm = a.adam_m[si], vv = a.adam_v[si];
-      a.x6d_io[((size_t)b * NJ + j) * 6 + k] = adam_update(xv[k], dx[k], mm, vv, sc);
-      a.adam_m[si] = mm;
-      a.adam_v[si] = vv;
+      for (int q = 0; q < NJ; ++q) acc += dBs[q][j][bl];
+      pose_update_beta(ua, b, j, acc, sc);
+    } else if (j < NB + 3 && ua.x6d_io && ua.cam_io) {
+      pose_update_cam(ua, b, j - NB, sc);
     }
   }
 }
@@ -870,15 +859,14 @@ int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale
 }
 
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
-  hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + PPB - 1) / PPB), dim3(PPB * NJ), 0, s, L.FT, L.R0T, L.AT, m.Jt, m.JS, m.parents,
-                     L.dATp, L.nslabA, L.strideA, L.dFTp, L.dRT, L.dbT, L.B, L.BP);
   PoseUpdateArgs a;
-  a.x6d_in = L.x6d_in; a.dRT = L.dRT; a.dbT = L.dbT; a.gx_extra = L.gx_extra; a.gb_extra = L.gb_extra;
+  a.x6d_in = L.x6d_in; a.gx_extra = L.gx_extra; a.gb_extra = L.gb_extra;
   a.dx6d = L.dx6d; a.dR = L.dR; a.dbetas = L.dbetas;
   a.x6d_io = L.x6d_io; a.betas_io = L.betas_io; a.adam_m = L.adam_m; a.adam_v = L.adam_v; a.step = L.step;
-  a.lr = L.lr; a.beta1 = L.beta1; a.beta2 = L.beta2; a.eps = L.eps; a.B = L.B; a.BP = L.BP;
+  a.lr = L.lr; a.beta1 = L.beta1; a.beta2 = L.beta2; a.eps = L.eps;
   a.gcam = L.gcam; a.cam_io = L.cam_io; a.cam_m = L.cam_m; a.cam_v = L.cam_v;
-  hipLaunchKernelGGL(k_pose_update, dim3((L.B + 63) / 64, NJ + 1), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + PPB - 1) / PPB), dim3(PPB * NJ), 0, s, L.FT, L.R0T, L.AT, m.Jt, m.JS, m.parents,
+                     L.dATp, L.nslabA, L.strideA, L.dFTp, a, L.B, L.BP);
   return 0;
 }
 

@@ -331,3 +331,33 @@ def test_forward_reuse_across_the_j_step(smpl_hip, smpl_model_np, j_h36m_np):
     np.testing.assert_allclose(s1.sum().item(), s0.sum().item(), rtol=1e-4)
     assert (x0 - x1).abs().mean().item() < 2e-7 and (x0 - x1).abs().max().item() < 6e-4
     assert (b0 - b1).abs().max().item() < 2e-4
+
+
+def test_silhouette_gradients_where_both_rasterisers_agree(smpl_hip, smpl_model_np, j_h36m_np):
+    """row f2 at a ragged batch of 67 poses: coverage agreement >= 99.98 % of the pixels, and -- with the upstream
+    gradient restricted to the pixels where both rasterisers see the same face at the same distance -- vertex and camera
+    gradients to 2e-3 of the oracle's (pytorch3d 0.3.0 restatement, scripts/mesh_renderer.py:23-79)."""
+    from oracle import silhouette_port as sp
+    eng_mod = _mod('engine')
+    B = 67
+    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, j_h36m_np, B, seed=53)
+    x6, betas, cam = T(batch['pose6d']), T(batch['betas']), T(batch['cam'])
+    R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(B, 24, 3, 3)
+    verts = oracle.OracleSMPL(smpl_model_np)(R[:, :1], R[:, 1:], betas).vertices
+    mask = (sp.soft_silhouette(verts, smpl_model_np['faces'], cam + torch.tensor([0.15, -0.1, 1.0]))[:, 0] > 0).float()
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_SILHOUETTE)
+    alpha = eng.silhouette_forward(verts.to(DEV).contiguous(), cam.to(DEV).contiguous()).cpu()
+    vr, cr = verts.clone().requires_grad_(True), cam.clone().requires_grad_(True)
+    ref = sp.soft_silhouette(vr, smpl_model_np['faces'], cr)[:, 0]
+    cov_ref, cov = ref.detach() > 0, alpha > 0
+    assert cov_ref.sum() > 3000 * B
+    assert (cov_ref != cov).float().mean().item() < 2e-4
+    same = cov_ref & cov & ((alpha - ref.detach()).abs() < 2e-3)
+    assert same.sum().item() > 0.97 * cov_ref.sum().item()
+    g = ((ref.detach() - mask) * 2 / (B * 224 * 224)) * same
+    (ref * g).sum().backward()
+    dv, dc = eng.silhouette_backward(g.to(DEV).contiguous())
+    rel_v = ((dv.cpu().double() - vr.grad.double()).norm() / vr.grad.double().norm()).item()
+    rel_c = ((dc.cpu().double() - cr.grad.double()).norm() / cr.grad.double().norm()).item()
+    assert rel_v < 2e-3, rel_v
+    assert rel_c < 2e-3, rel_c
