@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # kernel trace: the default bench command itself (100 timed steps); PMC passes: a short run (counters serialise kernels)
-FULL="python3 $PWD/bench.py"
+FULL="python3 $PWD/bench.py --no_cpu_baseline"
 CMD="python3 $PWD/bench.py --steps 5 --warmup 2 --no_cpu_baseline"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $FULL > $OUT/trace.log 2>&1
