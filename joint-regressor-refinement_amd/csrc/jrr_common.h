@@ -71,6 +71,21 @@ __device__ __forceinline__ const float* urow(const float* base, size_t row, int 
   asm volatile("" : "+s"(p));
   return p;
 }
+// "Row-quad" layout of the per-vertex arrays that only travel between the LBS kernels (v_posed):
+//     element (row v, pose b) of plane c lives at  ((c * VP/4 + v/4) * BP + b) * 4 + v % 4.
+// Registers 4g .. 4g+3 of a lane of the accumulator layout are the rows 8g + 4 half + {0,1,2,3} = ONE row quad
+// (index 2g + half) of that lane's pose, i.e. 16 contiguous bytes: a tile moves as four dwordx4 per lane (a wave
+// instruction = two contiguous 512-byte runs) instead of sixteen dword accesses.
+__device__ __forceinline__ f32x4* quad_ptr(float* base, size_t plane_quad0, int g, int BP, unsigned lane_q) {
+  float* p = base + ((plane_quad0 + 2 * g) * (size_t)BP) * 4;
+  asm volatile("" : "+s"(p));
+  return reinterpret_cast<f32x4*>(p) + lane_q;
+}
+__device__ __forceinline__ const f32x4* quad_ptr(const float* base, size_t plane_quad0, int g, int BP, unsigned lane_q) {
+  const float* p = base + ((plane_quad0 + 2 * g) * (size_t)BP) * 4;
+  asm volatile("" : "+s"(p));
+  return reinterpret_cast<const f32x4*>(p) + lane_q;
+}
 // uniform part of acc_row(q, half) = (q & 3) + 8 (q >> 2) + 4 half
 __device__ __forceinline__ constexpr int acc_row_u(int q) { return (q & 3) + 8 * (q >> 2); }
 

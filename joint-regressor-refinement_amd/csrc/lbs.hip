@@ -32,7 +32,7 @@ namespace jrr {
 //                h = 0: translation column c = 3 and c = 0;  h = 1: c = 1, 2, then the
 //                regressor product  joints^T += Jn . verts_r                 24 (+16) MFMA / wave
 //   The skinning-weight / regressor tiles (W^T, Jn) ride with stage 0 into a per-tile-parity
-//   region.  outputs: JP [nvc][3][17][BP] joint partials; optional VPb [3][VP][BP] (v_posed,
+//   region.  outputs: JP [nvc][3][17][BP] joint partials; optional VPb [3][VP/4][BP][4] (v_posed in row quads,
 //   kept for the backward pass) and VTb [3][VP][BP] (the vertices, same layout; k_verts_untranspose turns
 //   them into the reference's (B,6890,3) and/or projects them for the silhouette renderer).
 // ------------------------------------------------------------------------------------------
@@ -96,6 +96,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   const int b0 = bg * BG + wave * BT;
   const size_t bcol = (size_t)b0 + l31;
   const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)bcol;   // lane part of a (row, pose) address
+  const unsigned qoff = (unsigned)half * (unsigned)BP + (unsigned)bcol;          // lane part of a (row quad, pose) address, in quads
   // DMA addressing = wave-uniform base pointer (SGPR pair) + one 32-bit per-lane offset (VGPR), so
   // the 78 copies per tile cost scalar address arithmetic only.  Row-pair pattern: lanes 0-31
   // fetch row 2o, lanes 32-63 row 2o+1, 16 B per lane.
@@ -152,12 +153,12 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
       {
         const int sp = (s == 0) ? NSTAGE - 1 : s - 1;                     // previous stage
         const int hp = sp - NKCH;                                          // its skinning half-stage, if any
-        const int nst = (hp < 0) ? 0 : (STORE_VP ? 8 : 0) + ((STORE_VERTS && (hp & 1)) ? 16 : 0);
+        const int nst = (hp < 0) ? 0 : (STORE_VP ? 2 : 0) + ((STORE_VERTS && (hp & 1)) ? 16 : 0);
         // (`s` is a constant after unrolling: one of these survives per stage)
         if ((s == 0 && vt == t_begin) || nst == 0) barrier_keep_vm<0>();
-        else if (nst == 8) barrier_keep_vm<8>();
+        else if (nst == 2) barrier_keep_vm<2>();
         else if (nst == 16) barrier_keep_vm<16>();
-        else barrier_keep_vm<24>();
+        else barrier_keep_vm<18>();
       }
       if (s + 1 < NSTAGE) issue(vt, s + 1, (g + 1) & 1);
       else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1);
@@ -192,11 +193,13 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         }
       } else {
         const int h = s - NKCH, r = h >> 1;
-        if (STORE_VP) {   // spread the v_posed stores over the six skinning stages (8 registers each)
-          const int c = h >> 1, q0 = (h & 1) * 8;
+        if (STORE_VP) {   // spread the v_posed stores over the six skinning stages: two 16-byte row quads each
+          const int c = h >> 1, g0 = (h & 1) * 2;
 #pragma unroll
-          for (int q = q0; q < q0 + 8; ++q)
-            urow(VPb, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff] = vp[c][q];
+          for (int g = g0; g < g0 + 2; ++g) {
+            const f32x4 t = {vp[c][4 * g], vp[c][4 * g + 1], vp[c][4 * g + 2], vp[c][4 * g + 3]};
+            *quad_ptr(VPb, (size_t)c * (VP / 4) + vt * 8, g, BP, qoff) = t;
+          }
         }
         const float* wp = ldsW + half * 32 + l31;
         const float* a0 = buf + half * BG + wave * BT + l31;
@@ -332,9 +335,13 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 #pragma unroll
       for (int jp = 0; jp < 12; ++jp)
         ldsA[(r * 12 + jp) * 64 + lane] = AT[(size_t)((r * 4 + c) * NJ + 2 * jp + half) * BP + bcol];
-    auto load_vp = [&](int vt, f32x16& dstv) {
+    const unsigned qoff = (unsigned)half * (unsigned)BP + (unsigned)bcol;     // lane part of a (row quad, pose) address
+    auto load_vp = [&](int vt, f32x16& dstv) {      // four 16-byte row quads (jrr_common.h)
 #pragma unroll
-      for (int q = 0; q < 16; ++q) dstv[q] = urow(VPb, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff];
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *quad_ptr(VPb, (size_t)c * (VP / 4) + vt * 8, g, BP, qoff);
+        dstv[4 * g] = t[0]; dstv[4 * g + 1] = t[1]; dstv[4 * g + 2] = t[2]; dstv[4 * g + 3] = t[3];
+      }
     };
     f32x16 vpA = zero16(), vpB = zero16();            // v_posed tiles, ping-pong: the next tile's loads fly for a whole tile
     load_vp(t_begin, vpA);
@@ -342,9 +349,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
     int slot = 0;                                     // ring slot of tile vt
     auto tile = [&](int vt, const f32x16& vpc, f32x16& vpn) {
       // dverts of tile vt published; record vt + 1 landed; everybody is done with tile vt - 1.  This wave's record
-      // copies are older than its 16 v_posed prefetch loads and its 16 dvp stores of the previous tile: both stay in
+      // copies are older than its 4 v_posed prefetch loads and its 16 dvp stores of the previous tile: both stay in
       // flight across the barrier (the prefetch is consumed in the second half of THIS tile, the stores never).
-      barrier_keep_vm<32>();
+      barrier_keep_vm<20>();
       const int slot1 = (slot + 1 == BWD_RING) ? 0 : slot + 1, slot2 = (slot1 + 1 == BWD_RING) ? 0 : slot1 + 1;
       if (vt + 2 < t_end) issue(vt + 2, slot2);
       __builtin_amdgcn_sched_barrier(0);     // the counted wait relies on: record copies first, loads / stores after
