@@ -37,12 +37,13 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   if (!vt || !sd || !pd || !Jr || !W || !parents || !out) { jrr_set_error("jrr_model_create: null argument"); return JRR_ERR_ARG; }
   for (int j = 0; j < NJ; ++j)
     if (parents[j] >= j || (j > 0 && parents[j] < 0)) { jrr_set_error("parents[%d]=%d is not a topologically ordered tree", j, parents[j]); return JRR_ERR_ARG; }
-  const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
+  const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nDq = nDn, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
   const size_t nJt = 72 + 24, nJS = 720 + 16;   // padded to keep 16-byte alignment of what follows
-  std::vector<float> h(nDk + nDn + nWjv + nWvj + nJt + nJS, 0.f);
+  std::vector<float> h(nDk + nDn + nDq + nWjv + nWvj + nJt + nJS, 0.f);
   float* Dk = h.data();
   float* Dn = Dk + nDk;
-  float* Wjv = Dn + nDn;
+  float* Dq = Dn + nDn;
+  float* Wjv = Dq + nDq;
   float* Wvj = Wjv + nWjv;
   float* Jt = Wvj + nWvj;
   float* JS = Jt + nJt;
@@ -56,6 +57,7 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
         else val = vt[v * 3 + c];
         Dk[(((size_t)t * KFP + k) * 3 + c) * 32 + vv] = val;
         Dn[((size_t)c * VP + v) * KFP + k] = val;
+        Dq[(((size_t)c * (VP / 4) + (v >> 2)) * KFP + k) * 4 + (v & 3)] = val;
       }
     }
     for (int j = 0; j < NJ; ++j) {
@@ -87,7 +89,8 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   m->base = base;
   m->d.Dk = d;
   m->d.Dn = d + nDk;
-  m->d.Wjv = m->d.Dn + nDn;
+  m->d.Dq = m->d.Dn + nDn;
+  m->d.Wjv = m->d.Dq + nDq;
   m->d.Wvj = m->d.Wjv + nWjv;
   m->d.Jt = m->d.Wvj + nWvj;
   m->d.JS = m->d.Jt + nJt;
@@ -523,14 +526,7 @@ extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const 
 }
 
 static int blend_adjoint_gemm(jrr_engine* e, hipStream_t s) {
-  GemmArgs g;
-  g.A = e->m.Dn; g.lda = KFP;
-  g.Bm = e->DVP; g.ldb = e->BP;
-  g.Out = e->dFTp; g.ldo = e->BP;
-  g.bias = nullptr; g.mask = nullptr;
-  g.M = KFP; g.N = e->BP; g.K = 3 * VP;
-  g.split_stride = (size_t)KFP * e->BP;
-  return launch_gemm_224(g, EPI_STORE, e->nsplit, s);
+  return launch_blend_adjoint(e->m.Dq, e->DVP, e->dFTp, (size_t)KFP * e->BP, e->BP, e->nsplit, s);
 }
 
 static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s);

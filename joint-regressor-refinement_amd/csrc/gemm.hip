@@ -365,6 +365,104 @@ int launch_gemm_nt32(const float* A, size_t planeA, int ldA, int rowsA, const fl
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Blend-basis adjoint  dF^T[m][b] = sum_{c,v} D_c[v][m] dvp_c[v][b]   (M = 224 features, N = poses, K = 3 x 6912 vertices).
+// Both operands arrive in VERTEX QUADS ([v/4][column][4]): D from the model upload (Dq), dvp as k_lbs_bwd writes it.
+// A K-pair may take any two k as long as A and B agree, so step t of a quad pair takes vertex 4*(2g + half) + t: a lane's
+// four steps are ONE 16-byte LDS read per operand tile (7 + 1 ds_read_b128 per 28 MFMAs instead of 32 ds_read_b32).
+// Tile 224 x 128, four waves of 224 x 32 (7 accumulator tiles), chunks of 4 quads (16 vertices: A 14 KB -- one
+// contiguous block of Dq -- + B 8 KB), 3-deep LDS-DMA ring with counted waits (waves 0,1 issue 6 copies per chunk, waves
+// 2,3 issue 5), split-K over blockIdx.y.
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int BA_QUADS = 4;                                   // quads per chunk
+constexpr int BA_SA = BA_QUADS * KFP * 4, BA_SB = BA_QUADS * 128 * 4, BA_SLOT = BA_SA + BA_SB;   // floats
+__global__ __launch_bounds__(256, 2) void k_blend_adjoint(const float* __restrict__ Dq, const float* __restrict__ DVPq,
+                                                          float* __restrict__ dFTp, size_t split_stride, int BP) {
+  __shared__ __attribute__((aligned(16))) float lds[3 * BA_SLOT];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int nt = xcd_remap(blockIdx.x, gridDim.x);
+  const int n0 = nt * 128;
+  const int split = blockIdx.y, nsplit = gridDim.y;
+  constexpr int NCH = 3 * (VP / 4) / BA_QUADS;                // 1296 chunks over the three coordinate planes
+  const int c_begin = (int)((long)NCH * split / nsplit), c_end = (int)((long)NCH * (split + 1) / nsplit);
+  // copies per chunk: A = 14 linear 1 KB pieces (pieces wave, wave + 4, ...), B = 8 pieces (quad p / 2, poses (p % 2) * 64 + lane)
+  auto issue = [&](int ch, int slot) {
+    const float* a = Dq + (size_t)ch * BA_SA;                 // chunk ch = quads [4 ch, 4 ch + 4) of the flattened (plane, quad) axis
+    const float* b = DVPq + ((size_t)ch * BA_QUADS * BP + n0) * 4;
+    asm volatile("" : "+s"(a));
+    asm volatile("" : "+s"(b));
+    float* dA = lds + slot * BA_SLOT;
+    float* dB = dA + BA_SA;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = wave + 4 * i;
+      if (p < 14) __builtin_amdgcn_global_load_lds(JRR_GLB(a + p * 256 + lane * 4), JRR_LDS(dA + p * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = wave + 4 * i;
+      __builtin_amdgcn_global_load_lds(JRR_GLB(b + ((size_t)(p >> 1) * BP + (p & 1) * 64 + lane) * 4), JRR_LDS(dB + p * 256), 16, 0, 0);
+    }
+  };
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) acc[i] = zero16();
+  if (c_begin < c_end) issue(c_begin, 0);
+  if (c_begin + 1 < c_end) issue(c_begin + 1, 1);
+  int slot = 0;
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    // this wave's copies of chunk ch have landed once at most the next chunk's are outstanding (6 for waves 0,1; 5 for 2,3)
+    if (ch + 1 < c_end) {
+      if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (ch + 2 < c_end) issue(ch + 2, slot >= 1 ? slot - 1 : 2);
+    const f32x4* la = reinterpret_cast<const f32x4*>(lds + slot * BA_SLOT);
+    const f32x4* lb = reinterpret_cast<const f32x4*>(lds + slot * BA_SLOT + BA_SA);
+    slot = (slot == 2) ? 0 : slot + 1;
+    // operands of quad pair 1 are requested right after the first MFMA of pair 0
+    f32x4 a4[7], b4;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) a4[i] = la[half * KFP + 32 * i + l31];
+    b4 = lb[half * 128 + wave * 32 + l31];
+#pragma unroll
+    for (int gq = 0; gq < 2; ++gq) {
+      f32x4 ca[7], cb = b4;
+#pragma unroll
+      for (int i = 0; i < 7; ++i) ca[i] = a4[i];
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = mfma(ca[0][0], cb[0], acc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gq == 0) {
+#pragma unroll
+        for (int i = 0; i < 7; ++i) a4[i] = la[(2 + half) * KFP + 32 * i + l31];
+        b4 = lb[(2 + half) * 128 + wave * 32 + l31];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < 7; ++i)
+          if (t + i > 0) acc[i] = mfma(ca[i][t], cb[t], acc[i]);
+    }
+  }
+  float* out = dFTp + (size_t)split * split_stride;
+  const unsigned lane_off = (unsigned)(4 * half) * (unsigned)BP + (unsigned)(n0 + wave * 32 + l31);
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) urow(out, (size_t)(32 * i + acc_row_u(q)), BP)[lane_off] = acc[i][q];
+}
+
+int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s) {
+  hipLaunchKernelGGL(k_blend_adjoint, dim3(BP / 128, nsplit), dim3(256), 0, s, Dq, DVPq, dFTp, split_stride, BP);
+  return 0;
+}
+
 // 32x128 block tile (4 waves of 32x32 side by side), batched over gridDim.y: joints = Jn . verts from stored vertices
 int launch_gemm_32x128(const GemmArgs& g, int epi, int nsplit, int nbatch, hipStream_t s) {
   return launch_cfg<1, 1, 1, 4, 16>(g, epi, nsplit, s, nbatch);

@@ -109,7 +109,8 @@ struct Parents {
 // ---- device-resident SMPL model ------------------------------------------------------------
 struct Model {
   float* Dk;    // [VT][KFP][3][32]  blend basis, feature-major inside a vertex tile
-  float* Dn;    // [3][VP][KFP]      blend basis, feature-contiguous (for the dF GEMM)
+  float* Dn;    // [3][VP][KFP]      blend basis, feature-contiguous (folded-regressor tables)
+  float* Dq;    // [3][VP/4][KFP][4] blend basis in vertex quads (A operand of the blend adjoint, k_blend_adjoint)
   float* Wjv;   // [VT][24][32]      skinning weights W^T tile  (lane = vertex)
   float* Wvj;   // [VT][32][32]      skinning weights tile [vertex][joint padded to 32] (lane = joint)
   float* Jt;    // [24][3]           rest joints of the template

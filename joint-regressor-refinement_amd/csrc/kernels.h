@@ -92,6 +92,8 @@ int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
+// blend-basis adjoint dF^T[split][224][BP] = sum_{c, v in split} D_c[v][.] dvp_c[v][.], both operands in vertex quads
+int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s);
 int launch_gemm_nt32(const float* A, size_t planeA, int ldA, int rowsA, const float* Bm, size_t planeB, int ldB, float* Out,
                      int ldo, size_t split_stride, int N, int K, int nplanes, int ksplit, hipStream_t s);
 int launch_gemm_32x128(const GemmArgs& g, int epi, int nsplit, int nbatch, hipStream_t s);

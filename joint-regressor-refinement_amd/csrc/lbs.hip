@@ -270,7 +270,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
 //   one workgroup of four waves per (pose tile bt of 32 poses, vertex chunk vc); per vertex tile:
 //     dverts_r[v,b] = sum_i Jn[i,v] dj[b,i,r]                (K = 18)        -- and / or loaded (DV)
 //     T_{r,c}[v,b]  = sum_j W[v,j] A[b,j,r,c]                (K = 24, recomputed)
-//     dvp_c[v,b]    = sum_r T_{r,c} dverts_r                  -> DVP [3][VP][BP]
+//     dvp_c[v,b]    = sum_r T_{r,c} dverts_r                  -> DVP [3][VP/4][BP][4] (row quads)
 //     dA_{r,c}[j,b] += sum_v W[v,j] dverts_r[v,b] vp_c[v,b]   (sums over the tile's ROW index)
 //     dA_{c,3}[j,b] += sum_v W[v,j] dverts_c[v,b]
 //   Wave roles.  Waves 0..2 are the PLANE waves c = 0, 1, 2: T_{r,c} for the three r (36 MFMA), dvp_c, dA_{r,c} for the
@@ -349,9 +349,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
     int slot = 0;                                     // ring slot of tile vt
     auto tile = [&](int vt, const f32x16& vpc, f32x16& vpn) {
       // dverts of tile vt published; record vt + 1 landed; everybody is done with tile vt - 1.  This wave's record
-      // copies are older than its 4 v_posed prefetch loads and its 16 dvp stores of the previous tile: both stay in
+      // copies are older than its 4 v_posed prefetch loads and its 4 dvp stores of the previous tile: both stay in
       // flight across the barrier (the prefetch is consumed in the second half of THIS tile, the stores never).
-      barrier_keep_vm<20>();
+      barrier_keep_vm<8>();
       const int slot1 = (slot + 1 == BWD_RING) ? 0 : slot + 1, slot2 = (slot1 + 1 == BWD_RING) ? 0 : slot1 + 1;
       if (vt + 2 < t_end) issue(vt + 2, slot2);
       __builtin_amdgcn_sched_barrier(0);     // the counted wait relies on: record copies first, loads / stores after
@@ -391,9 +391,14 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
         }
       }
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {                     // dvp_c = sum_r T_{r,c} dverts_r
-        const float dvp = fmaf(T2[q], dv[2][q], fmaf(T1[q], dv[1][q], T0[q] * dv[0][q]));
-        urow(DVP, (size_t)c * VP + vt * 32 + acc_row_u(q), BP)[voff] = dvp;
+      for (int g = 0; g < 4; ++g) {                      // dvp_c = sum_r T_{r,c} dverts_r, stored as 16-byte row quads
+        f32x4 t;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int q = 4 * g + u;
+          t[u] = fmaf(T2[q], dv[2][q], fmaf(T1[q], dv[1][q], T0[q] * dv[0][q]));
+        }
+        *quad_ptr(DVP, (size_t)c * (VP / 4) + vt * 8, g, BP, qoff) = t;
       }
       const float* wvp = tab + TB_WVJ + l31;
       float wn = wvp[acc_row(0, half) * 32];
