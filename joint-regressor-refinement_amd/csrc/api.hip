@@ -136,6 +136,7 @@ struct jrr_engine {
   float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv;
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
   float *W2s, *zpart;                                // fc2.w rows scaled by fc4.w; partial fc4 dots [16][BP]
+  float *W0Tq, *W2Tq, *W2sq, *W0q;                   // the four GEMM weight operands in quads [k/4][m][4]
   float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc, *wgs;
   float *Ps, *gb;
   float *dsq, *ssq;                                  // per-pose squared adversarial errors of the last iteration [25][BP], [BP]
@@ -232,6 +233,10 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->W0T = c.take((size_t)768 * 1024);
     t->W2T = c.take((size_t)1024 * 1024);
     t->W2s = c.take((size_t)1024 * 1024);
+    t->W0Tq = c.take((size_t)768 * 1024);
+    t->W2Tq = c.take((size_t)1024 * 1024);
+    t->W2sq = c.take((size_t)1024 * 1024);
+    t->W0q = c.take((size_t)1024 * 768);
     t->zpart = c.take((size_t)16 * BP);
     t->H2T = c.take((size_t)768 * BP);
     t->A1T = c.take((size_t)1024 * BP);
@@ -444,6 +449,10 @@ extern "C" int jrr_engine_set_pose_disc(jrr_engine_t* e, const float* P, void* s
   launch_transpose(e->Pd + DP_FC0_W, e->W0T, 1024, 768, s);    // [out][in] -> [in][out]
   launch_transpose(e->Pd + DP_FC2_W, e->W2T, 1024, 1024, s);
   launch_scale_rows(e->Pd + DP_FC2_W, e->Pd + DP_FC4_W, e->W2s, 1024, 1024, s);   // row n of fc2.w times fc4.w[n]
+  launch_to_quads(e->W0T, 1024, e->W0Tq, 768, 1024, s);                // A operands A[k][m] of the four loop GEMMs, in quads
+  launch_to_quads(e->W2T, 1024, e->W2Tq, 1024, 1024, s);
+  launch_to_quads(e->W2s, 1024, e->W2sq, 1024, 1024, s);
+  launch_to_quads(e->Pd + DP_FC0_W, 768, e->W0q, 1024, 768, s);
   CHECK_LAUNCH();
   e->have_pd = true;
   return JRR_OK;
@@ -597,16 +606,19 @@ extern "C" int jrr_joint_loss(const float* joints, const float* gt_mm, float wei
 //   relu'(a2) dz on the way to the MFMA (dz from the partial dots in the prologue; fc2.w pre-scaled by w4: the
 //   rank-one output-layer adjoint is never materialised)  ->  fc0 adjoint GEMM  ->  k_dconv_bwd.
 // All four GEMMs: exact 128x64 tiles (512 workgroups at 4096 poses), 3-deep LDS-DMA ring.
-static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t s) {
-  launch_disc_conv_fwd(e->Pd, x6d, e->H2T, out, e->B, e->BP, s);
+// The loop path keeps every activation in quads [row/4][pose][4] (k_disc_gemm); the weight-gradient path of the outer
+// step (disc_backward_params) needs row-major activations for its transposes / row sums and runs the row-major kernels.
+static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t s, bool quad = true) {
+  launch_disc_conv_fwd(e->Pd, x6d, e->H2T, out, e->B, e->BP, s, quad ? 1 : 0);
   GemmArgs g;
   g.mask = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
-  g.A = e->W0T; g.lda = 1024; g.Bm = e->H2T; g.Out = e->A1T; g.bias = e->Pd + DP_FC0_B; g.M = 1024; g.K = 768;
-  int rc = launch_gemm_disc(g, EPI_BIAS_RELU, 0, s);
+  g.A = quad ? e->W0Tq : e->W0T; g.lda = 1024; g.Bm = e->H2T; g.Out = e->A1T; g.bias = e->Pd + DP_FC0_B; g.M = 1024; g.K = 768;
+  int rc = quad ? launch_disc_gemm_q(g, EPI_BIAS_RELU, 0, s) : launch_gemm_128x64(g, EPI_BIAS_RELU, 1, s);
   if (rc) return rc;
-  g.A = e->W2T; g.lda = 1024; g.Bm = e->A1T; g.Out = e->A2T; g.bias = e->Pd + DP_FC2_B; g.M = 1024; g.K = 1024;
+  g.A = quad ? e->W2Tq : e->W2T; g.lda = 1024; g.Bm = e->A1T; g.Out = e->A2T; g.bias = e->Pd + DP_FC2_B; g.M = 1024; g.K = 1024;
+  if (!quad) return launch_gemm_128x64(g, EPI_BIAS_RELU, 1, s);
   g.dotw = e->Pd + DP_FC4_W; g.dot_out = e->zpart;
-  return launch_gemm_disc(g, EPI_BIAS_RELU_DOT, 0, s);
+  return launch_disc_gemm_q(g, EPI_BIAS_RELU_DOT, 0, s);
 }
 
 static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, const float* gout, float scale,
@@ -614,18 +626,18 @@ static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, cons
   GemmArgs g;
   g.bias = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   // dA1T[k][b] = relu'(A1T) * sum_n (fc4.w[n] fc2.w[n][k]) relu'(A2T[n][b]) dz[b]
-  g.A = e->W2s; g.lda = 1024; g.Bm = e->A2T; g.Out = e->dA1T; g.mask = e->A1T; g.M = 1024; g.K = 1024;
+  g.A = e->W2sq; g.lda = 1024; g.Bm = e->A2T; g.Out = e->dA1T; g.mask = e->A1T; g.M = 1024; g.K = 1024;
   g.zpart = e->zpart; g.nzpart = 16; g.zbias = e->Pd + DP_FC4_B; g.gout = gout; g.gout_ld = 25; g.scale = scale; g.target = target;
   g.nvalid = e->B; g.sq0 = sq; g.out0 = out; g.out0_ld = 25;
-  int rc = launch_gemm_disc(g, EPI_MASK, 2, s);
+  int rc = launch_disc_gemm_q(g, EPI_MASK, 2, s);
   if (rc) return rc;
   // dH2T[k][b] = sum_n fc0.w[n][k] dA1T[n][b]
   GemmArgs h;
   h.bias = nullptr; h.split_stride = 0; h.N = e->BP; h.ldb = e->BP; h.ldo = e->BP;
-  h.A = e->Pd + DP_FC0_W; h.lda = 768; h.Bm = e->dA1T; h.Out = e->dH2T; h.mask = nullptr; h.M = 768; h.K = 1024;
-  rc = launch_gemm_disc(h, EPI_STORE, 0, s);
+  h.A = e->W0q; h.lda = 768; h.Bm = e->dA1T; h.Out = e->dH2T; h.mask = nullptr; h.M = 768; h.K = 1024;
+  rc = launch_disc_gemm_q(h, EPI_STORE, 0, s);
   if (rc) return rc;
-  launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s, sq);
+  launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s, sq, 1);
   return 0;
 }
 
@@ -664,7 +676,7 @@ extern "C" int jrr_pose_disc_vjp_input(jrr_engine_t* e, const float* x6d, const 
 // or the vector-Jacobian product for an arbitrary upstream gradient gout (B,25)
 static int disc_backward_params(jrr_engine* e, const float* x6d, const float* gout, float scale, float target, float* dP,
                                 float* sqerr, hipStream_t s) {
-  int rc = disc_forward(e, x6d, e->dsc, s);
+  int rc = disc_forward(e, x6d, e->dsc, s, false);        // row-major activations for the transposes / row sums below
   if (rc) return rc;
   launch_disc_out(e->Pd, e->A2T, e->dsc, e->dA2T, gout, scale, target, e->B, e->BP, s, e->dz0);
   if (sqerr) launch_sqerr_rows(e->dsc, 25, target, sqerr, e->B, s);

@@ -98,6 +98,7 @@ __device__ __forceinline__ float conv_head(const float* __restrict__ L, int j, i
 }
 
 // grid = (BP / 32) * 6 workgroups of 4 waves; wave w of block (bt, jg) owns poses [32 bt, +32) and joint 4 jg + w
+template <bool QUAD>
 __global__ __launch_bounds__(256) void k_dconv_fwd(const float* __restrict__ P, const float* __restrict__ x6d,
                                                    float* __restrict__ H2T, float* __restrict__ out, int B, int BP) {
   __shared__ float L[CL_FLOATS];
@@ -109,9 +110,19 @@ __global__ __launch_bounds__(256) void k_dconv_fwd(const float* __restrict__ P, 
   const bool ok = b < B;
   f32x16 h1, h2;
   conv_mlp_tile(L, x6d, b, ok, j, half, l31, h1, h2);
-  const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)b;
+  if (QUAD) {      // [row/4][pose][4]: registers 4g .. 4g+3 are one quad of this lane's pose (jrr_common.h)
+    const unsigned qoff = (unsigned)half * (unsigned)BP + (unsigned)b;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) urow(H2T, (size_t)(j * 32 + acc_row_u(q)), BP)[voff] = ok ? h2[q] : 0.f;   // padded poses: zeros
+    for (int g = 0; g < 4; ++g) {
+      f32x4 t = {h2[4 * g], h2[4 * g + 1], h2[4 * g + 2], h2[4 * g + 3]};
+      if (!ok) t = f32x4{0.f, 0.f, 0.f, 0.f};
+      *quad_ptr(H2T, (size_t)j * 8, g, BP, qoff) = t;
+    }
+  } else {
+    const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)b;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) urow(H2T, (size_t)(j * 32 + acc_row_u(q)), BP)[voff] = ok ? h2[q] : 0.f;   // padded poses: zeros
+  }
   if (out) {
     const float z = conv_head(L, j, half, h2);
     if (ok && half == 0) out[(size_t)b * 25 + 1 + j] = sigmoidf(z);
@@ -119,6 +130,7 @@ __global__ __launch_bounds__(256) void k_dconv_fwd(const float* __restrict__ P, 
 }
 
 // input gradient of the per-joint MLP + heads; dH2T = gradient arriving from fc0 (may be NULL), gout (B,25) nullable
+template <bool QUAD>
 __global__ __launch_bounds__(256) void k_dconv_bwd(const float* __restrict__ P, const float* __restrict__ x6d,
                                                    const float* __restrict__ dH2T, const float* __restrict__ gout,
                                                    float scale, float target, float* __restrict__ gx, int B, int BP,
@@ -138,11 +150,24 @@ __global__ __launch_bounds__(256) void k_dconv_bwd(const float* __restrict__ P, 
   const float up = gout ? (ok ? gout[(size_t)b * 25 + 1 + j] : 0.f) : scale * (sg - target);
   const float dz = ok ? up * sg * (1.f - sg) : 0.f;
   const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)b;
+  f32x16 din = zero16();                 // gradient arriving from fc0
+  if (dH2T) {
+    if (QUAD) {
+      const unsigned qoff = (unsigned)half * (unsigned)BP + (unsigned)b;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 t = *quad_ptr(dH2T, (size_t)j * 8, g, BP, qoff);
+        din[4 * g] = t[0]; din[4 * g + 1] = t[1]; din[4 * g + 2] = t[2]; din[4 * g + 3] = t[3];
+      }
+    } else {
+#pragma unroll
+      for (int q = 0; q < 16; ++q) din[q] = urow(dH2T, (size_t)(j * 32 + acc_row_u(q)), BP)[voff];
+    }
+  }
   f32x16 acc = zero16();
 #pragma unroll
   for (int q = 0; q < 16; ++q) {
-    float g = dz * L[CL_WH + j * 33 + acc_row(q, half)];
-    if (dH2T) g += urow(dH2T, (size_t)(j * 32 + acc_row_u(q)), BP)[voff];
+    const float g = dz * L[CL_WH + j * 33 + acc_row(q, half)] + din[q];
     const float dh2 = (h2[q] > 0.f) ? g : 0.f;
     acc = mfma(L[CL_W2 + acc_row(q, half) * 32 + l31], dh2, acc);        // dh1[c] += W2[o][c] dh2[o]
   }
@@ -506,8 +531,9 @@ int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_
   return 0;
 }
 
-int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_dconv_fwd, dim3((BP / 32) * 6), dim3(256), 0, s, P, x6d, H2T, out, B, BP);
+int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s, int quad) {
+  if (quad) hipLaunchKernelGGL((k_dconv_fwd<true>), dim3((BP / 32) * 6), dim3(256), 0, s, P, x6d, H2T, out, B, BP);
+  else hipLaunchKernelGGL((k_dconv_fwd<false>), dim3((BP / 32) * 6), dim3(256), 0, s, P, x6d, H2T, out, B, BP);
   return 0;
 }
 int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
@@ -516,8 +542,9 @@ int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, c
   return 0;
 }
 int launch_disc_conv_bwd(const float* P, const float* x6d, const float* dH2T, const float* gout, float scale,
-                         float target, float* gx, int B, int BP, hipStream_t s, float* sqj) {
-  hipLaunchKernelGGL(k_dconv_bwd, dim3((BP / 32) * 6), dim3(256), 0, s, P, x6d, dH2T, gout, scale, target, gx, B, BP, sqj);
+                         float target, float* gx, int B, int BP, hipStream_t s, float* sqj, int quad) {
+  if (quad) hipLaunchKernelGGL((k_dconv_bwd<true>), dim3((BP / 32) * 6), dim3(256), 0, s, P, x6d, dH2T, gout, scale, target, gx, B, BP, sqj);
+  else hipLaunchKernelGGL((k_dconv_bwd<false>), dim3((BP / 32) * 6), dim3(256), 0, s, P, x6d, dH2T, gout, scale, target, gx, B, BP, sqj);
   return 0;
 }
 int launch_shape_disc(const float* P, const float* betas, float* out, float* gb, float scale, float target, int B,

@@ -4,8 +4,6 @@
 // discriminator (scripts/discriminator.py:20-29,32-54), its input-gradient, and the blend-basis
 // adjoint dF = D . dVP is of this form with the pose index on the MFMA column (lane) axis.
 // Optional split-K (blockIdx.z) writes partial slabs that the consumer sums.
-#include <cstdlib>
-
 #include "jrr_common.h"
 #include "kernels.h"
 
@@ -219,37 +217,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
 
 // the pose discriminator's layers: exact 128x64 tiling, 3-deep ring; epi in {BIAS_RELU, BIAS_RELU_DOT, STORE, MASK},
 // btr = B-operand transform (see k_gemm_tn)
-template <int WM, int WN, int WAVES_M, int WAVES_N>
-static int launch_disc_cfg(const GemmArgs& g, int epi, int btr, hipStream_t s) {
-  constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N, GK = 32;
-  if (g.M % BM != 0 || g.N % BN != 0 || g.K % GK != 0 || g.lda % 4 != 0 || g.ldb % 4 != 0) {
-    jrr_set_error("gemm_disc: unsupported shape M=%d N=%d K=%d lda=%d ldb=%d", g.M, g.N, g.K, g.lda, g.ldb);
-    return JRR_ERR_ARG;
-  }
-  dim3 grid((g.M / BM) * (g.N / BN), 1, 1), block(64 * WAVES_M * WAVES_N);
-  if (epi == EPI_BIAS_RELU && !btr) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_BIAS_RELU, 3, 0, 2>), grid, block, 0, s, g);
-  else if (epi == EPI_BIAS_RELU_DOT && !btr) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_BIAS_RELU_DOT, 3, 0, 2>), grid, block, 0, s, g);
-  else if (epi == EPI_STORE && !btr) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_STORE, 3, 0, 2>), grid, block, 0, s, g);
-  else if (epi == EPI_MASK && !btr) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_MASK, 3, 0, 2>), grid, block, 0, s, g);
-  else if (epi == EPI_MASK && btr == 1) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_MASK, 3, 1, 2>), grid, block, 0, s, g);
-  else if (epi == EPI_MASK && btr == 2) hipLaunchKernelGGL((k_gemm_tn<WM, WN, WAVES_M, WAVES_N, GK, EPI_MASK, 3, 2, 2>), grid, block, 0, s, g);
-  else { jrr_set_error("gemm_disc: unsupported epilogue %d / transform %d", epi, btr); return JRR_ERR_ARG; }
-  return 0;
-}
-
-// the pose discriminator's layers: exact tiling, 3-deep ring; epi in {BIAS_RELU, BIAS_RELU_DOT, STORE, MASK},
-// btr = B-operand transform (see k_gemm_tn).  Returns the number of partial-dot slabs per column of this tiling
-// through *ndot (EPI_BIAS_RELU_DOT consumers).
-int launch_gemm_disc(const GemmArgs& g, int epi, int btr, hipStream_t s) {
-  static const int tile = getenv("JRR_DISC_TILE") ? atoi(getenv("JRR_DISC_TILE")) : 0;     // experiment switch
-  // M = 768 (fc0 adjoint) gives only 6 x 64 = 384 workgroups of 128x64: 96x64 tiles of two 96x32 waves fill all 512 slots
-  if (tile == 0 && g.M % 96 == 0 && g.M % 128 == 0 && (g.M / 128) * (g.N / 64) < 512 && (g.M / 96) * (g.N / 64) >= 512)
-    return launch_disc_cfg<3, 1, 1, 2>(g, epi, btr, s);
-  if (tile == 1) return launch_disc_cfg<2, 1, 2, 4>(g, epi, btr, s);    // 128x128, 8 waves of 64x32
-  if (tile == 2) return launch_disc_cfg<2, 2, 2, 2>(g, epi, btr, s);    // 128x128, 4 waves of 64x64
-  return launch_disc_cfg<2, 1, 2, 2>(g, epi, btr, s);                   // 128x64, 4 waves of 64x32
-}
-
 template <int WM, int WN, int WAVES_M, int WAVES_N, int GK>
 static int launch_cfg(const GemmArgs& g, int epi, int nsplit, hipStream_t s, int nbatch = 1) {
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
@@ -460,6 +427,175 @@ __global__ __launch_bounds__(256, 2) void k_blend_adjoint(const float* __restric
 
 int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s) {
   hipLaunchKernelGGL(k_blend_adjoint, dim3(BP / 128, nsplit), dim3(256), 0, s, Dq, DVPq, dFTp, split_stride, BP);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// Pose-discriminator layers on QUAD-layout operands: Out[m][n] = epilogue(sum_k A[k][m] B[k][n]) with every matrix stored
+// as [row/4][column][4] (weights re-laid once per upload; activations written that way by the producing epilogue, whose
+// lanes own four consecutive rows 8g + 4 half + {0..3} of their column = one quad = 16 bytes).  Same tricks as
+// k_blend_adjoint: a lane's four K steps are one ds_read_b128 per operand tile, stores / mask loads are dwordx4,
+// exact tiles, 3-deep LDS-DMA ring with counted waits, operand prefetch one quad pair ahead.
+//   tile (32 WM WAVES_M) x (32 WAVES_N), 32-deep chunks (8 quads); EPI / BTR as in k_gemm_tn.
+// ------------------------------------------------------------------------------------------------------------------
+template <int WM, int WAVES_M, int WAVES_N, int EPI, int BTR>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_disc_gemm(GemmArgs g) {
+  constexpr int NW = WAVES_M * WAVES_N, BM = 32 * WM * WAVES_M, BN = 32 * WAVES_N;
+  constexpr int SA = 8 * BM * 4, SB = 8 * BN * 4, SLOT = SA + SB;            // floats per ring slot
+  constexpr int OPA = SA / 256, OPB = SB / 256, PA = OPA / NW, PB = OPB / NW;  // 1 KB copies per chunk / per wave
+  static_assert(OPA % NW == 0 && OPB % NW == 0, "exact tiling required");
+  __shared__ __attribute__((aligned(16))) float lds[3 * SLOT];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int n_mt = g.M / BM;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int mt = L % n_mt, nt = L / n_mt;     // consecutive blocks share the activation panel
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int nch = g.K / 32;
+  unsigned offA[PA], offB[PB];
+#pragma unroll
+  for (int i = 0; i < PA; ++i) {
+    const int e = (wave + NW * i) * 64 + lane;             // linear 16-byte piece of the [8 quads][BM][4] image
+    offA[i] = ((unsigned)(e / BM) * (unsigned)g.M + (unsigned)(m0 + e % BM)) * 4u;
+  }
+#pragma unroll
+  for (int i = 0; i < PB; ++i) {
+    const int e = (wave + NW * i) * 64 + lane;
+    offB[i] = ((unsigned)(e / BN) * (unsigned)g.ldb + (unsigned)(n0 + e % BN)) * 4u;
+  }
+  auto issue = [&](int ch, int slot) {
+    const float* a = g.A + (size_t)ch * 8 * g.M * 4;
+    const float* b = g.Bm + (size_t)ch * 8 * g.ldb * 4;
+    asm volatile("" : "+s"(a));
+    asm volatile("" : "+s"(b));
+    float* dA = lds + slot * SLOT;
+    float* dB = dA + SA;
+#pragma unroll
+    for (int i = 0; i < PA; ++i) __builtin_amdgcn_global_load_lds(JRR_GLB(a + offA[i]), JRR_LDS(dA + (wave + NW * i) * 256), 16, 0, 0);
+#pragma unroll
+    for (int i = 0; i < PB; ++i) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave + NW * i) * 256), 16, 0, 0);
+  };
+  issue(0, 0);
+  if (nch > 1) issue(1, 1);
+  float cscale = 0.f;                                        // BTR = 2: dz of this lane's column (computed while the copies fly)
+  if (BTR == 2) {
+    const int n = n0 + wn * 32 + l31;
+    float z = g.zbias[0];
+    for (int t = 0; t < g.nzpart; ++t) z += g.zpart[(size_t)t * g.ldb + n];
+    const float sg = 1.f / (1.f + expf(-z));
+    const bool ok = n < g.nvalid;
+    const float up = g.gout ? (ok ? g.gout[(size_t)n * g.gout_ld] : 0.f) : g.scale * (sg - g.target);
+    cscale = ok ? up * sg * (1.f - sg) : 0.f;
+    if (mt == 0 && wm == 0 && half == 0 && ok) {
+      if (g.sq0) g.sq0[n] = (sg - g.target) * (sg - g.target);
+      if (g.out0) g.out0[(size_t)n * g.out0_ld] = sg;
+    }
+  }
+  f32x16 acc[WM];
+#pragma unroll
+  for (int i = 0; i < WM; ++i) acc[i] = zero16();
+  int slot = 0;
+  for (int ch = 0; ch < nch; ++ch) {
+    if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    if (ch + 2 < nch) issue(ch + 2, slot >= 1 ? slot - 1 : 2);
+    const f32x4* la = reinterpret_cast<const f32x4*>(lds + slot * SLOT) + wm * WM * 32 + l31;
+    const f32x4* lb = reinterpret_cast<const f32x4*>(lds + slot * SLOT + SA) + wn * 32 + l31;
+    slot = (slot == 2) ? 0 : slot + 1;
+    f32x4 a4[WM], b4;
+#pragma unroll
+    for (int i = 0; i < WM; ++i) a4[i] = la[half * BM + 32 * i];
+    b4 = lb[half * BN];
+#pragma unroll
+    for (int gq = 0; gq < 4; ++gq) {
+      f32x4 ca[WM], cb;
+#pragma unroll
+      for (int i = 0; i < WM; ++i) ca[i] = a4[i];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) cb[t] = BTR ? ((b4[t] > 0.f) ? cscale : 0.f) : b4[t];
+      __builtin_amdgcn_sched_barrier(0);
+      acc[0] = mfma(ca[0][0], cb[0], acc[0]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (gq + 1 < 4) {
+#pragma unroll
+        for (int i = 0; i < WM; ++i) a4[i] = la[(2 * gq + 2 + half) * BM + 32 * i];
+        b4 = lb[(2 * gq + 2 + half) * BN];
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int i = 0; i < WM; ++i)
+          if (t + i > 0) acc[i] = mfma(ca[i][t], cb[t], acc[i]);
+    }
+  }
+  // epilogue: registers 4q4 .. 4q4+3 of tile i = rows r0 + {0..3}, r0 = m0 + (wm WM + i) 32 + 8 q4 + 4 half: one output quad
+  const int n = n0 + wn * 32 + l31;
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < WM; ++i)
+#pragma unroll
+    for (int q4 = 0; q4 < 4; ++q4) {
+      const int r0u = m0 + (wm * WM + i) * 32 + 8 * q4;            // wave-uniform part of the row
+      const int r0 = r0u + 4 * half;
+      f32x4 v = {acc[i][4 * q4], acc[i][4 * q4 + 1], acc[i][4 * q4 + 2], acc[i][4 * q4 + 3]};
+      if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RELU_DOT) {
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(g.bias + r0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = fmaxf(v[u] + bb[u], 0.f);
+      }
+      if (EPI == EPI_BIAS_RELU_DOT) {
+        const f32x4 dw = *reinterpret_cast<const f32x4*>(g.dotw + r0);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) dot = fmaf(dw[u], v[u], dot);
+      }
+      const size_t qi = ((size_t)(r0u / 4 + half) * g.ldo + n);     // quad index of (row r0, column n)
+      if (EPI == EPI_MASK) {
+        const f32x4 mk = reinterpret_cast<const f32x4*>(g.mask)[qi];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (mk[u] > 0.f) ? v[u] : 0.f;
+      }
+      reinterpret_cast<f32x4*>(g.Out)[qi] = v;
+    }
+  if (EPI == EPI_BIAS_RELU_DOT) {      // rows of the two lane halves are disjoint: add them, one store per column
+    const float t = dot + __shfl_xor(dot, 32);
+    if (half == 0) g.dot_out[(size_t)(mt * WAVES_M + wm) * g.ldo + n] = t;
+  }
+}
+
+// quad-layout discriminator GEMM; returns the number of partial-dot slabs per column through *ndot (EPI_BIAS_RELU_DOT)
+int launch_disc_gemm_q(const GemmArgs& g, int epi, int btr, hipStream_t s, int* ndot) {
+  if (g.K % 32 != 0 || g.N % 64 != 0 || g.ldb % 4 != 0) { jrr_set_error("disc_gemm_q: unsupported shape M=%d N=%d K=%d", g.M, g.N, g.K); return JRR_ERR_ARG; }
+  // 128x64 tiles (4 waves of 64x32); when those give fewer than 512 workgroups but 96x64 tiles (2 waves of 96x32) reach it: those
+  const bool t96 = g.M % 96 == 0 && (g.M % 128 != 0 || ((g.M / 128) * (g.N / 64) < 512 && (g.M / 96) * (g.N / 64) >= 512));
+  if (!t96 && g.M % 128 != 0) { jrr_set_error("disc_gemm_q: M=%d is neither a multiple of 128 nor of 96", g.M); return JRR_ERR_ARG; }
+  if (ndot) *ndot = t96 ? g.M / 96 : (g.M / 128) * 2;
+  if (t96) {
+    dim3 grid((g.M / 96) * (g.N / 64)), block(128);
+    if (epi == EPI_STORE && !btr) hipLaunchKernelGGL((k_disc_gemm<3, 1, 2, EPI_STORE, 0>), grid, block, 0, s, g);
+    else { jrr_set_error("disc_gemm_q: 96-row tiles serve the plain store epilogue only"); return JRR_ERR_ARG; }
+    return 0;
+  }
+  dim3 grid((g.M / 128) * (g.N / 64)), block(256);
+  if (epi == EPI_BIAS_RELU && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_BIAS_RELU, 0>), grid, block, 0, s, g);
+  else if (epi == EPI_BIAS_RELU_DOT && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_BIAS_RELU_DOT, 0>), grid, block, 0, s, g);
+  else if (epi == EPI_STORE && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_STORE, 0>), grid, block, 0, s, g);
+  else if (epi == EPI_MASK && btr == 2) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_MASK, 2>), grid, block, 0, s, g);
+  else { jrr_set_error("disc_gemm_q: unsupported epilogue %d / transform %d", epi, btr); return JRR_ERR_ARG; }
+  return 0;
+}
+
+// [K][M] (row stride ld) -> quads [K/4][M][4]
+__global__ void k_to_quads(const float* __restrict__ in, int ld, float* __restrict__ out, int K, int M) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (size_t)K * M) return;
+  const int k = (int)(i / M), m = (int)(i % M);
+  out[((size_t)(k >> 2) * M + m) * 4 + (k & 3)] = in[(size_t)k * ld + m];
+}
+int launch_to_quads(const float* in, int ld, float* out, int K, int M, hipStream_t s) {
+  hipLaunchKernelGGL(k_to_quads, dim3((unsigned)(((size_t)K * M + 255) / 256)), dim3(256), 0, s, in, ld, out, K, M);
   return 0;
 }
 

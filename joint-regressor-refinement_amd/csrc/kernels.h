@@ -85,7 +85,8 @@ int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const fl
                     float* dJ, hipStream_t s);
 
 // gemm.hip
-int launch_gemm_disc(const GemmArgs& g, int epi, int btr, hipStream_t s);
+int launch_disc_gemm_q(const GemmArgs& g, int epi, int btr, hipStream_t s, int* ndot = nullptr);
+int launch_to_quads(const float* in, int ld, float* out, int K, int M, hipStream_t s);
 int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
@@ -122,7 +123,7 @@ int launch_evaluate(const float* pred, const float* target_mm, float* err, float
 
 // disc.hip
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s, int ldin = 0, int ldout = 0);
-int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s);
+int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s, int quad = 0);
 int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
                     float target, int B, int BP, hipStream_t s, float* dz0 = nullptr, float* sq0 = nullptr);
 int launch_disc_z_finish(const float* zpart, int nz, int ld, const float* zbias, float* out, int B, hipStream_t s);
@@ -137,7 +138,7 @@ int launch_shape_disc_bwd_params(const float* P, const float* betas, const float
                                  float* dparams, float* sqerr, int B, hipStream_t s);
 int launch_sqerr_rows(const float* out, int ncol, float target, float* sqerr, int B, hipStream_t s);
 int launch_disc_conv_bwd(const float* P, const float* x6d, const float* dH2T, const float* gout, float scale,
-                         float target, float* gx, int B, int BP, hipStream_t s, float* sqj = nullptr);
+                         float target, float* gx, int B, int BP, hipStream_t s, float* sqj = nullptr, int quad = 0);
 int launch_shape_disc(const float* P, const float* betas, float* out, float* gb, float scale, float target, int B,
                       hipStream_t s, const float* gout = nullptr, float* sq = nullptr);
 
