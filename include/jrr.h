@@ -9,7 +9,8 @@
  *
  * Conventions
  *  - plain pointers and sizes only; no torch / C++ types cross the boundary.
- *  - every `*_dev` pointer is device memory owned by the caller (PyTorch's allocator);
+ *  - every `*_dev` pointer is device memory owned by the caller (PyTorch's allocator), 16-byte aligned (whole
+ *    tensors and pose-granular contiguous slices of them are);
  *    every `*_host` pointer is host memory read synchronously during the call.
  *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
  *    kernels are enqueued on it, no entry point synchronises the device unless stated.

@@ -178,10 +178,10 @@ __global__ __launch_bounds__(256) void k_dconv_bwd(const float* __restrict__ P, 
     accx = mfma(L[CL_W0A + acc_row(q, half) * 32 + l31], dh1, accx);     // gx[c6] += W0[o][c6] dh1[o]
   }
   if (ok) {      // rows 0..3 live in registers 0..3 of lane half 0, rows 4,5 in registers 0,1 of half 1
-    float* dst = gx + ((size_t)b * NJ + j) * 6 + 4 * half;
-    dst[0] = accx[0];
-    dst[1] = accx[1];
-    if (half == 0) { dst[2] = accx[2]; dst[3] = accx[3]; }
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+    f32x2* dst = reinterpret_cast<f32x2*>(gx + ((size_t)b * NJ + j) * 6 + 4 * half);     // 8-byte aligned: even float offset
+    dst[0] = f32x2{accx[0], accx[1]};
+    if (half == 0) dst[1] = f32x2{accx[2], accx[3]};
   }
 }
 

@@ -187,6 +187,19 @@ __global__ void k_rodrigues_bwd(const float* __restrict__ aa, const float* __res
 // ------------------------------------------------------------------------------------------
 // helpers
 // ------------------------------------------------------------------------------------------
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// The per-(pose, joint) records of the pose-major API tensors ((B,24,6) poses / gradients, (B,154) Adam state) are 6
+// contiguous floats at an even float offset: three 8-byte accesses instead of six 4-byte ones (lanes are 576 / 616 bytes
+// apart, so every access is its own memory transaction: their count is what these kernels pay for).
+__device__ __forceinline__ void load6(const float* __restrict__ p, float v[6]) {
+  const f32x2* q = reinterpret_cast<const f32x2*>(p);
+  const f32x2 a = q[0], b = q[1], c = q[2];
+  v[0] = a[0]; v[1] = a[1]; v[2] = b[0]; v[3] = b[1]; v[4] = c[0]; v[5] = c[1];
+}
+__device__ __forceinline__ void store6(float* __restrict__ p, const float v[6]) {
+  f32x2* q = reinterpret_cast<f32x2*>(p);
+  q[0] = f32x2{v[0], v[1]}; q[1] = f32x2{v[2], v[3]}; q[2] = f32x2{v[4], v[5]};
+}
 __device__ __forceinline__ void load_rot(const float* __restrict__ x6d, const float* __restrict__ Rin, int b, int j,
                                          float R[9], Rot6& c) {
   if (Rin) {
@@ -194,8 +207,7 @@ __device__ __forceinline__ void load_rot(const float* __restrict__ x6d, const fl
     for (int k = 0; k < 9; ++k) R[k] = Rin[((size_t)b * NJ + j) * 9 + k];
   } else {
     float xv[6];
-#pragma unroll
-    for (int k = 0; k < 6; ++k) xv[k] = x6d[((size_t)b * NJ + j) * 6 + k];
+    load6(x6d + ((size_t)b * NJ + j) * 6, xv);
     rot6d_fwd(xv, R, c);
   }
 }
@@ -593,27 +605,26 @@ __device__ __forceinline__ void pose_update_joint(const PoseUpdateArgs& a, int b
   }
   float xv[6], R[9], dx[6];
   Rot6 c;
-#pragma unroll
-  for (int k = 0; k < 6; ++k) xv[k] = a.x6d_in[((size_t)b * NJ + j) * 6 + k];
+  load6(a.x6d_in + ((size_t)b * NJ + j) * 6, xv);
   rot6d_fwd(xv, R, c);
   rot6d_bwd(c, dRi, dx);
   if (a.gx_extra) {
+    float gx[6];
+    load6(a.gx_extra + ((size_t)b * NJ + j) * 6, gx);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) dx[k] += a.gx_extra[((size_t)b * NJ + j) * 6 + k];
+    for (int k = 0; k < 6; ++k) dx[k] += gx[k];
   }
-  if (a.dx6d) {
-#pragma unroll
-    for (int k = 0; k < 6; ++k) a.dx6d[((size_t)b * NJ + j) * 6 + k] = dx[k];
-  }
+  if (a.dx6d) store6(a.dx6d + ((size_t)b * NJ + j) * 6, dx);
   if (a.x6d_io) {
+    const size_t si = (size_t)b * NPARAM + j * 6;
+    float mm[6], vv[6], xn[6];
+    load6(a.adam_m + si, mm);
+    load6(a.adam_v + si, vv);
 #pragma unroll
-    for (int k = 0; k < 6; ++k) {
-      const size_t si = (size_t)b * NPARAM + j * 6 + k;
-      float mm = a.adam_m[si], vv = a.adam_v[si];
-      a.x6d_io[((size_t)b * NJ + j) * 6 + k] = adam_update(xv[k], dx[k], mm, vv, sc);
-      a.adam_m[si] = mm;
-      a.adam_v[si] = vv;
-    }
+    for (int k = 0; k < 6; ++k) xn[k] = adam_update(xv[k], dx[k], mm[k], vv[k], sc);
+    store6(a.x6d_io + ((size_t)b * NJ + j) * 6, xn);
+    store6(a.adam_m + si, mm);
+    store6(a.adam_v + si, vv);
   }
 }
 // shape coefficient l of pose b
