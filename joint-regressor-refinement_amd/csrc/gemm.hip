@@ -11,17 +11,11 @@ namespace jrr {
 
 
 // Operand chunks ([GK][BM] of A, [GK][BN] of Bm) are staged by LDS-DMA (global_load_lds_dwordx4)
-// into an NSLOT-deep ring, NSLOT-1 chunks ahead of the MFMAs, one workgroup barrier per chunk.
-//   NSLOT = 2: `vmcnt(0)` + barrier per chunk (any shape, partial tiles masked per lane).
-//   NSLOT = 3: needs an EXACT tiling (M % BM == 0, every wave issues the same PA + PB DMA instructions per chunk):
-//              the wait before the barrier is the counted `vmcnt(PA + PB)`, i.e. it leaves the next chunk's copies in
-//              flight (LDS-DMA stays in flight across s_barrier), so a chunk has two chunk-times to land.
-//   BTR = 1:   the B operand is turned into  (x > 0) ? colscale[column] : 0  on its way from LDS to the MFMA
-//              (pose discriminator: B = A2^T, colscale = dz: the rank-one output-layer adjoint relu'(a2) w4 dz
-//              without materialising it; the w4 factor is folded into the A operand by the caller).
-//   EPI_BIAS_RELU_DOT: as EPI_BIAS_RELU, plus the per-column partial dot products  sum_m dotw[m] * out[m][n]  over
-//              this wave's rows, written to dot_out[(m-tile * WAVES_M + wave row)][n]  (fc4 fused into fc2).
-template <int WM, int WN, int WAVES_M, int WAVES_N, int GK, int EPI, int NSLOT = 2, int BTR = 0, int PD = 1>
+// into a 2-deep ring, one chunk ahead of the MFMAs, one workgroup barrier per chunk; partial tiles are masked per lane.
+// (The hot products of the loop have their own kernels on quad-layout operands: k_blend_adjoint, k_disc_gemm.  This
+// generic kernel serves the folded-regressor tables, the outer step's weight-gradient GEMMs and the joint re-regression
+// from stored vertices.)  blockIdx.y batches independent products, blockIdx.z splits K.
+template <int WM, int WN, int WAVES_M, int WAVES_N, int GK, int EPI>
 __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) {
   constexpr int NW = WAVES_M * WAVES_N;
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
@@ -29,9 +23,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
   constexpr int OPA = (A16 + 63) / 64, OPB = (B16 + 63) / 64;   // wave-instructions per chunk
   constexpr int PA = (OPA + NW - 1) / NW, PB = (OPB + NW - 1) / NW;
   constexpr int SLOT = GK * (BM + BN);
-  constexpr bool EXACT = NSLOT > 2;
-  static_assert(!EXACT || (A16 % 64 == 0 && B16 % 64 == 0 && OPA % NW == 0 && OPB % NW == 0), "exact tiling required");
-  __shared__ float lds[NSLOT * SLOT];
+  __shared__ float lds[2 * SLOT];
 
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -51,14 +43,14 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
   for (int i = 0; i < PA; ++i) {
     const int p = (wave + NW * i) * 64 + lane;
     const int row = p / (BM / 4), col = (p % (BM / 4)) * 4;
-    okA[i] = EXACT || ((wave + NW * i) < OPA && p < A16 && (m0 + col) < g.M);
+    okA[i] = (wave + NW * i) < OPA && p < A16 && (m0 + col) < g.M;
     offA[i] = (unsigned)row * (unsigned)g.lda + (unsigned)col;
   }
 #pragma unroll
   for (int i = 0; i < PB; ++i) {
     const int p = (wave + NW * i) * 64 + lane;
     const int row = p / (BN / 4), col = (p % (BN / 4)) * 4;
-    okB[i] = EXACT || ((wave + NW * i) < OPB && p < B16);
+    okB[i] = (wave + NW * i) < OPB && p < B16;
     offB[i] = (unsigned)row * (unsigned)g.ldb + (unsigned)col;
   }
   const float* const Abase = g.A + (size_t)blockIdx.y * g.batchA + m0;
@@ -73,10 +65,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
     float* dB = dA + GK * BM;
 #pragma unroll
     for (int i = 0; i < PA; ++i)
-      if (EXACT || okA[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(a + offA[i]), JRR_LDS(dA + (wave + NW * i) * 256), 16, 0, 0);
+      if (okA[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(a + offA[i]), JRR_LDS(dA + (wave + NW * i) * 256), 16, 0, 0);
 #pragma unroll
     for (int i = 0; i < PB; ++i)
-      if (EXACT || okB[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave + NW * i) * 256), 16, 0, 0);
+      if (okB[i]) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave + NW * i) * 256), 16, 0, 0);
   };
 
   f32x16 acc[WM][WN];
@@ -86,83 +78,34 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
     for (int j = 0; j < WN; ++j) acc[i][j] = zero16();
 
   if (c_begin < c_end) issue(c_begin, 0);
-  if (NSLOT > 2 && c_begin + 1 < c_end) issue(c_begin + 1, 1);
-  // (computed while the first chunks are in flight)
-  // BTR: per-lane column scales (one per 32-column tile of this wave)
-  float cscale[WN];
-#pragma unroll
-  for (int j = 0; j < WN; ++j) cscale[j] = 0.f;
-  if (BTR == 1) {
-#pragma unroll
-    for (int j = 0; j < WN; ++j) cscale[j] = g.colscale[n0 + (wn * WN + j) * 32 + l31];
-  }
-  if (BTR == 2) {
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const int n = n0 + (wn * WN + j) * 32 + l31;
-      float z = g.zbias[0];
-      for (int t = 0; t < g.nzpart; ++t) z += g.zpart[(size_t)t * g.ldb + n];
-      const float sg = 1.f / (1.f + expf(-z));
-      const bool ok = n < g.nvalid;
-      const float up = g.gout ? (ok ? g.gout[(size_t)n * g.gout_ld] : 0.f) : g.scale * (sg - g.target);
-      cscale[j] = ok ? up * sg * (1.f - sg) : 0.f;
-      if (mt == 0 && wm == 0 && half == 0 && ok) {
-        if (g.sq0) g.sq0[n] = (sg - g.target) * (sg - g.target);
-        if (g.out0) g.out0[(size_t)n * g.out0_ld] = sg;
-      }
-    }
-  }
-
-  int slot = 0;     // ring slot of chunk ch
   for (int ch = c_begin; ch < c_end; ++ch) {
-    if (NSLOT == 2) {
-      __syncthreads();   // chunk ch landed (vmcnt(0) + barrier); the other slot is free
-      if (ch + 1 < c_end) issue(ch + 1, slot ^ 1);
-    } else {
-      // this wave's copies of chunk ch have landed once at most the next chunk's PA + PB are outstanding; after the
-      // barrier everybody's have, and everybody has finished reading chunk ch - 1, whose slot is refilled
-      if (ch + 1 < c_end) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __builtin_amdgcn_s_barrier();
-      if (ch + 2 < c_end) issue(ch + 2, slot >= 1 ? slot - 1 : NSLOT - 1);   // (slot + 2) % 3
-    }
-    const float* ap = lds + slot * SLOT + half * BM + wm * WM * 32 + l31;
-    const float* bp = lds + slot * SLOT + GK * BM + half * BN + wn * WN * 32 + l31;
-    slot = (slot + 1 == NSLOT) ? 0 : slot + 1;
-    // The operands of K-pair kk + PD are requested right after the first MFMA of pair kk has issued, so the reads
-    // complete under PD pairs' worth of MFMAs (the compiler's own schedule reads right before use and exposes the LDS
-    // latency once per pair).  PD = 1 covers tiles with >= 4 MFMAs per pair; the 2-MFMA pairs of the 64x32 wave tile
-    // (128 clocks) need PD = 2.
-    float a[PD][WM], b[PD][WN];
+    __syncthreads();   // chunk ch landed (vmcnt(0) + barrier); the other slot is free
+    if (ch + 1 < c_end) issue(ch + 1, (ch - c_begin + 1) & 1);
+    const float* ap = lds + ((ch - c_begin) & 1) * SLOT + half * BM + wm * WM * 32 + l31;
+    const float* bp = lds + ((ch - c_begin) & 1) * SLOT + GK * BM + half * BN + wn * WN * 32 + l31;
+    // The operands of K-pair kk+1 are requested right after the first MFMA of pair kk has issued, so the reads
+    // complete under this pair's MFMAs (the compiler's own schedule reads right before use and exposes the LDS
+    // latency once per pair).
+    float a[WM], b[WN];
 #pragma unroll
-    for (int d = 0; d < PD; ++d) {
+    for (int i = 0; i < WM; ++i) a[i] = ap[i * 32];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) a[d][i] = ap[(2 * d) * BM + i * 32];
-#pragma unroll
-      for (int j = 0; j < WN; ++j) b[d][j] = bp[(2 * d) * BN + j * 32];
-    }
+    for (int j = 0; j < WN; ++j) b[j] = bp[j * 32];
 #pragma unroll
     for (int kk = 0; kk < GK / 2; ++kk) {
       float ca[WM], cb[WN];
 #pragma unroll
-      for (int i = 0; i < WM; ++i) ca[i] = a[0][i];
+      for (int i = 0; i < WM; ++i) ca[i] = a[i];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) cb[j] = BTR ? ((b[0][j] > 0.f) ? cscale[j] : 0.f) : b[0][j];
-#pragma unroll
-      for (int d = 0; d + 1 < PD; ++d) {
-#pragma unroll
-        for (int i = 0; i < WM; ++i) a[d][i] = a[d + 1][i];
-#pragma unroll
-        for (int j = 0; j < WN; ++j) b[d][j] = b[d + 1][j];
-      }
+      for (int j = 0; j < WN; ++j) cb[j] = b[j];
       __builtin_amdgcn_sched_barrier(0);
       acc[0][0] = mfma(ca[0], cb[0], acc[0][0]);
       __builtin_amdgcn_sched_barrier(0);
-      if (kk + PD < GK / 2) {
+      if (kk + 1 < GK / 2) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) a[PD - 1][i] = ap[(2 * (kk + PD)) * BM + i * 32];
+        for (int i = 0; i < WM; ++i) a[i] = ap[(2 * kk + 2) * BM + i * 32];
 #pragma unroll
-        for (int j = 0; j < WN; ++j) b[PD - 1][j] = bp[(2 * (kk + PD)) * BN + j * 32];
+        for (int j = 0; j < WN; ++j) b[j] = bp[(2 * kk + 2) * BN + j * 32];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -177,9 +120,6 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
   // is one 32-bit offset -- one store per element instead of five VALU instructions of address arithmetic
   float* out = g.Out + (size_t)split * g.split_stride + (size_t)blockIdx.y * g.batchO;
   const unsigned lane_off = (unsigned)(4 * half) * (unsigned)g.ldo + (unsigned)(n0 + l31);
-  float dot[WN];
-#pragma unroll
-  for (int j = 0; j < WN; ++j) dot[j] = 0.f;
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -188,8 +128,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
       const int m = mu + 4 * half;
       if (m >= g.M) continue;
       float bias = 0.f;
-      if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS || EPI == EPI_BIAS_RELU_DOT) bias = g.bias[m];
-      const float dw = (EPI == EPI_BIAS_RELU_DOT) ? g.dotw[m] : 0.f;
+      if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS) bias = g.bias[m];
       float* orow = out + (size_t)mu * g.ldo;
       asm volatile("" : "+s"(orow));
       const float* mrow = (EPI == EPI_MASK) ? g.mask + (size_t)mu * g.ldo : nullptr;
@@ -198,25 +137,15 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_gemm_tn(GemmArgs g) 
       for (int j = 0; j < WN; ++j) {
         const unsigned off = lane_off + (unsigned)((wn * WN + j) * 32);
         float v = acc[i][j][q];
-        if (EPI == EPI_BIAS_RELU || EPI == EPI_BIAS_RELU_DOT) v = fmaxf(v + bias, 0.f);
-        if (EPI == EPI_BIAS_RELU_DOT) dot[j] = fmaf(dw, v, dot[j]);
+        if (EPI == EPI_BIAS_RELU) v = fmaxf(v + bias, 0.f);
         if (EPI == EPI_BIAS) v = v + bias;
         if (EPI == EPI_MASK) v = (mrow[off] > 0.f) ? v : 0.f;
         if (EPI == EPI_ACCUM) v += orow[off];
         orow[off] = v;
       }
     }
-  if (EPI == EPI_BIAS_RELU_DOT) {      // rows of the two lane halves are disjoint: add them, one store per column
-#pragma unroll
-    for (int j = 0; j < WN; ++j) {
-      const float t = dot[j] + __shfl_xor(dot[j], 32);
-      if (half == 0) g.dot_out[(size_t)(mt * WAVES_M + wm) * g.ldo + n0 + (wn * WN + j) * 32 + l31] = t;
-    }
-  }
 }
 
-// the pose discriminator's layers: exact 128x64 tiling, 3-deep ring; epi in {BIAS_RELU, BIAS_RELU_DOT, STORE, MASK},
-// btr = B-operand transform (see k_gemm_tn)
 template <int WM, int WN, int WAVES_M, int WAVES_N, int GK>
 static int launch_cfg(const GemmArgs& g, int epi, int nsplit, hipStream_t s, int nbatch = 1) {
   constexpr int BM = 32 * WM * WAVES_M, BN = 32 * WN * WAVES_N;
@@ -236,18 +165,18 @@ static int launch_cfg(const GemmArgs& g, int epi, int nsplit, hipStream_t s, int
   return 0;
 }
 
-// 128x128 block tile (2x2 waves of 64x64), 32-deep chunks: discriminator layers
+// 128x128 block tile (2x2 waves of 64x64), 32-deep chunks: outer-step weight gradients
 int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 2, 2, 2, 32>(g, epi, nsplit, s); }
-// 128x64 block tile (2x2 waves of 64x32): twice the workgroups of the 128x128 tile (2 per CU at N = 4096)
+// 128x64 block tile (2x2 waves of 64x32): row-major discriminator layers of the outer step, folded-regressor product
 int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 2, 2, 32>(g, epi, nsplit, s); }
-// 128x128 block tile, 8 waves (2x4 of 64x32): 2 waves per SIMD with one workgroup per CU
-int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 2, 4, 32>(g, epi, nsplit, s); }
 // 128x32 block tile (4 waves stacked in M): narrow-N products (folded-regressor table, N = 224 per plane)
 int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<1, 1, 4, 1, 16>(g, epi, nsplit, s); }
-// 224x128 block tile (4 waves of 224x32), 16-deep chunks: blend-basis adjoint, M = KFP = 224
+// 224x128 block tile (4 waves of 224x32), 16-deep chunks: folded-regressor adjoint, M = KFP = 224
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<7, 1, 1, 4, 16>(g, epi, nsplit, s); }
-// 64x128 block tile (4 waves of 64x32): the J-regressor gradient product, M = 51 padded to 64
-int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<2, 1, 1, 4, 16>(g, epi, nsplit, s); }
+// 32x128 block tile (4 waves of 32x32 side by side), batched over gridDim.y: joints = Jn . verts from stored vertices
+int launch_gemm_32x128(const GemmArgs& g, int epi, int nsplit, int nbatch, hipStream_t s) {
+  return launch_cfg<1, 1, 1, 4, 16>(g, epi, nsplit, s, nbatch);
+}
 
 // ------------------------------------------------------------------------------------------------------------------
 // "NT" product for operands whose REDUCTION index is the contiguous one (the pose index of the [feature][pose] arrays):
@@ -597,11 +526,6 @@ __global__ void k_to_quads(const float* __restrict__ in, int ld, float* __restri
 int launch_to_quads(const float* in, int ld, float* out, int K, int M, hipStream_t s) {
   hipLaunchKernelGGL(k_to_quads, dim3((unsigned)(((size_t)K * M + 255) / 256)), dim3(256), 0, s, in, ld, out, K, M);
   return 0;
-}
-
-// 32x128 block tile (4 waves of 32x32 side by side), batched over gridDim.y: joints = Jn . verts from stored vertices
-int launch_gemm_32x128(const GemmArgs& g, int epi, int nsplit, int nbatch, hipStream_t s) {
-  return launch_cfg<1, 1, 1, 4, 16>(g, epi, nsplit, s, nbatch);
 }
 
 }  // namespace jrr

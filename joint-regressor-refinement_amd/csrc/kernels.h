@@ -9,7 +9,7 @@ constexpr int DP_CONV0_W = 0, DP_CONV0_B = 192, DP_CONV2_W = 224, DP_CONV2_B = 1
 constexpr int DP_FC0_W = 2072, DP_FC0_B = 788504, DP_FC2_W = 789528, DP_FC2_B = 1838104;
 constexpr int DP_FC4_W = 1839128, DP_FC4_B = 1840152, DP_TOTAL = 1840153;
 
-enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_BIAS = 3, EPI_ACCUM = 4, EPI_BIAS_RELU_DOT = 5 };
+enum { EPI_STORE = 0, EPI_BIAS_RELU = 1, EPI_MASK = 2, EPI_BIAS = 3, EPI_ACCUM = 4, EPI_BIAS_RELU_DOT = 5 };   // 5: k_disc_gemm only
 
 struct GemmArgs {
   const float* A; int lda;      // A[k][m]
@@ -20,8 +20,8 @@ struct GemmArgs {
   int M, N, K;
   size_t split_stride;          // floats between split-K partial slabs
   size_t batchA = 0, batchB = 0, batchO = 0;   // floats between the operands / outputs of gridDim.y batched products
-  const float* colscale = nullptr;   // [n]   (BTR = 1: B operand -> (x > 0) ? colscale[n] : 0)
-  // BTR = 2: colscale[n] is the pose discriminator's output-layer adjoint dz[n], computed in the prologue from the
+  // k_disc_gemm, BTR = 2: the B operand x becomes (x > 0) ? dz[n] : 0 on its way to the MFMA, where dz[n] is the pose
+  // discriminator's output-layer adjoint of column n, computed in the prologue from the
   // partial dots of the fc2 launch: z = zbias[0] + sum_t zpart[t][n]; s = sigmoid(z);
   // dz = (gout ? gout[n * gout_ld] : scale * (s - target)) * s * (1 - s), 0 for n >= nvalid.  Workgroups of the first
   // m-tile also write sq0[n] = (s - target)^2 and out0[n * out0_ld] = s when those pointers are set.
@@ -89,10 +89,8 @@ int launch_disc_gemm_q(const GemmArgs& g, int epi, int btr, hipStream_t s, int* 
 int launch_to_quads(const float* in, int ld, float* out, int K, int M, hipStream_t s);
 int launch_gemm_128(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
-int launch_gemm_128w8(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
-int launch_gemm_64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 // blend-basis adjoint dF^T[split][224][BP] = sum_{c, v in split} D_c[v][.] dvp_c[v][.], both operands in vertex quads
 int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s);
 int launch_gemm_nt32(const float* A, size_t planeA, int ldA, int rowsA, const float* Bm, size_t planeB, int ldB, float* Out,

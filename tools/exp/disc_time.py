@@ -1,5 +1,5 @@
 """Time the pose-discriminator branch alone (forward + input gradient, 6 launches) at batch 4096.
-usage: [JRR_DISC_TILE=n] python tools/exp/disc_time.py [B]"""
+usage: python tools/exp/disc_time.py [B]"""
 import importlib, os, sys, time
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
@@ -20,4 +20,4 @@ t0 = time.perf_counter()
 for _ in range(n):
     eng.pose_disc_forward(x); eng.pose_disc_backward_input(x, 10.0, 1.0)
 torch.cuda.synchronize()
-print(f'tile={os.environ.get("JRR_DISC_TILE", "0")} B={B}: {(time.perf_counter() - t0) / n * 1e3:.4f} ms per forward + input-gradient (incl. the operator-level finish kernel)')
+print(f'B={B}: {(time.perf_counter() - t0) / n * 1e3:.4f} ms per forward + input-gradient (incl. the operator-level finish kernel)')
