@@ -246,8 +246,9 @@ def _lbs_np(model, R, betas, cols=None):
     skinned vertices (the rest joints always use every vertex)."""
     B = R.shape[0]
     vt = model['v_template'].astype(np.float64)
-    v_shaped = vt[None] + np.einsum('bl,vkl->bvk', betas, model['shapedirs'].astype(np.float64))
-    J = np.einsum('jv,bvk->bjk', model['J_regressor'].astype(np.float64), v_shaped)
+    sdirs = model['shapedirs'].astype(np.float64)
+    v_shaped = vt[None] + (betas @ sdirs.reshape(-1, sdirs.shape[-1]).T).reshape(B, -1, 3)
+    J = np.matmul(model['J_regressor'].astype(np.float64)[None], v_shaped)
     pf = (R[:, 1:] - np.eye(3)).reshape(B, -1)
     pd = model['posedirs'].astype(np.float64)
     W = model['lbs_weights'].astype(np.float64)
