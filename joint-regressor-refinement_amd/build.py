@@ -19,10 +19,7 @@ OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libjrr_hip.so')
 SOURCES = ['api.hip', 'prep.hip', 'lbs.hip', 'gemm.hip', 'disc.hip', 'eval.hip', 'fold.hip', 'sil.hip']
 HEADERS = ['jrr_common.h', 'kernels.h', os.path.join('..', '..', 'include', 'jrr.h')]
-# -Wno-pass-failed: k_lbs_fwd's K-pair loop has a trip count that only becomes constant once the enclosing stage
-# loop is unrolled; the first unroll pass reports a failure, the later one unrolls it (519 MFMAs in one loop body
-# in the ISA -- check with `--report` / tools/asm_trace.py after touching that loop).
-FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function', '-Wno-pass-failed']
+FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 
 
 def _hipcc() -> str:

@@ -2,6 +2,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+
+#include <type_traits>
 #include "../../include/jrr.h"
 
 namespace jrr {
@@ -88,6 +90,17 @@ __device__ __forceinline__ const f32x4* quad_ptr(const float* base, size_t plane
 }
 // uniform part of acc_row(q, half) = (q & 3) + 8 (q >> 2) + 4 half
 __device__ __forceinline__ constexpr int acc_row_u(int q) { return (q & 3) + 8 * (q >> 2); }
+
+// Compile-time loop: f(std::integral_constant<int, I>) for I = 0 .. N-1.  The stage loop of k_lbs_fwd needs its index as
+// a CONSTANT in every stage (trip counts, register indices, which stores a barrier may leave in flight); relying on the
+// unroller for that worked for three of the four template variants and silently left the fourth one rolled.
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  if constexpr (I < N) {
+    f(std::integral_constant<int, I>{});
+    static_for<I + 1, N>(f);
+  }
+}
 
 // Workgroup barrier that waits for this wave's LDS operations and for all but its N youngest vector-memory operations.
 // `__syncthreads()` drains vmcnt to 0, i.e. it also waits for every global STORE the wave has issued (write latency

@@ -145,28 +145,25 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   for (int vt = t_begin; vt < t_end; ++vt) {
     const float* ldsW = wj + (vt & 1) * WJ_FLOATS;
     const float* ldsJ = ldsW + W_FLOATS;
-#pragma unroll
-    for (int s = 0; s < NSTAGE; ++s, ++g) {
+    static_for<0, NSTAGE>([&](auto S_) {
+      constexpr int s = decltype(S_)::value;
       // Stage g landed; slot (g+1)&1 is free again.  The copies of stage g were issued at the start of the previous
       // stage, BEFORE that stage's v_posed / vertex stores: exactly those stores are left in flight (they get one more
       // stage to retire instead of stalling this barrier; barrier_keep_vm).  First stage of the kernel: nothing younger.
       {
-        const int sp = (s == 0) ? NSTAGE - 1 : s - 1;                     // previous stage
-        const int hp = sp - NKCH;                                          // its skinning half-stage, if any
-        const int nst = (hp < 0) ? 0 : (STORE_VP ? 2 : 0) + ((STORE_VERTS && (hp & 1)) ? 16 : 0);
-        // (`s` is a constant after unrolling: one of these survives per stage)
-        if ((s == 0 && vt == t_begin) || nst == 0) barrier_keep_vm<0>();
-        else if (nst == 2) barrier_keep_vm<2>();
-        else if (nst == 16) barrier_keep_vm<16>();
-        else barrier_keep_vm<18>();
+        constexpr int sp = (s == 0) ? NSTAGE - 1 : s - 1;                 // previous stage
+        constexpr int hp = sp - NKCH;                                      // its skinning half-stage, if any
+        constexpr int nst = (hp < 0) ? 0 : (STORE_VP ? 2 : 0) + ((STORE_VERTS && (hp & 1)) ? 16 : 0);
+        if (s == 0 && vt == t_begin) barrier_keep_vm<0>();
+        else barrier_keep_vm<nst>();
       }
       if (s + 1 < NSTAGE) issue(vt, s + 1, (g + 1) & 1);
       else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);   // the counted wait above relies on: copies first, this stage's stores after
       const float* buf = ring + (g & 1) * STG_FLOATS;
-      if (s < NKCH) {
+      if constexpr (s < NKCH) {
         if (s == 0) { vp[0] = zero16(); vp[1] = zero16(); vp[2] = zero16(); }
-        const int npairs = (s == NKCH - 1) ? (KF - (NKCH - 1) * KCH) / 2 : KCH / 2;   // 13 : 16
+        constexpr int npairs = (s == NKCH - 1) ? (KF - (NKCH - 1) * KCH) / 2 : KCH / 2;   // 13 : 16
         const float* dp = buf + half * 96 + l31;
         const float* fp = buf + KCH * 96 + half * BG + wave * BT + l31;
         // The operands of K-pair kk+2 are requested right after the FIRST MFMA of pair kk has issued: the reads
@@ -177,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         float f1 = fp[2 * BG], d10 = dp[2 * 96], d11 = dp[2 * 96 + 32], d12 = dp[2 * 96 + 64];
 #pragma unroll
         for (int kk = 0; kk < KCH / 2; ++kk) {
-          if (kk >= npairs) break;          // constant trip count for the unroller; folds once `s` is unrolled
+          if (kk >= npairs) break;
           const float fc = f0, c0 = d00, c1 = d01, c2 = d02;
           f0 = f1; d00 = d10; d01 = d11; d02 = d12;
           __builtin_amdgcn_sched_barrier(0);
@@ -192,9 +189,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
           vp[2] = mfma(c2, fc, vp[2]);
         }
       } else {
-        const int h = s - NKCH, r = h >> 1;
+        constexpr int h = s - NKCH, r = h >> 1;
         if (STORE_VP) {   // spread the v_posed stores over the six skinning stages: two 16-byte row quads each
-          const int c = h >> 1, g0 = (h & 1) * 2;
+          constexpr int c = h >> 1, g0 = (h & 1) * 2;
 #pragma unroll
           for (int g = g0; g < g0 + 2; ++g) {
             const f32x4 t = {vp[c][4 * g], vp[c][4 * g + 1], vp[c][4 * g + 2], vp[c][4 * g + 3]};
@@ -249,7 +246,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
           }
         }
       }
-    }
+      ++g;
+    });
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r)
