@@ -96,6 +96,10 @@ class SMPL:
             self._engines[key] = eng
         return self._engines[key]
 
+    def release_engines(self):
+        """drop the cached per-batch-size engines (each owns a workspace of ~0.4 MB per pose with vertex buffers)"""
+        self._engines = {}
+
     def __call__(self, global_orient=None, body_pose=None, betas=None, pose2rot=True, **_):
         """smplx.SMPL.forward's signature and default: pose2rot=True takes axis-angle global_orient (B,3) and
         body_pose (B,69) and converts them with batch_rodrigues (HIP kernel); the reference's hot path passes

@@ -361,3 +361,41 @@ def test_silhouette_gradients_where_both_rasterisers_agree(smpl_hip, smpl_model_
     rel_c = ((dc.cpu().double() - cr.grad.double()).norm() / cr.grad.double().norm()).item()
     assert rel_v < 2e-3, rel_v
     assert rel_c < 2e-3, rel_c
+
+
+def test_refine_run_all_terms_mid_size(smpl_hip, smpl_model_np, j_h36m_np):
+    """joint loss + pose-D + shape-D + 2-D reprojection term together (every term of scripts/optimize.py:252-253 except the
+    silhouette) at a ragged batch of 150, 4 iterations, against the oracle -- poses, betas AND the camera."""
+    eng_mod = _mod('engine')
+    B, n = 150, 4
+    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, j_h36m_np, B, seed=81)
+    x6, betas, cam0 = T(batch['pose6d']), T(batch['betas']), T(batch['cam'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(B, 24, 3, 3)
+    j0 = oracle.find_joints(smpl, betas, R[:, :1], R[:, 1:], T(j_h36m_np))
+    gen = torch.Generator().manual_seed(5)
+    gt_j2d = oracle.project_joints(j0, cam0 + torch.tensor([0.2, -0.1, 2.0]))[..., :2] + torch.randn(B, 17, 2, generator=gen) * 2.0
+    dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+    ssd = oracle.formula_state_dict(oracle.SHAPE_DISC_PARAM_SHAPES, seed=1)
+    o, p, b, hist, c = oracle.refine_poses(smpl, T(j_h36m_np), x6[:, :1], x6[:, 1:], betas, gt_c, n, disc_sd=dsd, shape_disc_sd=ssd,
+                                           gt_j2d=gt_j2d, cam=cam0)
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_POSE_DISC | eng_mod.FLAG_SHAPE_DISC)
+    eng.set_j_regressor(T(j_h36m_np))
+    eng.set_pose_disc(eng_mod.flatten_state_dict(dsd, eng_mod.DISC_KEYS))
+    eng.set_shape_disc(eng_mod.flatten_state_dict(ssd, eng_mod.SHAPE_DISC_KEYS))
+    xd, bd, cd = x6.clone().to(DEV), betas.clone().to(DEV), cam0.clone().to(DEV)
+    cm, cv = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV)
+    eng.set_reprojection(gt_j2d.to(DEV).contiguous(), cd, cm, cv)
+    m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+    step = torch.zeros(1, dtype=torch.int32, device=DEV)
+    sq = torch.zeros(B, device=DEV)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, n, sqerr=sq)
+    eng.set_reprojection(None)
+    assert (xd.cpu() - torch.cat([o, p], 1)).abs().max().item() < 6e-4 and (xd.cpu() - torch.cat([o, p], 1)).abs().mean().item() < 5e-6
+    assert (bd.cpu() - b).abs().max().item() < 3e-4
+    assert (cd.cpu() - c).abs().max().item() < 3e-4
+    np.testing.assert_allclose(float(sq.sum()) / (B * 51), hist[-1]['joint_loss'], rtol=2e-3)
+    pd, sd = eng.refine_aux_losses(True, True)
+    np.testing.assert_allclose(float(pd.sum()) / (B * 25), hist[-1]['pose_discriminated_loss'], rtol=1e-4)
+    np.testing.assert_allclose(float(sd.sum()) / B, hist[-1]['shape_discriminated_loss'], rtol=1e-4)
