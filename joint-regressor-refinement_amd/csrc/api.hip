@@ -500,7 +500,6 @@ extern "C" int jrr_rodrigues_backward(const float* aa, const float* dR, float* d
   return JRR_OK;
 }
 
-// sum the per-vertex-chunk joint partials (wide, memory-bound) so the per-pose kernel reads 51 values
 // The per-vertex-chunk joint partials JP [nvc][3][17][BP] and skinning-adjoint partials dATp [nvcb][12][24][BP] are summed
 // by their consumers (k_joints_loss, k_chain_bwd: a few pose-contiguous loads per thread); only the 16 split-K slabs of
 // dF^T (58 MB at 4096 poses) keep a wide reduction kernel of their own.
