@@ -133,7 +133,8 @@ struct jrr_engine {
   int nvc, nvcb, nsplit, nsplitJ;
   bool have_J, have_mask, have_pd, have_sd, has_model;
   // workspace sections
-  float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv;
+  float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv, *Jn_q;
+  bool tab_static;                                   // the W parts of the backward operand records are in place
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
   float *W2s, *zpart;                                // fc2.w rows scaled by fc4.w; partial fc4 dots [16][BP]
   float *W0Tq, *W2Tq, *W2sq, *W0q;                   // the four GEMM weight operands in quads [k/4][m][4]
@@ -182,8 +183,8 @@ static void plan_geometry(int BP, int& nvc, int& nvcb, int& nsplit, int& nsplitJ
   nsplit = (512 + nbg - 1) / nbg;
   if (nsplit > 32) nsplit = 32;
   if (nsplit < 1) nsplit = 1;
-  nsplitJ = 4;                                      // pose splits per coordinate plane of the J-gradient product
-  if (BP / 32 < nsplitJ) nsplitJ = BP / 32;
+  nsplitJ = 3;                                      // pose splits per plane of the J-gradient product: 162 x 3 workgroups
+  if (BP / 32 < nsplitJ) nsplitJ = BP / 32;         // = 0.95 of one round of the chip's 512 workgroup slots
 }
 
 struct Carver {
@@ -209,6 +210,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   t->Jn = c.take((size_t)NH * V);
   t->Jn_vi = c.take((size_t)VT * 1024);
   t->Jn_iv = c.take((size_t)VT * 2560);   // backward per-tile operand records [Jn | W^T | W | pad]
+  t->Jn_q = c.take((size_t)VP * 32);      // normalised regressor in vertex quads [VP/4][32][4]
   t->FT = c.take((size_t)KFP * BP);
   t->AT = c.take((size_t)12 * NJ * BP);
   t->VPb = c.take((size_t)3 * VP * BP);
@@ -429,8 +431,8 @@ extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const
   JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   e->have_mask = mask != nullptr;
-  launch_bwd_tab_static(e->m, e->Jn_iv, s);
-  launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, s);
+  if (!e->tab_static) { launch_bwd_tab_static(e->m, e->Jn_iv, s); e->tab_static = true; }   // model-only: once per engine
+  launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, e->Jn_q, s);
   e->fold_valid = false;
   if (e->folded) {
     int rc = fold_rebuild(e, s);
@@ -890,14 +892,11 @@ extern "C" int jrr_engine_set_forward_reuse(jrr_engine_t* e, int enabled) {
 }
 
 // joints^T partials from the STORED vertices: JPv[split][r][32][BP] = sum_{v in split} Jn[i,v] verts_r[v,b]
-// (one batched split-K product over the three coordinate planes; Jn_vi is [VP][32] = K-major, zero rows i >= 17)
+// (both operands in vertex quads: Jn_q [VP/4][32][4], VTb [3][VP/4][BP][4]; rows i >= 17 of Jn_q are zero)
 static int joints_from_stored_verts(jrr_engine* e, hipStream_t s) {
-  GemmArgs g;
-  g.A = e->Jn_vi; g.lda = 32; g.Bm = e->VTb; g.ldb = e->BP; g.Out = e->dFTp; g.ldo = e->BP;
-  g.bias = nullptr; g.mask = nullptr; g.M = 32; g.N = e->BP; g.K = VP;
-  g.batchA = 0; g.batchB = (size_t)VP * e->BP; g.batchO = (size_t)32 * e->BP;
-  g.split_stride = (size_t)3 * 32 * e->BP;
-  return launch_gemm_32x128(g, EPI_STORE, e->nsplit, 3, s);
+  // slab layout [split][plane][32][BP], what k_joints_loss reads with jp_rows = 32
+  return launch_gemm_q32(e->Jn_q, 32, 0, e->VTb, e->BP, (size_t)VP * e->BP, e->dFTp, e->BP, (size_t)3 * 32 * e->BP,
+                         (size_t)32 * e->BP, e->BP, VP, 3, e->nsplit, s);
 }
 
 // =============================================================================================
@@ -1020,8 +1019,7 @@ __global__ void k_djn_reduce(const float* __restrict__ P, int nslab, float* __re
 // dJ from the joint adjoint dJT [3][18][BP] (already in the engine) and the stored vertices VTb [3][VP][BP]
 static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s) {
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("dJ requires an engine created with JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
-  int rc = launch_gemm_nt32(e->dJT, (size_t)NHP * e->BP, e->BP, NHP, e->VTb, (size_t)VP * e->BP, e->BP, e->dJnp, VP,
-                            (size_t)32 * VP, VP, e->BP, 3, e->nsplitJ, s);
+  int rc = launch_jgrad_q(e->dJT, e->VTb, e->dJnp, e->BP, e->nsplitJ, s);
   if (rc) return rc;
   hipLaunchKernelGGL(k_djn_reduce, dim3((NH * VP + 255) / 256), dim3(256), 0, s, e->dJnp, 3 * e->nsplitJ, e->dJn);
   launch_jreg_bwd(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->Jn, e->rowsum, e->dJn, VP, dJ, s);

@@ -173,91 +173,211 @@ int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { 
 int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<1, 1, 4, 1, 16>(g, epi, nsplit, s); }
 // 224x128 block tile (4 waves of 224x32), 16-deep chunks: folded-regressor adjoint, M = KFP = 224
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s) { return launch_cfg<7, 1, 1, 4, 16>(g, epi, nsplit, s); }
-// 32x128 block tile (4 waves of 32x32 side by side), batched over gridDim.y: joints = Jn . verts from stored vertices
-int launch_gemm_32x128(const GemmArgs& g, int epi, int nsplit, int nbatch, hipStream_t s) {
-  return launch_cfg<1, 1, 1, 4, 16>(g, epi, nsplit, s, nbatch);
-}
 
 // ------------------------------------------------------------------------------------------------------------------
-// "NT" product for operands whose REDUCTION index is the contiguous one (the pose index of the [feature][pose] arrays):
-//     Out[split][m][n] = sum_{k in split} A_c[m][k] * B_c[n][k]        m < 32, c = coordinate plane of the split
-// J-regressor gradient dJn[i][v] = sum_{c,b} dj[c][i][b] verts_c[v][b]  (scripts/optimize.py:300-312) straight from the
-// coordinate-major vertex tiles k_lbs_fwd writes -- no pose-major copy of the 340 MB vertex buffer.
-// The MFMA wants the reduction index on the K axis with one value per lane, the data has it contiguous.  Two facts make
-// that cheap: (1) a K-pair may take ANY two k as long as both operands agree, so step t of an 8-group takes
-// k = 8g + 4*half + t and a lane's four steps are ONE 16-byte piece; (2) an LDS-DMA instruction copies 64 arbitrary
-// 16-byte pieces into 1 KB of LDS, so the gather [row][4 k] -> [k-quad][row] is done by the copy itself, and the
-// ds_read_b128 operand reads are contiguous per half-wave (conflict-free).
-// Tile: 32 (m) x 128 (n), four waves side by side, 32-deep chunks, 2-deep ring.
+// Products against the STORED vertices (row quads [3][VP/4][BP][4], written by k_lbs_fwd) -- the 340 MB buffer is read
+// once per product, in 1 KB runs, never transposed:
+//
+// k_gemm_q32   joints^T[i][b] = sum_v Jn[i][v] verts_c[v][b]          (reduction over the vertex = the QUAD index)
+//     Both operands are K-quads [k/4][row][4]: a lane's ds_read_b128 is four K-steps (a K-pair may take any two k as
+//     long as both operands agree: step t of an 8-group takes k = 8g + 4*half + t).  Tile 32 (m) x 128 (n), four waves
+//     side by side, 16-deep chunks, 4-deep LDS-DMA ring with counted vmcnt, split over k.
+//
+// k_jgrad_q    dJn[i][v] = sum_{c,b} dj[c][i][b] verts_c[v][b]        (scripts/optimize.py:300-312; reduction over the
+//     POSE index, the vertex quads are the OUTPUT columns).  A 16-byte piece of the vertex buffer is four vertices of one
+//     pose = four output columns of one K row: the lane with column index l reads the piece of vertex quad l and feeds
+//     element u to accumulator u, whose column l therefore is vertex 4 l + u -- four accumulators are a 32 x 128 tile
+//     with permuted columns, and the epilogue's 16-byte store puts them back in order.  The joint adjoint dj^T [18][BP]
+//     (pose-contiguous rows) is the A operand: the LDS-DMA gathers [row][4 poses] pieces into K-quads.  A workgroup
+//     owns 128 vertices of one plane and a range of poses; its four waves split every 32-pose chunk (8 poses each) and
+//     add their tiles through LDS at the end.  The LDS-DMA stores every vertex-quad row rotated by its own index, so the
+//     32 lanes of a half-wave (32 different rows, same pose) read conflict-free without padding; 4-deep ring of 20 KB
+//     slots (three chunks in flight: throughput of this stream = bytes in flight / ~5.7 us), counted vmcnt, two workgroups per CU = one round of 162 x 3 workgroups.
 // ------------------------------------------------------------------------------------------------------------------
-struct NtArgs {
-  const float* A; size_t planeA; int ldA; int rowsA;   // A_c = A + c*planeA; rows m >= rowsA read row rowsA - 1 (a zero row)
-  const float* Bm; size_t planeB; int ldB;             // B_c = Bm + c*planeB; row n at n*ldB
-  float* Out; int ldo; size_t split_stride;            // Out[split][32][ldo]
-  int K, ksplit;                                        // reduction length per plane, splits per plane
+struct Q32Args {
+  const float* A; int ldA; size_t planeA;     // A quads [K/4][ldA][4], rows 0..31 used; plane c at A + c*planeA
+  const float* Bm; int ldB; size_t planeB;    // B quads [K/4][ldB][4]
+  float* Out; int ldo; size_t ks_stride, plane_stride;   // tile (k-split ks, plane c) at Out + ks*ks_stride + c*plane_stride
+  int K, ksplit;
 };
-__global__ __launch_bounds__(256) void k_gemm_nt32(NtArgs g) {
-  constexpr int SA = 8 * 32 * 4, SB = 8 * 128 * 4, SLOT = SA + SB;     // floats: [k-quad 8][row][4]
-  __shared__ __attribute__((aligned(16))) float lds[2 * SLOT];
+__global__ __launch_bounds__(256) void k_gemm_q32(Q32Args g) {
+  // 16-deep chunks (4 k-quads): A 2 KB + B 8 KB per slot, 4-deep ring (three chunks in flight: the product is a
+  // stream over the 340 MB vertex buffer, 32 MFMA-rows of work per 128-byte column -- bytes in flight are what counts)
+  constexpr int SA = 4 * 32 * 4, SB = 4 * 128 * 4, SLOT = SA + SB, RING = 4;
+  __shared__ __attribute__((aligned(16))) float lds[RING * SLOT];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int n0 = blockIdx.x * 128;
   const int split = blockIdx.y, c = split / g.ksplit, ks = split % g.ksplit;
-  const int nch = g.K / 32;
+  const int nch = g.K / 16;
   const int c_begin = (int)((long)nch * ks / g.ksplit), c_end = (int)((long)nch * (ks + 1) / g.ksplit);
   const float* Ac = g.A + (size_t)c * g.planeA;
   const float* Bc = g.Bm + (size_t)c * g.planeB;
-  // this wave's copies per chunk: 4 of B (pieces p = (wave*4 + i)*64 + lane: k-quad p / 128, row p % 128), 1 of A
-  unsigned offB[4], offA;
+  // this wave's copies per chunk: 2 of B (pieces p = (wave*2 + i)*64 + lane: k-quad p / 128, row p % 128) and -- waves
+  // 0 and 1 -- 1 of A (pieces p = wave*64 + lane: k-quad p / 32, row p % 32)
+  unsigned offB[2], offA;
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const int p = (wave * 4 + i) * 64 + lane;
-    offB[i] = (unsigned)(n0 + (p & 127)) * (unsigned)g.ldB + 4u * (unsigned)(p >> 7);
+  for (int i = 0; i < 2; ++i) {
+    const int p = (wave * 2 + i) * 64 + lane;
+    offB[i] = ((unsigned)(p >> 7) * (unsigned)g.ldB + (unsigned)(n0 + (p & 127))) * 4u;
   }
   {
-    const int p = wave * 64 + lane, row = p & 31;
-    offA = (unsigned)(row < g.rowsA ? row : g.rowsA - 1) * (unsigned)g.ldA + 4u * (unsigned)(p >> 5);
+    const int p = (wave & 1) * 64 + lane;
+    offA = ((unsigned)(p >> 5) * (unsigned)g.ldA + (unsigned)(p & 31)) * 4u;
   }
+  const bool copiesA = wave < 2;
   auto issue = [&](int ch, int slot) {
-    const float* a = Ac + (size_t)ch * 32;
-    const float* b = Bc + (size_t)ch * 32;
+    const float* a = Ac + (size_t)ch * 4 * g.ldA * 4;
+    const float* b = Bc + (size_t)ch * 4 * g.ldB * 4;
     asm volatile("" : "+s"(a));
     asm volatile("" : "+s"(b));
     float* dA = lds + slot * SLOT;
     float* dB = dA + SA;
-    __builtin_amdgcn_global_load_lds(JRR_GLB(a + offA), JRR_LDS(dA + wave * 256), 16, 0, 0);
+    if (copiesA) __builtin_amdgcn_global_load_lds(JRR_GLB(a + offA), JRR_LDS(dA + wave * 256), 16, 0, 0);
 #pragma unroll
-    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave * 4 + i) * 256), 16, 0, 0);
+    for (int i = 0; i < 2; ++i) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave * 2 + i) * 256), 16, 0, 0);
   };
-  f32x16 acc = zero16();
-  if (c_begin < c_end) issue(c_begin, 0);
+  f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+  for (int i = 0; i < RING - 1; ++i)
+    if (c_begin + i < c_end) issue(c_begin + i, i);
+  int slot = 0;
   for (int ch = c_begin; ch < c_end; ++ch) {
-    __syncthreads();
-    const int slot = (ch - c_begin) & 1;
-    if (ch + 1 < c_end) issue(ch + 1, slot ^ 1);
+    // chunk ch landed: all but the copies of the (up to) two younger chunks; everybody is done with chunk ch - 1
+    const int younger = (c_end - 1 - ch < 2) ? c_end - 1 - ch : 2;
+    if (copiesA) { if (younger == 2) barrier_keep_vm<6>(); else if (younger == 1) barrier_keep_vm<3>(); else barrier_keep_vm<0>(); }
+    else         { if (younger == 2) barrier_keep_vm<4>(); else if (younger == 1) barrier_keep_vm<2>(); else barrier_keep_vm<0>(); }
+    if (ch + RING - 1 < c_end) issue(ch + RING - 1, (slot + RING - 1) & (RING - 1));
     const f32x4* la = reinterpret_cast<const f32x4*>(lds + slot * SLOT);
     const f32x4* lb = reinterpret_cast<const f32x4*>(lds + slot * SLOT + SA);
+    const f32x4 a0 = la[half * 32 + l31], b0 = lb[half * 128 + wave * 32 + l31];
+    const f32x4 a1 = la[(2 + half) * 32 + l31], b1 = lb[(2 + half) * 128 + wave * 32 + l31];
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
-      const f32x4 a4 = la[(gq * 2 + half) * 32 + l31];
-      const f32x4 b4 = lb[(gq * 2 + half) * 128 + wave * 32 + l31];
-#pragma unroll
-      for (int t = 0; t < 4; ++t) acc = mfma(a4[t], b4[t], acc);
+    for (int t = 0; t < 4; ++t) {       // two accumulator chains (a dependent MFMA issues every 112 clocks, not 64)
+      acc0 = mfma(a0[t], b0[t], acc0);
+      acc1 = mfma(a1[t], b1[t], acc1);
     }
+    slot = (slot + 1) & (RING - 1);
   }
-  float* out = g.Out + (size_t)split * g.split_stride;
+  float* out = g.Out + (size_t)ks * g.ks_stride + (size_t)c * g.plane_stride;
 #pragma unroll
-  for (int q = 0; q < 16; ++q) out[(size_t)acc_row(q, half) * g.ldo + n0 + wave * 32 + l31] = acc[q];
+  for (int q = 0; q < 16; ++q) out[(size_t)acc_row(q, half) * g.ldo + n0 + wave * 32 + l31] = acc0[q] + acc1[q];
 }
 
-int launch_gemm_nt32(const float* A, size_t planeA, int ldA, int rowsA, const float* Bm, size_t planeB, int ldB, float* Out,
-                     int ldo, size_t split_stride, int N, int K, int nplanes, int ksplit, hipStream_t s) {
-  if (N % 128 != 0 || K % 32 != 0 || ldA % 4 != 0 || ldB % 4 != 0 || rowsA < 1 || rowsA > 32) {
-    jrr_set_error("gemm_nt32: unsupported shape N=%d K=%d ldA=%d ldB=%d", N, K, ldA, ldB);
+int launch_gemm_q32(const float* A, int ldA, size_t planeA, const float* Bm, int ldB, size_t planeB, float* Out, int ldo,
+                    size_t ks_stride, size_t plane_stride, int N, int K, int nplanes, int ksplit, hipStream_t s) {
+  if (N % 128 != 0 || K % 16 != 0 || ldA < 32 || ldB < N) {
+    jrr_set_error("gemm_q32: unsupported shape N=%d K=%d ldA=%d ldB=%d", N, K, ldA, ldB);
     return JRR_ERR_ARG;
   }
-  NtArgs g{A, planeA, ldA, rowsA, Bm, planeB, ldB, Out, ldo, split_stride, K, ksplit};
-  hipLaunchKernelGGL(k_gemm_nt32, dim3(N / 128, nplanes * ksplit), dim3(256), 0, s, g);
+  Q32Args g{A, ldA, planeA, Bm, ldB, planeB, Out, ldo, ks_stride, plane_stride, K, ksplit};
+  hipLaunchKernelGGL(k_gemm_q32, dim3(N / 128, nplanes * ksplit), dim3(256), 0, s, g);
+  return 0;
+}
+
+struct JgArgs {
+  const float* dJT;    // [3][NHP][BP] joint adjoint, row NHP - 1 of every plane is zero
+  const float* VTq;    // [3][VP/4][BP][4]
+  float* Out;          // [3 * ksplit][32][VP] partial slabs
+  int BP, ksplit;
+};
+constexpr int JG_SB = 32 * 32 * 4, JG_SA = 8 * 32 * 4, JG_SLOT = JG_SB + JG_SA, JG_RING = 4;   // 16 KB + 4 KB per slot
+__global__ __launch_bounds__(256, 2) void k_jgrad_q(JgArgs g) {
+  __shared__ __attribute__((aligned(16))) float lds[JG_RING * JG_SLOT];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int vq0 = blockIdx.x * 32;                 // first vertex quad of this workgroup's 128 vertices
+  const int split = blockIdx.y, c = split / g.ksplit, ks = split % g.ksplit;
+  const int nch = g.BP / 32;
+  const int c_begin = (int)((long)nch * ks / g.ksplit), c_end = (int)((long)nch * (ks + 1) / g.ksplit);
+  const float* Ac = g.dJT + (size_t)c * NHP * g.BP;
+  const float* Bc = g.VTq + ((size_t)c * (VP / 4) + vq0) * g.BP * 4;
+  // Per chunk (32 poses) this wave copies 8 vertex-quad rows -- instruction i: rows r = 2 (4 wave + i) + half, the lane's
+  // piece is pose (l31 + r) % 32 of that row: each row lands ROTATED by its own index, which is what makes the reads
+  // below (32 rows, one pose) hit 16 different bank groups per 16 lanes without padding -- and one instruction of
+  // gathered dj^T pieces (piece p = wave*64 + lane: pose quad p / 32, joint row p % 32; rows >= 18 read the zero row 17).
+  unsigned offB[4], offA;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int r = 2 * (wave * 4 + i) + half;
+    offB[i] = ((unsigned)r * (unsigned)g.BP + (unsigned)((l31 + r) & 31)) * 4u;
+  }
+  {
+    const int p = wave * 64 + lane, row = p & 31;
+    offA = (unsigned)(row < NHP ? row : NHP - 1) * (unsigned)g.BP + 4u * (unsigned)(p >> 5);
+  }
+  auto issue = [&](int ch, int slot) {
+    const float* a = Ac + (size_t)ch * 32;
+    const float* b = Bc + (size_t)ch * 128;
+    asm volatile("" : "+s"(a));
+    asm volatile("" : "+s"(b));
+    float* dB = lds + slot * JG_SLOT;
+    float* dA = dB + JG_SB;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) __builtin_amdgcn_global_load_lds(JRR_GLB(b + offB[i]), JRR_LDS(dB + (wave * 4 + i) * 256), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds(JRR_GLB(a + offA), JRR_LDS(dA + wave * 256), 16, 0, 0);
+  };
+  f32x16 acc[4] = {zero16(), zero16(), zero16(), zero16()};
+  // All workgroups of a pose range would walk it in lockstep, i.e. request, at any moment, addresses that differ by
+  // multiples of the 64 KB+ row stride -- the same few HBM channels.  Each vertex tile therefore starts its (cyclic) walk
+  // at a different chunk; the order of the sum is still fixed per workgroup.
+  const int ncl = c_end - c_begin;
+  const int start = ncl > 0 ? (int)(blockIdx.x * 5u % (unsigned)ncl) : 0;
+  auto chunk_at = [&](int i) { const int o = start + i; return c_begin + (o >= ncl ? o - ncl : o); };
+#pragma unroll
+  for (int i = 0; i < JG_RING - 1; ++i)
+    if (i < ncl) issue(chunk_at(i), i);
+  const int kq = wave * 2 + half;                        // pose quad of this lane's four K-steps (this wave's 8 poses)
+  const int rot = (kq * 4 - l31) & 31;                   // where pose 4 kq sits in row l31
+  int slot = 0;
+  for (int i = 0; i < ncl; ++i) {
+    // chunk i landed (its 5 copies are older than the 5 of each younger chunk in flight); everybody is done with i - 1
+    if (i + 2 < ncl) barrier_keep_vm<10>();
+    else if (i + 1 < ncl) barrier_keep_vm<5>();
+    else barrier_keep_vm<0>();
+    if (i + JG_RING - 1 < ncl) issue(chunk_at(i + JG_RING - 1), (slot + JG_RING - 1) & (JG_RING - 1));
+    const float* lb = lds + slot * JG_SLOT + l31 * 128;
+    const f32x4 a4 = reinterpret_cast<const f32x4*>(lds + slot * JG_SLOT + JG_SB)[kq * 32 + l31];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const f32x4 b4 = *reinterpret_cast<const f32x4*>(lb + ((rot + t) & 31) * 4);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) acc[u] = mfma(a4[t], b4[u], acc[u]);
+    }
+    slot = (slot + 1) & (JG_RING - 1);
+  }
+  // add the four waves' tiles, two accumulators at a time: red[wave][q * 2 + uu][lane]  (32 KB)
+  float* red = lds;
+  f32x4 o[4];
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+    __syncthreads();
+#pragma unroll
+    for (int uu = 0; uu < 2; ++uu)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) red[((wave * 32) + q * 2 + uu) * 64 + lane] = acc[2 * h2 + uu][q];
+    __syncthreads();
+#pragma unroll
+    for (int qq = 0; qq < 4; ++qq)
+#pragma unroll
+      for (int uu = 0; uu < 2; ++uu) {
+        const int q = wave * 4 + qq;                  // this wave finishes accumulator registers 4 wave .. 4 wave + 3
+        float sacc = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) sacc += red[((w * 32) + q * 2 + uu) * 64 + lane];
+        o[qq][2 * h2 + uu] = sacc;
+      }
+  }
+  float* out = g.Out + (size_t)split * 32 * VP;
+#pragma unroll
+  for (int qq = 0; qq < 4; ++qq)
+    *reinterpret_cast<f32x4*>(out + (size_t)acc_row(wave * 4 + qq, half) * VP + (size_t)(vq0 + l31) * 4) = o[qq];
+}
+
+int launch_jgrad_q(const float* dJT, const float* VTq, float* Out, int BP, int ksplit, hipStream_t s) {
+  if (BP % 32 != 0 || ksplit < 1 || ksplit > BP / 32) { jrr_set_error("jgrad_q: unsupported shape BP=%d ksplit=%d", BP, ksplit); return JRR_ERR_ARG; }
+  JgArgs g{dJT, VTq, Out, BP, ksplit};
+  hipLaunchKernelGGL(k_jgrad_q, dim3(VP / 128, 3 * ksplit), dim3(256), 0, s, g);
   return 0;
 }
 

@@ -79,7 +79,7 @@ int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s);
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s);
 int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s);
-int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv,
+int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv, float* Jn_q,
                           hipStream_t s);
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
                     float* dJ, hipStream_t s);
@@ -93,9 +93,9 @@ int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 // blend-basis adjoint dF^T[split][224][BP] = sum_{c, v in split} D_c[v][.] dvp_c[v][.], both operands in vertex quads
 int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s);
-int launch_gemm_nt32(const float* A, size_t planeA, int ldA, int rowsA, const float* Bm, size_t planeB, int ldB, float* Out,
-                     int ldo, size_t split_stride, int N, int K, int nplanes, int ksplit, hipStream_t s);
-int launch_gemm_32x128(const GemmArgs& g, int epi, int nsplit, int nbatch, hipStream_t s);
+int launch_gemm_q32(const float* A, int ldA, size_t planeA, const float* Bm, int ldB, size_t planeB, float* Out, int ldo,
+                    size_t ks_stride, size_t plane_stride, int N, int K, int nplanes, int ksplit, hipStream_t s);
+int launch_jgrad_q(const float* dJT, const float* VTq, float* Out, int BP, int ksplit, hipStream_t s);
 
 // sil.hip
 int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s);

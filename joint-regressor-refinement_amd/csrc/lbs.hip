@@ -33,7 +33,7 @@ namespace jrr {
 //                regressor product  joints^T += Jn . verts_r                 24 (+16) MFMA / wave
 //   The skinning-weight / regressor tiles (W^T, Jn) ride with stage 0 into a per-tile-parity
 //   region.  outputs: JP [nvc][3][17][BP] joint partials; optional VPb [3][VP/4][BP][4] (v_posed in row quads,
-//   kept for the backward pass) and VTb [3][VP][BP] (the vertices, same layout; k_verts_untranspose turns
+//   kept for the backward pass) and VTb [3][VP/4][BP][4] (the vertices, same layout; k_verts_untranspose turns
 //   them into the reference's (B,6890,3) and/or projects them for the silhouette renderer).
 // ------------------------------------------------------------------------------------------
 constexpr int W_FLOATS = NJ * 32;             // 768
@@ -95,7 +95,6 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   }
   const int b0 = bg * BG + wave * BT;
   const size_t bcol = (size_t)b0 + l31;
-  const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)bcol;   // lane part of a (row, pose) address
   const unsigned qoff = (unsigned)half * (unsigned)BP + (unsigned)bcol;          // lane part of a (row quad, pose) address, in quads
   // DMA addressing = wave-uniform base pointer (SGPR pair) + one 32-bit per-lane offset (VGPR), so
   // the 78 copies per tile cost scalar address arithmetic only.  Row-pair pattern: lanes 0-31
@@ -153,7 +152,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
       {
         constexpr int sp = (s == 0) ? NSTAGE - 1 : s - 1;                 // previous stage
         constexpr int hp = sp - NKCH;                                      // its skinning half-stage, if any
-        constexpr int nst = (hp < 0) ? 0 : (STORE_VP ? 2 : 0) + ((STORE_VERTS && (hp & 1)) ? 16 : 0);
+        constexpr int nst = (hp < 0) ? 0 : (STORE_VP ? 2 : 0) + ((STORE_VERTS && (hp & 1)) ? 4 : 0);
         if (s == 0 && vt == t_begin) barrier_keep_vm<0>();
         else barrier_keep_vm<nst>();
       }
@@ -226,10 +225,12 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         } else {
           vr += T * vp[1];                       // T_{r,1} v_y
           vr += U * vp[2];                       // T_{r,2} v_z
-          if (STORE_VERTS) {      // vertices, coordinate-major and pose-contiguous like v_posed (coalesced)
+          if (STORE_VERTS) {      // vertices, in the row-quad layout of v_posed: four 16-byte stores per lane
 #pragma unroll
-            for (int q = 0; q < 16; ++q)
-              urow(VTb, (size_t)r * VP + vt * 32 + acc_row_u(q), BP)[voff] = vr[q];
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 t = {vr[4 * g], vr[4 * g + 1], vr[4 * g + 2], vr[4 * g + 3]};
+              *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g, BP, qoff) = t;
+            }
           }
           // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b]
           {   // three steps ahead: one MFMA per step
@@ -266,7 +267,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
 // ------------------------------------------------------------------------------------------
 // backward (to v_posed and to the skinning transforms)
 //   one workgroup of four waves per (pose tile bt of 32 poses, vertex chunk vc); per vertex tile:
-//     dverts_r[v,b] = sum_i Jn[i,v] dj[b,i,r]                (K = 18)        -- and / or loaded (DV)
+//     dverts_r[v,b] = sum_i Jn[i,v] dj[b,i,r]                (K = 18)        -- and / or loaded (DV, row quads)
 //     T_{r,c}[v,b]  = sum_j W[v,j] A[b,j,r,c]                (K = 24, recomputed)
 //     dvp_c[v,b]    = sum_r T_{r,c} dverts_r                  -> DVP [3][VP/4][BP][4] (row quads)
 //     dA_{r,c}[j,b] += sum_v W[v,j] dverts_r[v,b] vp_c[v,b]   (sums over the tile's ROW index)
@@ -307,7 +308,6 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
   const int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
   const int b0 = bt * BT;
   const size_t bcol = (size_t)b0 + l31;
-  const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)bcol;   // lane part of a (row, pose) address
   const unsigned lane_ln = (unsigned)lane * 4u;
 
   auto issue = [&](int vt, int slot) {
@@ -430,13 +430,17 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
     // ================= wave 3: dverts of the next tile for everybody, dA_{r,3} =================
     f32x16 acc3[3] = {zero16(), zero16(), zero16()};
     f32x16 dv[3];
+    const unsigned qoffh = (unsigned)half * (unsigned)BP + (unsigned)bcol;    // lane part of a (row quad, pose) address
     // vertex adjoint of tile vt: Jn^T dj on the matrix cores and / or the caller's adjoint from memory
     auto compute_dv = [&](int vt, const float* tab) {
       if (DV != 0) {
 #pragma unroll
         for (int r = 0; r < 3; ++r)
 #pragma unroll
-          for (int q = 0; q < 16; ++q) dv[r][q] = urow(dVT, (size_t)r * VP + vt * 32 + acc_row_u(q), BP)[voff];
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 t = *quad_ptr(dVT, (size_t)r * (VP / 4) + vt * 8, g, BP, qoffh);
+            dv[r][4 * g] = t[0]; dv[r][4 * g + 1] = t[1]; dv[r][4 * g + 2] = t[2]; dv[r][4 * g + 3] = t[3];
+          }
       } else {
         dv[0] = zero16(); dv[1] = zero16(); dv[2] = zero16();
       }
@@ -530,17 +534,20 @@ __global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __r
   else if (k - W_FLOATS - 1024 < TB_FLOATS - TB_WVJ - 1024) dst[TB_WVJ + 1024 + (k - W_FLOATS - 1024)] = 0.f;
 }
 
-// [3][VP][BP] vertices -> pose-major (B, ldv) rows of (v, xyz) and/or projected (x_ndc, y_ndc, Z, 0) records for
-// the silhouette renderer (scripts/optimize.py:80-82 flip/scale + scripts/mesh_renderer.py:52-57 camera).
-// One 32-vertex x 32-pose tile per block through LDS; every global access is contiguous.
+// [3][VP/4][BP][4] vertices (row quads) -> pose-major (B, ldv) rows of (v, xyz) and/or projected (x_ndc, y_ndc, Z, 0)
+// records for the silhouette renderer (scripts/optimize.py:80-82 flip/scale + scripts/mesh_renderer.py:52-57 camera).
+// One 32-vertex x 32-pose tile per block through LDS; every global access is contiguous (16 bytes per thread on the
+// quad side).
 __global__ void k_verts_untranspose(const float* __restrict__ VTb, float* __restrict__ verts, int ldv, int vlimit,
                                     const float* __restrict__ cam, f32x4* __restrict__ ndc, float focal, int B, int BP) {
   __shared__ float tile[32][97];
   const int v0 = blockIdx.x * 32, bb0 = blockIdx.y * 32;
-  for (int idx = threadIdx.x; idx < 96 * 32; idx += blockDim.x) {
-    const int rem = idx / 32, bl = idx % 32;       // rem = r*32 + vv
-    const int r = rem / 32, vv = rem % 32;
-    tile[bl][vv * 3 + r] = VTb[((size_t)r * VP + v0 + vv) * BP + bb0 + bl];
+  const f32x4* VTq = reinterpret_cast<const f32x4*>(VTb);
+  for (int idx = threadIdx.x; idx < 3 * 8 * 32; idx += blockDim.x) {
+    const int r = idx >> 8, vq = (idx >> 5) & 7, bl = idx & 31;
+    const f32x4 t = VTq[((size_t)r * (VP / 4) + (v0 >> 2) + vq) * BP + bb0 + bl];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) tile[bl][(vq * 4 + u) * 3 + r] = t[u];
   }
   __syncthreads();
   if (verts) {
@@ -571,7 +578,8 @@ int launch_verts_untranspose(const float* VTb, float* verts, int ldv, int vlimit
   return 0;
 }
 
-// (B,6890,3) -> [3][VP][BP] transpose of an external vertex adjoint (operator-level SMPL backward)
+// (B,6890,3) -> [3][VP/4][BP][4] (row quads) transpose of an external vertex adjoint (operator-level SMPL backward,
+// silhouette adjoint)
 __global__ void k_dverts_transpose(const float* __restrict__ dverts, int ldv, float* __restrict__ dVT, int B, int BP) {
   __shared__ float tile[32][97];
   const int v0 = blockIdx.x * 32, bb0 = blockIdx.y * 32;
@@ -583,18 +591,23 @@ __global__ void k_dverts_transpose(const float* __restrict__ dverts, int ldv, fl
     tile[bl][rem] = val;
   }
   __syncthreads();
-  for (int idx = threadIdx.x; idx < 96 * 32; idx += blockDim.x) {
-    int rem = idx / 32, bl = idx % 32;
-    int vv = rem / 3, r = rem % 3;
-    dVT[((size_t)r * VP + v0 + vv) * BP + bb0 + bl] = tile[bl][rem];
+  f32x4* dVq = reinterpret_cast<f32x4*>(dVT);
+  for (int idx = threadIdx.x; idx < 3 * 8 * 32; idx += blockDim.x) {
+    const int r = idx >> 8, vq = (idx >> 5) & 7, bl = idx & 31;
+    f32x4 t;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) t[u] = tile[bl][(vq * 4 + u) * 3 + r];
+    dVq[((size_t)r * (VP / 4) + (v0 >> 2) + vq) * BP + bb0 + bl] = t;
   }
 }
 
 // ------------------------------------------------------------------------------------------
 // J_regressor normalisation (scripts/utils.py:87-92) into the tile layouts, and its adjoint
 // ------------------------------------------------------------------------------------------
-__global__ void k_jreg_rowsum(const float* __restrict__ J, const float* __restrict__ mask, float* __restrict__ rowsum) {
-  __shared__ float red[256];
+constexpr int JREG_THREADS = 1024;     // one block per regressor row: 6890 columns, 7 per thread
+__global__ __launch_bounds__(JREG_THREADS) void k_jreg_rowsum(const float* __restrict__ J, const float* __restrict__ mask,
+                                                               float* __restrict__ rowsum) {
+  __shared__ float red[JREG_THREADS];
   const int i = blockIdx.x;
   float acc = 0.f;
   for (int v = threadIdx.x; v < V; v += blockDim.x) {
@@ -604,7 +617,7 @@ __global__ void k_jreg_rowsum(const float* __restrict__ J, const float* __restri
   }
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = JREG_THREADS / 2; s > 0; s >>= 1) {
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
@@ -613,7 +626,7 @@ __global__ void k_jreg_rowsum(const float* __restrict__ J, const float* __restri
 
 __global__ void k_jreg_tiles(const float* __restrict__ J, const float* __restrict__ mask,
                              const float* __restrict__ rowsum, float* __restrict__ Jn, float* __restrict__ Jn_vi,
-                             float* __restrict__ Jn_iv) {
+                             float* __restrict__ Jn_iv, float* __restrict__ Jn_q) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over VT*32*32 (tile, vv, i)
   if (idx >= VT * 1024) return;
   const int vt = idx >> 10, vv = (idx >> 5) & 31, i = idx & 31;
@@ -626,20 +639,21 @@ __global__ void k_jreg_tiles(const float* __restrict__ J, const float* __restric
     Jn[(size_t)i * V + v] = val;
   }
   Jn_vi[(size_t)vt * 1024 + vv * 32 + i] = val;
+  Jn_q[((size_t)(v >> 2) * 32 + i) * 4 + (v & 3)] = val;      // vertex quads [VP/4][32][4]: A operand of k_gemm_q32
   if (i < NHP) Jn_iv[(size_t)vt * TB_FLOATS + TB_JN + i * 32 + vv] = val;   // backward operand record
 }
 
 // dJ_raw = mask * relu'(J*mask) * (dJn - sum_v(dJn*Jn)) / rowsum      (dJn given as [17][ldn])
-__global__ void k_jreg_bwd(const float* __restrict__ J, const float* __restrict__ mask, const float* __restrict__ Jn,
-                           const float* __restrict__ rowsum, const float* __restrict__ dJn, int ldn,
-                           float* __restrict__ dJ) {
-  __shared__ float red[256];
+__global__ __launch_bounds__(JREG_THREADS) void k_jreg_bwd(const float* __restrict__ J, const float* __restrict__ mask,
+                                                            const float* __restrict__ Jn, const float* __restrict__ rowsum,
+                                                            const float* __restrict__ dJn, int ldn, float* __restrict__ dJ) {
+  __shared__ float red[JREG_THREADS];
   const int i = blockIdx.x;
   float acc = 0.f;
   for (int v = threadIdx.x; v < V; v += blockDim.x) acc += dJn[(size_t)i * ldn + v] * Jn[(size_t)i * V + v];
   red[threadIdx.x] = acc;
   __syncthreads();
-  for (int s = 128; s > 0; s >>= 1) {
+  for (int s = JREG_THREADS / 2; s > 0; s >>= 1) {
     if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
     __syncthreads();
   }
@@ -691,9 +705,9 @@ int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int
 }
 
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv,
-                          hipStream_t s) {
-  hipLaunchKernelGGL(k_jreg_rowsum, dim3(NH), dim3(256), 0, s, J, mask, rowsum);
-  hipLaunchKernelGGL(k_jreg_tiles, dim3(VT * 1024 / 256), dim3(256), 0, s, J, mask, rowsum, Jn, Jn_vi, Jn_iv);
+                          float* Jn_q, hipStream_t s) {
+  hipLaunchKernelGGL(k_jreg_rowsum, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, rowsum);
+  hipLaunchKernelGGL(k_jreg_tiles, dim3(VT * 1024 / 256), dim3(256), 0, s, J, mask, rowsum, Jn, Jn_vi, Jn_iv, Jn_q);
   return 0;
 }
 
@@ -704,7 +718,7 @@ int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s) {
 
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
                     float* dJ, hipStream_t s) {
-  hipLaunchKernelGGL(k_jreg_bwd, dim3(NH), dim3(256), 0, s, J, mask, Jn, rowsum, dJn, ldn, dJ);
+  hipLaunchKernelGGL(k_jreg_bwd, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, Jn, rowsum, dJn, ldn, dJ);
   return 0;
 }
 
