@@ -102,6 +102,16 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
     m->d.parents.depth[j] = (j == 0) ? 0 : m->d.parents.depth[parents[j]] + 1;
     if (m->d.parents.depth[j] > m->d.parents.maxd) m->d.parents.maxd = m->d.parents.depth[j];
   }
+  {
+    int n = 0;
+    for (int j = 0; j < NJ; ++j) {
+      m->d.parents.child_off[j] = (unsigned char)n;
+      for (int q = j + 1; q < NJ; ++q)
+        if (parents[q] == j) m->d.parents.child[n++] = (unsigned char)q;
+    }
+    m->d.parents.child_off[NJ] = (unsigned char)n;
+    for (; n < NJ; ++n) m->d.parents.child[n] = 0;
+  }
   *out = m;
   return JRR_OK;
 }
@@ -503,13 +513,18 @@ extern "C" int jrr_rodrigues_backward(const float* aa, const float* dR, float* d
 }
 
 // The per-vertex-chunk joint partials JP [nvc][3][17][BP] and skinning-adjoint partials dATp [nvcb][12][24][BP] are summed
-// by their consumers (k_joints_loss, k_chain_bwd: a few pose-contiguous loads per thread); only the 16 split-K slabs of
-// dF^T (58 MB at 4096 poses) keep a wide reduction kernel of their own.
+// by their consumers (k_joints_loss, k_chain_bwd: a few pose-contiguous loads per thread); the 16 split-K slabs of
+// dF^T (58 MB at 4096 poses) keep a wide reduction kernel of their own -- and so do the dA slabs when there are many of
+// them (small batches: 16 slabs at 1024 poses, where k_chain_bwd has only 32 blocks to sum them with).
+constexpr int MAX_SLABS_IN_CONSUMER = 4;
 static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s) {
   launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
+  if (e->nvcb > MAX_SLABS_IN_CONSUMER)
+    launch_reduce_slabs(e->dATp, e->nvcb, (size_t)12 * NJ * e->BP, e->dA, (size_t)12 * NJ * e->BP, s);
 }
 static void set_adjoint_slabs(jrr_engine* e, PrepBwdLaunch& L) {
-  L.dATp = e->dATp; L.nslabA = e->nvcb; L.strideA = (size_t)12 * NJ * e->BP; L.dFTp = e->dF;
+  const bool pre = e->nvcb > MAX_SLABS_IN_CONSUMER;
+  L.dATp = pre ? e->dA : e->dATp; L.nslabA = pre ? 1 : e->nvcb; L.strideA = (size_t)12 * NJ * e->BP; L.dFTp = e->dF;
 }
 
 static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,

@@ -117,6 +117,9 @@ struct Parents {
   int p[NJ];       // parent joint (p[0] = -1), parents precede children
   int depth[NJ];   // tree depth of each joint (root = 0)
   int maxd;        // deepest level
+  // children of joint j, ascending: child[child_off[j] .. child_off[j + 1])
+  unsigned char child_off[NJ + 1];
+  unsigned char child[NJ];
 };
 
 // ---- device-resident SMPL model ------------------------------------------------------------

@@ -25,3 +25,7 @@ for _ in range(5):
 eng.set_profiling(True); eng.refine_run(x, b, gt, m, v, st, 1e-2, 20); prof = eng.profile_read(); eng.set_profiling(False)
 tag = ' '.join(f'{k}={v}' for k, v in os.environ.items() if k.startswith('JRR_'))
 print(f'[{tag}] B={B}: median {sorted(ts)[2]:.4f} ms/iter (min {min(ts):.4f}); ' + ' '.join(f'{k}={t:.4f}' for k, (t, c) in prof.items() if c))
+import ctypes
+lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), PKG, 'libjrr_hip.so'))
+if hasattr(lib, 'jrr_debug_read'):
+    buf = (ctypes.c_longlong * 16)(); lib.jrr_debug_read(buf); print('chain_bwd phases (10 ns ticks): loads', buf[0], 'tree', buf[1], 'update', buf[2])
