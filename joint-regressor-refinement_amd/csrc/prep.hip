@@ -656,7 +656,6 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
                                                         const float* __restrict__ dF_, PoseUpdateArgs ua, int B, int BP) {
   constexpr int PP = PPB;
   __shared__ AdamScalars adam_sc;
-  if (ua.x6d_io && threadIdx.x == 0) adam_sc = adam_scalars(ua.step[0], ua.lr, ua.beta1, ua.beta2, ua.eps);
   // one thread per (pose, joint); levels of the kinematic tree are processed deepest first.  Each child
   // leaves its contribution to the parent's dG in its own LDS slot; the parent sums its children in
   // index order (no atomics: bitwise reproducible).
@@ -674,34 +673,77 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
   const int c_lo = par.child_off[j], c_hi = par.child_off[j + 1];
   __shared__ unsigned char childs[NJ];
   if (threadIdx.x < NJ) childs[threadIdx.x] = par.child[threadIdx.x];
+  // the rest-joint tables (72 + 720 floats) are read with per-lane (joint) indices: from LDS, not from memory
+  __shared__ float Jts[NJ * 3];
+  __shared__ float JSs[NJ * 3 * NB];
+  for (int i = threadIdx.x; i < NJ * 3 * NB; i += PP * NJ) JSs[i] = JS[i];
+  if (threadIdx.x < NJ * 3) Jts[threadIdx.x] = Jt[threadIdx.x];
   float beta[NB], dbeta[NB], Ji[3];
+  // Row addressing of the [row][BP] arrays: a scalar base + ONE 32-bit byte offset per lane, rows stepped by scalar
+  // multiples of the row pitch (a 64-bit per-lane multiply-add per element -- what `array[(size_t)row * BP + b]` with a
+  // per-lane row compiles to -- is quarter-rate: ~400 VALU instructions for this kernel's 94 loads).
+  const unsigned pitch = (unsigned)BP * 4u, lane_b = (unsigned)bb * 4u;
+  auto ld = [](const float* base, unsigned byte_off) {
+    return *reinterpret_cast<const float*>(reinterpret_cast<const char*>(base) + byte_off);
+  };
 #pragma unroll
-  for (int l = 0; l < NB; ++l) { beta[l] = FT[(size_t)(207 + l) * BP + bb]; dbeta[l] = 0.f; }
-  rest_joint(Jt, JS, j, beta, Ji);
-  // everything this joint needs from global memory, issued up front (independent, pose-contiguous)
+  for (int l = 0; l < NB; ++l) { beta[l] = ld(FT, (unsigned)(207 + l) * pitch + lane_b); dbeta[l] = 0.f; }
+  // everything this joint needs from global memory, issued up front (independent, pose-contiguous; joint 0 reads
+  // valid rows it does not use instead of branching around the loads)
   float dA[12], GiR[9], R[9], Gp[9], dFj[9];
+  const unsigned oj = (unsigned)j * pitch + lane_b;                         // row j
+  const unsigned opj = (unsigned)(p > 0 ? p : 0) * pitch + lane_b;          // row of the parent
+  const unsigned ofj = (unsigned)(j > 0 ? (j - 1) * 9 : 0) * pitch + lane_b;   // first pose-feature row of joint j
   // dA^T arrives as per-vertex-chunk partial slabs [nslabA][12][24][BP]: summed here, in slab order (deterministic)
-#pragma unroll
-  for (int e = 0; e < 12; ++e) dA[e] = dA_[(size_t)(e * NJ + j) * BP + bb];
-  for (int sl = 1; sl < nslabA; ++sl) {        // all 12 loads of a slab in flight together
+  // (two slabs' loads -- 24 -- in flight together)
+  {
     float t[12];
 #pragma unroll
-    for (int e = 0; e < 12; ++e) t[e] = dA_[(size_t)sl * strideA + (size_t)(e * NJ + j) * BP + bb];
+    for (int e = 0; e < 12; ++e) dA[e] = ld(dA_, oj + (unsigned)(e * NJ) * pitch);
+    if (nslabA > 1) {
+      const float* s1 = dA_ + strideA;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) t[e] = ld(s1, oj + (unsigned)(e * NJ) * pitch);
+#pragma unroll
+      for (int e = 0; e < 12; ++e) dA[e] += t[e];
+    }
+  }
+  for (int sl = 2; sl < nslabA; sl += 2) {
+    float t[12], u[12];
+    const bool two = sl + 1 < nslabA;
+    const float* s0 = dA_ + (size_t)sl * strideA;
+    const float* s1 = s0 + strideA;
+#pragma unroll
+    for (int e = 0; e < 12; ++e) t[e] = ld(s0, oj + (unsigned)(e * NJ) * pitch);
+    if (two) {
+#pragma unroll
+      for (int e = 0; e < 12; ++e) u[e] = ld(s1, oj + (unsigned)(e * NJ) * pitch);
+    }
 #pragma unroll
     for (int e = 0; e < 12; ++e) dA[e] += t[e];
+    if (two) {
+#pragma unroll
+      for (int e = 0; e < 12; ++e) dA[e] += u[e];
+    }
   }
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int cc = 0; cc < 3; ++cc) {
-      GiR[r * 3 + cc] = AT[(size_t)((r * 4 + cc) * NJ + j) * BP + bb];
-      Gp[r * 3 + cc] = (j > 0) ? AT[(size_t)((r * 4 + cc) * NJ + p) * BP + bb] : 0.f;
+      GiR[r * 3 + cc] = ld(AT, oj + (unsigned)((r * 4 + cc) * NJ) * pitch);
+      const float gp = ld(AT, opj + (unsigned)((r * 4 + cc) * NJ) * pitch);
+      Gp[r * 3 + cc] = (j > 0) ? gp : 0.f;
     }
 #pragma unroll
   for (int k = 0; k < 9; ++k) {
-    R[k] = (j > 0) ? FT[(size_t)((j - 1) * 9 + k) * BP + bb] + ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f) : 0.f;
-    dFj[k] = (j > 0) ? dF_[(size_t)((j - 1) * 9 + k) * BP + bb] : 0.f;
+    const float f = ld(FT, ofj + (unsigned)k * pitch), df = ld(dF_, ofj + (unsigned)k * pitch);
+    R[k] = (j > 0) ? f + ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f) : 0.f;
+    dFj[k] = (j > 0) ? df : 0.f;
   }
+  // Adam's bias corrections (two fp64 pow: ~400 instructions, one thread) under the loads issued above, not before them
+  if (ua.x6d_io && threadIdx.x == 0) adam_sc = adam_scalars(ua.step[0], ua.lr, ua.beta1, ua.beta2, ua.eps);
+  __syncthreads();                              // tables staged
+  rest_joint(Jts, JSs, j, beta, Ji);
 #pragma unroll
   for (int cc = 0; cc < 3; ++cc) Js[j][cc][bl] = Ji[cc];
   __syncthreads();
@@ -736,7 +778,7 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
 #pragma unroll
         for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
-          for (int l = 0; l < NB; ++l) dbeta[l] = fmaf(dJ[cc], JS[(0 * 3 + cc) * NB + l], dbeta[l]);
+          for (int l = 0; l < NB; ++l) dbeta[l] = fmaf(dJ[cc], JSs[(0 * 3 + cc) * NB + l], dbeta[l]);
       } else {
         float rel[3], drel[3];
 #pragma unroll
@@ -766,7 +808,7 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
         for (int cc = 0; cc < 3; ++cc)
 #pragma unroll
           for (int l = 0; l < NB; ++l)
-            dbeta[l] = fmaf(dJ[cc] + drel[cc], JS[(j * 3 + cc) * NB + l], fmaf(-drel[cc], JS[(p * 3 + cc) * NB + l], dbeta[l]));
+            dbeta[l] = fmaf(dJ[cc] + drel[cc], JSs[(j * 3 + cc) * NB + l], fmaf(-drel[cc], JSs[(p * 3 + cc) * NB + l], dbeta[l]));
       }
     }
     __syncthreads();
