@@ -146,6 +146,7 @@ struct jrr_engine {
   float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv, *Jn_q;
   bool tab_static;                                   // the W parts of the backward operand records are in place
   float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
+  float *convL;                                      // LDS image of the per-joint MLP parameters (k_conv_image)
   float *W2s, *zpart;                                // fc2.w rows scaled by fc4.w; partial fc4 dots [16][BP]
   float *W0Tq, *W2Tq, *W2sq, *W0q;                   // the four GEMM weight operands in quads [k/4][m][4]
   float *Pd, *W0T, *W2T, *H2T, *A1T, *A2T, *dA2T, *dA1T, *dH2T, *gx, *TrA, *TrB, *dz0, *dsc, *wgs;
@@ -250,6 +251,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->W2sq = c.take((size_t)1024 * 1024);
     t->W0q = c.take((size_t)1024 * 768);
     t->zpart = c.take((size_t)16 * BP);
+    t->convL = c.take(CONV_IMAGE_FLOATS);
     t->H2T = c.take((size_t)768 * BP);
     t->A1T = c.take((size_t)1024 * BP);
     t->A2T = c.take((size_t)1024 * BP);
@@ -465,6 +467,7 @@ extern "C" int jrr_engine_set_pose_disc(jrr_engine_t* e, const float* P, void* s
   launch_to_quads(e->W2T, 1024, e->W2Tq, 1024, 1024, s);
   launch_to_quads(e->W2s, 1024, e->W2sq, 1024, 1024, s);
   launch_to_quads(e->Pd + DP_FC0_W, 768, e->W0q, 1024, 768, s);
+  launch_conv_image(e->Pd, e->convL, s);
   CHECK_LAUNCH();
   e->have_pd = true;
   return JRR_OK;
@@ -625,7 +628,7 @@ extern "C" int jrr_joint_loss(const float* joints, const float* gt_mm, float wei
 // The loop path keeps every activation in quads [row/4][pose][4] (k_disc_gemm); the weight-gradient path of the outer
 // step (disc_backward_params) needs row-major activations for its transposes / row sums and runs the row-major kernels.
 static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t s, bool quad = true) {
-  launch_disc_conv_fwd(e->Pd, x6d, e->H2T, out, e->B, e->BP, s, quad ? 1 : 0);
+  launch_disc_conv_fwd(e->convL, x6d, e->H2T, out, e->B, e->BP, s, quad ? 1 : 0);
   GemmArgs g;
   g.mask = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   g.A = quad ? e->W0Tq : e->W0T; g.lda = 1024; g.Bm = e->H2T; g.Out = e->A1T; g.bias = e->Pd + DP_FC0_B; g.M = 1024; g.K = 768;
@@ -653,7 +656,7 @@ static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, cons
   h.A = e->W0q; h.lda = 768; h.Bm = e->dA1T; h.Out = e->dH2T; h.mask = nullptr; h.M = 768; h.K = 1024;
   rc = launch_disc_gemm_q(h, EPI_STORE, 0, s);
   if (rc) return rc;
-  launch_disc_conv_bwd(e->Pd, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s, sq, 1);
+  launch_disc_conv_bwd(e->convL, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s, sq, 1);
   return 0;
 }
 

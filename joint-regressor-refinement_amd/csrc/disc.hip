@@ -55,7 +55,11 @@ constexpr int CL_W0A = CL_W2 + 1024;      // [32][32]  W0a[o][c6] = conv0.w[o][c
 constexpr int CL_WH = CL_W0A + 1024;      // [24][33]  heads
 constexpr int CL_FLOATS = CL_WH + 24 * 33;
 
-__device__ __forceinline__ void conv_stage_params(const float* __restrict__ P, float* __restrict__ L) {
+// The LDS parameter image of the per-joint MLP kernels (layout CL_*), built ONCE per parameter upload (k_conv_image,
+// jrr_engine_set_pose_disc).  Building it inside every workgroup -- gathers of conv0.w, two orientations of conv2.w, three
+// dependent load rounds -- was 4.7 of k_dconv_fwd's 11.6 us (wall-clock stamps); copying the image is one round.
+static_assert(CL_FLOATS % 4 == 0 && CL_FLOATS <= CONV_IMAGE_FLOATS, "image copied in 16-byte pieces");
+__global__ void k_conv_image(const float* __restrict__ P, float* __restrict__ L) {
   for (int i = threadIdx.x; i < 256; i += blockDim.x) {
     const int c = i >> 5, o = i & 31;
     L[CL_W0P + i] = (c < 6) ? P[DP_CONV0_W + o * 6 + c] : 0.f;
@@ -69,6 +73,15 @@ __device__ __forceinline__ void conv_stage_params(const float* __restrict__ P, f
     L[CL_W0A + i] = (c < 6) ? P[DP_CONV0_W + o * 6 + c] : 0.f;
   }
   for (int i = threadIdx.x; i < 24 * 33; i += blockDim.x) L[CL_WH + i] = P[DP_HEADS + i];
+}
+int launch_conv_image(const float* P, float* img, hipStream_t s) {
+  hipLaunchKernelGGL(k_conv_image, dim3(1), dim3(256), 0, s, P, img);
+  return 0;
+}
+__device__ __forceinline__ void conv_stage_params(const float* __restrict__ img, float* __restrict__ L) {
+  const f32x4* src = reinterpret_cast<const f32x4*>(img);
+  f32x4* dst = reinterpret_cast<f32x4*>(L);
+  for (int i = threadIdx.x; i < CL_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
 }
 
 // h1, h2 (post-ReLU) of 32 poses x one joint, in accumulator layout
@@ -101,7 +114,7 @@ __device__ __forceinline__ float conv_head(const float* __restrict__ L, int j, i
 template <bool QUAD>
 __global__ __launch_bounds__(256) void k_dconv_fwd(const float* __restrict__ P, const float* __restrict__ x6d,
                                                    float* __restrict__ H2T, float* __restrict__ out, int B, int BP) {
-  __shared__ float L[CL_FLOATS];
+  __shared__ __attribute__((aligned(16))) float L[CL_FLOATS];
   conv_stage_params(P, L);
   __syncthreads();
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
@@ -135,7 +148,7 @@ __global__ __launch_bounds__(256) void k_dconv_bwd(const float* __restrict__ P, 
                                                    const float* __restrict__ dH2T, const float* __restrict__ gout,
                                                    float scale, float target, float* __restrict__ gx, int B, int BP,
                                                    float* __restrict__ sqj) {
-  __shared__ float L[CL_FLOATS];
+  __shared__ __attribute__((aligned(16))) float L[CL_FLOATS];
   conv_stage_params(P, L);
   __syncthreads();
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;

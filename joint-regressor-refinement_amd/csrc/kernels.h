@@ -121,6 +121,9 @@ int launch_evaluate(const float* pred, const float* target_mm, float* err, float
 
 // disc.hip
 int launch_transpose(const float* in, float* out, int rows, int cols, hipStream_t s, int ldin = 0, int ldout = 0);
+constexpr int CONV_IMAGE_FLOATS = 4224;     // LDS parameter image of the per-joint MLP kernels (disc.hip CL_*), rounded up
+int launch_conv_image(const float* P, float* img, hipStream_t s);
+// (the per-joint MLP launchers take the IMAGE, not the flat parameter vector)
 int launch_disc_conv_fwd(const float* P, const float* x6d, float* H2T, float* out, int B, int BP, hipStream_t s, int quad = 0);
 int launch_disc_out(const float* P, const float* A2T, float* out, float* dA2T, const float* gout, float scale,
                     float target, int B, int BP, hipStream_t s, float* dz0 = nullptr, float* sq0 = nullptr);

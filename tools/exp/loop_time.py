@@ -28,4 +28,4 @@ print(f'[{tag}] B={B}: median {sorted(ts)[2]:.4f} ms/iter (min {min(ts):.4f}); '
 import ctypes
 lib = ctypes.CDLL(os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), PKG, 'libjrr_hip.so'))
 if hasattr(lib, 'jrr_debug_read'):
-    buf = (ctypes.c_longlong * 16)(); lib.jrr_debug_read(buf); print("chain_bwd phases (10 ns ticks): loads", buf[0], "tree", buf[1], "update", buf[2], "restjoint", buf[3])
+    buf = (ctypes.c_longlong * 16)(); lib.jrr_debug_read(buf); print("phases:", list(buf))
