@@ -520,8 +520,12 @@ extern "C" int jrr_rodrigues_backward(const float* aa, const float* dR, float* d
 // dF^T (58 MB at 4096 poses) keep a wide reduction kernel of their own -- and so do the dA slabs when there are many of
 // them (small batches: 16 slabs at 1024 poses, where k_chain_bwd has only 32 blocks to sum them with).
 constexpr int MAX_SLABS_IN_CONSUMER = 4;
-static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s) {
-  launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
+// conv_x6d != NULL (fused loop with the pose discriminator): the per-joint MLP adjoint shares the launch of the dF^T sum.
+static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s, const float* conv_x6d = nullptr, float dscale = 0.f) {
+  if (conv_x6d)
+    launch_dconv_bwd_reduce(e->convL, conv_x6d, e->dH2T, nullptr, dscale, 1.f, e->gx, e->dsq, e->B, e->BP, e->dFTp, e->nsplit,
+                            (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
+  else launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
   if (e->nvcb > MAX_SLABS_IN_CONSUMER)
     launch_reduce_slabs(e->dATp, e->nvcb, (size_t)12 * NJ * e->BP, e->dA, (size_t)12 * NJ * e->BP, s);
 }
@@ -627,8 +631,9 @@ extern "C" int jrr_joint_loss(const float* joints, const float* gt_mm, float wei
 // All four GEMMs: exact 128x64 tiles (512 workgroups at 4096 poses), 3-deep LDS-DMA ring.
 // The loop path keeps every activation in quads [row/4][pose][4] (k_disc_gemm); the weight-gradient path of the outer
 // step (disc_backward_params) needs row-major activations for its transposes / row sums and runs the row-major kernels.
-static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t s, bool quad = true) {
-  launch_disc_conv_fwd(e->convL, x6d, e->H2T, out, e->B, e->BP, s, quad ? 1 : 0);
+// conv_done: the per-joint MLP already ran (fused into the chain-forward launch, launch_prep_fwd_dconv)
+static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t s, bool quad = true, bool conv_done = false) {
+  if (!conv_done) launch_disc_conv_fwd(e->convL, x6d, e->H2T, out, e->B, e->BP, s, quad ? 1 : 0);
   GemmArgs g;
   g.mask = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   g.A = quad ? e->W0Tq : e->W0T; g.lda = 1024; g.Bm = e->H2T; g.Out = e->A1T; g.bias = e->Pd + DP_FC0_B; g.M = 1024; g.K = 768;
@@ -640,8 +645,9 @@ static int disc_forward(jrr_engine* e, const float* x6d, float* out, hipStream_t
   return launch_disc_gemm_q(g, EPI_BIAS_RELU_DOT, 0, s);
 }
 
+// skip_conv: the caller runs the per-joint MLP adjoint itself (fused with the dF^T slab sum, launch_dconv_bwd_reduce)
 static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, const float* gout, float scale,
-                               float target, float* gx, hipStream_t s, float* sq = nullptr) {
+                               float target, float* gx, hipStream_t s, float* sq = nullptr, bool skip_conv = false) {
   GemmArgs g;
   g.bias = nullptr; g.split_stride = 0; g.N = e->BP; g.ldb = e->BP; g.ldo = e->BP;
   // dA1T[k][b] = relu'(A1T) * sum_n (fc4.w[n] fc2.w[n][k]) relu'(A2T[n][b]) dz[b]
@@ -656,7 +662,7 @@ static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, cons
   h.A = e->W0q; h.lda = 768; h.Bm = e->dA1T; h.Out = e->dH2T; h.mask = nullptr; h.M = 768; h.K = 1024;
   rc = launch_disc_gemm_q(h, EPI_STORE, 0, s);
   if (rc) return rc;
-  launch_disc_conv_bwd(e->convL, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s, sq, 1);
+  if (!skip_conv) launch_disc_conv_bwd(e->convL, x6d, e->dH2T, gout, scale, target, gx, e->B, e->BP, s, sq, 1);
   return 0;
 }
 
@@ -939,7 +945,11 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
                        e->VTb != nullptr && e->sil_mask == nullptr;
     e->fwd_cached = false;
     prof_mark(e, 0, s);
+    // with the pose discriminator its per-joint MLP rides in the chain-forward launch, and its adjoint in the launch of
+    // the dF^T slab sum (two independent latency-bound kernels side by side: prep.hip)
+    const bool fuse_conv = pd && !reuse;
     if (reuse) launch_step_inc(step, s);
+    else if (fuse_conv) launch_prep_fwd_dconv(e->m, x6d, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, e->convL, e->H2T, nullptr, s);
     else launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, s);
     prof_mark(e, 0, s);
     prof_mark(e, 1, s);
@@ -992,9 +1002,9 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     if (rc) return rc;
     if (pd) {
       prof_mark(e, 5, s);
-      rc = disc_forward(e, x6d, nullptr, s);
+      rc = disc_forward(e, x6d, nullptr, s, true, fuse_conv);
       if (rc) return rc;
-      rc = disc_backward_input(e, x6d, nullptr, nullptr, dscale, 1.f, e->gx, s, e->dsq);
+      rc = disc_backward_input(e, x6d, nullptr, nullptr, dscale, 1.f, e->gx, s, e->dsq, !folded);
       prof_mark(e, 5, s);
       if (rc) return rc;
     }
@@ -1005,7 +1015,7 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     }
     prof_mark(e, 7, s);
     if (folded) launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
-    else reduce_adjoint_partials(e, s);
+    else reduce_adjoint_partials(e, s, pd ? x6d : nullptr, dscale);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.betas_in = betas;
     if (folded) { L.dATp = e->dA; L.dFTp = e->dF; } else set_adjoint_slabs(e, L);

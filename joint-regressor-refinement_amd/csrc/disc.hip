@@ -10,10 +10,10 @@
 //   fc4.w 1839128 (1x1024) fc4.b 1840152
 #include "jrr_common.h"
 #include "kernels.h"
+#include "dconv.h"
 
 namespace jrr {
 
-__device__ __forceinline__ float sigmoidf(float z) { return 1.f / (1.f + expf(-z)); }
 
 // per-(pose, joint) shared MLP; lane = pose, blockIdx.y = joint
 __device__ __forceinline__ void joint_mlp(const float* __restrict__ P, const float x[6], float h1[32], float h2[32]) {
@@ -36,24 +36,6 @@ __device__ __forceinline__ void joint_mlp(const float* __restrict__ P, const flo
     h2[o] = fmaxf(acc, 0.f);
   }
 }
-
-// ------------------------------------------------------------------------------------------
-// The per-joint shared MLP (1x1 convs 6 -> 32 -> 32, scripts/discriminator.py:15-18,32-36) and the 24 per-joint heads
-// (:21-23,44-49) on the fp32 matrix cores.  One wave per (32 poses, joint): every layer is a 32 x 32 (channel, pose)
-// tile in the accumulator layout of v_mfma_f32_32x32x2_f32 (rows = channels in registers, columns = poses on lanes), so a
-// layer's output is the next layer's B operand without leaving registers (it sums over the tile's ROW index), forward
-// and adjoint alike.  The weights sit in LDS in the orientation each product reads conflict-free.
-//   forward : h1 = relu(W0 x + b0) [3 MFMA]   h2 = relu(W2 h1 + b2) [16]   z_j = wh_j . h2 + bh_j
-//   adjoint : dh2 = relu'(h2) (dz_j wh_j + dH2)   dh1 = relu'(h1) W2^T dh2 [16]   gx = W0^T dh1 [16]
-// ------------------------------------------------------------------------------------------
-constexpr int CL_W0P = 0;                 // [8][32]   W0p[c][o] = conv0.w[o][c], rows 6,7 zero
-constexpr int CL_B0 = CL_W0P + 256;       // [32]
-constexpr int CL_B2 = CL_B0 + 32;         // [32]
-constexpr int CL_W2T = CL_B2 + 32;        // [32][32]  W2T[c][o] = conv2.w[o][c]
-constexpr int CL_W2 = CL_W2T + 1024;      // [32][32]  conv2.w[o][c]
-constexpr int CL_W0A = CL_W2 + 1024;      // [32][32]  W0a[o][c6] = conv0.w[o][c6], columns 6.. zero
-constexpr int CL_WH = CL_W0A + 1024;      // [24][33]  heads
-constexpr int CL_FLOATS = CL_WH + 24 * 33;
 
 // The LDS parameter image of the per-joint MLP kernels (layout CL_*), built ONCE per parameter upload (k_conv_image,
 // jrr_engine_set_pose_disc).  Building it inside every workgroup -- gathers of conv0.w, two orientations of conv2.w, three
@@ -78,126 +60,21 @@ int launch_conv_image(const float* P, float* img, hipStream_t s) {
   hipLaunchKernelGGL(k_conv_image, dim3(1), dim3(256), 0, s, P, img);
   return 0;
 }
-__device__ __forceinline__ void conv_stage_params(const float* __restrict__ img, float* __restrict__ L) {
-  const f32x4* src = reinterpret_cast<const f32x4*>(img);
-  f32x4* dst = reinterpret_cast<f32x4*>(L);
-  for (int i = threadIdx.x; i < CL_FLOATS / 4; i += blockDim.x) dst[i] = src[i];
-}
-
-// h1, h2 (post-ReLU) of 32 poses x one joint, in accumulator layout
-__device__ __forceinline__ void conv_mlp_tile(const float* __restrict__ L, const float* __restrict__ x6d, int b, bool ok, int j,
-                                              int half, int l31, f32x16& h1, f32x16& h2) {
-  f32x16 acc = zero16();
-#pragma unroll
-  for (int kk = 0; kk < 3; ++kk) {
-    const float xv = ok ? x6d[((size_t)b * NJ + j) * 6 + 2 * kk + half] : 0.f;
-    acc = mfma(L[CL_W0P + (2 * kk + half) * 32 + l31], xv, acc);
-  }
-#pragma unroll
-  for (int q = 0; q < 16; ++q) h1[q] = fmaxf(acc[q] + L[CL_B0 + acc_row(q, half)], 0.f);
-  acc = zero16();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) acc = mfma(L[CL_W2T + acc_row(q, half) * 32 + l31], h1[q], acc);
-#pragma unroll
-  for (int q = 0; q < 16; ++q) h2[q] = fmaxf(acc[q] + L[CL_B2 + acc_row(q, half)], 0.f);
-}
-
-// z_j = wh_j . h2 + bh_j for the lane's pose (both lane halves return the full sum)
-__device__ __forceinline__ float conv_head(const float* __restrict__ L, int j, int half, const f32x16& h2) {
-  float part = 0.f;
-#pragma unroll
-  for (int q = 0; q < 16; ++q) part = fmaf(L[CL_WH + j * 33 + acc_row(q, half)], h2[q], part);
-  return part + __shfl_xor(part, 32) + L[CL_WH + j * 33 + 32];
-}
-
-// grid = (BP / 32) * 6 workgroups of 4 waves; wave w of block (bt, jg) owns poses [32 bt, +32) and joint 4 jg + w
+// stand-alone launches (operator-level entry points, outer-step paths): (BP / 32) * 6 workgroups of 4 waves
 template <bool QUAD>
-__global__ __launch_bounds__(256) void k_dconv_fwd(const float* __restrict__ P, const float* __restrict__ x6d,
+__global__ __launch_bounds__(256) void k_dconv_fwd(const float* __restrict__ img, const float* __restrict__ x6d,
                                                    float* __restrict__ H2T, float* __restrict__ out, int B, int BP) {
   __shared__ __attribute__((aligned(16))) float L[CL_FLOATS];
-  conv_stage_params(P, L);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-  const int bt = blockIdx.x / 6, j = (blockIdx.x % 6) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = bt * 32 + l31;
-  const bool ok = b < B;
-  f32x16 h1, h2;
-  conv_mlp_tile(L, x6d, b, ok, j, half, l31, h1, h2);
-  if (QUAD) {      // [row/4][pose][4]: registers 4g .. 4g+3 are one quad of this lane's pose (jrr_common.h)
-    const unsigned qoff = (unsigned)half * (unsigned)BP + (unsigned)b;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f32x4 t = {h2[4 * g], h2[4 * g + 1], h2[4 * g + 2], h2[4 * g + 3]};
-      if (!ok) t = f32x4{0.f, 0.f, 0.f, 0.f};
-      *quad_ptr(H2T, (size_t)j * 8, g, BP, qoff) = t;
-    }
-  } else {
-    const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)b;
-#pragma unroll
-    for (int q = 0; q < 16; ++q) urow(H2T, (size_t)(j * 32 + acc_row_u(q)), BP)[voff] = ok ? h2[q] : 0.f;   // padded poses: zeros
-  }
-  if (out) {
-    const float z = conv_head(L, j, half, h2);
-    if (ok && half == 0) out[(size_t)b * 25 + 1 + j] = sigmoidf(z);
-  }
+  dconv_fwd_body<QUAD>(L, blockIdx.x, img, x6d, H2T, out, B, BP);
 }
-
-// input gradient of the per-joint MLP + heads; dH2T = gradient arriving from fc0 (may be NULL), gout (B,25) nullable
 template <bool QUAD>
-__global__ __launch_bounds__(256) void k_dconv_bwd(const float* __restrict__ P, const float* __restrict__ x6d,
+__global__ __launch_bounds__(256) void k_dconv_bwd(const float* __restrict__ img, const float* __restrict__ x6d,
                                                    const float* __restrict__ dH2T, const float* __restrict__ gout,
                                                    float scale, float target, float* __restrict__ gx, int B, int BP,
                                                    float* __restrict__ sqj) {
   __shared__ __attribute__((aligned(16))) float L[CL_FLOATS];
-  conv_stage_params(P, L);
-  __syncthreads();
-  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-  const int bt = blockIdx.x / 6, j = (blockIdx.x % 6) * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const int b = bt * 32 + l31;
-  const bool ok = b < B;
-  f32x16 h1, h2;
-  conv_mlp_tile(L, x6d, b, ok, j, half, l31, h1, h2);
-  const float z = conv_head(L, j, half, h2);
-  const float sg = sigmoidf(z);
-  if (sqj && ok && half == 0) sqj[(size_t)(1 + j) * BP + b] = (sg - target) * (sg - target);
-  const float up = gout ? (ok ? gout[(size_t)b * 25 + 1 + j] : 0.f) : scale * (sg - target);
-  const float dz = ok ? up * sg * (1.f - sg) : 0.f;
-  const unsigned voff = (unsigned)(4 * half) * (unsigned)BP + (unsigned)b;
-  f32x16 din = zero16();                 // gradient arriving from fc0
-  if (dH2T) {
-    if (QUAD) {
-      const unsigned qoff = (unsigned)half * (unsigned)BP + (unsigned)b;
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 t = *quad_ptr(dH2T, (size_t)j * 8, g, BP, qoff);
-        din[4 * g] = t[0]; din[4 * g + 1] = t[1]; din[4 * g + 2] = t[2]; din[4 * g + 3] = t[3];
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < 16; ++q) din[q] = urow(dH2T, (size_t)(j * 32 + acc_row_u(q)), BP)[voff];
-    }
-  }
-  f32x16 acc = zero16();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const float g = dz * L[CL_WH + j * 33 + acc_row(q, half)] + din[q];
-    const float dh2 = (h2[q] > 0.f) ? g : 0.f;
-    acc = mfma(L[CL_W2 + acc_row(q, half) * 32 + l31], dh2, acc);        // dh1[c] += W2[o][c] dh2[o]
-  }
-  f32x16 accx = zero16();
-#pragma unroll
-  for (int q = 0; q < 16; ++q) {
-    const float dh1 = (h1[q] > 0.f) ? acc[q] : 0.f;
-    accx = mfma(L[CL_W0A + acc_row(q, half) * 32 + l31], dh1, accx);     // gx[c6] += W0[o][c6] dh1[o]
-  }
-  if (ok) {      // rows 0..3 live in registers 0..3 of lane half 0, rows 4,5 in registers 0,1 of half 1
-    typedef float f32x2 __attribute__((ext_vector_type(2)));
-    f32x2* dst = reinterpret_cast<f32x2*>(gx + ((size_t)b * NJ + j) * 6 + 4 * half);     // 8-byte aligned: even float offset
-    dst[0] = f32x2{accx[0], accx[1]};
-    if (half == 0) dst[1] = f32x2{accx[2], accx[3]};
-  }
+  dconv_bwd_body<QUAD>(L, blockIdx.x, img, x6d, dH2T, gout, scale, target, gx, B, BP, sqj);
 }
-
 // output layer: z = fc4.w . a2 + fc4.b ; s = sigmoid(z) ; dz = scale (s - target) s (1-s) ;
 // dA2T[n][b] = relu'(a2[n][b]) * w[n] * dz.  Block = 1024 threads = 16 waves x 64 poses,
 // wave q handles n in [64q, 64q+64).

@@ -8,6 +8,7 @@
 //   Adam                       torch.optim.Adam defaults, scripts/optimize.py:201-202,263-265
 #include "jrr_common.h"
 #include "kernels.h"
+#include "dconv.h"
 
 namespace jrr {
 
@@ -232,16 +233,16 @@ __device__ __forceinline__ void rest_joint(const float* __restrict__ Jt, const f
 // ------------------------------------------------------------------------------------------
 constexpr int PP = 32;   // poses per block of the (pose, joint)-parallel kernels
 
-__global__ __launch_bounds__(PP * NJ) void k_prep_fwd(const float* __restrict__ x6d, const float* __restrict__ Rin,
-                                                      const float* __restrict__ betas, const float* __restrict__ Jt,
-                                                      const float* __restrict__ JS, Parents par, float* __restrict__ FT,
-                                                      float* __restrict__ AT, float* __restrict__ R0T, int B, int BP,
-                                                      int32_t* step_inc) {
+__device__ __forceinline__ void prep_fwd_body(int blk, const float* __restrict__ x6d, const float* __restrict__ Rin,
+                                              const float* __restrict__ betas, const float* __restrict__ Jt,
+                                              const float* __restrict__ JS, const Parents& par, float* __restrict__ FT,
+                                              float* __restrict__ AT, float* __restrict__ R0T, int B, int BP,
+                                              int32_t* step_inc) {
   __shared__ float Gs[NJ][12][PP];
   __shared__ float Js[NJ][3][PP];
   const int bl = threadIdx.x & (PP - 1), j = threadIdx.x / PP;
-  const int b = blockIdx.x * PP + bl;
-  if (step_inc && blockIdx.x == 0 && threadIdx.x == 0) step_inc[0] += 1;   // Adam step count of this iteration
+  const int b = blk * PP + bl;
+  if (step_inc && blk == 0 && threadIdx.x == 0) step_inc[0] += 1;   // Adam step count of this iteration
   const bool ok = b < B;
   float R[9], J[3] = {0.f, 0.f, 0.f}, beta[NB];
   Rot6 c;
@@ -311,6 +312,29 @@ __global__ __launch_bounds__(PP * NJ) void k_prep_fwd(const float* __restrict__ 
     AT[(size_t)((r * 4 + 3) * NJ + j) * BP + b] =
         ok ? G[r * 4 + 3] - (G[r * 4 + 0] * J[0] + G[r * 4 + 1] * J[1] + G[r * 4 + 2] * J[2]) : 0.f;
   }
+}
+
+__global__ __launch_bounds__(PP * NJ) void k_prep_fwd(const float* __restrict__ x6d, const float* __restrict__ Rin,
+                                                      const float* __restrict__ betas, const float* __restrict__ Jt,
+                                                      const float* __restrict__ JS, Parents par, float* __restrict__ FT,
+                                                      float* __restrict__ AT, float* __restrict__ R0T, int B, int BP,
+                                                      int32_t* step_inc) {
+  prep_fwd_body(blockIdx.x, x6d, Rin, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc);
+}
+
+// Horizontal fusion (fused inner loop with the pose discriminator): the chain forward and the discriminator's per-joint MLP
+// both depend on x6d only and are both latency-bound with few workgroups (128 + 256 at 4096 poses) -- one launch, different
+// CUs.  Every launch costs ~3.8 us of fixed time on this stack (a one-thread kernel measures that), so two independent small
+// kernels side by side in one launch save one of those and the shorter kernel's whole duration.
+struct DconvFwdArgs { const float* img; float* H2T; float* out; };
+__global__ __launch_bounds__(PP * NJ) void k_prep_fwd_dconv(const float* __restrict__ x6d, const float* __restrict__ betas,
+                                                            const float* __restrict__ Jt, const float* __restrict__ JS,
+                                                            Parents par, float* __restrict__ FT, float* __restrict__ AT,
+                                                            float* __restrict__ R0T, int B, int BP, int32_t* step_inc,
+                                                            DconvFwdArgs d, int nprep) {
+  __shared__ __attribute__((aligned(16))) float L[CL_FLOATS];
+  if ((int)blockIdx.x < nprep) prep_fwd_body(blockIdx.x, x6d, nullptr, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc);
+  else dconv_fwd_body<true>(L, blockIdx.x - nprep, d.img, x6d, d.H2T, d.out, B, BP);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -844,6 +868,38 @@ __global__ void k_reduce_slabs(const f32x4* __restrict__ P, int nslab, size_t st
   }
 }
 
+// Horizontal fusion of the two independent kernels that precede k_chain_bwd in the fused loop: the split-K slab sum of
+// dF^T (bandwidth-bound, 58 MB) and the per-joint MLP adjoint of the discriminator (latency-bound).  Blocks [0, ndc) are the
+// MLP workgroups (the longer dependency chain: dispatched first -- measured 2 us better than last), the rest stride over the
+// slab sum.
+struct DconvBwdArgs { const float* img; const float* x6d; const float* dH2T; const float* gout; float scale, target; float* gx; float* sqj; };
+__global__ __launch_bounds__(256) void k_dconv_bwd_reduce(DconvBwdArgs d, int ndc, int B, int BP, const f32x4* __restrict__ P,
+                                                          int nslab, size_t stride4, f32x4* __restrict__ out, size_t n4) {
+  __shared__ __attribute__((aligned(16))) float L[CL_FLOATS];
+  if ((int)blockIdx.x < ndc) {
+    dconv_bwd_body<true>(L, blockIdx.x, d.img, d.x6d, d.dH2T, d.gout, d.scale, d.target, d.gx, B, BP, d.sqj);
+  } else {
+    const size_t nb = gridDim.x - ndc;
+    for (size_t i = (size_t)(blockIdx.x - ndc) * blockDim.x + threadIdx.x; i < n4; i += nb * blockDim.x) {
+      f32x4 acc = P[i];
+      for (int sl = 1; sl < nslab; ++sl) acc += P[(size_t)sl * stride4 + i];
+      out[i] = acc;
+    }
+  }
+}
+int launch_dconv_bwd_reduce(const float* img, const float* x6d, const float* dH2T, const float* gout, float scale, float target,
+                            float* gx, float* sqj, int B, int BP, const float* P, int nslab, size_t stride, float* out, size_t n,
+                            hipStream_t s) {
+  const size_t n4 = n / 4;
+  int rblocks = (int)((n4 + 255) / 256);
+  if (rblocks > 4096) rblocks = 4096;
+  const int ndc = (BP / 32) * 6;
+  DconvBwdArgs d{img, x6d, dH2T, gout, scale, target, gx, sqj};
+  hipLaunchKernelGGL(k_dconv_bwd_reduce, dim3(ndc + rblocks), dim3(256), 0, s, d, ndc, B, BP, (const f32x4*)P, nslab, stride / 4,
+                     (f32x4*)out, n4);
+  return 0;
+}
+
 int launch_reduce_slabs(const float* P, int nslab, size_t stride, float* out, size_t n, hipStream_t s, int accumulate) {
   size_t n4 = n / 4;
   int blocks = (int)((n4 + 255) / 256);
@@ -884,6 +940,15 @@ int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const fl
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s) {
   hipLaunchKernelGGL(k_prep_fwd, dim3(BP / PP), dim3(PP * NJ), 0, s, x6d, Rin, betas, m.Jt, m.JS, m.parents, FT, AT, R0T,
                      B, BP, step_inc);
+  return 0;
+}
+
+int launch_prep_fwd_dconv(const Model& m, const float* x6d, const float* betas, float* FT, float* AT, float* R0T, int B, int BP,
+                          int32_t* step_inc, const float* img, float* H2T, float* out, hipStream_t s) {
+  const int nprep = BP / PP;
+  DconvFwdArgs d{img, H2T, out};
+  hipLaunchKernelGGL(k_prep_fwd_dconv, dim3(nprep + (BP / 32) * 2), dim3(PP * NJ), 0, s, x6d, betas, m.Jt, m.JS, m.parents, FT, AT,
+                     R0T, B, BP, step_inc, d, nprep);
   return 0;
 }
 
