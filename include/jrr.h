@@ -259,8 +259,9 @@ int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n);
  * jrr_engine_profile_read synchronises on the recorded events and writes the MEAN duration in
  * milliseconds per launch of each class into ms_host[JRR_PROF_CLASSES] and the number of samples
  * into counts_host, then clears the recorded events.  Classes:
- *   0 k_prep_fwd  1 k_lbs_fwd  2 k_joints_loss  3 k_lbs_bwd  4 k_gemm_tn (blend adjoint)
- *   5 pose discriminator (7 launches)  6 k_shape_disc  7 k_prep_bwd (+Adam)  8 silhouette (fwd+bwd) */
+ *   0 chain forward (+ the pose discriminator's per-joint MLP, same launch)  1 k_lbs_fwd  2 k_joints_loss  3 k_lbs_bwd
+ *   4 blend adjoint  5 pose discriminator: the four wide-layer products  6 k_shape_disc
+ *   7 dF slab sum (+ per-joint MLP adjoint, same launch) and k_chain_bwd (+Adam)  8 silhouette (fwd+bwd) */
 enum { JRR_PROF_CLASSES = 9 };
 int jrr_engine_set_profiling(jrr_engine_t* e, int enabled);
 int jrr_engine_profile_read(jrr_engine_t* e, float* ms_host, int32_t* counts_host);

@@ -323,7 +323,7 @@ class RefineEngine:
         check(self.lib.jrr_refine_run(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(adam_m), ptr(adam_v),
                                       ptr(step), float(lr), int(n_iters), ptr(sqerr), self._s()), 'refine_run')
 
-    PROF_CLASSES = ['k_prep_fwd', 'k_lbs_fwd', 'k_joints_loss', 'k_lbs_bwd', 'k_gemm_tn_blend_adjoint', 'pose_disc_7_launches',
+    PROF_CLASSES = ['k_prep_fwd', 'k_lbs_fwd', 'k_joints_loss', 'k_lbs_bwd', 'k_gemm_tn_blend_adjoint', 'pose_disc_gemms',
                     'k_shape_disc', 'k_prep_bwd', 'silhouette_fwd_bwd']
 
     def set_profiling(self, on: bool):

@@ -1,4 +1,4 @@
-"""Time the pose-discriminator branch alone (forward + input gradient, 6 launches) at batch 4096.
+"""Time the pose-discriminator branch alone (forward + input gradient, stand-alone: 6 launches) at batch 4096.
 usage: python tools/exp/disc_time.py [B]"""
 import importlib, os, sys, time
 import torch
