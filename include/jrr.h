@@ -216,7 +216,8 @@ int jrr_silhouette_forward(jrr_engine_t* e, const float* verts_dev, const float*
 int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha_dev, float* dverts_dev, float* dcam_dev,
                             void* stream);
 /* Enable (mask_dev != NULL, (B,224,224)) / disable the term 100 * mean((silhouette - mask)^2) of the inner
- * loop (scripts/optimize.py:234-237,252); shares the camera parameter with jrr_engine_set_reprojection.  */
+ * loop (scripts/optimize.py:234-237,252); shares the camera parameter with jrr_engine_set_reprojection.
+ * The engine caches sum(mask^2) per pose at the next jrr_refine_run: call this again after changing the mask's contents. */
 int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask_dev, float* cam_dev, float* cam_m_dev,
                               float* cam_v_dev);
 

@@ -154,7 +154,7 @@ struct jrr_engine {
   float *dsq, *ssq;                                  // per-pose squared adversarial errors of the last iteration [25][BP], [BP]
   long long* probe;                                  // shader-clock probe of k_lbs_fwd (profiling)
   float *ndc, *dvpm, *sqsil; unsigned* cover; int* ncover;   // soft silhouette (JRR_FLAG_SILHOUETTE)
-  const float* sil_mask;
+  const float* sil_mask; float* smask; bool smask_valid;     // target masks, per-pose sum(mask^2)
   float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
   bool folded, fold_valid;
   // forward reuse (jrr_engine_set_forward_reuse): state left by jrr_j_regressor_grad's SMPL forward
@@ -281,6 +281,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->cover = (unsigned*)c.take((size_t)BP * 224 * 224);
     t->ncover = (int*)c.take((size_t)BP);
     t->sqsil = c.take((size_t)BP);
+    t->smask = c.take((size_t)BP);
   }
   if (flags & JRR_FLAG_FOLDED) {
     t->JW = c.take((size_t)VP * FOLD_MJ);
@@ -881,7 +882,7 @@ extern "C" int jrr_silhouette_forward(jrr_engine_t* e, const float* verts, const
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   launch_sil_project(verts, V * 3, cam, e->ndc, e->B, s);
-  launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, nullptr, e->cover, e->ncover, alpha, nullptr, e->B, s);
+  launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, e->cover, e->ncover, alpha, e->B, s);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -905,6 +906,7 @@ extern "C" int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask, flo
     e->cam = cam; e->cam_m = cam_m; e->cam_v = cam_v;
   }
   e->sil_mask = mask;
+  e->smask_valid = false;          // sum(mask^2) per pose: recomputed on the stream of the next jrr_refine_run
   return JRR_OK;
 }
 
@@ -980,7 +982,8 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
       prof_mark(e, 8, s);
       const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * 224.0 * 224.0));
       launch_verts_untranspose(e->VTb, nullptr, 0, 0, e->cam, e->ndc, e->B, e->BP, s);   // project straight from the tiles
-      launch_sil_raster_adj(e->ndc, e->m.faces, e->m.nfaces, e->sil_mask, e->cover, e->ncover, e->sqsil, silscale, e->dvpm,
+      if (!e->smask_valid) { launch_mask_sq(e->sil_mask, e->smask, e->B, s); e->smask_valid = true; }
+      launch_sil_raster_adj(e->ndc, e->m.faces, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil, silscale, e->dvpm,
                             VP * 3, e->gcam, e->gt_j2d ? 1 : 0, e->B, s);   // forward, loss and adjoint in one kernel
       launch_dverts_transpose(e->dvpm, VP * 3, e->VTb, e->B, e->BP, s);     // the vertex buffer becomes the transposed adjoint
       prof_mark(e, 8, s);

@@ -108,10 +108,12 @@ int launch_jgrad_q(const float* dJT, const float* VTq, float* Out, int BP, int k
 int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s);
 // cover [B][224*224] / ncover [B]: the covered pixels of each pose (pixel << 14 | winning face), written by the
 // rasteriser and consumed by the adjoint
-int launch_sil_raster(const float* ndc, const int* faces, int nfaces, const float* mask, unsigned* cover, int* ncover,
-                      float* alpha, float* sqsil, int B, hipStream_t s);
-int launch_sil_raster_adj(const float* ndc, const int* faces, int nfaces, const float* mask, unsigned* cover, int* ncover,
-                          float* sqsil, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
+int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* cover, int* ncover, float* alpha, int B,
+                      hipStream_t s);
+// smask [B] = per-pose sum(mask^2) over the image (launch_mask_sq): the rasteriser only visits the mesh's pixel box
+int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s);
+int launch_sil_raster_adj(const float* ndc, const int* faces, int nfaces, const float* mask, const float* smask, unsigned* cover,
+                          int* ncover, float* sqsil, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
                           hipStream_t s);
 int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, const int* ncover, const float* mask,
                    const float* galpha, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,

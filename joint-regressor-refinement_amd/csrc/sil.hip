@@ -29,7 +29,6 @@ constexpr int SIL_STRIP = 40;            // rows per LDS z-buffer strip (40*224*
 constexpr int SIL_RT = 1024;             // threads of the raster workgroup (one workgroup per pose and per CU: LDS-bound)
 constexpr int SIL_FPT = 14;              // faces per thread, kept in registers (14 * 1024 >= 13776)
 constexpr int SIL_FBITS = 14;             // covered-pixel list entry = pixel << 14 | face (faces < 16384, pixels < 65536)
-constexpr int SIL_PPT = (40 * 224 + 1023) / 1024;   // pixels per thread and strip
 constexpr int SIL_EB = 6;                 // list entries fetched together per thread in the resolve
 static_assert((3 * V + 2) % 2 == 0, "z-buffer alignment");
 static_assert(V * 2 * 4 <= 40 * 224 * 8, "adjoint accumulators must fit the z-buffer");
@@ -100,7 +99,8 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
                                                        unsigned* __restrict__ cover, int* __restrict__ ncover,
                                                        float* __restrict__ alpha_out, float* __restrict__ sqsil,
                                                        float scale, float* __restrict__ dverts, int ldv,
-                                                       float* __restrict__ gcam, int accumulate_cam) {
+                                                       float* __restrict__ gcam, int accumulate_cam,
+                                                       const float* __restrict__ smask) {
   extern __shared__ unsigned long long smem64[];      // 8-byte aligned whatever static LDS precedes it
   float* vx = reinterpret_cast<float*>(smem64);       // [V]; the vertex arrays first: ds offsets stay < 64 KB
   unsigned long long* zb = smem64 + SIL_VPAD / 2;     // [SIL_STRIP][SIL]
@@ -113,11 +113,25 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   const int b = blockIdx.x;
   const NdcV* vb = ndc + (size_t)b * V;
   unsigned* lst = cover + (size_t)b * SIL * SIL;
+  __shared__ float bbp[4][SIL_RT / 64];   // per-wave partial bounding box of the projected vertices
   if (threadIdx.x == 0) ncov = 0;
   if (threadIdx.x < SIL) pxt[threadIdx.x] = pix_x(threadIdx.x);
+  float bxn = 3e38f, bxx = -3e38f, byn = 3e38f, byx = -3e38f;
   for (int v = threadIdx.x; v < V; v += SIL_RT) {
     const NdcV p = vb[v];
     vx[v] = p.x; vy[v] = p.y; vz[v] = p.z;
+    bxn = fminf(bxn, p.x); bxx = fmaxf(bxx, p.x); byn = fminf(byn, p.y); byx = fmaxf(byx, p.y);
+  }
+  if (alpha_out)                      // stand-alone forward: background alpha; covered pixels are overwritten in pass 2
+    for (int i = threadIdx.x; i < SIL * SIL; i += SIL_RT) alpha_out[(size_t)b * SIL * SIL + i] = 0.f;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    bxn = fminf(bxn, __shfl_xor(bxn, o)); bxx = fmaxf(bxx, __shfl_xor(bxx, o));
+    byn = fminf(byn, __shfl_xor(byn, o)); byx = fmaxf(byx, __shfl_xor(byx, o));
+  }
+  if ((threadIdx.x & 63) == 0) {
+    const int w = threadIdx.x >> 6;
+    bbp[0][w] = bxn; bbp[1][w] = bxx; bbp[2][w] = byn; bbp[3][w] = byx;
   }
   // this thread's faces: vertex indices now, pixel-row range after the vertices have landed
   int fi[SIL_FPT][3];
@@ -142,9 +156,32 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
     frow[u] = ylo | (yhi << 16);
   }
   float err = 0.f;
-  for (int y0 = 0; y0 < SIL; y0 += SIL_STRIP) {
-    const int y1 = min(y0 + SIL_STRIP, SIL);                           // rows [y0, y1)
-    for (int i = threadIdx.x; i < SIL_STRIP * SIL; i += SIL_RT) zb[i] = ~0ull;
+  // The z-buffer only ever holds the pixel bounding box of the projected mesh (a person covers 8-9 % of the crop and
+  // its box ~23 %): strips of as many box rows as fit 70 KB -- 1.8 strips per pose on the synthetic batches instead of the
+  // 6 a full-width sweep needs, and every face-sweep / clear / background pass is per strip.  Pixels outside the box
+  // are background by construction: their squared error is sum(mask^2) over the image (per pose, computed once when the
+  // mask is set) minus the covered pixels' share.
+  int bx0, bx1, by0, by1;
+  {
+    float xn = 3e38f, xx = -3e38f, yn = 3e38f, yx = -3e38f;
+#pragma unroll
+    for (int w = 0; w < SIL_RT / 64; ++w) {
+      xn = fminf(xn, bbp[0][w]); xx = fmaxf(xx, bbp[1][w]); yn = fminf(yn, bbp[2][w]); yx = fmaxf(yx, bbp[3][w]);
+    }
+    // pixel centres inside [min, max] (same formula as the per-face boxes, which are subsets); +-inf / NaN clamp to the image
+    const float fx0 = (SIL * (1.f - xx) - 1.f) * 0.5f - 1e-3f, fx1 = (SIL * (1.f - xn) - 1.f) * 0.5f + 1e-3f;
+    const float fy0 = (SIL * (1.f - yx) - 1.f) * 0.5f - 1e-3f, fy1 = (SIL * (1.f - yn) - 1.f) * 0.5f + 1e-3f;
+    bx0 = (fx0 > 0.f) ? (int)ceilf(fminf(fx0, (float)SIL)) : 0;
+    bx1 = (fx1 < (float)(SIL - 1)) ? (int)floorf(fmaxf(fx1, -1.f)) : SIL - 1;
+    by0 = (fy0 > 0.f) ? (int)ceilf(fminf(fy0, (float)SIL)) : 0;
+    by1 = (fy1 < (float)(SIL - 1)) ? (int)floorf(fmaxf(fy1, -1.f)) : SIL - 1;
+  }
+  const int bw = bx1 - bx0 + 1;
+  const int rows_per = (bw > 0) ? (SIL_STRIP * SIL) / bw : SIL;
+  for (int y0 = by0; y0 <= by1 && bw > 0; y0 += rows_per) {
+    const int y1 = min(y0 + rows_per, by1 + 1);                        // rows [y0, y1) of the box columns [bx0, bx1]
+    const int npx = (y1 - y0) * bw;
+    for (int i = threadIdx.x; i < npx; i += SIL_RT) zb[i] = ~0ull;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SIL_FPT; ++u) {
@@ -156,7 +193,7 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
       const float cx = vx[fi[u][2]], cy = vy[fi[u][2]], cz = vz[fi[u][2]];
       const float xmax = fmaxf(ax, fmaxf(bx, cx)), xmin = fminf(ax, fminf(bx, cx));
       int xlo = (int)ceilf((SIL * (1.f - xmax) - 1.f) * 0.5f - 1e-3f), xhi = (int)floorf((SIL * (1.f - xmin) - 1.f) * 0.5f + 1e-3f);
-      xlo = max(xlo, 0); xhi = min(xhi, SIL - 1);
+      xlo = max(xlo, bx0); xhi = min(xhi, bx1);
       if (xlo > xhi) continue;
       const float area = edge_fn(cx, cy, ax, ay, bx, by);
       if (!(fabsf(area) > SIL_EPS)) continue;                    // also rejects NaN
@@ -172,7 +209,7 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
         const float pz = w0 * az + w1 * bz + w2 * cz;
         if (w0 > 0.f && w1 > 0.f && w2 > 0.f && pz >= 0.f) {
           const unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
-          atomicMin(&zb[(yi - y0) * SIL + xi], key);
+          atomicMin(&zb[(yi - y0) * bw + (xi - bx0)], key);
         }
         const bool wrap = xi >= xhi;
         xi = wrap ? xlo : xi + 1;
@@ -180,34 +217,24 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
       }
     }
     __syncthreads();
-    // resolve, pass 1: background pixels are finished here; covered pixels are appended to the pose's list
-    // (pixel << 14 | face) -- 8-9 % of the image, handled densely in pass 2 instead of under divergence here.
-    // The thread's <= 9 pixels are fetched together; one LDS atomic per wave reserves the list slots.
+    // resolve, pass 1: the covered pixels (8-9 % of the image) are appended to the pose's list (pixel << 14 | face) and
+    // handled densely in pass 2 instead of under divergence here; one LDS atomic per wave reserves the list slots.
+    // One box row per wave and step, lanes over the columns.
     {
-      unsigned long long key[SIL_PPT];
-      float mk[SIL_PPT];
-      const int npx = (y1 - y0) * SIL;
-#pragma unroll
-      for (int k = 0; k < SIL_PPT; ++k) {
-        const int i = threadIdx.x + k * SIL_RT;
-        key[k] = (i < npx) ? zb[i] : ~0ull;
-        mk[k] = (mask && i < npx) ? mask[(size_t)b * SIL * SIL + y0 * SIL + i] : 0.f;
-      }
-#pragma unroll
-      for (int k = 0; k < SIL_PPT; ++k) {
-        const int i = threadIdx.x + k * SIL_RT;
-        const bool cov = key[k] != ~0ull;
-        const unsigned long long bal = __ballot(cov);
-        if (bal) {                                                       // wave-uniform
-          const int lane = threadIdx.x & 63, leader = __ffsll((long long)bal) - 1;
-          int base = 0;
-          if (lane == leader) base = atomicAdd(&ncov, __popcll(bal));
-          base = __shfl(base, leader);
-          if (cov) lst[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned)(y0 * SIL + i) << SIL_FBITS) | (unsigned)(key[k] & 0xffffffffu);
-        }
-        if (!cov && i < npx) {
-          if (alpha_out) alpha_out[(size_t)b * SIL * SIL + y0 * SIL + i] = 0.f;
-          err += mk[k] * mk[k];
+      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      for (int r = wave; r < y1 - y0; r += SIL_RT / 64) {
+        for (int x0 = 0; x0 < bw; x0 += 64) {
+          const int x = x0 + lane;
+          const unsigned long long key = (x < bw) ? zb[r * bw + x] : ~0ull;
+          const bool cov = key != ~0ull;
+          const unsigned long long bal = __ballot(cov);
+          if (bal) {                                                       // wave-uniform
+            const int leader = __ffsll((long long)bal) - 1;
+            int base = 0;
+            if (lane == leader) base = atomicAdd(&ncov, __popcll(bal));
+            base = __shfl(base, leader);
+            if (cov) lst[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned)((y0 + r) * SIL + bx0 + x) << SIL_FBITS) | (unsigned)(key & 0xffffffffu);
+          }
         }
       }
     }
@@ -250,7 +277,7 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
       const float dist = sil_nearest_edge(px, py, x, y, ka, tt);
       const float al = sil_alpha(dist);
       if (alpha_out) alpha_out[(size_t)b * SIL * SIL + pix] = al;
-      if (mask) { const float dm = al - tg[u]; err += dm * dm; }
+      if (mask) { const float dm = al - tg[u]; err += dm * dm - tg[u] * tg[u]; }   // (the pixel's background share is in smask)
       if (ADJ) {
         const float gd = scale * (al - tg[u]) * al * (1.f - al) * SIL_ISIGMA;          // d loss / d dist
         if (gd == 0.f) continue;
@@ -305,7 +332,7 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
       if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
       __syncthreads();
     }
-    if (threadIdx.x == 0) sqsil[b] = red[0];
+    if (threadIdx.x == 0) sqsil[b] = red[0] + (smask ? smask[b] : 0.f);
   }
 }
 
@@ -406,6 +433,25 @@ __global__ __launch_bounds__(SIL_BT) void k_sil_bwd(const NdcV* __restrict__ ndc
   }
 }
 
+// per-pose sum(mask^2) over the image (the squared error of an all-background rendering), once per mask
+__global__ __launch_bounds__(256) void k_mask_sq(const float* __restrict__ mask, float* __restrict__ smask) {
+  __shared__ float red[256];
+  const int b = blockIdx.x;
+  float acc = 0.f;
+  for (int i = threadIdx.x; i < SIL * SIL; i += 256) { const float m = mask[(size_t)b * SIL * SIL + i]; acc = fmaf(m, m, acc); }
+  red[threadIdx.x] = acc;
+  __syncthreads();
+  for (int s = 128; s > 0; s >>= 1) {
+    if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) smask[b] = red[0];
+}
+int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_mask_sq, dim3(B), dim3(256), 0, s, mask, smask);
+  return 0;
+}
+
 static bool g_sil_attr = false;
 static void sil_attrs() {
   if (g_sil_attr) return;
@@ -418,23 +464,23 @@ int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc
   hipLaunchKernelGGL(k_sil_project, dim3((B * V + 255) / 256), dim3(256), 0, s, verts, ldv, cam, (NdcV*)ndc, B);
   return 0;
 }
-int launch_sil_raster(const float* ndc, const int* faces, int nfaces, const float* mask, unsigned* cover, int* ncover,
-                      float* alpha, float* sqsil, int B, hipStream_t s) {
+int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* cover, int* ncover, float* alpha, int B,
+                      hipStream_t s) {
   sil_attrs();
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
   hipLaunchKernelGGL(k_sil_raster<false>, dim3(B), dim3(SIL_RT), SIL_VPAD * 4 + SIL_STRIP * SIL * 8, s, (const NdcV*)ndc, faces,
-                     nfaces, mask, cover, ncover, alpha, sqsil, 0.f, nullptr, 0, nullptr, 0);
+                     nfaces, nullptr, cover, ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, 0, nullptr);
   return 0;
 }
 // rasterise + squared error against mask + the adjoint of scale/2 * sum((alpha - mask)^2) in one kernel;
 // writes ALL of dverts[b][0 .. 6890*3); gcam: overwrite or accumulate
-int launch_sil_raster_adj(const float* ndc, const int* faces, int nfaces, const float* mask, unsigned* cover, int* ncover,
-                          float* sqsil, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
+int launch_sil_raster_adj(const float* ndc, const int* faces, int nfaces, const float* mask, const float* smask, unsigned* cover,
+                          int* ncover, float* sqsil, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
                           hipStream_t s) {
   sil_attrs();
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
   hipLaunchKernelGGL(k_sil_raster<true>, dim3(B), dim3(SIL_RT), SIL_VPAD * 4 + SIL_STRIP * SIL * 8, s, (const NdcV*)ndc, faces,
-                     nfaces, mask, cover, ncover, nullptr, sqsil, scale, dverts, ldv, gcam, accumulate_cam);
+                     nfaces, mask, cover, ncover, nullptr, sqsil, scale, dverts, ldv, gcam, accumulate_cam, smask);
   return 0;
 }
 // writes ALL of dverts[b][0 .. 6890*3) (no zero-fill needed); gcam: overwrite or accumulate
