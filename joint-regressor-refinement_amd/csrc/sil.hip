@@ -10,7 +10,7 @@
 // Kernels (one mesh = 6890 vertices / 13776 faces of ~1 pixel each at 224x224):
 //   k_sil_project  per (pose, vertex): world -> (x_ndc, y_ndc, view depth Z)
 //   k_sil_raster   per pose (one 1024-thread workgroup, ~155 KB LDS): projected vertices resident in LDS, face
-//                  indices in registers; the image is swept in 40-row strips: each thread tests the pixel centres
+//                  indices in registers; the pixel box of the projected mesh is swept in strips of 8960 pixels: each thread tests the pixel centres
 //                  inside its faces' bounding boxes and keeps the nearest face per pixel with a 64-bit atomicMin on
 //                  an LDS z-buffer keyed (depth bits << 32 | face index).  Background pixels are finished per
 //                  strip; covered pixels (8-9 %) go to a per-pose list (pixel << 14 | face) and are resolved densely
@@ -25,7 +25,7 @@
 namespace jrr {
 
 constexpr int SIL = 224;                 // image size (scripts/optimize.py:110 Mesh_Renderer(image_size=224))
-constexpr int SIL_STRIP = 40;            // rows per LDS z-buffer strip (40*224*8 B = 70 KB; 6 strips, the last of 24 rows)
+constexpr int SIL_STRIP = 40;            // z-buffer capacity in full-width rows (40*224*8 B = 70 KB); strips cover the mesh's pixel box
 constexpr int SIL_RT = 1024;             // threads of the raster workgroup (one workgroup per pose and per CU: LDS-bound)
 constexpr int SIL_FPT = 14;              // faces per thread, kept in registers (14 * 1024 >= 13776)
 constexpr int SIL_FBITS = 14;             // covered-pixel list entry = pixel << 14 | face (faces < 16384, pixels < 65536)
@@ -87,7 +87,7 @@ __device__ __forceinline__ float sil_alpha(float dist) { return 1.f / (1.f + exp
 
 // One workgroup per pose.  The pose's projected vertices (3 x 6890 floats = 81 KB) are loaded ONCE into LDS and
 // each thread keeps the vertex indices of its <= 14 faces (and their pixel-row ranges) in registers, so the only
-// global traffic of the face passes is zero: the image is swept in 6 strips of 40 rows (LDS z-buffer 70 KB), and a
+// global traffic of the face passes is zero: the mesh's pixel box is swept in strips of <= 8960 pixels (LDS z-buffer 70 KB), and a
 // face is only touched in the strip(s) its rows fall into.
 //
 // ADJ (the fused inner loop): the adjoint of scale * sum((alpha - mask)^2)/2... i.e. g_alpha = scale * (alpha - mask)
