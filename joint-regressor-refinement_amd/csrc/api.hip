@@ -153,7 +153,7 @@ struct jrr_engine {
   float *Ps, *gb;
   float *dsq, *ssq;                                  // per-pose squared adversarial errors of the last iteration [25][BP], [BP]
   long long* probe;                                  // shader-clock probe of k_lbs_fwd (profiling)
-  float *ndc, *dvpm, *sqsil; unsigned* cover; int* ncover;   // soft silhouette (JRR_FLAG_SILHOUETTE)
+  float *ndc, *sqsil; unsigned* cover; int* ncover;   // soft silhouette (JRR_FLAG_SILHOUETTE)
   const float* sil_mask; float* smask; bool smask_valid;     // target masks, per-pose sum(mask^2)
   float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
   bool folded, fold_valid;
@@ -277,7 +277,6 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   if (flags & (JRR_FLAG_SILHOUETTE | JRR_FLAG_KEEP_VERTS)) t->VTb = c.take((size_t)3 * VP * BP);
   if (flags & JRR_FLAG_SILHOUETTE) {
     t->ndc = c.take((size_t)BP * V * 4);
-    t->dvpm = c.take((size_t)BP * VP * 3);
     t->cover = (unsigned*)c.take((size_t)BP * 224 * 224);
     t->ncover = (int*)c.take((size_t)BP);
     t->sqsil = c.take((size_t)BP);
@@ -981,11 +980,10 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     if (sil) {   // 100 * mean((silhouette - mask)^2), optimize.py:234-237,252
       prof_mark(e, 8, s);
       const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * 224.0 * 224.0));
-      launch_verts_untranspose(e->VTb, nullptr, 0, 0, e->cam, e->ndc, e->B, e->BP, s);   // project straight from the tiles
       if (!e->smask_valid) { launch_mask_sq(e->sil_mask, e->smask, e->B, s); e->smask_valid = true; }
-      launch_sil_raster_adj(e->ndc, e->m.faces, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil, silscale, e->dvpm,
-                            VP * 3, e->gcam, e->gt_j2d ? 1 : 0, e->B, s);   // forward, loss and adjoint in one kernel
-      launch_dverts_transpose(e->dvpm, VP * 3, e->VTb, e->B, e->BP, s);     // the vertex buffer becomes the transposed adjoint
+      // projection, rasterisation, loss and adjoint in one kernel, straight from / into the row-quad vertex buffer
+      launch_sil_raster_adj(e->VTb, e->BP, e->cam, e->m.faces, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil,
+                            silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s);
       prof_mark(e, 8, s);
     }
     prof_mark(e, 3, s);

@@ -112,8 +112,8 @@ int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* 
                       hipStream_t s);
 // smask [B] = per-pose sum(mask^2) over the image (launch_mask_sq): the rasteriser only visits the mesh's pixel box
 int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s);
-int launch_sil_raster_adj(const float* ndc, const int* faces, int nfaces, const float* mask, const float* smask, unsigned* cover,
-                          int* ncover, float* sqsil, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
+int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
+                          unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
                           hipStream_t s);
 int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, const int* ncover, const float* mask,
                    const float* galpha, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,

@@ -93,12 +93,19 @@ __device__ __forceinline__ float sil_alpha(float dist) { return 1.f / (1.f + exp
 // ADJ (the fused inner loop): the adjoint of scale * sum((alpha - mask)^2)/2... i.e. g_alpha = scale * (alpha - mask)
 // is taken in the same kernel: after the last strip the z-buffer's LDS holds the vertex-adjoint accumulators,
 // written out pose-major.
+// ADJ also selects the vertex interface: <false> (stand-alone forward) reads the projected records `ndc` written by
+// k_sil_project; <true> (fused loop) reads the pose's vertices straight from the LBS kernels' row-quad buffer
+// VQ [3][VP/4][BP][4] (16-byte pieces, one per vertex quad and plane), projects them itself, and at the end OVERWRITES the
+// same pieces with the vertex adjoint -- the layout k_lbs_bwd<2> consumes.  No pose-major copies of the vertices or of
+// their adjoint exist (two transposes of 0.35 ms and 0.8 GB of buffers gone).  A 128-byte line of VQ holds 8 consecutive
+// poses, so consecutive poses are given to the SAME XCD (blockIdx % 8 selects the XCD) and meet in its L2.
 template <bool ADJ>
 __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ ndc, const int* __restrict__ faces,
                                                        int nfaces, const float* __restrict__ mask,
                                                        unsigned* __restrict__ cover, int* __restrict__ ncover,
                                                        float* __restrict__ alpha_out, float* __restrict__ sqsil,
-                                                       float scale, float* __restrict__ dverts, int ldv,
+                                                       float scale, float* __restrict__ VQ, int BP,
+                                                       const float* __restrict__ cam, int B,
                                                        float* __restrict__ gcam, int accumulate_cam,
                                                        const float* __restrict__ smask) {
   extern __shared__ unsigned long long smem64[];      // 8-byte aligned whatever static LDS precedes it
@@ -110,17 +117,45 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   __shared__ float gcs[3];
   __shared__ float pxt[SIL];          // pixel centres
   __shared__ int ncov;
-  const int b = blockIdx.x;
+  int b = blockIdx.x;
+  if (ADJ) {                                 // poses [x per, (x + 1) per) on XCD x; BP is a multiple of 128
+    const int per = BP >> 3;
+    b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
+    if (b >= B) {                            // padded pose (whole workgroup): its adjoint is zero
+      f32x4* P4 = reinterpret_cast<f32x4*>(VQ);
+      for (int q = threadIdx.x; q < 3 * (VP / 4); q += SIL_RT) P4[(size_t)q * BP + b] = f32x4{0.f, 0.f, 0.f, 0.f};
+      return;
+    }
+  }
   const NdcV* vb = ndc + (size_t)b * V;
   unsigned* lst = cover + (size_t)b * SIL * SIL;
   __shared__ float bbp[4][SIL_RT / 64];   // per-wave partial bounding box of the projected vertices
   if (threadIdx.x == 0) ncov = 0;
   if (threadIdx.x < SIL) pxt[threadIdx.x] = pix_x(threadIdx.x);
   float bxn = 3e38f, bxx = -3e38f, byn = 3e38f, byx = -3e38f;
-  for (int v = threadIdx.x; v < V; v += SIL_RT) {
-    const NdcV p = vb[v];
-    vx[v] = p.x; vy[v] = p.y; vz[v] = p.z;
-    bxn = fminf(bxn, p.x); bxx = fmaxf(bxx, p.x); byn = fminf(byn, p.y); byx = fmaxf(byx, p.y);
+  f32x4* VQ4 = reinterpret_cast<f32x4*>(VQ);
+  float tcam[3] = {0.f, 0.f, 0.f};
+  if (ADJ) {
+    tcam[0] = cam[(size_t)b * 3]; tcam[1] = cam[(size_t)b * 3 + 1]; tcam[2] = cam[(size_t)b * 3 + 2];
+    for (int q = threadIdx.x; q < VP / 4; q += SIL_RT) {
+      const f32x4 t0 = VQ4[(size_t)q * BP + b], t1 = VQ4[((size_t)(VP / 4) + q) * BP + b], t2 = VQ4[((size_t)2 * (VP / 4) + q) * BP + b];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int v = 4 * q + u;
+        if (v < V) {      // scripts/optimize.py:80-82 flip / scale + mesh_renderer.py:52-57 camera (k_sil_project's arithmetic)
+          const float X = -2.f * t0[u] + tcam[0], Y = -2.f * t1[u] + tcam[1], Z = 2.f * t2[u] + tcam[2];
+          const float xn = SIL_F * X / Z, yn = SIL_F * Y / Z;
+          vx[v] = xn; vy[v] = yn; vz[v] = Z;
+          bxn = fminf(bxn, xn); bxx = fmaxf(bxx, xn); byn = fminf(byn, yn); byx = fmaxf(byx, yn);
+        }
+      }
+    }
+  } else {
+    for (int v = threadIdx.x; v < V; v += SIL_RT) {
+      const NdcV p = vb[v];
+      vx[v] = p.x; vy[v] = p.y; vz[v] = p.z;
+      bxn = fminf(bxn, p.x); bxx = fmaxf(bxx, p.x); byn = fminf(byn, p.y); byx = fmaxf(byx, p.y);
+    }
   }
   if (alpha_out)                      // stand-alone forward: background alpha; covered pixels are overwritten in pass 2
     for (int i = threadIdx.x; i < SIL * SIL; i += SIL_RT) alpha_out[(size_t)b * SIL * SIL + i] = 0.f;
@@ -302,18 +337,25 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   }
   if (ADJ) {
     __syncthreads();
-    float* dv = dverts + (size_t)b * ldv;
     float gc[3] = {0.f, 0.f, 0.f};
-    for (int v = threadIdx.x; v < V; v += SIL_RT) {
-      const float Gx = acc[v * 2], Gy = acc[v * 2 + 1];
-      float g[3] = {0.f, 0.f, 0.f};
-      if (Gx != 0.f || Gy != 0.f) {
-        const float iz = 1.f / vz[v];
-        g[0] = SIL_F * iz * Gx; g[1] = SIL_F * iz * Gy; g[2] = -(vx[v] * Gx + vy[v] * Gy) * iz;
-      }
-      dv[v * 3] = -2.f * g[0]; dv[v * 3 + 1] = -2.f * g[1]; dv[v * 3 + 2] = 2.f * g[2];
+    for (int q = threadIdx.x; q < VP / 4; q += SIL_RT) {       // the pose's pieces of VQ now take the vertex adjoint
+      f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, o2 = o0;
 #pragma unroll
-      for (int c = 0; c < 3; ++c) gc[c] += g[c];
+      for (int u = 0; u < 4; ++u) {
+        const int v = 4 * q + u;
+        if (v < V) {
+          const float Gx = acc[v * 2], Gy = acc[v * 2 + 1];
+          float g[3] = {0.f, 0.f, 0.f};
+          if (Gx != 0.f || Gy != 0.f) {
+            const float iz = 1.f / vz[v];
+            g[0] = SIL_F * iz * Gx; g[1] = SIL_F * iz * Gy; g[2] = -(vx[v] * Gx + vy[v] * Gy) * iz;
+          }
+          o0[u] = -2.f * g[0]; o1[u] = -2.f * g[1]; o2[u] = 2.f * g[2];
+#pragma unroll
+          for (int c = 0; c < 3; ++c) gc[c] += g[c];
+        }
+      }
+      VQ4[(size_t)q * BP + b] = o0; VQ4[((size_t)(VP / 4) + q) * BP + b] = o1; VQ4[((size_t)2 * (VP / 4) + q) * BP + b] = o2;
     }
     if (gcam) {                                                          // wave sums, then 16 LDS atomics per component
       if (threadIdx.x < 3) gcs[threadIdx.x] = 0.f;
@@ -476,18 +518,20 @@ int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* 
   sil_attrs();
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
   hipLaunchKernelGGL(k_sil_raster<false>, dim3(B), dim3(SIL_RT), SIL_VPAD * 4 + SIL_STRIP * SIL * 8, s, (const NdcV*)ndc, faces,
-                     nfaces, nullptr, cover, ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, 0, nullptr);
+                     nfaces, nullptr, cover, ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr);
   return 0;
 }
-// rasterise + squared error against mask + the adjoint of scale/2 * sum((alpha - mask)^2) in one kernel;
-// writes ALL of dverts[b][0 .. 6890*3); gcam: overwrite or accumulate
-int launch_sil_raster_adj(const float* ndc, const int* faces, int nfaces, const float* mask, const float* smask, unsigned* cover,
-                          int* ncover, float* sqsil, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
+// fused loop: project the pose's vertices from the row-quad buffer VQ [3][VP/4][BP][4], rasterise, squared error against
+// mask, and the adjoint of scale/2 * sum((alpha - mask)^2) written back over the same pieces of VQ; gcam: overwrite or
+// accumulate
+int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
+                          unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
                           hipStream_t s) {
   sil_attrs();
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
-  hipLaunchKernelGGL(k_sil_raster<true>, dim3(B), dim3(SIL_RT), SIL_VPAD * 4 + SIL_STRIP * SIL * 8, s, (const NdcV*)ndc, faces,
-                     nfaces, mask, cover, ncover, nullptr, sqsil, scale, dverts, ldv, gcam, accumulate_cam, smask);
+  const int grid = BP;                     // pose = (block % 8) * (BP / 8) + block / 8; blocks of padded poses zero their pieces
+  hipLaunchKernelGGL(k_sil_raster<true>, dim3(grid), dim3(SIL_RT), SIL_VPAD * 4 + SIL_STRIP * SIL * 8, s, (const NdcV*)nullptr, faces,
+                     nfaces, mask, cover, ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask);
   return 0;
 }
 // writes ALL of dverts[b][0 .. 6890*3) (no zero-fill needed); gcam: overwrite or accumulate
