@@ -31,7 +31,7 @@ constexpr int SIL_FPT = 14;              // faces per thread, kept in registers 
 constexpr int SIL_FBITS = 14;             // covered-pixel list entry = pixel << 14 | face (faces < 16384, pixels < 65536)
 constexpr int SIL_EB = 6;                 // list entries fetched together per thread in the resolve
 static_assert((3 * V + 2) % 2 == 0, "z-buffer alignment");
-static_assert(V * 2 * 4 <= 40 * 224 * 8, "adjoint accumulators must fit the z-buffer");
+static_assert(V * 8 <= 40 * 224 * 8, "adjoint accumulators must fit the z-buffer");
 constexpr int SIL_VPAD = 3 * V + 2;      // floats of the LDS vertex arrays, padded so the u64 z-buffer is 8-byte aligned
 constexpr float SIL_F = 5000.f / 224.f;  // NDC focal length
 // BlendParams sigma = 1e-4 (mesh_renderer.py:28); only its reciprocal is used
@@ -114,7 +114,6 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   float* vy = vx + V;
   float* vz = vx + 2 * V;
   __shared__ float red[SIL_RT];
-  __shared__ float gcs[3];
   __shared__ float pxt[SIL];          // pixel centres
   __shared__ int ncov;
   int b = blockIdx.x;
@@ -289,10 +288,21 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   // z-buffer's LDS (2 x 6890 floats); the chain through x_ndc = f X / Z, y_ndc = f Y / Z is linear in (G_x, G_y)
   // with per-VERTEX coefficients and is applied once per vertex at write-out:
   //   gX = f G_x / Z, gY = f G_y / Z, gZ = -(x G_x + y G_y) / Z;  d/d verts = (-2 gX, -2 gY, 2 gZ), d/d cam = (gX, gY, gZ)
-  // (LDS float atomics retire one lane at a time: 4 per covered pixel instead of 6, and one sweep.)
-  float* acc = reinterpret_cast<float*>(zb);
+  // LDS atomics retire about one lane per 2.5 clocks, so their NUMBER is what counts: (G_x, G_y) of a vertex are kept as two
+  // 32-bit fixed-point integers in ONE 64-bit word, value = (ix << 32) + iy as a signed 64-bit sum, added with one
+  // ds_add_u64 -- 2 atomics per covered pixel (6 in world space, 4 with float pairs; 10.5 of the pass's 19.7 us were
+  // atomics).  Integer addition is associative: the adjoint is bitwise reproducible, which the float version was not.
+  // Quantum q = scale * 2^-19: one contribution is at most 86 scale (|c| <= 2 * 1e4 scale * |alpha - mask| * max_x
+  // e^-x sqrt(x) * 0.01), twenty of one sign on a vertex stay below 2^31 q; the rounding error per contribution,
+  // q / 2 = 1e-6 scale, is 1e-5 .. 1e-8 of the contributions that matter.
+  unsigned long long* acc = reinterpret_cast<unsigned long long*>(zb);
+  const float fq = scale * (1.f / 524288.f), fqi = (scale > 0.f) ? 524288.f / scale : 0.f;
+  auto pack2 = [&](float gx, float gy) {
+    const long long ix = (long long)__float2int_rn(gx * fqi), iy = (long long)__float2int_rn(gy * fqi);
+    return (unsigned long long)((ix << 32) + iy);
+  };
   if (ADJ) {
-    for (int i = threadIdx.x; i < V * 2; i += SIL_RT) acc[i] = 0.f;
+    for (int i = threadIdx.x; i < V; i += SIL_RT) acc[i] = 0ull;
     __syncthreads();
   }
   for (int e0 = threadIdx.x; e0 < n; e0 += SIL_RT * SIL_EB) {
@@ -330,8 +340,8 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
         // dist = |p - q|^2, q = a + t (b - a): d/da = -2 (1-t) r, d/db = -2 t r (t clamped: the same formulas)
         const float rx = px - (xa + tt * (xb - xa)), ry = py - (ya + tt * (yb - ya));
         const float ca = -2.f * (1.f - tt) * gd, cb = -2.f * tt * gd;
-        if (ca != 0.f) { atomicAdd(&acc[ida * 2], ca * rx); atomicAdd(&acc[ida * 2 + 1], ca * ry); }
-        if (cb != 0.f) { atomicAdd(&acc[idb * 2], cb * rx); atomicAdd(&acc[idb * 2 + 1], cb * ry); }
+        if (ca != 0.f) atomicAdd(&acc[ida], pack2(ca * rx, ca * ry));
+        if (cb != 0.f) atomicAdd(&acc[idb], pack2(cb * rx, cb * ry));
       }
     }
   }
@@ -344,7 +354,10 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
       for (int u = 0; u < 4; ++u) {
         const int v = 4 * q + u;
         if (v < V) {
-          const float Gx = acc[v * 2], Gy = acc[v * 2 + 1];
+          const long long sum = (long long)acc[v];
+          const int iy = (int)(unsigned)(sum & 0xffffffffll);                  // low word, sign-extended
+          const int ix = (int)((sum - (long long)iy) >> 32);
+          const float Gx = (float)ix * fq, Gy = (float)iy * fq;
           float g[3] = {0.f, 0.f, 0.f};
           if (Gx != 0.f || Gy != 0.f) {
             const float iz = 1.f / vz[v];
@@ -357,21 +370,24 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
       }
       VQ4[(size_t)q * BP + b] = o0; VQ4[((size_t)(VP / 4) + q) * BP + b] = o1; VQ4[((size_t)2 * (VP / 4) + q) * BP + b] = o2;
     }
-    if (gcam) {                                                          // wave sums, then 16 LDS atomics per component
-      if (threadIdx.x < 3) gcs[threadIdx.x] = 0.f;
-      __syncthreads();
+    if (gcam) {                                                          // wave sums, added in wave order (deterministic)
+      __syncthreads();                                                   // (red is free: nobody reads it before this point)
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float w = gc[c];
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
-        if ((threadIdx.x & 63) == 0) atomicAdd(&gcs[c], w);
+        if ((threadIdx.x & 63) == 0) red[c * (SIL_RT / 64) + (threadIdx.x >> 6)] = w;
       }
       __syncthreads();
       if (threadIdx.x < 3) {
-        if (accumulate_cam) gcam[(size_t)b * 3 + threadIdx.x] += gcs[threadIdx.x];
-        else gcam[(size_t)b * 3 + threadIdx.x] = gcs[threadIdx.x];
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < SIL_RT / 64; ++w) t += red[threadIdx.x * (SIL_RT / 64) + w];
+        if (accumulate_cam) gcam[(size_t)b * 3 + threadIdx.x] += t;
+        else gcam[(size_t)b * 3 + threadIdx.x] = t;
       }
+      __syncthreads();                                                   // red is reused by the error sum below
     }
   }
   if (sqsil) {

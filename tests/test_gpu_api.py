@@ -340,3 +340,16 @@ def test_refine_run_with_silhouette_term(smpl_hip, smpl_model_np, j_h36m_np):
     assert (cd.cpu() - c).abs().max().item() < 2e-3
     assert (cd.cpu() - cam0).abs().max().item() > 5e-3
     assert 'silhouette_loss' in hist[0]
+    # the silhouette adjoint accumulates in fixed point (integer LDS adds): the loop is bitwise reproducible
+    outs = []
+    for _ in range(2):
+        x2, b2, c2 = x6.clone().to(DEV), betas.clone().to(DEV), cam0.clone().to(DEV)
+        cm, cv = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV)
+        eng.set_silhouette(mask.to(DEV).contiguous(), c2, cm, cv)
+        m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+        step = torch.zeros(1, dtype=torch.int32, device=DEV)
+        eng.refine_run(x2, b2, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, n)
+        eng.set_silhouette(None)
+        outs.append((x2.cpu(), b2.cpu(), c2.cpu()))
+    assert all(torch.equal(a, b_) for a, b_ in zip(outs[0], outs[1]))
+    assert torch.equal(outs[0][0], xd.cpu())
