@@ -132,6 +132,16 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   if (threadIdx.x == 0) ncov = 0;
   if (threadIdx.x < SIL) pxt[threadIdx.x] = pix_x(threadIdx.x);
   float bxn = 3e38f, bxx = -3e38f, byn = 3e38f, byx = -3e38f;
+  // this thread's faces: vertex indices now (requested BEFORE the vertex loads below: both batches of loads fly together),
+  // pixel-row range after the vertices have landed
+  int fi[SIL_FPT][3];
+  int frow[SIL_FPT];                  // first row | last row << 16
+#pragma unroll
+  for (int u = 0; u < SIL_FPT; ++u) {
+    const int f = threadIdx.x + u * SIL_RT;
+#pragma unroll
+    for (int k = 0; k < 3; ++k) fi[u][k] = (f < nfaces) ? faces[f * 3 + k] : 0;
+  }
   f32x4* VQ4 = reinterpret_cast<f32x4*>(VQ);
   float tcam[3] = {0.f, 0.f, 0.f};
   if (ADJ) {
@@ -166,15 +176,6 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   if ((threadIdx.x & 63) == 0) {
     const int w = threadIdx.x >> 6;
     bbp[0][w] = bxn; bbp[1][w] = bxx; bbp[2][w] = byn; bbp[3][w] = byx;
-  }
-  // this thread's faces: vertex indices now, pixel-row range after the vertices have landed
-  int fi[SIL_FPT][3];
-  int frow[SIL_FPT];                  // first row | last row << 16
-#pragma unroll
-  for (int u = 0; u < SIL_FPT; ++u) {
-    const int f = threadIdx.x + u * SIL_RT;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) fi[u][k] = (f < nfaces) ? faces[f * 3 + k] : 0;
   }
   __syncthreads();
 #pragma unroll
