@@ -39,7 +39,8 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
     if (parents[j] >= j || (j > 0 && parents[j] < 0)) { jrr_set_error("parents[%d]=%d is not a topologically ordered tree", j, parents[j]); return JRR_ERR_ARG; }
   const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nDq = nDn, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
   const size_t nJt = 72 + 24, nJS = 720 + 16;   // padded to keep 16-byte alignment of what follows
-  std::vector<float> h(nDk + nDn + nDq + nWjv + nWvj + nJt + nJS, 0.f);
+  const size_t nWc = (size_t)VT * KJS * 32, nJl = (size_t)VT * KJS;
+  std::vector<float> h(nDk + nDn + nDq + nWjv + nWvj + nJt + nJS + nWc + nJl, 0.f);
   float* Dk = h.data();
   float* Dn = Dk + nDk;
   float* Dq = Dn + nDn;
@@ -47,6 +48,8 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   float* Wvj = Wjv + nWjv;
   float* Jt = Wvj + nWvj;
   float* JS = Jt + nJt;
+  float* Wc = JS + nJS;
+  int32_t* Jl = reinterpret_cast<int32_t*>(Wc + nWc);
   for (int v = 0; v < V; ++v) {
     const int t = v >> 5, vv = v & 31;
     for (int c = 0; c < 3; ++c) {
@@ -64,6 +67,23 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
       Wjv[((size_t)t * NJ + j) * 32 + vv] = W[(size_t)v * NJ + j];
       Wvj[((size_t)t * 32 + vv) * 32 + j] = W[(size_t)v * NJ + j];
     }
+  }
+  // joint-sparse skinning tables (jrr_common.h): per 32-vertex tile the joints with a non-zero weight
+  int sparse_ok = 1;
+  for (int t = 0; t < VT; ++t) {
+    int n = 0;
+    for (int j = 0; j < NJ; ++j) {
+      bool used = false;
+      for (int vv = 0; vv < 32 && !used; ++vv) { const int v = t * 32 + vv; used = v < V && W[(size_t)v * NJ + j] != 0.f; }
+      if (!used) continue;
+      if (n < KJS) {
+        Jl[t * KJS + n] = j;
+        for (int vv = 0; vv < 32; ++vv) { const int v = t * 32 + vv; Wc[((size_t)t * KJS + n) * 32 + vv] = v < V ? W[(size_t)v * NJ + j] : 0.f; }
+      }
+      ++n;
+    }
+    if (n > KJS) sparse_ok = 0;
+    for (; n < KJS; ++n) Jl[t * KJS + n] = 0;      // padding: joint 0 with zero weights
   }
   // folded rest-joint regressor: J(beta) = Jt + JS beta   (smplx vertices2joints(J_regressor, v_shaped))
   for (int j = 0; j < NJ; ++j)
@@ -94,6 +114,11 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   m->d.Wvj = m->d.Wjv + nWjv;
   m->d.Jt = m->d.Wvj + nWvj;
   m->d.JS = m->d.Jt + nJt;
+  m->d.Wc = m->d.JS + nJS;
+  m->d.jl = reinterpret_cast<int*>(m->d.Wc + nWc);
+  // JRR_DENSE_SKINNING=1 forces the dense kernels (verification of the joint-sparse path against them: tests)
+  { const char* dense = getenv("JRR_DENSE_SKINNING"); if (dense && dense[0] == '1') sparse_ok = 0; }
+  m->d.sparse_ok = sparse_ok;
   m->d.parents.maxd = 0;
   m->d.faces = nullptr;
   m->d.nfaces = 0;

@@ -58,12 +58,21 @@ __device__ __forceinline__ void dma16u(const float* base_uniform, unsigned lane_
   __builtin_amdgcn_global_load_lds(JRR_GLB(base_uniform + lane_off), JRR_LDS(lds_dst_wave), 16, 0, 0);
 }
 
-template <bool STORE_VP, bool STORE_VERTS>
+// SPARSE (joint-sparse skinning, Model::sparse_ok): a tile's skinning product only runs over the tile's own <= KJS
+// joints -- Wjv then is the compacted W^T [VT][KJS][32], jl the joint lists -- in THREE stages per tile (r = 0, 1, 2:
+// the four A^T blocks (r, c) of the listed joints, 16 KB; T_{r,3}, T_{r,0}, T_{r,1}, T_{r,2} = 4 x 4 MFMA; combine;
+// regressor 16 MFMA) instead of six half-stages of 24 (+16) MFMA: 423 instead of 519 MFMA per tile, 48 instead of
+// 144 KB of A^T streamed per tile.  Skipped terms are exact zeros: the result is the dense product's up to the
+// grouping of the K pairs.
+template <bool STORE_VP, bool STORE_VERTS, bool SPARSE>
 __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk, const float* __restrict__ Wjv,
                                                     const float* __restrict__ Jn_vi, const float* __restrict__ FT,
                                                     const float* __restrict__ AT, float* __restrict__ VPb,
                                                     float* __restrict__ JP, float* __restrict__ VTb, int B, int BP,
-                                                    int nvc, long long* __restrict__ probe, int paired) {
+                                                    int nvc, long long* __restrict__ probe, int paired,
+                                                    const int* __restrict__ jl) {
+  constexpr int NST = SPARSE ? NKCH + 3 : NSTAGE;            // stages per vertex tile
+  constexpr int WT_FLOATS = SPARSE ? KJS * 32 : W_FLOATS;    // W^T rows staged per tile
   __shared__ float lds[2 * STG_FLOATS + 2 * WJ_FLOATS];
   // shader-clock probe (profiling only), see jrr_engine_probe_read
   const long long probe_t0 = probe ? clock64() : 0, probe_w0 = probe ? wall_clock64() : 0;
@@ -104,6 +113,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   const unsigned lane_ln = (unsigned)lane * 4u;                                  // floats
   const float* const Fbg = FT + (size_t)bg * BG;
   const float* const Abg = AT + (size_t)bg * BG;
+  unsigned lane_jl = 0;        // SPARSE: (row of this lane's joint of the current tile) * BP + pose offset, floats
 
   // ---- DMA issue for stage s of tile vt into ring slot `slot` ----
   auto issue = [&](int vt, int s, int slot) {
@@ -120,8 +130,17 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
       }
       if (s == 0) {
         float* wdst = wj + (vt & 1) * WJ_FLOATS;
-        if (wv < 3) dma16u(Wjv + (size_t)vt * W_FLOATS + wv * 256, lane_ln, wdst + wv * 256);
+        if (wv < WT_FLOATS / 256) dma16u(Wjv + (size_t)vt * WT_FLOATS + wv * 256, lane_ln, wdst + wv * 256);
         dma16u(Jn_vi + (size_t)vt * JN_FLOATS + wv * 256, lane_ln, wdst + W_FLOATS + wv * 256);
+      }
+    } else if (SPARSE) {
+      // four blocks [KJS joints][128 poses] of A^T, components (r, 3), (r, 0), (r, 1), (r, 2); this wave copies rows
+      // 2 wv and 2 wv + 1 of each: the rows of joints jl[2 wv], jl[2 wv + 1] (lane offset `lane_jl`, set per tile)
+      const int r = s - NKCH;
+#pragma unroll
+      for (int ci = 0; ci < 4; ++ci) {
+        const int c = (ci == 0) ? 3 : ci - 1;
+        dma16u(Abg + (size_t)((r * 4 + c) * NJ) * BP, lane_jl, dst + ci * (KJS * BG) + wv * 256);
       }
     } else {
       const int h = s - NKCH, r = h >> 1;
@@ -144,19 +163,25 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   for (int vt = t_begin; vt < t_end; ++vt) {
     const float* ldsW = wj + (vt & 1) * WJ_FLOATS;
     const float* ldsJ = ldsW + W_FLOATS;
-    static_for<0, NSTAGE>([&](auto S_) {
+    if (SPARSE) {      // the skinning copies of this tile are issued from its stage NKCH - 1 on
+      const int j0 = jl[vt * KJS + 2 * wv], j1 = jl[vt * KJS + 2 * wv + 1];      // wave-uniform: scalar loads
+      lane_jl = (unsigned)(half ? j1 : j0) * (unsigned)BP + (unsigned)l31 * 4u;
+    }
+    static_for<0, NST>([&](auto S_) {
       constexpr int s = decltype(S_)::value;
       // Stage g landed; slot (g+1)&1 is free again.  The copies of stage g were issued at the start of the previous
       // stage, BEFORE that stage's v_posed / vertex stores: exactly those stores are left in flight (they get one more
       // stage to retire instead of stalling this barrier; barrier_keep_vm).  First stage of the kernel: nothing younger.
       {
-        constexpr int sp = (s == 0) ? NSTAGE - 1 : s - 1;                 // previous stage
-        constexpr int hp = sp - NKCH;                                      // its skinning half-stage, if any
-        constexpr int nst = (hp < 0) ? 0 : (STORE_VP ? 2 : 0) + ((STORE_VERTS && (hp & 1)) ? 4 : 0);
+        constexpr int sp = (s == 0) ? NST - 1 : s - 1;                    // previous stage
+        constexpr int hp = sp - NKCH;                                      // its skinning (half-)stage, if any
+        constexpr int nst = (hp < 0) ? 0
+                            : SPARSE ? (STORE_VP ? 4 : 0) + (STORE_VERTS ? 4 : 0)
+                                     : (STORE_VP ? 2 : 0) + ((STORE_VERTS && (hp & 1)) ? 4 : 0);
         if (s == 0 && vt == t_begin) barrier_keep_vm<0>();
         else barrier_keep_vm<nst>();
       }
-      if (s + 1 < NSTAGE) issue(vt, s + 1, (g + 1) & 1);
+      if (s + 1 < NST) issue(vt, s + 1, (g + 1) & 1);
       else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);   // the counted wait above relies on: copies first, this stage's stores after
       const float* buf = ring + (g & 1) * STG_FLOATS;
@@ -186,6 +211,56 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
           __builtin_amdgcn_sched_barrier(0);
           vp[1] = mfma(c1, fc, vp[1]);
           vp[2] = mfma(c2, fc, vp[2]);
+        }
+      } else if constexpr (SPARSE) {
+        constexpr int r = s - NKCH;
+        if (STORE_VP) {   // v_posed plane r leaves with skinning stage r: four 16-byte row quads
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 t = {vp[r][4 * g4], vp[r][4 * g4 + 1], vp[r][4 * g4 + 2], vp[r][4 * g4 + 3]};
+            *quad_ptr(VPb, (size_t)r * (VP / 4) + vt * 8, g4, BP, qoff) = t;
+          }
+        }
+        const float* wp = ldsW + half * 32 + l31;                       // W^T rows of the listed joints: row 2 p + half
+        const float* ab = buf + half * BG + wave * BT + l31;             // block ci at + ci * KJS * BG, row pair p at + 2 p BG
+        float w[KJS / 2], x0[KJS / 2], x1[KJS / 2];
+#pragma unroll
+        for (int pq = 0; pq < KJS / 2; ++pq) { w[pq] = wp[2 * pq * 32]; x0[pq] = ab[2 * pq * BG]; x1[pq] = ab[KJS * BG + 2 * pq * BG]; }
+        f32x16 T = zero16(), U = zero16();
+        float y0[KJS / 2], y1[KJS / 2];
+#pragma unroll
+        for (int pq = 0; pq < KJS / 2; ++pq) {                            // T_{r,3}, T_{r,0}; the next two blocks' operands meanwhile
+          T = mfma(w[pq], x0[pq], T);
+          y0[pq] = ab[2 * KJS * BG + 2 * pq * BG]; y1[pq] = ab[3 * KJS * BG + 2 * pq * BG];
+          U = mfma(w[pq], x1[pq], U);
+        }
+        vr = T + U * vp[0];                      // T_{r,3} + T_{r,0} v_x
+        T = zero16(); U = zero16();
+#pragma unroll
+        for (int pq = 0; pq < KJS / 2; ++pq) {                            // T_{r,1}, T_{r,2}
+          T = mfma(w[pq], y0[pq], T);
+          U = mfma(w[pq], y1[pq], U);
+        }
+        vr += T * vp[1];                         // T_{r,1} v_y
+        vr += U * vp[2];                         // T_{r,2} v_z
+        if (STORE_VERTS) {
+#pragma unroll
+          for (int g4 = 0; g4 < 4; ++g4) {
+            const f32x4 t = {vr[4 * g4], vr[4 * g4 + 1], vr[4 * g4 + 2], vr[4 * g4 + 3]};
+            *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g4, BP, qoff) = t;
+          }
+        }
+        {   // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b]; three steps ahead: one MFMA per step
+          float j0 = ldsJ[acc_row(0, half) * 32 + l31], j1 = ldsJ[acc_row(1, half) * 32 + l31], j2 = ldsJ[acc_row(2, half) * 32 + l31];
+#pragma unroll
+          for (int q = 0; q < 16; ++q) {
+            const float jc = j0;
+            j0 = j1; j1 = j2;
+            __builtin_amdgcn_sched_barrier(0);
+            jacc[r] = mfma(jc, vr[q], jacc[r]);
+            __builtin_amdgcn_sched_barrier(0);
+            if (q + 3 < 16) j2 = ldsJ[acc_row(q + 3, half) * 32 + l31];
+          }
         }
       } else {
         constexpr int h = s - NKCH, r = h >> 1;
@@ -259,7 +334,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     }
   if (probe && blockIdx.x == 0 && tid == 0) {
     probe[0] = clock64() - probe_t0;                 // shader clocks this wave was resident
-    probe[1] = (long long)(t_end - t_begin) * LBS_FWD_MFMA_PER_TILE;   // MFMA instructions it issued
+    probe[1] = (long long)(t_end - t_begin) * (SPARSE ? (KF / 2) * 3 + 3 * 2 * KJS + 3 * 16 : LBS_FWD_MFMA_PER_TILE);   // MFMA instructions it issued
     probe[2] = wall_clock64() - probe_w0;            // the same interval on the constant 100 MHz counter
   }
 }
@@ -674,14 +749,20 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
   dim3 grid((BP / BG) * nvc), block(256);
   // exactly one round of two workgroups per CU, an even number of chunks and whole pose groups per XCD
   const int paired = (grid.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? 1 : 0;
-  if (VPb && verts)
-    hipLaunchKernelGGL((k_lbs_fwd<true, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe, paired);
-  else if (VPb)
-    hipLaunchKernelGGL((k_lbs_fwd<true, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe, paired);
-  else if (verts)
-    hipLaunchKernelGGL((k_lbs_fwd<false, true>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe, paired);
-  else
-    hipLaunchKernelGGL((k_lbs_fwd<false, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe, paired);
+#define JRR_LBS_FWD(SVP, SVT)                                                                                                     \
+  do {                                                                                                                            \
+    if (m.sparse_ok)                                                                                                              \
+      hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, true>), grid, block, 0, s, m.Dk, m.Wc, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,   \
+                         probe, paired, m.jl);                                                                                    \
+    else                                                                                                                          \
+      hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, \
+                         probe, paired, m.jl);                                                                                    \
+  } while (0)
+  if (VPb && verts) JRR_LBS_FWD(true, true);
+  else if (VPb) JRR_LBS_FWD(true, false);
+  else if (verts) JRR_LBS_FWD(false, true);
+  else JRR_LBS_FWD(false, false);
+#undef JRR_LBS_FWD
   return 0;
 }
 
