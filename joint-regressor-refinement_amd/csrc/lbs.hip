@@ -362,11 +362,14 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
 // DV: 0 = vertex adjoint from the joint adjoint dJT (Jn^T dj), 1 = loaded from dVT, 2 = both (sum)
 constexpr int BWD_RING = 3;
 constexpr int DVBUF_FLOATS = 3 * 16 * 64;        // three 32x32 tiles as [r][register quad][lane][4]
-template <int DV>
+// SPARSE (Model::sparse_ok): T_{r,c} is recomputed over the tile's own <= KJS joints only (the record's W^T block then
+// holds the KJS compacted rows, written by k_bwd_tab_static): 12 instead of 36 MFMA per plane wave and tile.
+template <int DV, bool SPARSE>
 __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb, const float* __restrict__ AT,
                                                     const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                     const float* __restrict__ dVT, float* __restrict__ DVP,
-                                                    float* __restrict__ dATp, int BP, int nvc, int n_bt) {
+                                                    float* __restrict__ dATp, int BP, int nvc, int n_bt,
+                                                    const int* __restrict__ jl) {
   __shared__ __attribute__((aligned(16))) float lds[BWD_RING * TB_FLOATS + DVBUF_FLOATS + 3 * 36 * 64 + 27 * 64];
   float* const ring = lds;
   f32x4* const dvbuf = reinterpret_cast<f32x4*>(lds + BWD_RING * TB_FLOATS);
@@ -444,7 +447,23 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
       // T_{r,c} for the three r as three interleaved accumulator chains sharing the W operand; operands of joint pair
       // jp + 1 are requested right after the first MFMA of pair jp (a wave never parks on lgkmcnt between products)
       f32x16 T0 = zero16(), T1 = zero16(), T2 = zero16();
-      {
+      if constexpr (SPARSE) {
+        // operand of joint j for this lane half: ldsA[(r * 12 + j / 2) * 64 + (j % 2) * 32 + l31] = ldsA[r * 768 + 32 j + l31]
+        const float* wp = tab + TB_WJV + half * 32 + l31;
+        float w[KJS / 2], a0[KJS / 2], a1[KJS / 2], a2[KJS / 2];
+#pragma unroll
+        for (int pq = 0; pq < KJS / 2; ++pq) {
+          const int j0 = jl[vt * KJS + 2 * pq], j1 = jl[vt * KJS + 2 * pq + 1];          // wave-uniform: scalar loads
+          const float* ap = ldsA + (half ? j1 : j0) * 32 + l31;
+          w[pq] = wp[2 * pq * 32]; a0[pq] = ap[0]; a1[pq] = ap[12 * 64]; a2[pq] = ap[24 * 64];
+        }
+#pragma unroll
+        for (int pq = 0; pq < KJS / 2; ++pq) {
+          T0 = mfma(w[pq], a0[pq], T0);
+          T1 = mfma(w[pq], a1[pq], T1);
+          T2 = mfma(w[pq], a2[pq], T2);
+        }
+      } else {
         const float* wp = tab + TB_WJV + half * 32 + l31;
         const float* ap = ldsA + lane;
         float w = wp[0], a0 = ap[0], a1 = ap[12 * 64], a2 = ap[24 * 64];
@@ -599,12 +618,14 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 }
 
 // static (W) parts of the per-tile backward operand records
-__global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __restrict__ Wvj, float* __restrict__ Tb) {
+// (Wc != NULL: the W^T block takes the KJS compacted rows of the joint-sparse path, zeros behind them)
+__global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __restrict__ Wvj, float* __restrict__ Tb,
+                                 const float* __restrict__ Wc) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over VT * 2048
   if (idx >= VT * 2048) return;
   const int vt = idx >> 11, k = idx & 2047;
   float* dst = Tb + (size_t)vt * TB_FLOATS;
-  if (k < W_FLOATS) dst[TB_WJV + k] = Wjv[(size_t)vt * W_FLOATS + k];
+  if (k < W_FLOATS) dst[TB_WJV + k] = Wc ? (k < KJS * 32 ? Wc[(size_t)vt * KJS * 32 + k] : 0.f) : Wjv[(size_t)vt * W_FLOATS + k];
   else if (k < W_FLOATS + 1024) dst[TB_WVJ + (k - W_FLOATS)] = Wvj[(size_t)vt * 1024 + (k - W_FLOATS)];
   else if (k - W_FLOATS - 1024 < TB_FLOATS - TB_WVJ - 1024) dst[TB_WVJ + 1024 + (k - W_FLOATS - 1024)] = 0.f;
 }
@@ -768,15 +789,19 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
 
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s) {
-  (void)m;
   const int n_bt = BP / BT;                     // one workgroup per (pose tile, vertex chunk)
   dim3 grid(n_bt * nvc), block(256);
-  if (dVT && dJT)
-    hipLaunchKernelGGL((k_lbs_bwd<2>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt);
-  else if (dVT)
-    hipLaunchKernelGGL((k_lbs_bwd<1>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt);
-  else
-    hipLaunchKernelGGL((k_lbs_bwd<0>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt);
+#define JRR_LBS_BWD(DVM)                                                                                                        \
+  do {                                                                                                                          \
+    if (m.sparse_ok)                                                                                                            \
+      hipLaunchKernelGGL((k_lbs_bwd<DVM, true>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl);     \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((k_lbs_bwd<DVM, false>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl);    \
+  } while (0)
+  if (dVT && dJT) JRR_LBS_BWD(2);
+  else if (dVT) JRR_LBS_BWD(1);
+  else JRR_LBS_BWD(0);
+#undef JRR_LBS_BWD
   return 0;
 }
 
@@ -793,7 +818,7 @@ int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, floa
 }
 
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s) {
-  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb);
+  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb, m.sparse_ok ? m.Wc : nullptr);
   return 0;
 }
 
