@@ -44,6 +44,13 @@ FLOP_LBS_FWD_PER_POSE = 2 * 20670 * 10 + 2 * 207 * 20670 + 2 * 6890 * 24 * 12 + 
 FLOP_LBS_BWD_PER_POSE = 2 * 17 * 6890 * 3 + 2 * 6890 * 24 * 9 + 2 * 6890 * 9 + 2 * 6890 * 24 * 12   # dverts, T, dvp, dA
 FLOP_BLEND_ADJ_PER_POSE = 2 * 217 * 20670                                                             # dF = D . dvp
 FLOP_DISC_PER_POSE = 2 * 2 * (24 * (192 + 1024) + 786432 + 1048576 + 1024 + 768)                     # fwd + input-grad
+# Joint-sparse skinning (engine info `joint_sparse`): every SMPL vertex has <= 4 skinning influences and a
+# tile of 32 consecutive vertices <= 8 joints in total, so the skinning products run over 8 joints per tile instead of 24.  The
+# roofline counts the FLOP of the formulation that actually runs; the dense-formulation rate is printed beside it (it may
+# exceed the MFMA peak: the skipped multiplications are by structural zeros).
+KJS = 8
+FLOP_LBS_FWD_SPARSE = FLOP_LBS_FWD_PER_POSE - 2 * 6890 * (24 - KJS) * 12
+FLOP_LBS_BWD_SPARSE = FLOP_LBS_BWD_PER_POSE - 2 * 6890 * (24 - KJS) * 9
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
 
 
@@ -344,7 +351,10 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     it_s = a.steps / elapsed
     dom_ms, dom_n = prof['k_lbs_fwd']
-    achieved = FLOP_LBS_FWD_PER_POSE * B / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    sparse = bool(eng.info.get('joint_sparse'))
+    flop_fwd = FLOP_LBS_FWD_SPARSE if sparse else FLOP_LBS_FWD_PER_POSE
+    flop_bwd = FLOP_LBS_BWD_SPARSE if sparse else FLOP_LBS_BWD_PER_POSE
+    achieved = flop_fwd * B / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tpath):
@@ -352,7 +362,8 @@ def main():
             traffic = json.load(open(tpath)).get('k_lbs_fwd_hbm_bytes_per_launch') if B == 4096 else None
         except Exception:
             traffic = None
-    step_flop = FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
+    step_flop = flop_fwd + flop_bwd + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
+    step_flop_dense = FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
     inner_ms = ms_per_step - nj_region * j_ms / a.steps
     out = {
         'metric': 'pose-refinement iters/sec, batch 4096, at 1/2/4/8 MI355X',   # BASELINE.json's metric string; batch = poses per GPU (weak scaling)
@@ -376,14 +387,22 @@ def main():
                      # HBM side of the same kernel (PMC bytes per launch / live duration) against the 8 TB/s spec
                      'hbm_gb_s': round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms > 0 else None,
                      'hbm_frac_of_8tb_s': round(traffic / (dom_ms * 1e-3) / 8e12, 4) if traffic and dom_ms > 0 else None,
-                     'algorithmic_flop_per_launch': FLOP_LBS_FWD_PER_POSE * B,
+                     'algorithmic_flop_per_launch': flop_fwd * B,
+                     'formulation': ('joint-sparse skinning: each 32-vertex tile multiplies by its own <= 8 of the 24 joints '
+                                     '(exact: the skipped terms are zeros); FLOP counted for THIS formulation') if sparse
+                                    else 'dense skinning (SURVEY.md section 8d counts)',
+                     'dense_formulation': {'flop_per_launch': FLOP_LBS_FWD_PER_POSE * B,
+                                           'rate_tflops': round(FLOP_LBS_FWD_PER_POSE * B / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
+                                           'note': 'the reference formulation\'s FLOP over the same time; not a roofline figure'},
                      # the WHOLE inner iteration against the same peak: dense algorithmic FLOP of its four MFMA stages
                      # (k_lbs_fwd + k_lbs_bwd + blend adjoint + discriminator fwd/input-grad) over the measured step time
                      # without the J step's share
                      'whole_step': {'flop_per_pose_iter': step_flop,
                                     'achieved': round(step_flop * B / (inner_ms * 1e-3) / 1e12, 2),
                                     'frac': round(step_flop * B / (inner_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                    'inner_only_ms_per_step': round(inner_ms, 4)},
+                                    'inner_only_ms_per_step': round(inner_ms, 4),
+                                    'dense_formulation_flop_per_pose_iter': step_flop_dense,
+                                    'dense_formulation_rate_tflops': round(step_flop_dense * B / (inner_ms * 1e-3) / 1e12, 2)},
                      # in-kernel probe (s_memtime / s_memrealtime, workgroup 0 / wave 0): the clock the chip holds on
                      # this kernel (`peak` assumes 2.4 GHz), hence the MFMA-pipe utilisation of the whole launch, and
                      # how much of the launch the FIRST-dispatched workgroup is resident (the two workgroups of a CU

@@ -426,8 +426,8 @@ extern "C" int jrr_engine_set_batch_norm(jrr_engine_t* e, int bn) {
 
 extern "C" int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n) {
   if (!e || !out) return JRR_ERR_ARG;
-  int32_t v[8] = {e->B, e->BP, e->bnorm, e->nvc, e->nvcb, e->nsplit, e->nsplitJ, e->flags};
-  for (int i = 0; i < n && i < 8; ++i) out[i] = v[i];
+  int32_t v[9] = {e->B, e->BP, e->bnorm, e->nvc, e->nvcb, e->nsplit, e->nsplitJ, e->flags, e->has_model ? e->m.sparse_ok : 0};
+  for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
   return JRR_OK;
 }
 

@@ -109,9 +109,9 @@ class RefineEngine:
             check(self.lib.jrr_engine_create(model.handle if model is not None else None, self.batch, int(batch_norm or batch), c_void_p(base), nbytes,
                                              self.flags, byref(h)), 'jrr_engine_create')
         self.handle = h
-        info = (c_int32 * 8)()
-        self.lib.jrr_engine_info(self.handle, info, 8)
-        self.info = dict(zip(['B', 'BP', 'batch_norm', 'nvc', 'nvcb', 'nsplit', 'nsplitJ', 'flags'], list(info)))
+        info = (c_int32 * 9)()
+        self.lib.jrr_engine_info(self.handle, info, 9)
+        self.info = dict(zip(['B', 'BP', 'batch_norm', 'nvc', 'nvcb', 'nsplit', 'nsplitJ', 'flags', 'joint_sparse'], list(info)))
 
     def __del__(self):
         try:

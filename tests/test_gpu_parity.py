@@ -565,3 +565,51 @@ def test_kat_k3_k4_k5_on_the_kernels(eng_mod, dmodel, smpl_model_np, j_h36m_np):
     _, v1 = eng.find_joints_forward(zb, x6d=xr, return_verts=True)
     _, v2 = e5.find_joints_forward(zb, x6d=xr, return_verts=True)
     assert (v2 - v1 - t.to(DEV)).abs().max().item() < 5e-6
+
+
+def test_joint_sparse_skinning_matches_the_dense_kernels(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    """The LBS kernels skin each 32-vertex tile by its own <= 8 joints when the model allows it (engine info
+    `joint_sparse`).  Same engine calls on a model forced to the dense kernels (JRR_DENSE_SKINNING=1 at upload): the
+    skipped terms are exact zeros, so joints / vertices / gradients agree to fp32 round-off of the re-grouped K pairs;
+    a model whose first tile is skinned by all 24 joints must fall back to the dense kernels by itself."""
+    import os
+    B = 130
+    b = _batch(smpl_model_np, j_h36m_np, B, seed=77)
+    x6d, betas = T(b['pose6d']).to(DEV), T(b['betas']).to(DEV)
+    gt = T(b['gt_j3d']); gt_c = (gt - gt[:, :1]).contiguous().to(DEV)
+    os.environ['JRR_DENSE_SKINNING'] = '1'
+    try:
+        dense_model = eng_mod.DeviceModel(smpl_model_np, DEV)
+    finally:
+        del os.environ['JRR_DENSE_SKINNING']
+    outs = {}
+    for name, dm in (('sparse', dmodel), ('dense', dense_model)):
+        eng = eng_mod.RefineEngine(dm, B, flags=eng_mod.FLAG_KEEP_VERTS)
+        assert eng.info['joint_sparse'] == (1 if name == 'sparse' else 0)
+        eng.set_j_regressor(T(j_h36m_np))
+        joints, verts = eng.find_joints_forward(betas, x6d=x6d, return_verts=True)
+        g = torch.Generator().manual_seed(5)
+        dj = torch.randn(B, 17, 3, generator=g).to(DEV)
+        dx, db, dJ = eng.find_joints_backward(betas, dj, x6d=x6d, want_dJ=True)[:3]
+        xs, bs = x6d.clone(), betas.clone()
+        m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+        step = torch.zeros(1, dtype=torch.int32, device=DEV)
+        eng.refine_run(xs, bs, gt_c, m, v, step, 1e-2, 3)
+        outs[name] = [t.cpu() for t in (joints, verts, dx, db, xs, bs)]
+    names = ['joints', 'verts', 'dx6d', 'dbetas', 'x6d after 3 iterations', 'betas after 3 iterations']
+    tol = [2e-6, 2e-6, None, None, 6e-4, 6e-4]
+    for n, a, c, t in zip(names, outs['sparse'], outs['dense'], tol):
+        if t is None:
+            assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item() + 1e-9, n
+        else:
+            assert (a - c).abs().max().item() < t, n
+    wide = dict(smpl_model_np)
+    W = smpl_model_np['lbs_weights'].copy()
+    W[0] = 1.0 / 24.0
+    wide['lbs_weights'] = W
+    eng = eng_mod.RefineEngine(eng_mod.DeviceModel(wide, DEV), 4, flags=0)
+    assert eng.info['joint_sparse'] == 0
+    eng.set_j_regressor(T(j_h36m_np))
+    jw = eng.find_joints_forward(betas[:4].contiguous(), x6d=x6d[:4].contiguous())
+    ref = _oracle_joints(wide, T(j_h36m_np), T(b['pose6d'][:4]), T(b['betas'][:4]))
+    assert (jw.cpu().double() - ref).abs().max().item() < 5e-6
