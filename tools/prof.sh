@@ -36,8 +36,8 @@ def pick(d, key):
         if key in k:
             return v
     return {}
-f = pick(out['pmc_fetch'], 'k_lbs_fwd<true, false>').get('FETCH_SIZE')
-w = pick(out['pmc_write'], 'k_lbs_fwd<true, false>').get('WRITE_SIZE')
+f = pick(out['pmc_fetch'], 'k_lbs_fwd<true, false').get('FETCH_SIZE')
+w = pick(out['pmc_write'], 'k_lbs_fwd<true, false').get('WRITE_SIZE')
 if f is not None and w is not None:
     out['traffic'] = {'k_lbs_fwd_hbm_bytes_per_launch': int((2 * f + w) * 1024), 'FETCH_SIZE_KB': f, 'WRITE_SIZE_KB': w,
                       'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)'}
