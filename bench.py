@@ -45,12 +45,11 @@ FLOP_LBS_BWD_PER_POSE = 2 * 17 * 6890 * 3 + 2 * 6890 * 24 * 9 + 2 * 6890 * 9 + 2
 FLOP_BLEND_ADJ_PER_POSE = 2 * 217 * 20670                                                             # dF = D . dvp
 FLOP_DISC_PER_POSE = 2 * 2 * (24 * (192 + 1024) + 786432 + 1048576 + 1024 + 768)                     # fwd + input-grad
 # Joint-sparse skinning (engine info `joint_sparse`): every SMPL vertex has <= 4 skinning influences and a
-# tile of 32 consecutive vertices <= 8 joints in total, so the skinning products run over 8 joints per tile instead of 24.  The
+# tile of 32 consecutive vertices few joints in total, so the skinning products run over 8 (or 12) joints per tile instead of 24.  The
 # roofline counts the FLOP of the formulation that actually runs; the dense-formulation rate is printed beside it (it may
 # exceed the MFMA peak: the skipped multiplications are by structural zeros).
-KJS = 8
-FLOP_LBS_FWD_SPARSE = FLOP_LBS_FWD_PER_POSE - 2 * 6890 * (24 - KJS) * 12
-FLOP_LBS_BWD_SPARSE = FLOP_LBS_BWD_PER_POSE - 2 * 6890 * (24 - KJS) * 9
+def flop_lbs_fwd_sparse(kjs): return FLOP_LBS_FWD_PER_POSE - 2 * 6890 * (24 - kjs) * 12
+def flop_lbs_bwd_sparse(kjs): return FLOP_LBS_BWD_PER_POSE - 2 * 6890 * (24 - kjs) * 9
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
 
 
@@ -351,9 +350,10 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     it_s = a.steps / elapsed
     dom_ms, dom_n = prof['k_lbs_fwd']
-    sparse = bool(eng.info.get('joint_sparse'))
-    flop_fwd = FLOP_LBS_FWD_SPARSE if sparse else FLOP_LBS_FWD_PER_POSE
-    flop_bwd = FLOP_LBS_BWD_SPARSE if sparse else FLOP_LBS_BWD_PER_POSE
+    kjs = int(eng.info.get('joint_sparse') or 0)      # joints per vertex tile the LBS kernels multiply by (0: all 24)
+    sparse = kjs > 0
+    flop_fwd = flop_lbs_fwd_sparse(kjs) if sparse else FLOP_LBS_FWD_PER_POSE
+    flop_bwd = flop_lbs_bwd_sparse(kjs) if sparse else FLOP_LBS_BWD_PER_POSE
     achieved = flop_fwd * B / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
     traffic = None
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
@@ -388,7 +388,7 @@ def main():
                      'hbm_gb_s': round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms > 0 else None,
                      'hbm_frac_of_8tb_s': round(traffic / (dom_ms * 1e-3) / 8e12, 4) if traffic and dom_ms > 0 else None,
                      'algorithmic_flop_per_launch': flop_fwd * B,
-                     'formulation': ('joint-sparse skinning: each 32-vertex tile multiplies by its own <= 8 of the 24 joints '
+                     'formulation': (f'joint-sparse skinning: each 32-vertex tile multiplies by its own <= {kjs} of the 24 joints '
                                      '(exact: the skipped terms are zeros); FLOP counted for THIS formulation') if sparse
                                     else 'dense skinning (SURVEY.md section 8d counts)',
                      'dense_formulation': {'flop_per_launch': FLOP_LBS_FWD_PER_POSE * B,

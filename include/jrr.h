@@ -252,9 +252,9 @@ int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d_dev, const float* bet
  * calls (any other engine call drops the cached forward).  Default: off.                                            */
 int jrr_engine_set_forward_reuse(jrr_engine_t* e, int enabled);
 
-/* launch geometry: {B, BP, batch_norm, nvc, nvcb, nsplit, nsplitJ, flags, joint_sparse}; joint_sparse = 1 when every
- * 32-vertex tile of the model is skinned by at most 8 joints and the LBS kernels multiply by those only (exact: the skipped
- * terms are zeros; JRR_DENSE_SKINNING=1 in the environment of jrr_model_create forces the dense kernels) */
+/* launch geometry: {B, BP, batch_norm, nvc, nvcb, nsplit, nsplitJ, flags, joint_sparse}; joint_sparse = 8 or 12 when every
+ * 32-vertex tile of the model is skinned by at most that many joints and the LBS kernels multiply by those only (exact: the
+ * skipped terms are zeros), 0 = dense kernels (also forced by JRR_DENSE_SKINNING=1 in the environment of jrr_model_create) */
 int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n);
 
 /* Per-kernel timing of jrr_refine_run with HIP events recorded on the launch stream.

@@ -39,7 +39,7 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
     if (parents[j] >= j || (j > 0 && parents[j] < 0)) { jrr_set_error("parents[%d]=%d is not a topologically ordered tree", j, parents[j]); return JRR_ERR_ARG; }
   const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nDq = nDn, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
   const size_t nJt = 72 + 24, nJS = 720 + 16;   // padded to keep 16-byte alignment of what follows
-  const size_t nWc = (size_t)VT * KJS * 32, nJl = (size_t)VT * KJS;
+  const size_t nWc = (size_t)(VT + 1) * KJS_MAX * 32, nJl = (size_t)VT * KJS_MAX;
   std::vector<float> h(nDk + nDn + nDq + nWjv + nWvj + nJt + nJS + nWc + nJl, 0.f);
   float* Dk = h.data();
   float* Dn = Dk + nDk;
@@ -69,21 +69,32 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
     }
   }
   // joint-sparse skinning tables (jrr_common.h): per 32-vertex tile the joints with a non-zero weight
-  int sparse_ok = 1;
-  for (int t = 0; t < VT; ++t) {
-    int n = 0;
-    for (int j = 0; j < NJ; ++j) {
-      bool used = false;
-      for (int vv = 0; vv < 32 && !used; ++vv) { const int v = t * 32 + vv; used = v < V && W[(size_t)v * NJ + j] != 0.f; }
-      if (!used) continue;
-      if (n < KJS) {
-        Jl[t * KJS + n] = j;
-        for (int vv = 0; vv < 32; ++vv) { const int v = t * 32 + vv; Wc[((size_t)t * KJS + n) * 32 + vv] = v < V ? W[(size_t)v * NJ + j] : 0.f; }
+  int kjs = 0;
+  {
+    std::vector<std::vector<int>> lists(VT);
+    size_t most = 0;
+    for (int t = 0; t < VT; ++t) {
+      for (int j = 0; j < NJ; ++j) {
+        bool used = false;
+        for (int vv = 0; vv < 32 && !used; ++vv) { const int v = t * 32 + vv; used = v < V && W[(size_t)v * NJ + j] != 0.f; }
+        if (used) lists[t].push_back(j);
       }
-      ++n;
+      most = std::max(most, lists[t].size());
     }
-    if (n > KJS) sparse_ok = 0;
-    for (; n < KJS; ++n) Jl[t * KJS + n] = 0;      // padding: joint 0 with zero weights
+    kjs = most <= 8 ? 8 : most <= (size_t)KJS_MAX ? KJS_MAX : 0;
+    // JRR_DENSE_SKINNING=1 forces the dense kernels, JRR_SKIN_JOINTS=12 the 12-joint variant (verification: tests)
+    { const char* dense = getenv("JRR_DENSE_SKINNING"); if (dense && dense[0] == '1') kjs = 0; }
+    { const char* kj = getenv("JRR_SKIN_JOINTS"); if (kj && atoi(kj) == 12 && kjs == 8) kjs = 12; }
+    for (int t = 0; t < VT && kjs; ++t) {
+      for (int n = 0; n < kjs; ++n) {
+        const int j = n < (int)lists[t].size() ? lists[t][n] : 0;      // padding: joint 0 with zero weights
+        Jl[t * kjs + n] = j;
+        for (int vv = 0; vv < 32; ++vv) {
+          const int v = t * 32 + vv;
+          Wc[((size_t)t * kjs + n) * 32 + vv] = (n < (int)lists[t].size() && v < V) ? W[(size_t)v * NJ + j] : 0.f;
+        }
+      }
+    }
   }
   // folded rest-joint regressor: J(beta) = Jt + JS beta   (smplx vertices2joints(J_regressor, v_shaped))
   for (int j = 0; j < NJ; ++j)
@@ -116,9 +127,7 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   m->d.JS = m->d.Jt + nJt;
   m->d.Wc = m->d.JS + nJS;
   m->d.jl = reinterpret_cast<int*>(m->d.Wc + nWc);
-  // JRR_DENSE_SKINNING=1 forces the dense kernels (verification of the joint-sparse path against them: tests)
-  { const char* dense = getenv("JRR_DENSE_SKINNING"); if (dense && dense[0] == '1') sparse_ok = 0; }
-  m->d.sparse_ok = sparse_ok;
+  m->d.kjs = kjs;
   m->d.parents.maxd = 0;
   m->d.faces = nullptr;
   m->d.nfaces = 0;
@@ -426,7 +435,7 @@ extern "C" int jrr_engine_set_batch_norm(jrr_engine_t* e, int bn) {
 
 extern "C" int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n) {
   if (!e || !out) return JRR_ERR_ARG;
-  int32_t v[9] = {e->B, e->BP, e->bnorm, e->nvc, e->nvcb, e->nsplit, e->nsplitJ, e->flags, e->has_model ? e->m.sparse_ok : 0};
+  int32_t v[9] = {e->B, e->BP, e->bnorm, e->nvc, e->nvcb, e->nsplit, e->nsplitJ, e->flags, e->has_model ? e->m.kjs : 0};
   for (int i = 0; i < n && i < 9; ++i) out[i] = v[i];
   return JRR_OK;
 }

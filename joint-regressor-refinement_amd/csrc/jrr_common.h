@@ -24,7 +24,7 @@ constexpr int BG = 128;        // poses per forward workgroup (4 waves)
 constexpr int FOLD_MJ = 512;   // (H36M joint, SMPL joint) pairs 17*24 = 408, padded
 constexpr int FOLD_M = 1280;   // (i, j, c) triples 1224, padded to 10 x 128
 constexpr int NPARAM = 154;    // 144 pose6d + 10 betas per pose
-constexpr int KJS = 8;         // joints per vertex tile in the joint-sparse skinning path
+constexpr int KJS_MAX = 12;    // most joints per vertex tile the joint-sparse skinning kernels are built for (8 and 12)
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -130,12 +130,12 @@ struct Model {
   float* Dq;    // [3][VP/4][KFP][4] blend basis in vertex quads (A operand of the blend adjoint, k_blend_adjoint)
   float* Wjv;   // [VT][24][32]      skinning weights W^T tile  (lane = vertex)
   float* Wvj;   // [VT][32][32]      skinning weights tile [vertex][joint padded to 32] (lane = joint)
-  // Joint-sparse skinning: every SMPL vertex has <= 4 influences, and a tile of 32 consecutive vertices usually <= KJS
-  // joints in total.  Per tile: the ascending list of its joints (padded with joint 0 and zero weights) and the
-  // W^T rows of exactly those joints.  sparse_ok = every tile of THIS model fits; otherwise the dense kernels run.
-  float* Wc;    // [VT][KJS][32]
-  int* jl;      // [VT][KJS]
-  int sparse_ok;
+  // Joint-sparse skinning: every SMPL vertex has <= 4 influences, and a tile of 32 consecutive vertices usually few
+  // joints in total.  kjs = 8 or 12 when EVERY tile of this model has at most that many (0: the dense kernels run).  Per
+  // tile: the ascending list of its joints (padded to kjs with joint 0 and zero weights) and the W^T rows of exactly those.
+  float* Wc;    // [VT][kjs][32] (+ one tile of slack)
+  int* jl;      // [VT][kjs]
+  int kjs;
   float* Jt;    // [24][3]           rest joints of the template
   float* JS;    // [24][3][10]       rest-joint shape directions
   Parents parents;

@@ -58,21 +58,24 @@ __device__ __forceinline__ void dma16u(const float* base_uniform, unsigned lane_
   __builtin_amdgcn_global_load_lds(JRR_GLB(base_uniform + lane_off), JRR_LDS(lds_dst_wave), 16, 0, 0);
 }
 
-// SPARSE (joint-sparse skinning, Model::sparse_ok): a tile's skinning product only runs over the tile's own <= KJS
-// joints -- Wjv then is the compacted W^T [VT][KJS][32], jl the joint lists -- in THREE stages per tile (r = 0, 1, 2:
-// the four A^T blocks (r, c) of the listed joints, 16 KB; T_{r,3}, T_{r,0}, T_{r,1}, T_{r,2} = 4 x 4 MFMA; combine;
-// regressor 16 MFMA) instead of six half-stages of 24 (+16) MFMA: 423 instead of 519 MFMA per tile, 48 instead of
-// 144 KB of A^T streamed per tile.  Skipped terms are exact zeros: the result is the dense product's up to the
+// KJ > 0 (joint-sparse skinning, Model::kjs = 8 or 12): a tile's skinning product only runs over the tile's own <= KJ
+// joints -- Wjv then is the compacted W^T [VT][KJ][32], jl the joint lists -- in THREE stages per tile (r = 0, 1, 2:
+// the four A^T blocks (r, c) of the listed joints, 16 KB; T_{r,3}, T_{r,0}, T_{r,1}, T_{r,2} = 4 x KJ/2 MFMA; combine;
+// regressor 16 MFMA) instead of six half-stages of 24 (+16) MFMA: with KJ = 8, 423 instead of 519 MFMA per tile and 48
+// instead of 144 KB of A^T streamed per tile (KJ = 12: 447 MFMA, 72 KB).  Skipped terms are exact zeros: the result is the dense product's up to the
 // grouping of the K pairs.
-template <bool STORE_VP, bool STORE_VERTS, bool SPARSE>
+template <bool STORE_VP, bool STORE_VERTS, int KJ>
 __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk, const float* __restrict__ Wjv,
                                                     const float* __restrict__ Jn_vi, const float* __restrict__ FT,
                                                     const float* __restrict__ AT, float* __restrict__ VPb,
                                                     float* __restrict__ JP, float* __restrict__ VTb, int B, int BP,
                                                     int nvc, long long* __restrict__ probe, int paired,
                                                     const int* __restrict__ jl) {
+  constexpr bool SPARSE = KJ > 0;
+  constexpr int KJS = SPARSE ? KJ : 8;                       // (8: keeps the dead sparse branch of the dense variant well-formed)
   constexpr int NST = SPARSE ? NKCH + 3 : NSTAGE;            // stages per vertex tile
   constexpr int WT_FLOATS = SPARSE ? KJS * 32 : W_FLOATS;    // W^T rows staged per tile
+  constexpr int WT_COPIES = (WT_FLOATS + 255) / 256;
   __shared__ float lds[2 * STG_FLOATS + 2 * WJ_FLOATS];
   // shader-clock probe (profiling only), see jrr_engine_probe_read
   const long long probe_t0 = probe ? clock64() : 0, probe_w0 = probe ? wall_clock64() : 0;
@@ -113,7 +116,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   const unsigned lane_ln = (unsigned)lane * 4u;                                  // floats
   const float* const Fbg = FT + (size_t)bg * BG;
   const float* const Abg = AT + (size_t)bg * BG;
-  unsigned lane_jl = 0;        // SPARSE: (row of this lane's joint of the current tile) * BP + pose offset, floats
+  unsigned lane_jl[2] = {0, 0};   // SPARSE: (row of this lane's joint of the current tile) * BP + pose offset, floats
 
   // ---- DMA issue for stage s of tile vt into ring slot `slot` ----
   auto issue = [&](int vt, int s, int slot) {
@@ -130,17 +133,19 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
       }
       if (s == 0) {
         float* wdst = wj + (vt & 1) * WJ_FLOATS;
-        if (wv < WT_FLOATS / 256) dma16u(Wjv + (size_t)vt * WT_FLOATS + wv * 256, lane_ln, wdst + wv * 256);
+        if (wv < WT_COPIES) dma16u(Wjv + (size_t)vt * WT_FLOATS + wv * 256, lane_ln, wdst + wv * 256);   // (KJ = 12: the 2nd copy runs 128 floats into the next tile's rows; unused)
         dma16u(Jn_vi + (size_t)vt * JN_FLOATS + wv * 256, lane_ln, wdst + W_FLOATS + wv * 256);
       }
     } else if (SPARSE) {
-      // four blocks [KJS joints][128 poses] of A^T, components (r, 3), (r, 0), (r, 1), (r, 2); this wave copies rows
-      // 2 wv and 2 wv + 1 of each: the rows of joints jl[2 wv], jl[2 wv + 1] (lane offset `lane_jl`, set per tile)
+      // four blocks [KJS joints][128 poses] of A^T, components (r, 3), (r, 0), (r, 1), (r, 2); this wave copies row pair
+      // wv of each -- the rows of joints jl[2 wv], jl[2 wv + 1] (lane offset `lane_jl[0]`, set per tile) -- and, with 12
+      // joints, waves 0 and 1 also row pair 4 + wv (`lane_jl[1]`)
       const int r = s - NKCH;
 #pragma unroll
       for (int ci = 0; ci < 4; ++ci) {
         const int c = (ci == 0) ? 3 : ci - 1;
-        dma16u(Abg + (size_t)((r * 4 + c) * NJ) * BP, lane_jl, dst + ci * (KJS * BG) + wv * 256);
+        dma16u(Abg + (size_t)((r * 4 + c) * NJ) * BP, lane_jl[0], dst + ci * (KJS * BG) + wv * 256);
+        if (KJS > 8 && wv < KJS / 2 - 4) dma16u(Abg + (size_t)((r * 4 + c) * NJ) * BP, lane_jl[1], dst + ci * (KJS * BG) + (4 + wv) * 256);
       }
     } else {
       const int h = s - NKCH, r = h >> 1;
@@ -165,7 +170,11 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     const float* ldsJ = ldsW + W_FLOATS;
     if (SPARSE) {      // the skinning copies of this tile are issued from its stage NKCH - 1 on
       const int j0 = jl[vt * KJS + 2 * wv], j1 = jl[vt * KJS + 2 * wv + 1];      // wave-uniform: scalar loads
-      lane_jl = (unsigned)(half ? j1 : j0) * (unsigned)BP + (unsigned)l31 * 4u;
+      lane_jl[0] = (unsigned)(half ? j1 : j0) * (unsigned)BP + (unsigned)l31 * 4u;
+      if (KJS > 8 && wv < KJS / 2 - 4) {
+        const int j2 = jl[vt * KJS + 8 + 2 * wv], j3 = jl[vt * KJS + 8 + 2 * wv + 1];
+        lane_jl[1] = (unsigned)(half ? j3 : j2) * (unsigned)BP + (unsigned)l31 * 4u;
+      }
     }
     static_for<0, NST>([&](auto S_) {
       constexpr int s = decltype(S_)::value;
@@ -362,14 +371,16 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
 // DV: 0 = vertex adjoint from the joint adjoint dJT (Jn^T dj), 1 = loaded from dVT, 2 = both (sum)
 constexpr int BWD_RING = 3;
 constexpr int DVBUF_FLOATS = 3 * 16 * 64;        // three 32x32 tiles as [r][register quad][lane][4]
-// SPARSE (Model::sparse_ok): T_{r,c} is recomputed over the tile's own <= KJS joints only (the record's W^T block then
-// holds the KJS compacted rows, written by k_bwd_tab_static): 12 instead of 36 MFMA per plane wave and tile.
-template <int DV, bool SPARSE>
+// KJ > 0 (Model::kjs): T_{r,c} is recomputed over the tile's own <= KJ joints only (the record's W^T block then
+// holds the KJ compacted rows, written by k_bwd_tab_static): with KJ = 8, 12 instead of 36 MFMA per plane wave and tile.
+template <int DV, int KJ>
 __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb, const float* __restrict__ AT,
                                                     const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                     const float* __restrict__ dVT, float* __restrict__ DVP,
                                                     float* __restrict__ dATp, int BP, int nvc, int n_bt,
                                                     const int* __restrict__ jl) {
+  constexpr bool SPARSE = KJ > 0;
+  constexpr int KJS = SPARSE ? KJ : 8;
   __shared__ __attribute__((aligned(16))) float lds[BWD_RING * TB_FLOATS + DVBUF_FLOATS + 3 * 36 * 64 + 27 * 64];
   float* const ring = lds;
   f32x4* const dvbuf = reinterpret_cast<f32x4*>(lds + BWD_RING * TB_FLOATS);
@@ -618,14 +629,14 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 }
 
 // static (W) parts of the per-tile backward operand records
-// (Wc != NULL: the W^T block takes the KJS compacted rows of the joint-sparse path, zeros behind them)
+// (Wc != NULL: the W^T block takes the kjs compacted rows of the joint-sparse path, zeros behind them)
 __global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __restrict__ Wvj, float* __restrict__ Tb,
-                                 const float* __restrict__ Wc) {
+                                 const float* __restrict__ Wc, int kjs) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over VT * 2048
   if (idx >= VT * 2048) return;
   const int vt = idx >> 11, k = idx & 2047;
   float* dst = Tb + (size_t)vt * TB_FLOATS;
-  if (k < W_FLOATS) dst[TB_WJV + k] = Wc ? (k < KJS * 32 ? Wc[(size_t)vt * KJS * 32 + k] : 0.f) : Wjv[(size_t)vt * W_FLOATS + k];
+  if (k < W_FLOATS) dst[TB_WJV + k] = Wc ? (k < kjs * 32 ? Wc[(size_t)vt * kjs * 32 + k] : 0.f) : Wjv[(size_t)vt * W_FLOATS + k];
   else if (k < W_FLOATS + 1024) dst[TB_WVJ + (k - W_FLOATS)] = Wvj[(size_t)vt * 1024 + (k - W_FLOATS)];
   else if (k - W_FLOATS - 1024 < TB_FLOATS - TB_WVJ - 1024) dst[TB_WVJ + 1024 + (k - W_FLOATS - 1024)] = 0.f;
 }
@@ -772,11 +783,14 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
   const int paired = (grid.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? 1 : 0;
 #define JRR_LBS_FWD(SVP, SVT)                                                                                                     \
   do {                                                                                                                            \
-    if (m.sparse_ok)                                                                                                              \
-      hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, true>), grid, block, 0, s, m.Dk, m.Wc, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,   \
+    if (m.kjs == 8)                                                                                                               \
+      hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, 8>), grid, block, 0, s, m.Dk, m.Wc, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,      \
+                         probe, paired, m.jl);                                                                                    \
+    else if (m.kjs == 12)                                                                                                         \
+      hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, 12>), grid, block, 0, s, m.Dk, m.Wc, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,     \
                          probe, paired, m.jl);                                                                                    \
     else                                                                                                                          \
-      hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, false>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, \
+      hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, 0>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,     \
                          probe, paired, m.jl);                                                                                    \
   } while (0)
   if (VPb && verts) JRR_LBS_FWD(true, true);
@@ -793,10 +807,12 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
   dim3 grid(n_bt * nvc), block(256);
 #define JRR_LBS_BWD(DVM)                                                                                                        \
   do {                                                                                                                          \
-    if (m.sparse_ok)                                                                                                            \
-      hipLaunchKernelGGL((k_lbs_bwd<DVM, true>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl);     \
+    if (m.kjs == 8)                                                                                                             \
+      hipLaunchKernelGGL((k_lbs_bwd<DVM, 8>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl);        \
+    else if (m.kjs == 12)                                                                                                       \
+      hipLaunchKernelGGL((k_lbs_bwd<DVM, 12>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl);       \
     else                                                                                                                        \
-      hipLaunchKernelGGL((k_lbs_bwd<DVM, false>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl);    \
+      hipLaunchKernelGGL((k_lbs_bwd<DVM, 0>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl);        \
   } while (0)
   if (dVT && dJT) JRR_LBS_BWD(2);
   else if (dVT) JRR_LBS_BWD(1);
@@ -818,7 +834,7 @@ int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, floa
 }
 
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s) {
-  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb, m.sparse_ok ? m.Wc : nullptr);
+  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb, m.kjs ? m.Wc : nullptr, m.kjs);
   return 0;
 }
 

@@ -568,8 +568,8 @@ def test_kat_k3_k4_k5_on_the_kernels(eng_mod, dmodel, smpl_model_np, j_h36m_np):
 
 
 def test_joint_sparse_skinning_matches_the_dense_kernels(eng_mod, dmodel, smpl_model_np, j_h36m_np):
-    """The LBS kernels skin each 32-vertex tile by its own <= 8 joints when the model allows it (engine info
-    `joint_sparse`).  Same engine calls on a model forced to the dense kernels (JRR_DENSE_SKINNING=1 at upload): the
+    """The LBS kernels skin each 32-vertex tile by its own <= 8 (or <= 12) joints when the model allows it (engine info
+    `joint_sparse` = 8 / 12 / 0).  Same engine calls on a model forced to the dense kernels (JRR_DENSE_SKINNING=1 at upload): the
     skipped terms are exact zeros, so joints / vertices / gradients agree to fp32 round-off of the re-grouped K pairs;
     a model whose first tile is skinned by all 24 joints must fall back to the dense kernels by itself."""
     import os
@@ -582,10 +582,15 @@ def test_joint_sparse_skinning_matches_the_dense_kernels(eng_mod, dmodel, smpl_m
         dense_model = eng_mod.DeviceModel(smpl_model_np, DEV)
     finally:
         del os.environ['JRR_DENSE_SKINNING']
+    os.environ['JRR_SKIN_JOINTS'] = '12'          # the 12-joint variant on a model that would fit 8
+    try:
+        model12 = eng_mod.DeviceModel(smpl_model_np, DEV)
+    finally:
+        del os.environ['JRR_SKIN_JOINTS']
     outs = {}
-    for name, dm in (('sparse', dmodel), ('dense', dense_model)):
+    for name, dm, kjs in (('sparse', dmodel, 8), ('sparse12', model12, 12), ('dense', dense_model, 0)):
         eng = eng_mod.RefineEngine(dm, B, flags=eng_mod.FLAG_KEEP_VERTS)
-        assert eng.info['joint_sparse'] == (1 if name == 'sparse' else 0)
+        assert eng.info['joint_sparse'] == kjs
         eng.set_j_regressor(T(j_h36m_np))
         joints, verts = eng.find_joints_forward(betas, x6d=x6d, return_verts=True)
         g = torch.Generator().manual_seed(5)
@@ -598,11 +603,12 @@ def test_joint_sparse_skinning_matches_the_dense_kernels(eng_mod, dmodel, smpl_m
         outs[name] = [t.cpu() for t in (joints, verts, dx, db, xs, bs)]
     names = ['joints', 'verts', 'dx6d', 'dbetas', 'x6d after 3 iterations', 'betas after 3 iterations']
     tol = [2e-6, 2e-6, None, None, 6e-4, 6e-4]
-    for n, a, c, t in zip(names, outs['sparse'], outs['dense'], tol):
-        if t is None:
-            assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item() + 1e-9, n
-        else:
-            assert (a - c).abs().max().item() < t, n
+    for variant in ('sparse', 'sparse12'):
+        for n, a, c, t in zip(names, outs[variant], outs['dense'], tol):
+            if t is None:
+                assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item() + 1e-9, (variant, n)
+            else:
+                assert (a - c).abs().max().item() < t, (variant, n)
     wide = dict(smpl_model_np)
     W = smpl_model_np['lbs_weights'].copy()
     W[0] = 1.0 / 24.0
