@@ -1,4 +1,6 @@
 // C ABI (include/jrr.h): model upload, engine/workspace planning and the launch sequences.
+#include <algorithm>
+#include <array>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
@@ -39,8 +41,8 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
     if (parents[j] >= j || (j > 0 && parents[j] < 0)) { jrr_set_error("parents[%d]=%d is not a topologically ordered tree", j, parents[j]); return JRR_ERR_ARG; }
   const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nDq = nDn, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
   const size_t nJt = 72 + 24, nJS = 720 + 16;   // padded to keep 16-byte alignment of what follows
-  const size_t nWc = (size_t)(VT + 1) * KJS_MAX * 32, nJl = (size_t)VT * KJS_MAX;
-  std::vector<float> h(nDk + nDn + nDq + nWjv + nWvj + nJt + nJS + nWc + nJl, 0.f);
+  const size_t nWc = (size_t)(VT + 1) * KJS_MAX * 32, nJl = (size_t)VT * KJS_MAX, nPerm = (size_t)VP + 6912;   // p2v [VP], v2p [V] padded
+  std::vector<float> h(nDk + nDn + nDq + nWjv + nWvj + nJt + nJS + nWc + nJl + nPerm, 0.f);
   float* Dk = h.data();
   float* Dn = Dk + nDk;
   float* Dq = Dn + nDn;
@@ -50,8 +52,54 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   float* JS = Jt + nJt;
   float* Wc = JS + nJS;
   int32_t* Jl = reinterpret_cast<int32_t*>(Wc + nWc);
-  for (int v = 0; v < V; ++v) {
-    const int t = v >> 5, vv = v & 31;
+  int32_t* P2V = Jl + nJl;
+  int32_t* V2P = P2V + VP;
+  // ---- internal vertex order (jrr_common.h): the file order unless it does not fit the joint-sparse kernels and the
+  //      joint-sorted order does (or JRR_VERTEX_ORDER=sorted asks for it: tests) ----
+  auto tile_joints = [&](const std::vector<int>& order) {      // most joints any 32-row tile touches
+    size_t most = 0;
+    for (int t = 0; t < VT; ++t) {
+      bool used[NJ] = {false};
+      for (int vv = 0; vv < 32; ++vv) {
+        const int p_ = t * 32 + vv;
+        if (p_ >= V) break;
+        for (int j = 0; j < NJ; ++j) used[j] = used[j] || W[(size_t)order[p_] * NJ + j] != 0.f;
+      }
+      size_t n = 0;
+      for (int j = 0; j < NJ; ++j) n += used[j];
+      most = std::max(most, n);
+    }
+    return most;
+  };
+  std::vector<int> order(V);
+  for (int v = 0; v < V; ++v) order[v] = v;
+  bool permuted = false;
+  {
+    const char* ask = getenv("JRR_VERTEX_ORDER");
+    const bool force = ask && strcmp(ask, "sorted") == 0;
+    const size_t most_file = tile_joints(order);
+    if (force || most_file > 8) {
+      // key of a vertex: its joints by descending weight (dominant joint first), then the file index
+      std::vector<std::array<int, 5>> keys(V);
+      for (int v = 0; v < V; ++v) {
+        std::vector<std::pair<float, int>> inf;
+        for (int j = 0; j < NJ; ++j) if (W[(size_t)v * NJ + j] != 0.f) inf.push_back({-W[(size_t)v * NJ + j], j});
+        std::sort(inf.begin(), inf.end());
+        for (int k = 0; k < 4; ++k) keys[v][k] = k < (int)inf.size() ? inf[k].second : NJ;
+        keys[v][4] = v;
+      }
+      std::vector<int> sorted(order);
+      std::sort(sorted.begin(), sorted.end(), [&](int a, int b) { return keys[a] < keys[b]; });
+      const size_t most_sorted = tile_joints(sorted);
+      auto cls = [](size_t m) { return m <= 8 ? 0 : m <= (size_t)KJS_MAX ? 1 : 2; };
+      if (force || cls(most_sorted) < cls(most_file)) { order = sorted; permuted = true; }
+    }
+  }
+  for (int p_ = 0; p_ < VP; ++p_) P2V[p_] = p_ < V ? order[p_] : -1;
+  for (int p_ = 0; p_ < V; ++p_) V2P[order[p_]] = p_;
+  for (int p_ = 0; p_ < V; ++p_) {
+    const int v = order[p_];                 // vertex of the file stored in row p_
+    const int t = p_ >> 5, vv = p_ & 31;
     for (int c = 0; c < 3; ++c) {
       for (int k = 0; k < KF; ++k) {
         float val;
@@ -59,8 +107,8 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
         else if (k < 217) val = sd[((size_t)v * 3 + c) * NB + (k - 207)];
         else val = vt[v * 3 + c];
         Dk[(((size_t)t * KFP + k) * 3 + c) * 32 + vv] = val;
-        Dn[((size_t)c * VP + v) * KFP + k] = val;
-        Dq[(((size_t)c * (VP / 4) + (v >> 2)) * KFP + k) * 4 + (v & 3)] = val;
+        Dn[((size_t)c * VP + p_) * KFP + k] = val;
+        Dq[(((size_t)c * (VP / 4) + (p_ >> 2)) * KFP + k) * 4 + (p_ & 3)] = val;
       }
     }
     for (int j = 0; j < NJ; ++j) {
@@ -76,7 +124,7 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
     for (int t = 0; t < VT; ++t) {
       for (int j = 0; j < NJ; ++j) {
         bool used = false;
-        for (int vv = 0; vv < 32 && !used; ++vv) { const int v = t * 32 + vv; used = v < V && W[(size_t)v * NJ + j] != 0.f; }
+        for (int vv = 0; vv < 32 && !used; ++vv) { const int p_ = t * 32 + vv; used = p_ < V && W[(size_t)order[p_] * NJ + j] != 0.f; }
         if (used) lists[t].push_back(j);
       }
       most = std::max(most, lists[t].size());
@@ -90,8 +138,8 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
         const int j = n < (int)lists[t].size() ? lists[t][n] : 0;      // padding: joint 0 with zero weights
         Jl[t * kjs + n] = j;
         for (int vv = 0; vv < 32; ++vv) {
-          const int v = t * 32 + vv;
-          Wc[((size_t)t * kjs + n) * 32 + vv] = (n < (int)lists[t].size() && v < V) ? W[(size_t)v * NJ + j] : 0.f;
+          const int p_ = t * 32 + vv;
+          Wc[((size_t)t * kjs + n) * 32 + vv] = (n < (int)lists[t].size() && p_ < V) ? W[(size_t)order[p_] * NJ + j] : 0.f;
         }
       }
     }
@@ -128,8 +176,13 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   m->d.Wc = m->d.JS + nJS;
   m->d.jl = reinterpret_cast<int*>(m->d.Wc + nWc);
   m->d.kjs = kjs;
+  m->v2p_host = nullptr;
+  if (permuted) { m->v2p_host = new int[V]; memcpy(m->v2p_host, V2P, (size_t)V * sizeof(int)); }
+  m->d.p2v = permuted ? reinterpret_cast<int*>(m->d.jl + nJl) : nullptr;
+  m->d.v2p = permuted ? m->d.p2v + VP : nullptr;
   m->d.parents.maxd = 0;
   m->d.faces = nullptr;
+  m->d.faces_int = nullptr;
   m->d.nfaces = 0;
   for (int j = 0; j < NJ; ++j) {
     m->d.parents.p[j] = parents[j];
@@ -155,8 +208,15 @@ extern "C" int jrr_model_set_faces(jrr_model_t* m, const int32_t* faces, int n_f
   for (int i = 0; i < n_faces * 3; ++i)
     if (faces[i] < 0 || faces[i] >= V) { jrr_set_error("face index %d out of range", faces[i]); return JRR_ERR_ARG; }
   if (m->d.faces) (void)hipFree(m->d.faces);
+  if (m->d.faces_int) { (void)hipFree(m->d.faces_int); m->d.faces_int = nullptr; }
   JRR_HIP(hipMalloc((void**)&m->d.faces, (size_t)n_faces * 3 * sizeof(int)));
   JRR_HIP(hipMemcpy(m->d.faces, faces, (size_t)n_faces * 3 * sizeof(int), hipMemcpyHostToDevice));
+  if (m->v2p_host) {      // the fused rasteriser reads the vertices in the internal order: faces in row indices
+    std::vector<int32_t> fi((size_t)n_faces * 3);
+    for (size_t i = 0; i < fi.size(); ++i) fi[i] = m->v2p_host[faces[i]];
+    JRR_HIP(hipMalloc((void**)&m->d.faces_int, fi.size() * sizeof(int)));
+    JRR_HIP(hipMemcpy(m->d.faces_int, fi.data(), fi.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
   m->d.nfaces = n_faces;
   return JRR_OK;
 }
@@ -164,7 +224,9 @@ extern "C" int jrr_model_set_faces(jrr_model_t* m, const int32_t* faces, int n_f
 extern "C" void jrr_model_destroy(jrr_model_t* m) {
   if (!m) return;
   if (m->d.faces) (void)hipFree(m->d.faces);
+  if (m->d.faces_int) (void)hipFree(m->d.faces_int);
   if (m->base) (void)hipFree(m->base);
+  delete[] m->v2p_host;
   delete m;
 }
 
@@ -442,7 +504,7 @@ extern "C" int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n) {
 
 // H[(i,j,c)][k] = sum_v Jn[i,v] W[v,j] D_c[k,v]  and  G0 (fold.hip); both layouts of H
 static int fold_rebuild(jrr_engine* e, hipStream_t s) {
-  launch_fold_jw(e->Jn, e->m.Wjv, e->JW, e->G0, s);
+  launch_fold_jw(e->Jn, e->m.Wjv, e->JW, e->G0, e->m.p2v, s);
   for (int c = 0; c < 3; ++c) {
     GemmArgs g;
     g.A = e->JW; g.lda = FOLD_MJ;                          // A[k = v][m = (i,j)]
@@ -478,7 +540,7 @@ extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   e->have_mask = mask != nullptr;
   if (!e->tab_static) { launch_bwd_tab_static(e->m, e->Jn_iv, s); e->tab_static = true; }   // model-only: once per engine
-  launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, e->Jn_q, s);
+  launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, e->Jn_q, e->m.p2v, s);
   e->fold_valid = false;
   if (e->folded) {
     int rc = fold_rebuild(e, s);
@@ -585,7 +647,7 @@ extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const 
   const bool kv = (e->flags & JRR_FLAG_KEEP_VERTS) != 0;
   if (verts && !e->VTb) { jrr_set_error("return_verts needs an engine created with JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
   smpl_forward(e, x6d, R, betas, true, kv || verts, nullptr, s);
-  if (verts) launch_verts_untranspose(e->VTb, verts, V * 3, V, nullptr, nullptr, e->B, e->BP, s);
+  if (verts) launch_verts_untranspose(e->VTb, verts, V * 3, V, nullptr, nullptr, e->B, e->BP, s, e->m.p2v);
   launch_joints_loss(e->JP, e->nvc, nullptr, nullptr, 0.f, joints, nullptr, nullptr, e->B, e->BP, s);
   CHECK_LAUNCH();
   return JRR_OK;
@@ -632,7 +694,7 @@ extern "C" int jrr_smpl_vertices_backward(jrr_engine_t* e, const float* x6d, con
   hipStream_t s = (hipStream_t)stream;
   e->fwd_cached = false;
   // the caller's adjoint, transposed into its own [3][VP][BP] buffer (the stored vertices stay valid for a later dJ)
-  launch_dverts_transpose(dverts, V * 3, e->dVTb, e->B, e->BP, s);
+  launch_dverts_transpose(dverts, V * 3, e->dVTb, e->B, e->BP, s, e->m.p2v);
   launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, nullptr, e->dVTb, e->DVP, e->dATp, e->BP, e->nvcb, s);
   int rc = blend_adjoint_gemm(e, s);
   if (rc) return rc;
@@ -1016,7 +1078,7 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
       const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * 224.0 * 224.0));
       if (!e->smask_valid) { launch_mask_sq(e->sil_mask, e->smask, e->B, s); e->smask_valid = true; }
       // projection, rasterisation, loss and adjoint in one kernel, straight from / into the row-quad vertex buffer
-      launch_sil_raster_adj(e->VTb, e->BP, e->cam, e->m.faces, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil,
+      launch_sil_raster_adj(e->VTb, e->BP, e->cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil,
                             silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s);
       prof_mark(e, 8, s);
     }
@@ -1085,7 +1147,7 @@ static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s) {
   int rc = launch_jgrad_q(e->dJT, e->VTb, e->dJnp, e->BP, e->nsplitJ, s);
   if (rc) return rc;
   hipLaunchKernelGGL(k_djn_reduce, dim3((NH * VP + 255) / 256), dim3(256), 0, s, e->dJnp, 3 * e->nsplitJ, e->dJn);
-  launch_jreg_bwd(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->Jn, e->rowsum, e->dJn, VP, dJ, s);
+  launch_jreg_bwd(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->Jn, e->rowsum, e->dJn, VP, dJ, e->m.v2p, s);
   CHECK_LAUNCH();
   return JRR_OK;
 }

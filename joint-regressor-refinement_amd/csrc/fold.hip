@@ -17,14 +17,16 @@ namespace jrr {
 constexpr int FP = 32;   // poses per block
 
 // JW[v][m = i*24 + j] = Jn[i][v] * W[v][j]   (m < 408; columns 408..511 zero), v over the padded range
-__global__ void k_fold_jw(const float* __restrict__ Jn, const float* __restrict__ Wjv, float* __restrict__ JW) {
+// (row v of the internal vertex order holds vertex p2v[v] of the regressor's columns; NULL = identity)
+__global__ void k_fold_jw(const float* __restrict__ Jn, const float* __restrict__ Wjv, float* __restrict__ JW,
+                          const int* __restrict__ p2v) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over VP * 512
   if (idx >= VP * FOLD_MJ) return;
   const int v = idx / FOLD_MJ, m = idx % FOLD_MJ;
   float val = 0.f;
   if (m < NH * NJ && v < V) {
     const int i = m / NJ, j = m % NJ;
-    val = Jn[(size_t)i * V + v] * Wjv[((size_t)(v >> 5) * NJ + j) * 32 + (v & 31)];
+    val = Jn[(size_t)i * V + (p2v ? p2v[v] : v)] * Wjv[((size_t)(v >> 5) * NJ + j) * 32 + (v & 31)];
   }
   JW[idx] = val;
 }
@@ -107,8 +109,8 @@ __global__ __launch_bounds__(FP * NJ) void k_fold_bwd_dA(const float* __restrict
   for (int e = 0; e < 12; ++e) dA[(size_t)(e * NJ + j) * BP + b] = acc[e];
 }
 
-int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, hipStream_t s) {
-  hipLaunchKernelGGL(k_fold_jw, dim3(VP * FOLD_MJ / 256), dim3(256), 0, s, Jn, Wjv, JW);
+int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, const int* p2v, hipStream_t s) {
+  hipLaunchKernelGGL(k_fold_jw, dim3(VP * FOLD_MJ / 256), dim3(256), 0, s, Jn, Wjv, JW, p2v);
   hipLaunchKernelGGL(k_fold_g0, dim3(FOLD_MJ / 64), dim3(64), 0, s, JW, G0);
   return 0;
 }

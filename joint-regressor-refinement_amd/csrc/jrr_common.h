@@ -136,10 +136,19 @@ struct Model {
   float* Wc;    // [VT][kjs][32] (+ one tile of slack)
   int* jl;      // [VT][kjs]
   int kjs;
+  // Internal vertex order.  Nothing inside the LBS path depends on WHICH vertex sits in which row (every consumer sums
+  // over vertices), so jrr_model_create may store the vertices in an order that makes the tiles joint-coherent (sorted
+  // by their influencing joints) when the file order does not fit kjs.  p2v / v2p are NULL for the identity; otherwise
+  // p2v[row] = vertex of that row (-1: padding), v2p[vertex] = row.  They are applied where vertex identity is visible:
+  // J_regressor columns in / dJ out, the (B,6890,3) vertices out / their adjoint in, and the face indices of the fused
+  // rasteriser.
+  int* p2v;     // [VP] or NULL
+  int* v2p;     // [V] or NULL
   float* Jt;    // [24][3]           rest joints of the template
   float* JS;    // [24][3][10]       rest-joint shape directions
   Parents parents;
-  int* faces;   // [nfaces][3] (device) or NULL
+  int* faces;   // [nfaces][3] (device) or NULL; vertex indices of the caller's mesh
+  int* faces_int;   // the same faces in internal row indices (only when p2v != NULL; fused rasteriser)
   int nfaces;
 };
 
@@ -150,6 +159,7 @@ inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 struct jrr_model {
   jrr::Model d;
   void* base;
+  int* v2p_host;   // host copy of Model::v2p (jrr_model_set_faces), NULL for the identity order
 };
 
 // error plumbing (api.hip)

@@ -81,15 +81,15 @@ int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, con
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
                    float* VTb, int B, int BP, int nvc, hipStream_t s, long long* probe = nullptr);
 int launch_verts_untranspose(const float* VTb, float* verts, int ldv, int vlimit, const float* cam, float* ndc, int B, int BP,
-                             hipStream_t s);
+                             hipStream_t s, const int* p2v = nullptr);
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s);
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s);
-int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s);
+int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s, const int* p2v = nullptr);
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv, float* Jn_q,
-                          hipStream_t s);
+                          const int* p2v, hipStream_t s);
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
-                    float* dJ, hipStream_t s);
+                    float* dJ, const int* v2p, hipStream_t s);
 
 // gemm.hip
 int launch_disc_gemm_q(const GemmArgs& g, int epi, int btr, hipStream_t s, int* ndot = nullptr);
@@ -120,7 +120,7 @@ int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, co
                    hipStream_t s);
 
 // fold.hip
-int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, hipStream_t s);
+int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, const int* p2v, hipStream_t s);
 int launch_fold_fwd(const float* MT, const float* AT, const float* G0, float* Jsum, int BP, hipStream_t s);
 int launch_fold_bwd(const float* dJT, const float* AT, const float* MT, const float* G0, float* dMT, float* dA, int BP,
                     hipStream_t s);

@@ -645,8 +645,10 @@ __global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __r
 // records for the silhouette renderer (scripts/optimize.py:80-82 flip/scale + scripts/mesh_renderer.py:52-57 camera).
 // One 32-vertex x 32-pose tile per block through LDS; every global access is contiguous (16 bytes per thread on the
 // quad side).
+// (p2v != NULL: row v of the buffer is vertex p2v[v] of the caller's mesh -- the store then is per vertex, 12 bytes)
 __global__ void k_verts_untranspose(const float* __restrict__ VTb, float* __restrict__ verts, int ldv, int vlimit,
-                                    const float* __restrict__ cam, f32x4* __restrict__ ndc, float focal, int B, int BP) {
+                                    const float* __restrict__ cam, f32x4* __restrict__ ndc, float focal, int B, int BP,
+                                    const int* __restrict__ p2v) {
   __shared__ float tile[32][97];
   const int v0 = blockIdx.x * 32, bb0 = blockIdx.y * 32;
   const f32x4* VTq = reinterpret_cast<const f32x4*>(VTb);
@@ -661,40 +663,45 @@ __global__ void k_verts_untranspose(const float* __restrict__ VTb, float* __rest
     for (int idx = threadIdx.x; idx < 32 * 96; idx += blockDim.x) {
       const int bl = idx / 96, rem = idx % 96;
       const int b = bb0 + bl, v = v0 + rem / 3;
-      if (b < B && v < vlimit) verts[(size_t)b * ldv + v0 * 3 + rem] = tile[bl][rem];
+      if (p2v) {
+        const int vo = v < V ? p2v[v] : -1;
+        if (b < B && vo >= 0 && vo < vlimit) verts[(size_t)b * ldv + vo * 3 + rem % 3] = tile[bl][rem];
+      } else if (b < B && v < vlimit) verts[(size_t)b * ldv + v0 * 3 + rem] = tile[bl][rem];
     }
   }
   if (ndc) {
     for (int idx = threadIdx.x; idx < 32 * 32; idx += blockDim.x) {
       const int bl = idx / 32, vv = idx % 32;
       const int b = bb0 + bl, v = v0 + vv;
-      if (b < B && v < V) {
+      const int vo = (v < V) ? (p2v ? p2v[v] : v) : -1;
+      if (b < B && vo >= 0) {
         const float X = -2.f * tile[bl][vv * 3] + cam[(size_t)b * 3], Y = -2.f * tile[bl][vv * 3 + 1] + cam[(size_t)b * 3 + 1];
         const float Z = 2.f * tile[bl][vv * 3 + 2] + cam[(size_t)b * 3 + 2];
         f32x4 o = {focal * X / Z, focal * Y / Z, Z, 0.f};
-        ndc[(size_t)b * V + v] = o;
+        ndc[(size_t)b * V + vo] = o;
       }
     }
   }
 }
 
 int launch_verts_untranspose(const float* VTb, float* verts, int ldv, int vlimit, const float* cam, float* ndc, int B, int BP,
-                             hipStream_t s) {
+                             hipStream_t s, const int* p2v) {
   hipLaunchKernelGGL(k_verts_untranspose, dim3(VT, BP / 32), dim3(256), 0, s, VTb, verts, ldv, vlimit, cam, (f32x4*)ndc,
-                     5000.f / 224.f, B, BP);
+                     5000.f / 224.f, B, BP, p2v);
   return 0;
 }
 
 // (B,6890,3) -> [3][VP/4][BP][4] (row quads) transpose of an external vertex adjoint (operator-level SMPL backward,
 // silhouette adjoint)
-__global__ void k_dverts_transpose(const float* __restrict__ dverts, int ldv, float* __restrict__ dVT, int B, int BP) {
+__global__ void k_dverts_transpose(const float* __restrict__ dverts, int ldv, float* __restrict__ dVT, int B, int BP,
+                                   const int* __restrict__ p2v) {
   __shared__ float tile[32][97];
   const int v0 = blockIdx.x * 32, bb0 = blockIdx.y * 32;
   for (int idx = threadIdx.x; idx < 32 * 96; idx += blockDim.x) {
     int bl = idx / 96, rem = idx % 96;   // rem = vv*3 + r
     int b = bb0 + bl, v = v0 + rem / 3;
     float val = 0.f;
-    if (b < B && v < V) val = dverts[(size_t)b * ldv + v0 * 3 + rem];
+    if (b < B && v < V) val = p2v ? dverts[(size_t)b * ldv + p2v[v] * 3 + rem % 3] : dverts[(size_t)b * ldv + v0 * 3 + rem];
     tile[bl][rem] = val;
   }
   __syncthreads();
@@ -733,17 +740,18 @@ __global__ __launch_bounds__(JREG_THREADS) void k_jreg_rowsum(const float* __res
 
 __global__ void k_jreg_tiles(const float* __restrict__ J, const float* __restrict__ mask,
                              const float* __restrict__ rowsum, float* __restrict__ Jn, float* __restrict__ Jn_vi,
-                             float* __restrict__ Jn_iv, float* __restrict__ Jn_q) {
+                             float* __restrict__ Jn_iv, float* __restrict__ Jn_q, const int* __restrict__ p2v) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over VT*32*32 (tile, vv, i)
   if (idx >= VT * 1024) return;
   const int vt = idx >> 10, vv = (idx >> 5) & 31, i = idx & 31;
-  const int v = vt * 32 + vv;
+  const int v = vt * 32 + vv;                  // row of the internal vertex order
+  const int vo = (v < V) ? (p2v ? p2v[v] : v) : -1;   // the regressor column stored there
   float val = 0.f;
-  if (i < NH && v < V) {
-    float x = J[(size_t)i * V + v];
-    if (mask) x *= mask[(size_t)i * V + v];
+  if (i < NH && vo >= 0) {
+    float x = J[(size_t)i * V + vo];
+    if (mask) x *= mask[(size_t)i * V + vo];
     val = fmaxf(x, 0.f) / rowsum[i];
-    Jn[(size_t)i * V + v] = val;
+    Jn[(size_t)i * V + vo] = val;            // Jn keeps the regressor's own column order
   }
   Jn_vi[(size_t)vt * 1024 + vv * 32 + i] = val;
   Jn_q[((size_t)(v >> 2) * 32 + i) * 4 + (v & 3)] = val;      // vertex quads [VP/4][32][4]: A operand of k_gemm_q32
@@ -753,11 +761,13 @@ __global__ void k_jreg_tiles(const float* __restrict__ J, const float* __restric
 // dJ_raw = mask * relu'(J*mask) * (dJn - sum_v(dJn*Jn)) / rowsum      (dJn given as [17][ldn])
 __global__ __launch_bounds__(JREG_THREADS) void k_jreg_bwd(const float* __restrict__ J, const float* __restrict__ mask,
                                                             const float* __restrict__ Jn, const float* __restrict__ rowsum,
-                                                            const float* __restrict__ dJn, int ldn, float* __restrict__ dJ) {
+                                                            const float* __restrict__ dJn, int ldn, float* __restrict__ dJ,
+                                                            const int* __restrict__ v2p) {
   __shared__ float red[JREG_THREADS];
   const int i = blockIdx.x;
   float acc = 0.f;
-  for (int v = threadIdx.x; v < V; v += blockDim.x) acc += dJn[(size_t)i * ldn + v] * Jn[(size_t)i * V + v];
+  // dJn comes in the internal vertex order (row v2p[v] holds column v; NULL = identity)
+  for (int v = threadIdx.x; v < V; v += blockDim.x) acc += dJn[(size_t)i * ldn + (v2p ? v2p[v] : v)] * Jn[(size_t)i * V + v];
   red[threadIdx.x] = acc;
   __syncthreads();
   for (int s = JREG_THREADS / 2; s > 0; s >>= 1) {
@@ -768,7 +778,7 @@ __global__ __launch_bounds__(JREG_THREADS) void k_jreg_bwd(const float* __restri
   for (int v = threadIdx.x; v < V; v += blockDim.x) {
     float mk = mask ? mask[(size_t)i * V + v] : 1.f;
     float x = J[(size_t)i * V + v] * mk;
-    float g = (x > 0.f) ? (dJn[(size_t)i * ldn + v] - dot) / rs * mk : 0.f;
+    float g = (x > 0.f) ? (dJn[(size_t)i * ldn + (v2p ? v2p[v] : v)] - dot) / rs * mk : 0.f;
     dJ[(size_t)i * V + v] = g;
   }
 }
@@ -821,15 +831,15 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
   return 0;
 }
 
-int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_dverts_transpose, dim3(VT, BP / 32), dim3(256), 0, s, dverts, ldv, dVT, B, BP);
+int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s, const int* p2v) {
+  hipLaunchKernelGGL(k_dverts_transpose, dim3(VT, BP / 32), dim3(256), 0, s, dverts, ldv, dVT, B, BP, p2v);
   return 0;
 }
 
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv,
-                          float* Jn_q, hipStream_t s) {
+                          float* Jn_q, const int* p2v, hipStream_t s) {
   hipLaunchKernelGGL(k_jreg_rowsum, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, rowsum);
-  hipLaunchKernelGGL(k_jreg_tiles, dim3(VT * 1024 / 256), dim3(256), 0, s, J, mask, rowsum, Jn, Jn_vi, Jn_iv, Jn_q);
+  hipLaunchKernelGGL(k_jreg_tiles, dim3(VT * 1024 / 256), dim3(256), 0, s, J, mask, rowsum, Jn, Jn_vi, Jn_iv, Jn_q, p2v);
   return 0;
 }
 
@@ -839,8 +849,8 @@ int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s) {
 }
 
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
-                    float* dJ, hipStream_t s) {
-  hipLaunchKernelGGL(k_jreg_bwd, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, Jn, rowsum, dJn, ldn, dJ);
+                    float* dJ, const int* v2p, hipStream_t s) {
+  hipLaunchKernelGGL(k_jreg_bwd, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, Jn, rowsum, dJn, ldn, dJ, v2p);
   return 0;
 }
 

@@ -619,3 +619,51 @@ def test_joint_sparse_skinning_matches_the_dense_kernels(eng_mod, dmodel, smpl_m
     jw = eng.find_joints_forward(betas[:4].contiguous(), x6d=x6d[:4].contiguous())
     ref = _oracle_joints(wide, T(j_h36m_np), T(b['pose6d'][:4]), T(b['betas'][:4]))
     assert (jw.cpu().double() - ref).abs().max().item() < 5e-6
+
+
+def test_internal_vertex_order_is_invisible(eng_mod, dmodel, smpl_model_np, j_h36m_np):
+    """jrr_model_create may store the vertices in a joint-sorted order when the file order does not fit the joint-sparse
+    kernels (JRR_VERTEX_ORDER=sorted forces it).  Vertex identity is visible in four places -- J_regressor columns in,
+    dJ out, (B,6890,3) vertices out, their adjoint in -- and through the face indices of the fused rasteriser: all must
+    come out as with the file order."""
+    import os
+    B = 70
+    b = _batch(smpl_model_np, j_h36m_np, B, seed=78)
+    x6d, betas = T(b['pose6d']).to(DEV), T(b['betas']).to(DEV)
+    gt = T(b['gt_j3d']); gt_c = (gt - gt[:, :1]).contiguous().to(DEV)
+    cam = T(b['cam']).to(DEV)
+    os.environ['JRR_VERTEX_ORDER'] = 'sorted'
+    try:
+        sorted_model = eng_mod.DeviceModel(smpl_model_np, DEV)
+    finally:
+        del os.environ['JRR_VERTEX_ORDER']
+    g = torch.Generator().manual_seed(6)
+    dj = torch.randn(B, 17, 3, generator=g).to(DEV)
+    dv = (torch.randn(B, 6890, 3, generator=g) * 1e-3).to(DEV)
+    outs = []
+    for dm in (dmodel, sorted_model):
+        eng = eng_mod.RefineEngine(dm, B, flags=eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_SILHOUETTE)
+        eng.set_j_regressor(T(j_h36m_np))
+        joints, verts = eng.find_joints_forward(betas, x6d=x6d, return_verts=True)
+        dx, db, dJ = eng.find_joints_backward(betas, dj, x6d=x6d, want_dJ=True)[:3]
+        eng.find_joints_forward(betas, x6d=x6d, return_verts=True)          # (the vertex adjoint belongs to this forward)
+        dxv = eng.smpl_vertices_backward(betas, dv, x6d=x6d)[0]
+        mask = (eng.silhouette_forward(verts, cam) > 0).float().contiguous()
+        xs, bs, cs = x6d.clone(), betas.clone(), (cam + 0.05).contiguous()
+        cm, cv = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV)
+        eng.set_silhouette(mask, cs, cm, cv)
+        m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+        step = torch.zeros(1, dtype=torch.int32, device=DEV)
+        eng.refine_run(xs, bs, gt_c, m, v, step, 1e-2, 3)
+        eng.set_silhouette(None)
+        outs.append([t.cpu() for t in (joints, verts, dx, db, dJ, dxv, mask, xs, cs)])
+    names = ['joints', 'verts', 'dx6d', 'dbetas', 'dJ', 'dx6d from a vertex adjoint', 'silhouette', 'x6d after 3 iterations', 'cam after 3 iterations']
+    for n, a, c in zip(names, outs[0], outs[1]):
+        if n == 'silhouette':
+            assert (a != c).float().mean().item() < 1e-4, n
+        elif 'after' in n:
+            assert (a - c).abs().max().item() < 2e-3, n
+        elif n in ('joints', 'verts'):
+            assert (a - c).abs().max().item() < 2e-6, n
+        else:
+            assert (a - c).abs().max().item() <= 3e-5 * c.abs().max().item() + 1e-9, n
