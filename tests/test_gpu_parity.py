@@ -573,6 +573,8 @@ def test_joint_sparse_skinning_matches_the_dense_kernels(eng_mod, dmodel, smpl_m
     skipped terms are exact zeros, so joints / vertices / gradients agree to fp32 round-off of the re-grouped K pairs;
     a model whose first tile is skinned by all 24 joints must fall back to the dense kernels by itself."""
     import os
+    if any(k in os.environ for k in ('JRR_DENSE_SKINNING', 'JRR_SKIN_JOINTS', 'JRR_VERTEX_ORDER')):
+        pytest.skip('the suite itself runs under a forced skinning variant')
     B = 130
     b = _batch(smpl_model_np, j_h36m_np, B, seed=77)
     x6d, betas = T(b['pose6d']).to(DEV), T(b['betas']).to(DEV)
