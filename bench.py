@@ -2,7 +2,10 @@
 """Headline benchmark: pose-refinement inner-loop iterations/sec at batch 4096 per MI355X.
 
     python bench.py --gpus N --steps K --warmup W
-    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+    N > 1 without a torchrun environment: bench.py starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 ... bench.py <same flags>` itself, as a CHILD process and before anything touches the GPU,
+    relays rank 0's JSON line and exits with the child's status (a launch under torchrun is used as it is); a world size
+    that differs from --gpus is an error.  The line carries the evidence of the rank count (`collective`).
 
 One step = one inner iteration of /root/reference/scripts/optimize.py:220-265 restricted to
 BASELINE.json configs[2] ("batch=4096 full loop: 3D-joint loss + pose-discriminator adversarial
@@ -14,7 +17,7 @@ N > 1 is weak scaling: every rank owns 4096 poses (global batch 4096*N), the MSE
 normalised by the GLOBAL batch, and the shared J_regressor is stepped every --j_step_every inner
 iterations (reference cadence 100, scripts/optimize.py:300-312) with ONE RCCL all-reduce on its
 gradient.  A timed region is EXACTLY --steps iterations between barrier + synchronize pairs; it is
-repeated until >= ~0.3 s of device time has been timed and the MEDIAN region is reported (every
+repeated until >= ~3 s of device time has been timed and the MEDIAN region is reported (every
 region's time is listed under `repeat_ms_per_step`).  Reported separately, never part of `value`:
 `cadence1` (J step + all-reduce after EVERY iteration: BASELINE configs[3] "each step"), the
 pose-discriminator update, the folded-regressor mode, BASELINE configs[4] (`config5`), the CPU baseline.
@@ -64,13 +67,15 @@ def parse():
     ap.add_argument('--j_step_every', type=int, default=100,
                     help='inner iterations per J_regressor step (reference: 100); the timed region always contains at least '
                          'one J step with its all-reduce: the effective cadence is min(j_step_every, steps)')
-    ap.add_argument('--min_timed_ms', type=float, default=300.0, help='repeat the K-step timed region until this much is timed')
-    ap.add_argument('--max_repeats', type=int, default=15)
+    ap.add_argument('--min_timed_ms', type=float, default=3000.0, help='repeat the K-step timed region until this much is timed')
+    ap.add_argument('--max_repeats', type=int, default=150)
     ap.add_argument('--no_cpu_baseline', action='store_true')
     ap.add_argument('--cpu_batch', type=int, default=1024, help='cpu_baseline sample batch (scaled to batch-4096 units)')
     ap.add_argument('--cpu_seconds', type=float, default=8.0, help='time budget per cpu_baseline variant')
     ap.add_argument('--no_folded', action='store_true', help='skip the separately reported folded-regressor mode')
     ap.add_argument('--no_config5', action='store_true', help='skip the separately reported BASELINE configs[4] block')
+    ap.add_argument('--no_skin_variants', action='store_true',
+                    help='skip the separately reported 12-joint / dense skinning runs (what a body model with a less coherent vertex order runs)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL); gloo for debugging')
     ap.add_argument('--single_device', action='store_true',
                     help='debug: every rank uses cuda:0 (exercises the N > 1 code path on a 1-GPU box; use with --backend gloo)')
@@ -95,24 +100,28 @@ def cpu_model_name():
     return 'unknown'
 
 
-def cpu_baseline(model_np, J_np, batch_np, disc_sd, B, budget_s, use_disc):
+def cpu_baseline(model_np, J_np, batch_np, disc_sd, B, budget_s, use_disc, B_full):
     """The oracle (oracle/reference_port.py: torch-CPU restatement in the reference's op order, autograd backward,
-    torch.optim.Adam) timed on this box's host cores on the SAME workload at batch B, three ways:
-      one_eval            1 SMPL evaluation per iteration (the de-duplicated loop the HIP path computes), best thread count
-      reference_3_evals   3 SMPL evaluations per iteration as scripts/optimize.py:228,231,234 does, same thread count
-      single_thread       one_eval on 1 thread
+    torch.optim.Adam) timed on this box's host cores on the SAME workload, BASELINE.md section 2:
+      one_eval            batch B: 1 SMPL evaluation per iteration (the de-duplicated loop the HIP path computes), best thread count
+      reference_3_evals   batch B: 3 SMPL evaluations per iteration as scripts/optimize.py:228,231,234 does, same thread count
+      single_thread       batch B: one_eval on 1 thread
+      full_batch          batch B_full (the metric's own batch): ONE iteration after one warm-up iteration, no scaling
+      config1_forward_b4  BASELINE configs[0]: batch 4, SMPL forward + J_regressor evaluation only (scripts/test.py path)
     torch's intra-op pool is far from linear on these small ops, so a 1-iteration sweep picks the thread count."""
     import oracle
     T = torch.from_numpy
     smpl = oracle.OracleSMPL(model_np)
-    x6 = T(batch_np['pose6d'][:B])
-    betas = T(batch_np['betas'][:B])
-    gt_c = oracle.move_pelvis(T(batch_np['gt_j3d'][:B]))
     sd = {k: v.clone() for k, v in disc_sd.items()} if use_disc else None
 
-    def run(n, evals=1):
+    def inputs(n):
+        x6 = T(batch_np['pose6d'][:n])
+        return x6, T(batch_np['betas'][:n]), oracle.move_pelvis(T(batch_np['gt_j3d'][:n]))
+
+    def run(n_it, evals=1, n=B):
+        x6, betas, gt_c = inputs(n)
         t0 = time.perf_counter()
-        oracle.refine_poses(smpl, T(J_np), x6[:, :1], x6[:, 1:], betas, gt_c, n, disc_sd=sd, smpl_evals=evals)
+        oracle.refine_poses(smpl, T(J_np), x6[:, :1], x6[:, 1:], betas, gt_c, n_it, disc_sd=sd, smpl_evals=evals)
         return time.perf_counter() - t0
 
     def timed(evals, threads):
@@ -121,7 +130,7 @@ def cpu_baseline(model_np, J_np, batch_np, disc_sd, B, budget_s, use_disc):
         n = max(1, min(40, int(budget_s / max(dt1, 1e-3))))
         dt = run(n, evals)
         return {'it_s_at_sample_batch': round(n / dt, 4), 'iterations': n, 'seconds': round(dt, 2), 'threads': threads,
-                'smpl_evals_per_iter': evals}
+                'smpl_evals_per_iter': evals, 'batch': B}
 
     ncpu = os.cpu_count() or 1
     best_t, best_n = None, 1
@@ -131,14 +140,64 @@ def cpu_baseline(model_np, J_np, batch_np, disc_sd, B, budget_s, use_disc):
         dt = run(1)
         if best_t is None or dt < best_t:
             best_t, best_n = dt, nt
-    return {'one_eval': timed(1, best_n), 'reference_3_evals': timed(3, best_n), 'single_thread': timed(1, 1)}, best_n
+    out = {'one_eval': timed(1, best_n), 'reference_3_evals': timed(3, best_n), 'single_thread': timed(1, 1)}
+    torch.set_num_threads(best_n)
+    if B_full > B and B_full <= batch_np['pose6d'].shape[0]:
+        run(1, 1, B_full)
+        dt = run(1, 1, B_full)
+        out['full_batch'] = {'it_s_at_sample_batch': round(1.0 / dt, 4), 'iterations': 1, 'seconds': round(dt, 2),
+                             'threads': best_n, 'smpl_evals_per_iter': 1, 'batch': B_full}
+    # BASELINE configs[0]: batch 4, forward + regressor only
+    x6, betas, _ = inputs(4)
+    Jt = T(J_np)
+    def fwd4():
+        Ro = oracle.rot6d_to_rotmat(x6[:, :1].reshape(-1, 6)).view(-1, 1, 3, 3)
+        Rp = oracle.rot6d_to_rotmat(x6[:, 1:].reshape(-1, 6)).view(-1, 23, 3, 3)
+        with torch.no_grad():
+            return oracle.find_joints(smpl, betas, Ro, Rp, Jt)
+    fwd4()
+    t0 = time.perf_counter(); n4 = 0
+    while time.perf_counter() - t0 < 1.0:
+        fwd4(); n4 += 1
+    dt4 = time.perf_counter() - t0
+    out['config1_forward_b4'] = {'evals_per_s': round(n4 / dt4, 2), 'ms_per_eval': round(dt4 / n4 * 1e3, 3), 'batch': 4,
+                                 'threads': best_n, 'workload': 'BASELINE configs[0]: SMPL forward + J_regressor eval, batch 4'}
+    return out, best_n
+
+
+def self_launch(a):
+    """--gpus N > 1 outside torchrun: start the N ranks as a CHILD `torch.distributed.run` before anything here has touched
+    the GPU (a process that has initialised the GPU must never exec / be replaced), relay rank 0's JSON line, exit with the
+    child's status."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:
+        sk.bind(('127.0.0.1', 0))
+        port = sk.getsockname()[1]
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={a.gpus}', '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ, MASTER_ADDR='127.0.0.1', HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get('HSA_ENABLE_IPC_MODE_LEGACY', '0'))
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    json_lines = [l for l in lines if l.startswith('{')]
+    for l in lines:
+        if not l.startswith('{'):
+            print(l, file=sys.stderr)
+    if json_lines:
+        print(json_lines[-1])
+    sys.stdout.flush()
+    sys.exit(r.returncode if r.returncode != 0 or json_lines else 1)
 
 
 def main():
     a = parse()
+    if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        self_launch(a)                 # does not return; nothing above has touched the GPU
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        raise SystemExit(f'bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)')
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
     if a.single_device:
@@ -152,6 +211,19 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
         else:
             dist.init_process_group(a.backend)
+    # evidence of what the collective spans: every rank's (rank, device index, device name, pid) and a sum of ranks
+    me = [rank, torch.cuda.current_device(), torch.cuda.get_device_name(dev), os.getpid()]
+    ranks_seen, ar_check = [me], 0.0
+    if dist is not None:
+        gathered = [None] * world
+        dist.all_gather_object(gathered, me)
+        ranks_seen = gathered
+        t = torch.tensor([float(rank)], device=dev)
+        dist.all_reduce(t)
+        ar_check = float(t.item())
+    collective = {'backend': (a.backend + (' (RCCL)' if a.backend == 'nccl' else '')) if dist is not None else None, 'world': world,
+                  'ranks_seen': ranks_seen, 'allreduce_check': ar_check, 'allreduce_expected': world * (world - 1) / 2,
+                  'single_device_debug': bool(a.single_device)}
 
     sm = importlib.import_module(PKG + '.smpl_model')
     eng_mod = importlib.import_module(PKG + '.engine')
@@ -164,9 +236,8 @@ def main():
     dmodel = eng_mod.DeviceModel(model_np, dev)
     flags = eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0) | (eng_mod.FLAG_SILHOUETTE if use_sil else 0)
     eng = eng_mod.RefineEngine(dmodel, B, batch_norm=B * world, flags=flags)
-    J = torch.from_numpy(J_np).to(dev)
+    J = torch.from_numpy(J_np).to(dev).contiguous()
     eng.set_j_regressor(J)
-    eng.set_forward_reuse(True)     # the iteration after a J step reuses that step's SMPL forward (same poses, new regressor)
     disc_flat, disc_sd = default_disc_flat(0)
     if use_disc:
         eng.set_pose_disc(disc_flat.to(dev))
@@ -195,49 +266,66 @@ def main():
         sil_refs = silhouette_setup(eng, x6d, betas)   # noqa: F841  (the engine keeps raw pointers)
     Jm, Jv = torch.zeros_like(J), torch.zeros_like(J)
     Jstep = torch.zeros(1, dtype=torch.int32, device=dev)
+    dJ = torch.zeros_like(J)          # the all-reduce bucket of the J step: allocated once
+    after_j = [False]                 # the previous engine call was a J step on (x6d, betas): the next iteration reuses its forward
 
     def j_step():
-        """scripts/optimize.py:300-312 data-parallel: local dJ (normalised by the global batch),
-        one RCCL all-reduce, replicated Adam(lr=args.j_reg_lr=1e-2), re-normalise."""
-        dJ = eng.j_regressor_grad(x6d, betas, gt_c)
+        """scripts/optimize.py:300-312 data-parallel: local dJ (normalised by the global batch), ONE RCCL all-reduce,
+        replicated Adam(lr=args.j_reg_lr=1e-2) + re-normalisation (one call); no allocation, nothing read back."""
+        eng.j_regressor_grad(x6d, betas, gt_c, out=dJ)
         if dist is not None:
             dist.all_reduce(dJ)
-        Jstep.add_(1)
-        eng_mod.adam_step(J, dJ, Jm, Jv, Jstep, 1e-2)
-        eng.set_j_regressor(J)
-
-    done = [0]
-    n_jsteps = [0]
+        eng.j_step_apply(J, dJ, Jm, Jv, Jstep, 1e-2)
+        after_j[0] = not use_sil
 
     def run(n, cadence):
-        """n inner iterations with the J step at its cadence"""
+        """n inner iterations with a J step after every `cadence`-th one (counted from the start of the call).
+        One process: ONE C call for everything (jrr_refine_run_j_steps).  N > 1: the all-reduce sits between the two
+        halves of each J step, so the host issues refine_run / j_regressor_grad / all_reduce / j_step_apply per segment."""
+        nj = n // cadence
+        if dist is None:
+            if nj:
+                eng.refine_run_j_steps(x6d, betas, gt_c, m, v, step, 1e-2, nj * cadence, cadence, J, Jm, Jv, Jstep, 1e-2, sqerr=sq,
+                                       after_j_step=after_j[0])
+                after_j[0] = not use_sil
+            if n - nj * cadence:
+                eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, n - nj * cadence, sqerr=sq, after_j_step=after_j[0])
+                after_j[0] = False
+            return nj
         left = n
         while left > 0:
-            seg = min(left, cadence - done[0] % cadence)
-            eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, seg, sqerr=sq)
-            done[0] += seg
+            seg = min(left, cadence)
+            eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, seg, sqerr=sq, after_j_step=after_j[0])
+            after_j[0] = False
             left -= seg
-            if done[0] % cadence == 0:
+            if seg == cadence:
                 j_step()
-                n_jsteps[0] += 1
+        return nj
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
-    def timed_region(n, cadence):
+    def timed_region(n, cadence, fn=None):
         """EXACTLY n steps between barrier + synchronize pairs; max over ranks"""
-        done[0] = 0; n_jsteps[0] = 0   # the cadence counter restarts with the timed region
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
-        run(n, cadence)
+        nj = (fn or run)(n, cadence)
         torch.cuda.synchronize(); barrier()
         el = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
-        return el, n_jsteps[0]
+        return el, nj
+
+    def repeats_for(el, lo=1):
+        reps = int(min(a.max_repeats, max(lo, np.ceil(a.min_timed_ms * 1e-3 / max(el, 1e-6)))))
+        if dist is not None:           # every rank must run the same number of regions
+            t = torch.tensor([reps], device=dev, dtype=torch.int64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            reps = int(t.item())
+        return reps
 
     cadence = max(1, min(a.j_step_every, a.steps))   # >= 1 J step (SMPL fwd, dJ, RCCL all-reduce, Adam) per timed region
     run(a.warmup, cadence)
@@ -245,18 +333,25 @@ def main():
     regions = []
     el, nj_region = timed_region(a.steps, cadence)
     regions.append(el)
-    reps = int(min(a.max_repeats, max(1, np.ceil(a.min_timed_ms * 1e-3 / max(el, 1e-6)))))
-    if dist is not None:           # every rank must run the same number of regions
-        t = torch.tensor([reps], device=dev, dtype=torch.int64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        reps = int(t.item())
-    for _ in range(reps - 1):
+    for _ in range(repeats_for(el) - 1):
         regions.append(timed_region(a.steps, cadence)[0])
     elapsed = statistics.median(regions)
     loss_joint = float(sq.sum().item()) / (B * 51)
 
-    # ---- BASELINE configs[3] "all-reduce on the J_regressor gradient EACH step": J step after every iteration ----
-    c1_el, _ = timed_region(a.steps, 1)
+    # ---- BASELINE configs[3] "all-reduce on the J_regressor gradient EACH step": J step after every iteration,
+    #      timed like `value` (median of >= 5 regions) ----
+    c1_regions = [timed_region(a.steps, 1)[0]]
+    for _ in range(max(4, min(repeats_for(c1_regions[0]), 10) - 1)):
+        c1_regions.append(timed_region(a.steps, 1)[0])
+    c1_el = statistics.median(c1_regions)
+
+    # ---- the inner iteration ALONE (no J step in the region, no forward reuse): the denominator of roofline.whole_step ----
+    def run_inner(n, _cadence):
+        eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, n, sqerr=sq)
+        after_j[0] = False
+        return 0
+    in_regions = [timed_region(a.steps, 0, run_inner)[0] for _ in range(3)]
+    inner_ms = statistics.median(in_regions) / a.steps * 1e3
 
     # ---- per-kernel timing (HIP events on the launch stream) over the same number of steps ----
     eng.set_profiling(True)
@@ -274,6 +369,7 @@ def main():
         j_step()
     torch.cuda.synchronize(); barrier()
     j_ms = (time.perf_counter() - tj) / nj * 1e3
+    after_j[0] = False
 
     # ---- pose-discriminator update (scripts/optimize.py:276-284; one per outer batch in the reference): two D
     #      forward + weight-gradient passes, all-reduce of the 1.84 M-float gradient, Adam(lr 1e-3), re-upload.
@@ -284,9 +380,10 @@ def main():
         dm_, dv_ = torch.zeros_like(dflat), torch.zeros_like(dflat)
         dstep = torch.zeros(1, dtype=torch.int32, device=dev)
         spin_pose = torch.from_numpy(batch_np['pose6d']).to(dev).contiguous()
+        g = torch.zeros_like(dflat)
 
         def d_step():
-            g = torch.zeros_like(dflat)
+            g.zero_()
             eng.pose_disc_backward_params(x6d, 0.0, g)
             eng.pose_disc_backward_params(spin_pose, 1.0, g)
             if dist is not None:
@@ -304,9 +401,9 @@ def main():
         d_ms = (time.perf_counter() - td) / nj * 1e3
         eng.set_pose_disc(disc_flat.to(dev))
 
-    def side_run(flags_, setup=None):
-        """a separately reported mode on a fresh copy of the same batch: warm-up, then --steps timed iterations"""
-        e2 = eng_mod.RefineEngine(dmodel, B, batch_norm=B * world, flags=flags_)
+    def side_run(flags_, setup=None, model=None):
+        """a separately reported mode on a fresh copy of the same batch: warm-up, then --steps timed iterations (median of 3)"""
+        e2 = eng_mod.RefineEngine(model or dmodel, B, batch_norm=B * world, flags=flags_)
         if flags_ & eng_mod.FLAG_FOLDED:
             e2.set_folded(True)
         e2.set_j_regressor(J)
@@ -318,16 +415,20 @@ def main():
         fm, fv = torch.zeros(B, 154, device=dev), torch.zeros(B, 154, device=dev)
         fstep = torch.zeros(1, dtype=torch.int32, device=dev)
         e2.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, a.warmup)
-        torch.cuda.synchronize(); barrier()
-        tf = time.perf_counter()
-        e2.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, a.steps)
-        torch.cuda.synchronize(); barrier()
-        fel = time.perf_counter() - tf
-        if dist is not None:
-            t = torch.tensor([fel], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            fel = float(t.item())
-        return {'value': round(a.steps / fel * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(fel / a.steps * 1e3, 4)}
+
+        def go(n, _c):
+            e2.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, n)
+            return 0
+        fel = statistics.median([timed_region(a.steps, 0, go)[0] for _ in range(3)])
+        out_ = {'value': round(a.steps / fel * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(fel / a.steps * 1e3, 4),
+                'joint_sparse': int(e2.info.get('joint_sparse') or 0)}
+        if setup is silhouette_setup:
+            e2.set_profiling(True)
+            e2.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, max(2, min(a.steps, 10)))
+            pr = e2.profile_read()
+            e2.set_profiling(False)
+            out_['kernels_ms'] = {k: round(t, 4) for k, (t, n) in pr.items() if n}
+        return out_
 
     # ---- folded-regressor mode (a different algorithm with its own denominator) ----
     folded = None
@@ -341,6 +442,31 @@ def main():
     if not a.no_config5 and not use_sil and use_disc:
         config5 = side_run(eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_POSE_DISC | eng_mod.FLAG_SILHOUETTE, silhouette_setup)
         config5['workload'] = 'BASELINE configs[4]: configs[2] + soft-silhouette loss (224x224 rasteriser as HIP kernel) in the inner loop'
+    # ---- what a body model with a less coherent vertex order runs: the 12-joint-per-tile kernels and the dense kernels
+    #      (the synthetic body's ring-major vertex order is what lets the headline use the 8-joint kernels) ----
+    skin_variants = None
+    if not a.no_skin_variants and not use_sil:
+        skin_variants = {}
+        for name, env in (('skin12', {'JRR_SKIN_JOINTS': '12'}), ('dense', {'JRR_DENSE_SKINNING': '1'})):
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)                       # read by jrr_model_create
+            try:
+                mdl = eng_mod.DeviceModel(model_np, dev)
+            finally:
+                for k, vv in old.items():
+                    if vv is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = vv
+            r = side_run(eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0), model=mdl)
+            kj = r['joint_sparse']
+            fl = ((flop_lbs_fwd_sparse(kj) + flop_lbs_bwd_sparse(kj)) if kj else (FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE)) \
+                + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
+            r.update({'flop_per_pose_iter': fl, 'achieved_tflops': round(fl * B / (r['ms_per_step'] * 1e-3) / 1e12, 2),
+                      'frac_of_f32_mfma_peak': round(fl * B / (r['ms_per_step'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                      'forced_by': env})
+            skin_variants[name] = r
+            del mdl
 
     if rank != 0:
         if dist is not None:
@@ -364,7 +490,7 @@ def main():
             traffic = None
     step_flop = flop_fwd + flop_bwd + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
     step_flop_dense = FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
-    inner_ms = ms_per_step - nj_region * j_ms / a.steps
+    c1_ms = c1_el / a.steps * 1e3
     out = {
         'metric': 'pose-refinement iters/sec, batch 4096, at 1/2/4/8 MI355X',   # BASELINE.json's metric string; batch = poses per GPU (weak scaling)
         'value': round(it_s * world, 3), 'unit': f'it/s (x{B} poses)', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
@@ -377,7 +503,9 @@ def main():
                    'j_step_every': cadence, 'j_steps_in_timed_region': nj_region, 'parallelism': f'dp{world}', 'joint_loss_last': loss_joint,
                    'timed_regions': len(regions), 'value_is': 'median region',
                    'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in regions],
+                   'host_calls_per_region': 'one C call (jrr_refine_run_j_steps)' if dist is None else 'refine_run + j_regressor_grad + all_reduce + j_step_apply per J step',
                    'geometry': eng.info},
+        'collective': collective,
         'roofline': {'bound': 'mfma', 'kernel': 'k_lbs_fwd<true,false>', 'achieved': round(achieved, 2),
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                      'traffic': traffic,
@@ -394,13 +522,13 @@ def main():
                      'dense_formulation': {'flop_per_launch': FLOP_LBS_FWD_PER_POSE * B,
                                            'rate_tflops': round(FLOP_LBS_FWD_PER_POSE * B / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
                                            'note': 'the reference formulation\'s FLOP over the same time; not a roofline figure'},
-                     # the WHOLE inner iteration against the same peak: dense algorithmic FLOP of its four MFMA stages
-                     # (k_lbs_fwd + k_lbs_bwd + blend adjoint + discriminator fwd/input-grad) over the measured step time
-                     # without the J step's share
+                     # the WHOLE inner iteration against the same peak: algorithmic FLOP of its four MFMA stages
+                     # (k_lbs_fwd + k_lbs_bwd + blend adjoint + discriminator fwd/input-grad) over the time of a region of
+                     # inner iterations ONLY (no J step, no forward reuse; median of 3 regions)
                      'whole_step': {'flop_per_pose_iter': step_flop,
                                     'achieved': round(step_flop * B / (inner_ms * 1e-3) / 1e12, 2),
                                     'frac': round(step_flop * B / (inner_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                    'inner_only_ms_per_step': round(inner_ms, 4),
+                                    'inner_only_ms_per_step': round(inner_ms, 4), 'timed': 'its own regions: no J step, no forward reuse',
                                     'dense_formulation_flop_per_pose_iter': step_flop_dense,
                                     'dense_formulation_rate_tflops': round(step_flop_dense * B / (inner_ms * 1e-3) / 1e12, 2)},
                      # in-kernel probe (s_memtime / s_memrealtime, workgroup 0 / wave 0): the clock the chip holds on
@@ -413,10 +541,13 @@ def main():
                      'first_workgroup_resident_frac': round(probe[4] * 1e-6 / dom_ms, 3) if probe[4] and dom_ms > 0 else None},
         'kernels_ms': {k: round(t, 4) for k, (t, n) in prof.items() if n},
         'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
-                   'allreduce_bytes': 17 * 6890 * 4, 'in_timed_region': nj_region},
-        'cadence1': {'value': round(a.steps / c1_el * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(c1_el / a.steps * 1e3, 4),
-                     'j_step_every': 1, 'note': 'BASELINE configs[3] / north_star "all-reduce on the J_regressor gradient each step": '
-                                                'the J step (+ its all-reduce) after EVERY inner iteration, timed like `value`'},
+                   'allreduce_bytes': 17 * 6890 * 4, 'in_timed_region': nj_region, 'host_calls': 2 + (1 if dist is not None else 0)},
+        'cadence1': {'value': round(a.steps / c1_el * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(c1_ms, 4),
+                     'j_step_every': 1, 'timed_regions': len(c1_regions), 'value_is': 'median region',
+                     'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1_regions],
+                     'spread_frac': round((max(c1_regions) - min(c1_regions)) / c1_el, 4),
+                     'note': 'BASELINE configs[3] / north_star "all-reduce on the J_regressor gradient each step": '
+                             'the J step (+ its all-reduce) after EVERY inner iteration, timed like `value`'},
     }
     # outer-step work.  `value` already contains the J step (+ all-reduce) at cadence
     # `j_step_every`; the pose-D update is timed separately.  Two derived rates: everything at the measured
@@ -424,23 +555,27 @@ def main():
     out['outer_step'] = {'j_step_ms': round(j_ms, 3), 'pose_d_update_ms': None if d_ms is None else round(d_ms, 3),
                          'inner_only_ms_per_step': round(inner_ms, 4),
                          'it_s_incl_pose_d_update_at_cadence': round(world / ((ms_per_step + (d_ms or 0.0) / cadence) * 1e-3), 3),
-                         'it_s_all_outer_work_every_iteration': round(world / ((c1_el / a.steps * 1e3 + (d_ms or 0.0)) * 1e-3), 3),
+                         'it_s_all_outer_work_every_iteration': round(world / ((c1_ms + (d_ms or 0.0)) * 1e-3), 3),
                          'j_allreduce_bytes': 17 * 6890 * 4, 'pose_d_allreduce_bytes': 1840153 * 4 if use_disc else 0}
     if folded is not None:
         out['folded_mode'] = folded
     if config5 is not None:
         out['config5'] = config5
+    if skin_variants is not None:
+        out['skin_variants'] = skin_variants
     if not a.no_cpu_baseline and world == 1:   # the CPU baseline leg runs at N = 1 only
         cb = min(a.cpu_batch or B, B)
-        variants, nthreads = cpu_baseline(model_np, J_np, batch_np, disc_sd, cb, a.cpu_seconds, use_disc)
+        variants, nthreads = cpu_baseline(model_np, J_np, batch_np, disc_sd, cb, a.cpu_seconds, use_disc, B)
         for vv in variants.values():
-            vv['value_batch4096_units'] = round(vv['it_s_at_sample_batch'] * cb / B, 5)
+            if 'it_s_at_sample_batch' in vv:
+                vv['value_batch4096_units'] = round(vv['it_s_at_sample_batch'] * vv['batch'] / B, 5)
         out['cpu_baseline'] = {'value': variants['one_eval']['value_batch4096_units'], 'unit': f'it/s (x{B} poses)', 'cores': nthreads,
                                'kind': 'port', 'cpu_model': cpu_model_name(), 'host_threads': os.cpu_count(),
                                'sample': f"{variants['one_eval']['iterations']} inner iterations at batch {cb} of the same workload "
                                          f'(oracle/reference_port.py: torch-CPU ops in the reference order, autograd, torch.optim.Adam; '
                                          f"1 SMPL eval/iter), {variants['one_eval']['seconds']} s on {nthreads} threads picked from a "
-                                         f'1-iteration sweep over 8/16/32/64, scaled x{cb}/{B} to batch-{B} units',
+                                         f'1-iteration sweep over 8/16/32/64, scaled x{cb}/{B} to batch-{B} units; `full_batch` = one '
+                                         f'iteration at batch {B} itself, `config1_forward_b4` = BASELINE configs[0]',
                                'variants': variants}
     print(json.dumps(out))
     if dist is not None:

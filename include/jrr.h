@@ -53,7 +53,9 @@ enum {
   JRR_FLAG_SHAPE_DISC = 2,  /* shape-discriminator term (optimize.py:244,249-250) */
   JRR_FLAG_KEEP_VERTS = 4,  /* reserve a (B,6890,3) vertex buffer for return_verts / J step */
   JRR_FLAG_FOLDED = 8,      /* reserve the folded-regressor tables (jrr_engine_set_folded) */
-  JRR_FLAG_SILHOUETTE = 16  /* reserve the soft-silhouette buffers (needs JRR_FLAG_KEEP_VERTS and model faces) */
+  JRR_FLAG_SILHOUETTE = 16, /* reserve the soft-silhouette buffers (needs JRR_FLAG_KEEP_VERTS and model faces) */
+  JRR_FLAG_NO_MODEL = 32    /* discriminator-only engine (model == NULL): the SMPL sections (~230 KB per pose) are not
+                               part of the workspace; only JRR_FLAG_POSE_DISC / JRR_FLAG_SHAPE_DISC may accompany it */
 };
 
 typedef struct jrr_model jrr_model_t;   /* device-resident, re-laid-out SMPL constants */
@@ -221,6 +223,15 @@ int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha_dev, float* dve
 int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask_dev, float* cam_dev, float* cam_m_dev,
                               float* cam_v_dev);
 
+/* The silhouette term as the fused inner loop evaluates it (projection from the engine's internal vertex layout, nearest
+ * face per pixel, loss and adjoint in one kernel), exposed as an operator: SMPL forward of (x6d, betas), then
+ * sqsil_dev[b] = sum_pixels (silhouette - mask)^2 and the gradient of 100 * mean((silhouette - mask)^2) (mean over
+ * batch_norm * 224 * 224; scripts/optimize.py:234-237,252) w.r.t. the SMPL vertices, dverts_dev (B,6890,3), and the
+ * camera, dcam_dev (B,3).  mask_dev (B,224,224).  Outputs nullable.  Needs JRR_FLAG_SILHOUETTE | JRR_FLAG_KEEP_VERTS.
+ * Bitwise reproducible (fixed-point accumulation), unlike jrr_silhouette_backward.                                   */
+int jrr_silhouette_loss_grad(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev, const float* cam_dev,
+                             const float* mask_dev, float* sqsil_dev, float* dverts_dev, float* dcam_dev, void* stream);
+
 /* ---- fused inner loop ---------------------------------------------------------------------
  * n_iters iterations of scripts/optimize.py:220-265 restricted to the engine's loss terms:
  * rot6d->R, SMPL, J-regress, pelvis-centre, MSE x10000 [+ pose-D x10] [+ shape-D x10],
@@ -239,18 +250,52 @@ int jrr_refine_run(jrr_engine_t* e, float* x6d_dev, float* betas_dev, const floa
 int jrr_refine_aux_losses(jrr_engine_t* e, float* pose_disc_sq_dev, float* shape_disc_sq_dev, void* stream);
 
 /* J step, scripts/optimize.py:300-312: gradient of mean((move_pelvis(joints)-gt/1000)^2) w.r.t.
- * the raw J_regressor for the current (detached) poses; dJ_dev (17,6890).                      */
+ * the raw J_regressor for the current (detached) poses; dJ_dev (17,6890).  sqerr_dev (B, nullable): per-pose squared
+ * joint error; joints_dev (B,17,3, nullable): the joints of this forward, i.e. of the regressor BEFORE its step (what
+ * utils.evaluate reads at scripts/optimize.py:314-315).                                                        */
 int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev,
-                         const float* gt_centred_mm_dev, float* dJ_dev, float* sqerr_dev, void* stream);
+                         const float* gt_centred_mm_dev, float* dJ_dev, float* sqerr_dev, float* joints_dev, void* stream);
+
+/* The second half of the J step in one call: step_dev += 1, torch.optim.Adam(lr) on the raw regressor J_dev (17,6890)
+ * in place with the (all-reduced) gradient dJ_dev and the state m_dev / v_dev, then J*mask -> ReLU -> row-normalise into
+ * the engine's layouts (= jrr_adam_step + jrr_engine_set_j_regressor).  Under data parallelism the J step is
+ * jrr_j_regressor_grad -> ONE RCCL all-reduce of dJ -> jrr_j_step_apply (scripts/optimize.py:300-312).  mask_dev nullable. */
+int jrr_j_step_apply(jrr_engine_t* e, float* J_dev, const float* dJ_dev, float* m_dev, float* v_dev, int32_t* step_dev,
+                     float lr, const float* mask_dev, void* stream);
 
 /* Forward reuse across the J step (needs JRR_FLAG_KEEP_VERTS).  jrr_j_regressor_grad evaluates SMPL on the current
  * poses; the inner iteration that follows evaluates it on the SAME poses (only the regressor has changed in between,
- * scripts/optimize.py:300-312 then :220-229).  When enabled, a jrr_refine_run whose x6d / betas POINTERS equal those of the
- * immediately preceding jrr_j_regressor_grad re-regresses the joints of its first iteration from the stored vertices
- * with the new regressor instead of repeating the forward -- the same arithmetic up to the summation order of the
- * regressor product.  The caller guarantees that nothing but jrr_refine_run modifies the pose buffers between the two
- * calls (any other engine call drops the cached forward).  Default: off.                                            */
-int jrr_engine_set_forward_reuse(jrr_engine_t* e, int enabled);
+ * scripts/optimize.py:300-312 then :220-229).  jrr_refine_run_after_j_step is jrr_refine_run whose FIRST iteration
+ * re-regresses its joints from the J step's stored vertices with the new regressor instead of repeating the forward --
+ * the same arithmetic up to the summation order of the regressor product.  Reuse is explicit per call: by calling this
+ * entry point the caller states that the previous calls on this engine were jrr_j_regressor_grad on the same x6d / betas
+ * buffers (optionally followed by jrr_j_step_apply / jrr_engine_set_j_regressor) and that nothing has written those
+ * buffers since.  What the engine can check it checks: any other entry point drops the cached forward, and the call then
+ * returns JRR_ERR_STATE (also when the pointers differ) instead of differentiating through a stale forward.           */
+int jrr_refine_run_after_j_step(jrr_engine_t* e, float* x6d_dev, float* betas_dev, const float* gt_centred_mm_dev,
+                                float* adam_m_dev, float* adam_v_dev, int32_t* step_dev, float lr, int n_iters,
+                                float* sqerr_dev, void* stream);
+
+/* The inner loop WITH its J steps in one call, for a single process (no collective between the two halves of a J step):
+ * n_iters iterations of jrr_refine_run; after every j_every-th one the J step of scripts/optimize.py:300-312
+ * (jrr_j_regressor_grad into engine scratch, jrr_j_step_apply with J_dev / J_m_dev / J_v_dev / J_step_dev / j_lr /
+ * mask_dev), the next iteration reusing its forward.  j_sqerr_dev (B, nullable): per-pose squared joint error of the
+ * last J step.  after_j_step != 0: as jrr_refine_run_after_j_step for the first iteration.  BASELINE configs[3]'s
+ * "J_regressor step each iteration" at world size 1 is j_every = 1.  Needs JRR_FLAG_KEEP_VERTS.                       */
+int jrr_refine_run_j_steps(jrr_engine_t* e, float* x6d_dev, float* betas_dev, const float* gt_centred_mm_dev,
+                           float* adam_m_dev, float* adam_v_dev, int32_t* step_dev, float lr, int n_iters,
+                           float* sqerr_dev, int j_every, float* J_dev, float* J_m_dev, float* J_v_dev,
+                           int32_t* J_step_dev, float j_lr, const float* mask_dev, float* j_sqerr_dev, int after_j_step,
+                           void* stream);
+
+/* Loss history of the inner loop (scripts/optimize.py:255-261 prints the five weighted terms when i % 10 == 0): while
+ * hist_dev != NULL, every `every`-th iteration run by jrr_refine_run* (counted from this call, first one included)
+ * appends one record of 5 floats {loss_j2d/100, silhouette_loss*100, joint_loss*10000, pose_discriminated_loss*10,
+ * shape_discriminated_loss*10} (inactive terms 0) to hist_dev, up to capacity_records.  Each value is this engine's
+ * share of the global mean (local sum / batch_norm denominators): under data parallelism the ranks' records add up.
+ * jrr_engine_loss_history_count returns the number of records written so far.  hist_dev == NULL disables.            */
+int jrr_engine_set_loss_history(jrr_engine_t* e, float* hist_dev, int capacity_records, int every);
+int jrr_engine_loss_history_count(const jrr_engine_t* e);
 
 /* launch geometry: {B, BP, batch_norm, nvc, nvcb, nsplit, nsplitJ, flags, joint_sparse}; joint_sparse = 8 or 12 when every
  * 32-vertex tile of the model is skinned by at most that many joints and the LBS kernels multiply by those only (exact: the

@@ -56,10 +56,15 @@ SIGNATURES = {
     'jrr_camera_prefit': (c_int, [_P, _P, _P, _P, _P, c_int, c_float, _P, _P]),
     'jrr_silhouette_forward': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_silhouette_backward': (c_int, [_P, _P, _P, _P, _P]),
+    'jrr_silhouette_loss_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_engine_set_silhouette': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_refine_run': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),
-    'jrr_j_regressor_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P]),
-    'jrr_engine_set_forward_reuse': (c_int, [_P, c_int]),
+    'jrr_j_regressor_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    'jrr_j_step_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P, _P]),
+    'jrr_refine_run_after_j_step': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),
+    'jrr_refine_run_j_steps': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, c_int, _P, _P, _P, _P, c_float, _P, _P, c_int, _P]),
+    'jrr_engine_set_loss_history': (c_int, [_P, _P, c_int, c_int]),
+    'jrr_engine_loss_history_count': (c_int, [_P]),
     'jrr_engine_info': (c_int, [_P, POINTER(c_int32), c_int]),
     'jrr_engine_set_profiling': (c_int, [_P, c_int]),
     'jrr_engine_profile_read': (c_int, [_P, POINTER(c_float), POINTER(c_int32)]),

@@ -253,8 +253,11 @@ struct jrr_engine {
   const float* sil_mask; float* smask; bool smask_valid;     // target masks, per-pose sum(mask^2)
   float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
   bool folded, fold_valid;
-  // forward reuse (jrr_engine_set_forward_reuse): state left by jrr_j_regressor_grad's SMPL forward
-  bool reuse_enabled, fwd_cached; const float *fc_x6d, *fc_betas;
+  // forward reuse (jrr_refine_run_after_j_step): state left by jrr_j_regressor_grad's SMPL forward; dropped by every
+  // entry point that overwrites FT / AT / VPb / VTb or may run between the two calls (drop_cached_forward)
+  bool fwd_cached; const float *fc_x6d, *fc_betas;
+  float* dJraw;                                      // (17,6890) gradient scratch of the in-call J steps (jrr_refine_run_j_steps)
+  float* hist; int hist_cap, hist_every, hist_n; long long hist_iter;   // loss history (jrr_engine_set_loss_history)
   float *VTb;       // [3][VP][BP] vertices / transposed vertex adjoint (KEEP_VERTS or SILHOUETTE)
   float *dVTb, *dJnp, *dJn;   // transposed external vertex adjoint [3][VP][BP]; J-gradient partial slabs [3*nsplitJ][32][VP]
   int32_t* step_scratch;
@@ -312,26 +315,28 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   jrr_engine* t = e ? e : &tmp;
   t->rowsum = c.take(32);
   t->probe = (long long*)c.take(16);   // 3 x int64 used
-  t->Jraw = c.take((size_t)NH * V);
-  t->Jmask = c.take((size_t)NH * V);
-  t->Jn = c.take((size_t)NH * V);
-  t->Jn_vi = c.take((size_t)VT * 1024);
-  t->Jn_iv = c.take((size_t)VT * 2560);   // backward per-tile operand records [Jn | W^T | W | pad]
-  t->Jn_q = c.take((size_t)VP * 32);      // normalised regressor in vertex quads [VP/4][32][4]
-  t->FT = c.take((size_t)KFP * BP);
-  t->AT = c.take((size_t)12 * NJ * BP);
-  t->VPb = c.take((size_t)3 * VP * BP);
-  t->JP = c.take((size_t)nvc * 3 * NH * BP);
-  t->dJT = c.take((size_t)3 * NHP * BP);
-  t->DVP = c.take((size_t)3 * VP * BP);
-  t->dATp = c.take((size_t)nvcb * 12 * NJ * BP);
-  t->dFTp = c.take((size_t)nsplit * KFP * BP);
-  t->Jsum = c.take((size_t)3 * NH * BP);
-  t->dA = c.take((size_t)12 * NJ * BP);
-  t->dF = c.take((size_t)KFP * BP);
-  t->R0T = c.take((size_t)16 * BP);
-  t->dRT = c.take((size_t)NJ * 9 * BP);
-  t->dbT = c.take((size_t)16 * BP);
+  if (!(flags & JRR_FLAG_NO_MODEL)) {  // SMPL sections (~230 KB per pose): not carved for a discriminator-only engine
+    t->Jraw = c.take((size_t)NH * V);
+    t->Jmask = c.take((size_t)NH * V);
+    t->Jn = c.take((size_t)NH * V);
+    t->Jn_vi = c.take((size_t)VT * 1024);
+    t->Jn_iv = c.take((size_t)VT * 2560);   // backward per-tile operand records [Jn | W^T | W | pad]
+    t->Jn_q = c.take((size_t)VP * 32);      // normalised regressor in vertex quads [VP/4][32][4]
+    t->FT = c.take((size_t)KFP * BP);
+    t->AT = c.take((size_t)12 * NJ * BP);
+    t->VPb = c.take((size_t)3 * VP * BP);
+    t->JP = c.take((size_t)nvc * 3 * NH * BP);
+    t->dJT = c.take((size_t)3 * NHP * BP);
+    t->DVP = c.take((size_t)3 * VP * BP);
+    t->dATp = c.take((size_t)nvcb * 12 * NJ * BP);
+    t->dFTp = c.take((size_t)nsplit * KFP * BP);
+    t->Jsum = c.take((size_t)3 * NH * BP);
+    t->dA = c.take((size_t)12 * NJ * BP);
+    t->dF = c.take((size_t)KFP * BP);
+    t->R0T = c.take((size_t)16 * BP);
+    t->dRT = c.take((size_t)NJ * 9 * BP);
+    t->dbT = c.take((size_t)16 * BP);
+  }
   t->joints = c.take((size_t)BP * NH * 3);
   t->sqerr = c.take((size_t)BP);
   t->step_scratch = (int32_t*)c.take(64);
@@ -390,6 +395,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->dVTb = c.take((size_t)3 * VP * BP);
     t->dJnp = c.take((size_t)3 * nsplitJ * 32 * VP);
     t->dJn = c.take((size_t)NH * VP);
+    t->dJraw = c.take((size_t)NH * V);
   }
   if (e) {
     e->BP = BP; e->nvc = nvc; e->nvcb = nvcb; e->nsplit = nsplit; e->nsplitJ = nsplitJ;
@@ -405,10 +411,11 @@ extern "C" size_t jrr_engine_workspace_bytes(int batch, int flags) {
 extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_norm, void* ws, size_t ws_bytes,
                                  int flags, jrr_engine_t** out) {
   if (!ws || !out || batch <= 0) { jrr_set_error("jrr_engine_create: bad argument"); return JRR_ERR_ARG; }
-  if (!model && (flags & ~(JRR_FLAG_POSE_DISC | JRR_FLAG_SHAPE_DISC))) {
+  if (!model && (flags & ~(JRR_FLAG_POSE_DISC | JRR_FLAG_SHAPE_DISC | JRR_FLAG_NO_MODEL))) {
     jrr_set_error("jrr_engine_create: a model-less engine serves the discriminators only");
     return JRR_ERR_ARG;
   }
+  if (model && (flags & JRR_FLAG_NO_MODEL)) { jrr_set_error("jrr_engine_create: JRR_FLAG_NO_MODEL with a model"); return JRR_ERR_ARG; }
   if (((uintptr_t)ws & 255) != 0) { jrr_set_error("workspace must be 256-byte aligned"); return JRR_ERR_ARG; }
   const size_t need = jrr_engine_workspace_bytes(batch, flags);
   if (ws_bytes < need) { jrr_set_error("workspace too small: %zu < %zu", ws_bytes, need); return JRR_ERR_WORKSPACE; }
@@ -522,6 +529,7 @@ static int fold_rebuild(jrr_engine* e, hipStream_t s) {
 
 extern "C" int jrr_engine_set_folded(jrr_engine_t* e, int enabled, void* stream) {
   if (!e) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (enabled && !(e->flags & JRR_FLAG_FOLDED)) { jrr_set_error("engine created without JRR_FLAG_FOLDED"); return JRR_ERR_STATE; }
   e->folded = enabled != 0;
   if (e->folded && e->have_J && !e->fold_valid) {
@@ -553,6 +561,7 @@ extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const
 
 extern "C" int jrr_engine_set_pose_disc(jrr_engine_t* e, const float* P, void* stream) {
   if (!e || !P) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!(e->flags & JRR_FLAG_POSE_DISC)) { jrr_set_error("engine created without JRR_FLAG_POSE_DISC"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   JRR_HIP(hipMemcpyAsync(e->Pd, P, (size_t)DP_TOTAL * 4, hipMemcpyDeviceToDevice, s));
@@ -571,6 +580,7 @@ extern "C" int jrr_engine_set_pose_disc(jrr_engine_t* e, const float* P, void* s
 
 extern "C" int jrr_engine_set_shape_disc(jrr_engine_t* e, const float* P, void* stream) {
   if (!e || !P) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!(e->flags & JRR_FLAG_SHAPE_DISC)) { jrr_set_error("engine created without JRR_FLAG_SHAPE_DISC"); return JRR_ERR_STATE; }
   JRR_HIP(hipMemcpyAsync(e->Ps, P, (size_t)JRR_SHAPE_DISC_PARAMS * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
   e->have_sd = true;
@@ -665,6 +675,7 @@ extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const
   if (!e || !betas || !djoints || ((x6d == nullptr) == (R == nullptr))) { jrr_set_error("find_joints_backward: bad argument"); return JRR_ERR_ARG; }
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
+  e->fwd_cached = false;
   launch_joints_loss(nullptr, 0, nullptr, djoints, 0.f, nullptr, nullptr, e->dJT, e->B, e->BP, s);   // (B,17,3) -> [3][18][BP]
   if (dx6d || dR || dbetas) {
     launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
@@ -764,6 +775,7 @@ static int disc_backward_input(jrr_engine* e, const float* x6d, float* out, cons
 
 extern "C" int jrr_pose_disc_forward(jrr_engine_t* e, const float* x6d, float* out, void* stream) {
   if (!e || !x6d || !out) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   int rc = disc_forward(e, x6d, out, s);
@@ -776,6 +788,7 @@ extern "C" int jrr_pose_disc_forward(jrr_engine_t* e, const float* x6d, float* o
 extern "C" int jrr_pose_disc_backward_input(jrr_engine_t* e, const float* x6d, float weight, float target, float* dx,
                                             void* stream) {
   if (!e || !x6d || !dx) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
   const float scale = (float)(2.0 * (double)weight / ((double)e->bnorm * 25.0));
   int rc = disc_backward_input(e, x6d, nullptr, nullptr, scale, target, dx, (hipStream_t)stream);
@@ -786,6 +799,7 @@ extern "C" int jrr_pose_disc_backward_input(jrr_engine_t* e, const float* x6d, f
 
 extern "C" int jrr_pose_disc_vjp_input(jrr_engine_t* e, const float* x6d, const float* gout, float* dx, void* stream) {
   if (!e || !x6d || !gout || !dx) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
   int rc = disc_backward_input(e, x6d, nullptr, gout, 0.f, 0.f, dx, (hipStream_t)stream);
   if (rc) return rc;
@@ -856,18 +870,21 @@ static int disc_backward_params(jrr_engine* e, const float* x6d, const float* go
 extern "C" int jrr_pose_disc_backward_params(jrr_engine_t* e, const float* x6d, float target, float* dP, float* sqerr,
                                              void* stream) {
   if (!e || !x6d || !dP) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
   return disc_backward_params(e, x6d, nullptr, (float)(2.0 / ((double)e->bnorm * 25.0)), target, dP, sqerr, (hipStream_t)stream);
 }
 
 extern "C" int jrr_pose_disc_vjp_params(jrr_engine_t* e, const float* x6d, const float* gout, float* dP, void* stream) {
   if (!e || !x6d || !gout || !dP) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!e->have_pd) { jrr_set_error("pose discriminator not set"); return JRR_ERR_STATE; }
   return disc_backward_params(e, x6d, gout, 0.f, 0.f, dP, nullptr, (hipStream_t)stream);
 }
 
 extern "C" int jrr_shape_disc_vjp_params(jrr_engine_t* e, const float* betas, const float* gout, float* dP, void* stream) {
   if (!e || !betas || !gout || !dP) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!e->have_sd) { jrr_set_error("shape discriminator not set"); return JRR_ERR_STATE; }
   launch_shape_disc_bwd_params(e->Ps, betas, gout, 0.f, 0.f, dP, nullptr, e->B, (hipStream_t)stream);
   CHECK_LAUNCH();
@@ -877,6 +894,7 @@ extern "C" int jrr_shape_disc_vjp_params(jrr_engine_t* e, const float* betas, co
 extern "C" int jrr_shape_disc_backward_params(jrr_engine_t* e, const float* betas, float target, float* dP, float* sqerr,
                                               void* stream) {
   if (!e || !betas || !dP) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!e->have_sd) { jrr_set_error("shape discriminator not set"); return JRR_ERR_STATE; }
   const float scale = (float)(2.0 / ((double)e->bnorm * 1.0));
   launch_shape_disc_bwd_params(e->Ps, betas, nullptr, scale, target, dP, sqerr, e->B, (hipStream_t)stream);
@@ -886,6 +904,7 @@ extern "C" int jrr_shape_disc_backward_params(jrr_engine_t* e, const float* beta
 
 extern "C" int jrr_shape_disc_forward(jrr_engine_t* e, const float* betas, float* out, void* stream) {
   if (!e || !betas || !out) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!e->have_sd) { jrr_set_error("shape discriminator not set"); return JRR_ERR_STATE; }
   launch_shape_disc(e->Ps, betas, out, nullptr, 0.f, 0.f, e->B, (hipStream_t)stream);
   CHECK_LAUNCH();
@@ -894,6 +913,7 @@ extern "C" int jrr_shape_disc_forward(jrr_engine_t* e, const float* betas, float
 
 extern "C" int jrr_shape_disc_vjp_input(jrr_engine_t* e, const float* betas, const float* gout, float* dbetas, void* stream) {
   if (!e || !betas || !gout || !dbetas) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (!e->have_sd) { jrr_set_error("shape discriminator not set"); return JRR_ERR_STATE; }
   launch_shape_disc(e->Ps, betas, nullptr, dbetas, 0.f, 0.f, e->B, (hipStream_t)stream, gout);
   CHECK_LAUNCH();
@@ -902,6 +922,7 @@ extern "C" int jrr_shape_disc_vjp_input(jrr_engine_t* e, const float* betas, con
 
 extern "C" int jrr_refine_aux_losses(jrr_engine_t* e, float* pose_disc_sq, float* shape_disc_sq, void* stream) {
   if (!e) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   hipStream_t s = (hipStream_t)stream;
   if (pose_disc_sq) {
     if (!((e->flags & JRR_FLAG_POSE_DISC) && e->have_pd)) { jrr_set_error("pose discriminator term not active"); return JRR_ERR_STATE; }
@@ -943,6 +964,7 @@ extern "C" int jrr_project_joints(const float* joints, const float* cam, float* 
 
 extern "C" int jrr_engine_set_reprojection(jrr_engine_t* e, const float* gt_j2d, float* cam, float* cam_m, float* cam_v) {
   if (!e) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (gt_j2d && (!cam || !cam_m || !cam_v)) { jrr_set_error("set_reprojection: cam / cam_m / cam_v required"); return JRR_ERR_ARG; }
   e->gt_j2d = gt_j2d; e->cam = cam; e->cam_m = cam_m; e->cam_v = cam_v;
   return JRR_OK;
@@ -976,6 +998,7 @@ extern "C" int jrr_silhouette_forward(jrr_engine_t* e, const float* verts, const
   int rc = sil_check(e);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  e->fwd_cached = false;
   launch_sil_project(verts, V * 3, cam, e->ndc, e->B, s);
   launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, e->cover, e->ncover, alpha, e->B, s);
   CHECK_LAUNCH();
@@ -987,6 +1010,7 @@ extern "C" int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha, flo
   int rc = sil_check(e);
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
+  e->fwd_cached = false;
   launch_sil_bwd(e->ndc, e->m.faces, e->cover, e->ncover, nullptr, galpha, 0.f, dverts, V * 3, dcam, 0, e->B, s);
   CHECK_LAUNCH();
   return JRR_OK;
@@ -994,6 +1018,7 @@ extern "C" int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha, flo
 
 extern "C" int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask, float* cam, float* cam_m, float* cam_v) {
   if (!e) return JRR_ERR_ARG;
+  e->fwd_cached = false;
   if (mask) {
     int rc = sil_check(e);
     if (rc) return rc;
@@ -1005,10 +1030,28 @@ extern "C" int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask, flo
   return JRR_OK;
 }
 
-extern "C" int jrr_engine_set_forward_reuse(jrr_engine_t* e, int enabled) {
-  if (!e) return JRR_ERR_ARG;
-  e->reuse_enabled = enabled != 0;
+// The silhouette term exactly as the fused inner loop evaluates it (k_sil_raster<true>: in-kernel projection from the
+// row-quad vertex buffer, packed fixed-point adjoint, write-back over the vertex pieces), as an operator: SMPL forward of
+// (x6d, betas), then loss and gradient w.r.t. the vertices and the camera.
+extern "C" int jrr_silhouette_loss_grad(jrr_engine_t* e, const float* x6d, const float* betas, const float* cam,
+                                        const float* mask, float* sqsil, float* dverts, float* dcam, void* stream) {
+  if (!e || !x6d || !betas || !cam || !mask) { jrr_set_error("silhouette_loss_grad: null"); return JRR_ERR_ARG; }
+  int rc = sil_check(e);
+  if (rc) return rc;
+  if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
+  if (!e->VTb) { jrr_set_error("silhouette_loss_grad needs JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
   e->fwd_cached = false;
+  smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s);
+  launch_mask_sq(mask, e->smask, e->B, s);
+  e->smask_valid = false;
+  const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * 224.0 * 224.0));      // optimize.py:252 weight 100
+  launch_sil_raster_adj(e->VTb, e->BP, cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, mask, e->smask, e->cover,
+                        e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s);
+  if (sqsil) JRR_HIP(hipMemcpyAsync(sqsil, e->sqsil, (size_t)e->B * 4, hipMemcpyDeviceToDevice, s));
+  if (dverts) launch_verts_untranspose(e->VTb, dverts, V * 3, V, nullptr, nullptr, e->B, e->BP, s, e->m.p2v);
+  if (dcam) JRR_HIP(hipMemcpyAsync(dcam, e->gcam, (size_t)e->B * 3 * 4, hipMemcpyDeviceToDevice, s));
+  CHECK_LAUNCH();
   return JRR_OK;
 }
 
@@ -1023,8 +1066,54 @@ static int joints_from_stored_verts(jrr_engine* e, hipStream_t s) {
 // =============================================================================================
 // fused inner loop (scripts/optimize.py:220-265)
 // =============================================================================================
-extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const float* gt_mm, float* adam_m,
-                              float* adam_v, int32_t* step, float lr, int n_iters, float* sqerr, void* stream) {
+// k-th record of the loss history: the five weighted terms of scripts/optimize.py:252-253 as this rank's share of the
+// global means (sum over the local poses / the global denominators), from the per-pose sums the iteration left behind
+__global__ void __launch_bounds__(1024) k_loss_record(const float* __restrict__ sqj, const float* __restrict__ sq2d,
+                                                      const float* __restrict__ sqsil, const float* __restrict__ dsq,
+                                                      const float* __restrict__ ssq, int B, int BP, float bnorm,
+                                                      float* __restrict__ rec) {
+  __shared__ float red[5][1024];
+  float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
+  for (int b = threadIdx.x; b < B; b += 1024) {
+    if (sq2d) acc[0] += sq2d[b];
+    if (sqsil) acc[1] += sqsil[b];
+    acc[2] += sqj[b];
+    if (dsq) { float a = 0.f; for (int k = 0; k < 25; ++k) a += dsq[(size_t)k * BP + b]; acc[3] += a; }
+    if (ssq) acc[4] += ssq[b];
+  }
+  for (int t = 0; t < 5; ++t) red[t][threadIdx.x] = acc[t];
+  __syncthreads();
+  for (int w = 512; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) for (int t = 0; t < 5; ++t) red[t][threadIdx.x] += red[t][threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    rec[0] = red[0][0] / (bnorm * 34.f) * 0.01f;            // loss_j2d / 100
+    rec[1] = red[1][0] / (bnorm * 224.f * 224.f) * 100.f;   // silhouette_loss * 100
+    rec[2] = red[2][0] / (bnorm * 51.f) * 10000.f;          // joint_loss * 10000
+    rec[3] = red[3][0] / (bnorm * 25.f) * 10.f;             // pose_discriminated_loss * 10
+    rec[4] = red[4][0] / bnorm * 10.f;                      // shape_discriminated_loss * 10
+  }
+}
+
+extern "C" int jrr_engine_set_loss_history(jrr_engine_t* e, float* hist_dev, int capacity_records, int every) {
+  if (!e || (hist_dev && (capacity_records <= 0 || every <= 0))) return JRR_ERR_ARG;
+  e->hist = hist_dev; e->hist_cap = hist_dev ? capacity_records : 0; e->hist_every = every; e->hist_n = 0; e->hist_iter = 0;
+  return JRR_OK;
+}
+extern "C" int jrr_engine_loss_history_count(const jrr_engine_t* e) { return e ? e->hist_n : JRR_ERR_ARG; }
+
+static int j_step_local(jrr_engine* e, const float* x6d, const float* betas, const float* gt_mm, float* dJ, float* sqerr, hipStream_t s,
+                        float* joints = nullptr);
+static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, float* v, int32_t* step, float lr, const float* mask,
+                        hipStream_t s);
+
+// Shared-parameter state of the in-call J steps (jrr_refine_run_j_steps)
+struct JStepArgs { int every; float* J; float* m; float* v; int32_t* step; float lr; const float* mask; float* sqerr; };
+
+static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const float* gt_mm, float* adam_m,
+                           float* adam_v, int32_t* step, float lr, int n_iters, float* sqerr, bool reuse_first,
+                           const JStepArgs* js, void* stream) {
   if (!e || !x6d || !betas || !gt_mm || !adam_m || !adam_v || !step || n_iters < 0) { jrr_set_error("refine_run: bad argument"); return JRR_ERR_ARG; }
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   const bool pd = (e->flags & JRR_FLAG_POSE_DISC) && e->have_pd;
@@ -1033,13 +1122,23 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
   const float jscale = (float)(2.0 * 10000.0 / ((double)e->bnorm * 51.0));   // optimize.py:252 weight 10000
   const float dscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 25.0));      // optimize.py:253 weight 10
   const float sscale = (float)(2.0 * 10.0 / ((double)e->bnorm * 1.0));
+  if (reuse_first) {
+    // the caller states that the previous call on this engine was the J step on exactly these poses and that nothing
+    // has written them since; everything the engine can check is checked
+    const bool ok = e->fwd_cached && e->fc_x6d == x6d && e->fc_betas == betas && e->VTb != nullptr;
+    if (!ok) {
+      jrr_set_error("refine_run_after_j_step: the previous call on this engine was not jrr_j_regressor_grad on the same pose buffers");
+      return JRR_ERR_STATE;
+    }
+  }
+  bool reuse_next = reuse_first;
   for (int it = 0; it < n_iters; ++it) {
     const bool folded = e->folded && e->fold_valid;
     // The J step that preceded this call ran the SMPL forward on exactly these poses (jrr_j_regressor_grad keeps
     // v_posed, the skinning transforms and the vertices): the first iteration re-regresses the joints with the NEW
-    // regressor from the stored vertices instead of repeating the 0.47 ms forward (jrr_engine_set_forward_reuse).
-    const bool reuse = it == 0 && e->reuse_enabled && e->fwd_cached && e->fc_x6d == x6d && e->fc_betas == betas && !folded &&
-                       e->VTb != nullptr && e->sil_mask == nullptr;
+    // regressor from the stored vertices instead of repeating the 0.47 ms forward (jrr_refine_run_after_j_step).
+    const bool reuse = reuse_next && e->fwd_cached && !folded && e->sil_mask == nullptr;
+    reuse_next = false;
     e->fwd_cached = false;
     prof_mark(e, 0, s);
     // with the pose discriminator its per-joint MLP rides in the chain-forward launch, and its adjoint in the launch of
@@ -1123,9 +1222,45 @@ extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const f
     if (e->gt_j2d || sil) { L.gcam = e->gcam; L.cam_io = e->cam; L.cam_m = e->cam_m; L.cam_v = e->cam_v; }
     launch_prep_bwd(L, e->m, s);
     prof_mark(e, 7, s);
+    if (e->hist) {      // scripts/optimize.py:255-261: the five weighted terms every `hist_every`-th iteration
+      if (e->hist_iter % e->hist_every == 0 && e->hist_n < e->hist_cap) {
+        hipLaunchKernelGGL(k_loss_record, dim3(1), dim3(1024), 0, s, sqerr ? sqerr : e->sqerr, e->gt_j2d ? e->sq2d : nullptr,
+                           sil ? e->sqsil : nullptr, pd ? e->dsq : nullptr, sd ? e->ssq : nullptr, e->B, e->BP, (float)e->bnorm,
+                           e->hist + (size_t)e->hist_n * 5);
+        ++e->hist_n;
+      }
+      ++e->hist_iter;
+    }
+    if (js && (it + 1) % js->every == 0) {      // scripts/optimize.py:300-312 inside the call (single process: no collective)
+      int rcj = j_step_local(e, x6d, betas, gt_mm, e->dJraw, js->sqerr, s);
+      if (rcj) return rcj;
+      rcj = j_step_apply(e, js->J, e->dJraw, js->m, js->v, js->step, js->lr, js->mask, s);
+      if (rcj) return rcj;
+      reuse_next = true;
+    }
   }
   CHECK_LAUNCH();
   return JRR_OK;
+}
+
+extern "C" int jrr_refine_run(jrr_engine_t* e, float* x6d, float* betas, const float* gt_mm, float* adam_m,
+                              float* adam_v, int32_t* step, float lr, int n_iters, float* sqerr, void* stream) {
+  return refine_run_impl(e, x6d, betas, gt_mm, adam_m, adam_v, step, lr, n_iters, sqerr, false, nullptr, stream);
+}
+
+extern "C" int jrr_refine_run_after_j_step(jrr_engine_t* e, float* x6d, float* betas, const float* gt_mm, float* adam_m,
+                                           float* adam_v, int32_t* step, float lr, int n_iters, float* sqerr, void* stream) {
+  return refine_run_impl(e, x6d, betas, gt_mm, adam_m, adam_v, step, lr, n_iters, sqerr, true, nullptr, stream);
+}
+
+extern "C" int jrr_refine_run_j_steps(jrr_engine_t* e, float* x6d, float* betas, const float* gt_mm, float* adam_m,
+                                      float* adam_v, int32_t* step, float lr, int n_iters, float* sqerr, int j_every,
+                                      float* J, float* J_m, float* J_v, int32_t* J_step, float j_lr, const float* mask,
+                                      float* j_sqerr, int after_j_step, void* stream) {
+  if (!e || j_every <= 0 || !J || !J_m || !J_v || !J_step) { jrr_set_error("refine_run_j_steps: bad argument"); return JRR_ERR_ARG; }
+  if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("J step requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
+  JStepArgs js{j_every, J, J_m, J_v, J_step, j_lr, mask, j_sqerr};
+  return refine_run_impl(e, x6d, betas, gt_mm, adam_m, adam_v, step, lr, n_iters, sqerr, after_j_step != 0, &js, stream);
 }
 
 // =============================================================================================
@@ -1153,14 +1288,38 @@ static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s) {
 }
 
 extern "C" int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d, const float* betas, const float* gt_mm,
-                                    float* dJ, float* sqerr, void* stream) {
+                                    float* dJ, float* sqerr, float* joints, void* stream) {
   if (!e || !x6d || !betas || !gt_mm || !dJ) return JRR_ERR_ARG;
   if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("J step requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
-  hipStream_t s = (hipStream_t)stream;
+  return j_step_local(e, x6d, betas, gt_mm, dJ, sqerr, (hipStream_t)stream, joints);
+}
+
+// torch.optim.Adam on the raw regressor with the (all-reduced) gradient, then J*mask -> ReLU -> row-normalise into the
+// engine's layouts: the second half of the J step in ONE call (step counter incremented on the device).  The forward
+// cached by jrr_j_regressor_grad stays valid: it does not depend on the regressor.
+extern "C" int jrr_j_step_apply(jrr_engine_t* e, float* J, const float* dJ, float* m, float* v, int32_t* step, float lr,
+                                const float* mask, void* stream) {
+  if (!e || !J || !dJ || !m || !v || !step) { jrr_set_error("j_step_apply: null"); return JRR_ERR_ARG; }
+  if (!e->has_model) { jrr_set_error("engine was created without an SMPL model (discriminators only)"); return JRR_ERR_STATE; }
+  return j_step_apply(e, J, dJ, m, v, step, lr, mask, (hipStream_t)stream);
+}
+
+static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, float* v, int32_t* step, float lr, const float* mask,
+                        hipStream_t s) {
+  launch_step_inc(step, s);
+  launch_adam_flat(J, dJ, m, v, (size_t)NH * V, step, lr, 0.9f, 0.999f, 1e-8f, s);
+  const bool cached = e->fwd_cached;
+  int rc = jrr_engine_set_j_regressor(e, J, mask, (void*)s);
+  e->fwd_cached = cached;
+  return rc;
+}
+
+static int j_step_local(jrr_engine* e, const float* x6d, const float* betas, const float* gt_mm, float* dJ, float* sqerr, hipStream_t s,
+                        float* joints) {
   smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s);      // v_posed kept: the next inner iteration may reuse this forward
   e->fwd_cached = true; e->fc_x6d = x6d; e->fc_betas = betas;
   const float scale = (float)(2.0 * 1.0 / ((double)e->bnorm * 51.0));   // optimize.py:307 unweighted MSE
-  launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, scale, e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);
+  launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, scale, joints ? joints : e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);
   return j_grad_from_verts(e, dJ, s);
 }

@@ -22,22 +22,29 @@ from . import engine as _engine
 
 class _ModuleEngines:
     """(batch, device) -> model-less RefineEngine holding this module's parameters; the 7.4 MB upload (and the two
-    weight transposes behind it) is repeated only when a parameter has changed (torch's per-tensor version counter)."""
+    weight transposes behind it) is repeated only when a parameter has changed (torch's per-tensor version counter).
+    The engine itself records which parameter version it holds (`param_version`), so that anything else that uploads
+    weights into it (the restore path of _PoseDiscFn.backward) invalidates the record.  At most MAX_ENGINES engines are
+    kept per module (least recently used first out): a workspace is ~60 KB per pose for the pose discriminator."""
+    MAX_ENGINES = 4
 
     def __init__(self, flag: int):
         self.flag = flag
         self.engines: Dict = {}
-        self.uploaded: Dict = {}
 
     def get(self, module: nn.Module, batch: int, device, flat: torch.Tensor, setter: str):
         key = (batch, str(device))
-        if key not in self.engines:
-            self.engines[key] = _engine.RefineEngine(None, batch, flags=self.flag, device=device)
-        eng = self.engines[key]
+        eng = self.engines.pop(key, None)
+        if eng is None:
+            eng = _engine.RefineEngine(None, batch, flags=self.flag, device=device)
+            eng.param_version = None
+            while len(self.engines) >= self.MAX_ENGINES:
+                self.engines.pop(next(iter(self.engines)))
+        self.engines[key] = eng                      # most recently used last
         version = tuple((p.data_ptr(), p._version) for p in module.parameters())
-        if self.uploaded.get(key) != version:
+        if eng.param_version != version:
             getattr(eng, setter)(flat.detach())
-            self.uploaded[key] = version
+            eng.param_version = version
         return eng
 
 
@@ -55,16 +62,17 @@ class _PoseDiscFn(torch.autograd.Function):
         x, flat = ctx.saved_tensors
         eng = ctx.eng
         gout = gout.contiguous()
-        if eng.generation != ctx.gen:          # another forward has used the engine since: restore this one's state
-            eng.set_pose_disc(flat)
+        if eng.generation != ctx.gen:          # another call has used the engine since: restore this forward's state
+            eng.set_pose_disc(flat)            # (possibly older weights than the module's current ones:
+            eng.param_version = None           #  the module must upload again before its next forward)
             eng.pose_disc_forward(x)
         dx = eng.pose_disc_vjp_input(x, gout) if ctx.needs_input_grad[0] else None
         dflat = None
         if ctx.needs_input_grad[1]:
             dflat = torch.zeros_like(flat)
-            eng.pose_disc_vjp_params(x, gout, dflat)
-        ctx.gen = eng.generation
-        return dx, dflat, None
+            eng.pose_disc_vjp_params(x, gout, dflat)   # re-runs the forward with ROW-MAJOR activations: the quad
+        ctx.gen = -1                                   # state pose_disc_vjp_input reads is gone -> a second backward
+        return dx, dflat, None                         # through this node (retain_graph) restores it first
 
 
 class Discriminator(nn.Module):

@@ -20,6 +20,7 @@ FLAG_SHAPE_DISC = 2
 FLAG_KEEP_VERTS = 4
 FLAG_FOLDED = 8
 FLAG_SILHOUETTE = 16
+FLAG_NO_MODEL = 32
 SIL = 224
 
 NUM_VERTS, NUM_JOINTS, NUM_H36M, NUM_BETAS = 6890, 24, 17, 10
@@ -93,7 +94,7 @@ class RefineEngine:
         self.device = model.device if model is not None else torch.device(device if device is not None else 'cuda:0')
         self.batch = int(batch)
         self.batch_norm = int(batch_norm or batch)
-        self.flags = int(flags)
+        self.flags = int(flags) | (FLAG_NO_MODEL if model is None else 0)   # no SMPL workspace for a discriminator-only engine
         # Forward-generation counter: the adjoint entry points read the engine's internal state of the MOST RECENT
         # forward (include/jrr.h: "must follow it"), while autograd defers backward.  Every call that overwrites that
         # state bumps the counter; the autograd wrappers compare it with the value saved at forward time and re-run
@@ -135,10 +136,6 @@ class RefineEngine:
         check(self.lib.jrr_engine_set_batch_norm(self.handle, int(n)), 'set_batch_norm')
         self.batch_norm = int(n)
         self.info['batch_norm'] = int(n)
-
-    def set_forward_reuse(self, enabled: bool):
-        """let the inner iteration that follows a J step reuse that step's SMPL forward (include/jrr.h)"""
-        check(self.lib.jrr_engine_set_forward_reuse(self.handle, int(bool(enabled))), 'set_forward_reuse')
 
     def set_folded(self, enabled: bool):
         """refine_run through the folded regressor tables (engine must have FLAG_FOLDED)"""
@@ -302,6 +299,20 @@ class RefineEngine:
         check(self.lib.jrr_silhouette_backward(self.handle, ptr(galpha), ptr(dverts), ptr(dcam), self._s()), 'silhouette_backward')
         return dverts, dcam
 
+    def silhouette_loss_grad(self, x6d, betas, cam, mask, want_dverts=True):
+        """the silhouette term as the fused loop evaluates it: per-pose sum (silhouette - mask)^2, d/dverts (B,6890,3) and
+        d/dcam (B,3) of 100 * mean((silhouette - mask)^2)  (jrr_silhouette_loss_grad)"""
+        self.generation += 1
+        B = self.batch
+        self._chk(x6d, (B, NUM_JOINTS, 6), 'x6d'); self._chk(betas, (B, NUM_BETAS), 'betas')
+        self._chk(cam, (B, 3), 'cam'); self._chk(mask, (B, SIL, SIL), 'mask')
+        sq = torch.empty(B, device=self.device)
+        dv = torch.empty(B, NUM_VERTS, 3, device=self.device) if want_dverts else None
+        dc = torch.empty(B, 3, device=self.device)
+        check(self.lib.jrr_silhouette_loss_grad(self.handle, ptr(x6d), ptr(betas), ptr(cam), ptr(mask), ptr(sq), ptr(dv), ptr(dc),
+                                                self._s()), 'silhouette_loss_grad')
+        return sq, dv, dc
+
     def set_silhouette(self, mask=None, cam=None, cam_m=None, cam_v=None):
         """enable (tensors) / disable (None) the silhouette term of refine_run"""
         if mask is not None:
@@ -311,8 +322,7 @@ class RefineEngine:
         self._sil_refs = (mask, cam, cam_m, cam_v)
         check(self.lib.jrr_engine_set_silhouette(self.handle, ptr(mask), ptr(cam), ptr(cam_m), ptr(cam_v)), 'set_silhouette')
 
-    def refine_run(self, x6d, betas, gt_centred_mm, adam_m, adam_v, step, lr: float, n_iters: int, sqerr=None):
-        self.generation += 1
+    def _refine_args(self, x6d, betas, gt_centred_mm, adam_m, adam_v, step):
         B = self.batch
         self._chk(x6d, (B, NUM_JOINTS, 6), 'x6d')
         self._chk(betas, (B, NUM_BETAS), 'betas')
@@ -320,8 +330,51 @@ class RefineEngine:
         self._chk(adam_m, (B, 154), 'adam_m')
         self._chk(adam_v, (B, 154), 'adam_v')
         assert step.dtype == torch.int32 and step.is_cuda
-        check(self.lib.jrr_refine_run(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(adam_m), ptr(adam_v),
-                                      ptr(step), float(lr), int(n_iters), ptr(sqerr), self._s()), 'refine_run')
+
+    def refine_run(self, x6d, betas, gt_centred_mm, adam_m, adam_v, step, lr: float, n_iters: int, sqerr=None,
+                   after_j_step: bool = False):
+        """n_iters inner iterations in ONE C call.  after_j_step=True (jrr_refine_run_after_j_step): the caller states that
+        the previous call on this engine was j_regressor_grad (+ j_step_apply) on these very buffers; the first iteration
+        then reuses that forward.  A mismatch the engine can detect raises instead of reusing a stale forward."""
+        self.generation += 1
+        self._refine_args(x6d, betas, gt_centred_mm, adam_m, adam_v, step)
+        fn = self.lib.jrr_refine_run_after_j_step if after_j_step else self.lib.jrr_refine_run
+        check(fn(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(adam_m), ptr(adam_v),
+                 ptr(step), float(lr), int(n_iters), ptr(sqerr), self._s()), 'refine_run')
+
+    def refine_run_j_steps(self, x6d, betas, gt_centred_mm, adam_m, adam_v, step, lr: float, n_iters: int, j_every: int,
+                           J, J_m, J_v, J_step, j_lr: float, mask=None, sqerr=None, j_sqerr=None, after_j_step: bool = False):
+        """the inner loop with a J step after every j_every-th iteration, all inside ONE C call (single process only:
+        there is no collective between the two halves of a J step); J / J_m / J_v / J_step are updated in place"""
+        self.generation += 1
+        self._refine_args(x6d, betas, gt_centred_mm, adam_m, adam_v, step)
+        for t, n in ((J, 'J'), (J_m, 'J_m'), (J_v, 'J_v')):
+            self._chk(t, (NUM_H36M, NUM_VERTS), n)
+        assert J_step.dtype == torch.int32 and J_step.is_cuda
+        check(self.lib.jrr_refine_run_j_steps(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(adam_m), ptr(adam_v),
+                                              ptr(step), float(lr), int(n_iters), ptr(sqerr), int(j_every), ptr(J), ptr(J_m),
+                                              ptr(J_v), ptr(J_step), float(j_lr), ptr(mask), ptr(j_sqerr), int(bool(after_j_step)),
+                                              self._s()), 'refine_run_j_steps')
+
+    def j_step_apply(self, J, dJ, J_m, J_v, J_step, lr: float, mask=None):
+        """second half of the J step: Adam on the raw regressor with the (all-reduced) gradient + re-normalisation, one call"""
+        self.generation += 1
+        for t, n in ((J, 'J'), (dJ, 'dJ'), (J_m, 'J_m'), (J_v, 'J_v')):
+            self._chk(t, (NUM_H36M, NUM_VERTS), n)
+        assert J_step.dtype == torch.int32 and J_step.is_cuda
+        check(self.lib.jrr_j_step_apply(self.handle, ptr(J), ptr(dJ), ptr(J_m), ptr(J_v), ptr(J_step), float(lr), ptr(mask),
+                                        self._s()), 'j_step_apply')
+
+    def set_loss_history(self, records: int = 0, every: int = 10):
+        """scripts/optimize.py:255-261: keep the five weighted loss terms of every `every`-th iteration (records = 0: off)"""
+        self._hist = torch.zeros(records, 5, device=self.device) if records > 0 else None
+        check(self.lib.jrr_engine_set_loss_history(self.handle, ptr(self._hist), int(records), int(every)), 'set_loss_history')
+
+    def loss_history(self) -> Optional[torch.Tensor]:
+        """(n,5) device tensor of the records written so far: [j2d/100, silhouette*100, joint*10000, poseD*10, shapeD*10]"""
+        if getattr(self, '_hist', None) is None:
+            return None
+        return self._hist[:self.lib.jrr_engine_loss_history_count(self.handle)]
 
     PROF_CLASSES = ['k_prep_fwd', 'k_lbs_fwd', 'k_joints_loss', 'k_lbs_bwd', 'k_gemm_tn_blend_adjoint', 'pose_disc_gemms',
                     'k_shape_disc', 'k_prep_bwd', 'silhouette_fwd_bwd']
@@ -344,11 +397,16 @@ class RefineEngine:
         check(self.lib.jrr_engine_probe_read(self.handle, out), 'probe_read')
         return tuple(int(x) for x in out)
 
-    def j_regressor_grad(self, x6d, betas, gt_centred_mm, sqerr=None):
+    def j_regressor_grad(self, x6d, betas, gt_centred_mm, sqerr=None, out=None, joints=None):
+        """local dJ (first half of the J step); `out` (17,6890): write into a caller-owned buffer (e.g. a slice of the flat
+        all-reduce bucket) instead of allocating; `joints` (B,17,3): receives the joints of this forward (old regressor)"""
         self.generation += 1
-        dJ = torch.empty(NUM_H36M, NUM_VERTS, device=self.device)
+        dJ = out if out is not None else torch.empty(NUM_H36M, NUM_VERTS, device=self.device)
+        self._chk(dJ, (NUM_H36M, NUM_VERTS), 'dJ')
+        if joints is not None:
+            self._chk(joints, (self.batch, NUM_H36M, 3), 'joints')
         check(self.lib.jrr_j_regressor_grad(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(dJ), ptr(sqerr),
-                                            self._s()), 'j_regressor_grad')
+                                            ptr(joints), self._s()), 'j_regressor_grad')
         return dJ
 
 

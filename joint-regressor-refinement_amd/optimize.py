@@ -16,10 +16,20 @@ Per outer batch (reference line numbers):
   :314-337  MPJPE / PA-MPJPE before and after the J step, logging (all ten scalars of the reference's record)
 
 Data parallelism (new): one process per GPU, the batch is sharded contiguously, per-pose state is
-rank-local, the MSE means are normalised by the GLOBAL batch; the only collectives are one
-sum-all-reduce per shared-parameter step (J gradient; discriminator gradients) and the scalar sums of
-the log record.  Every rank draws the same global batch (same seed) and keeps rows [lo, hi), so a
-sharded run reproduces the single-process run on the same global batch.
+rank-local, the MSE means are normalised by the GLOBAL batch.  The inner loop has no collective.  The
+outer step issues ONE sum-all-reduce over a flat bucket
+
+    [ dJ (17 x 6890) | dD (1 840 153) | dShapeD (171) | log-record sums | loss-history records ]  ~ 7.83 MB
+
+followed by the replicated Adam steps; the bucket's scalar tail is read back ONCE per outer batch (no
+`.item()` inside the loop, none per shared-parameter step).  The MPJPE of the regressor AFTER its step
+needs the stepped regressor, so those two sums ride in the NEXT batch's bucket (a last 2-float
+all-reduce flushes them after the final batch): the record of batch k is logged when batch k+1's bucket
+has been read.  A J step inside the inner loop (`--j_step_every` < `--inner_iters`) is
+jrr_j_regressor_grad -> one all-reduce of dJ -> jrr_j_step_apply, with no host synchronisation; in a
+single process the whole loop including those J steps is ONE C call (jrr_refine_run_j_steps).
+Every rank draws the same global batch (same seed) and keeps rows [lo, hi), so a sharded run
+reproduces the single-process run on the same global batch.
 """
 from __future__ import annotations
 
@@ -87,6 +97,34 @@ def _dataset_batches(root: str, B_global: int, seed: int, device, drop_last: boo
                'gt_j2d': batch['gt_j2d'].float(), 'seed': seed * 1000 + it}
 
 
+N_J = _engine.NUM_H36M * _engine.NUM_VERTS
+N_SCALARS = 10     # joint, pose-discriminated, shape-discriminated, pose-D, shape-D, J error, MPJPE / PA-MPJPE before the
+                   # J step (sums over the local poses) and the previous batch's MPJPE / PA-MPJPE after its J step
+
+
+class SharedBucket:
+    """The flat gradient + log bucket of one outer step: one buffer, one all-reduce, one read-back."""
+
+    def __init__(self, device, use_pd: bool, use_sd: bool, hist_records: int):
+        def pad(n):                # every section starts 256-byte aligned (the C ABI wants 16-byte aligned pointers)
+            return (n + 63) // 64 * 64
+        nD = _engine.DISC_PARAMS if use_pd else 0
+        nS = _engine.SHAPE_DISC_PARAMS if use_sd else 0
+        oD, oS = pad(N_J), pad(N_J) + pad(nD)
+        oT = oS + pad(nS)
+        self.flat = torch.zeros(oT + N_SCALARS + 5 * hist_records, device=device)
+        self.dJ = self.flat[:N_J].view(_engine.NUM_H36M, _engine.NUM_VERTS)
+        self.dD = self.flat[oD:oD + nD]
+        self.dS = self.flat[oS:oS + nS]
+        self.tail = self.flat[oT:]                                  # what is read back: scalars, then the history
+        self.scalars = self.tail[:N_SCALARS]
+        self.hist = self.tail[N_SCALARS:].view(-1, 5)
+        self.nbytes = self.flat.numel() * 4
+
+    def put(self, k: int, per_pose: torch.Tensor):
+        self.scalars[k:k + 1].copy_(per_pose.sum().reshape(1))
+
+
 def optimize_pose_refiner(log=print) -> Dict:
     dist = jdist.init(args.dist_backend)
     rank, local_rank, world = jdist.env_rank_world()
@@ -97,8 +135,8 @@ def optimize_pose_refiner(log=print) -> Dict:
     smpl = SMPL(args.smpl_dir, batch_size=1, allow_synthetic=args.synthetic or args.smpl_dir == 'SPIN/data/smpl').to(device)   # :96-99
     J_np = smpl_model.default_h36m_regressor(args.j_regressor_init,
                                              allow_default=args.synthetic or args.j_regressor_init == 'SPIN/data/J_regressor_h36m.npy')
-    J_regressor = torch.from_numpy(J_np).float().to(device)                                # :105-107
-    j_reg_mask = utils.find_j_reg_mask(J_regressor)                                        # :130
+    J_regressor = torch.from_numpy(J_np).float().to(device).contiguous()                   # :105-107
+    j_reg_mask = utils.find_j_reg_mask(J_regressor).contiguous()                           # :130
 
     use_pd, use_sd = not args.no_pose_disc, bool(args.shape_disc)
     pose_discriminator = Discriminator()                                                   # :112-113 (torch default init)
@@ -112,13 +150,15 @@ def optimize_pose_refiner(log=print) -> Dict:
     flags = _engine.FLAG_KEEP_VERTS | (_engine.FLAG_POSE_DISC if use_pd else 0) | (_engine.FLAG_SHAPE_DISC if use_sd else 0) \
         | (_engine.FLAG_SILHOUETTE if args.silhouette else 0)
     engines: Dict = {}
+    n_hist = (args.inner_iters + 9) // 10                                                  # :255 `if i % 10 == 0`
+    bucket = SharedBucket(device, use_pd, use_sd, n_hist)
+    after_sums = torch.zeros(2, device=device)             # MPJPE / PA-MPJPE sums after the J step: next batch's bucket
 
     def engine_for(B_local: int, B_global: int):
         """one engine per shard size (the last batch of a dataset may be ragged: drop_last=False)"""
         if B_local not in engines:
             engines[B_local] = _engine.RefineEngine(smpl.device_model, B_local, batch_norm=B_global, flags=flags)
         eng = engines[B_local]
-        eng.set_forward_reuse(True)       # an inner iteration right after a J step reuses that step's SMPL forward
         eng.set_batch_norm(B_global)
         eng.set_j_regressor(J_regressor, j_reg_mask)
         if use_pd:
@@ -133,8 +173,26 @@ def optimize_pose_refiner(log=print) -> Dict:
         source = _synthetic_batches(smpl.model_np, J_np, args.batch_size, args.synthetic_batches, args.seed)
 
     history = []
+    pending = None             # the previous batch's record, waiting for its after-the-J-step metrics
     x6d = betas = None
     lo = hi = 0
+
+    def finish(rec, B_global, after):
+        """complete a record with the all-reduced MPJPE / PA-MPJPE of the stepped regressor and log it (:323-337)"""
+        mpjpe_a, pampjpe_a = float(after[0]) * 1000 / B_global, float(after[1]) * 1000 / B_global
+        rec['mpjpe'], rec['pampjpe'] = mpjpe_a, pampjpe_a
+        rec['mpjpe difference'] = rec.pop('_mpjpe_before') - mpjpe_a
+        rec['pampjpe difference'] = rec.pop('_pampjpe_before') - pampjpe_a
+        history.append(rec)
+        if rank == 0:
+            log(rec)                                                                        # wandb.log analogue
+            if args.wandb_log:
+                try:
+                    import wandb
+                    wandb.log(rec)
+                except ImportError:
+                    pass
+
     for it, full in enumerate(source):                                                     # :144-148
         B_global = int(full['pose6d'].shape[0])
         lo, hi = jdist.shard_bounds(B_global, rank, world)
@@ -168,70 +226,96 @@ def optimize_pose_refiner(log=print) -> Dict:
             eng.set_silhouette(sil_mask, cam, cam_m, cam_v)
 
         t0 = time.perf_counter()
-        done = 0
-        while done < args.inner_iters:                                                     # :220-265
-            seg = min(args.j_step_every - done % args.j_step_every, args.inner_iters - done)
-            eng.refine_run(x6d, betas, gt_j3d, m, v, step, 1e-2, seg, sqerr=sq)
-            done += seg
-            if done % args.j_step_every == 0 and done < args.inner_iters:
-                _j_step(eng, J_regressor, J_opt, x6d, betas, gt_j3d, j_reg_mask)
-        joint_loss = _global_mean(sq, B_global * 51)
+        eng.set_loss_history(n_hist, 10)                                                   # :255-261 (read back with the bucket)
+        # ---- the 100 inner iterations (:220-265); J steps inside the loop only when --j_step_every < --inner_iters ----
+        n_inloop = (args.inner_iters - 1) // args.j_step_every * args.j_step_every if args.inner_iters > 0 else 0
+        if n_inloop and world == 1:         # one C call for the iterations AND their J steps (no collective needed)
+            eng.refine_run_j_steps(x6d, betas, gt_j3d, m, v, step, 1e-2, n_inloop, args.j_step_every, J_regressor, J_opt.m,
+                                   J_opt.v, J_opt.step, J_opt.lr, mask=j_reg_mask, sqerr=sq)
+        else:
+            for done in range(0, n_inloop, args.j_step_every):
+                eng.refine_run(x6d, betas, gt_j3d, m, v, step, 1e-2, args.j_step_every, sqerr=sq, after_j_step=done > 0)
+                _j_step_in_loop(eng, J_regressor, J_opt, x6d, betas, gt_j3d, j_reg_mask, bucket.dJ)
+        eng.refine_run(x6d, betas, gt_j3d, m, v, step, 1e-2, args.inner_iters - n_inloop, sqerr=sq, after_j_step=n_inloop > 0)
+        bucket.flat.zero_()
+        bucket.put(0, sq)                                                                   # joint_loss (:238-239)
         pose_disc_sq, shape_disc_sq = eng.refine_aux_losses(use_pd, use_sd) if args.inner_iters > 0 else (None, None)
-        pose_discriminated_loss = _global_mean(pose_disc_sq, B_global * 25) if pose_disc_sq is not None else None   # :246-247
-        shape_discriminated_loss = _global_mean(shape_disc_sq, B_global) if shape_disc_sq is not None else None    # :249-250
+        if pose_disc_sq is not None:
+            bucket.put(1, pose_disc_sq)                                                     # :246-247
+        if shape_disc_sq is not None:
+            bucket.put(2, shape_disc_sq)                                                    # :249-250
+        hist = eng.loss_history()
+        if hist is not None and hist.shape[0]:
+            bucket.hist[:hist.shape[0]].copy_(hist)
+        eng.set_loss_history(0)
         if args.reprojection:
             eng.set_reprojection(None)
         if args.silhouette:
             eng.set_silhouette(None)
 
-        # ---- pose-discriminator update (:276-284) ----
-        pose_d_loss = None
+        # ---- LOCAL gradients of the three shared-parameter steps, written straight into the bucket ----
+        if use_pd:                                                                          # :276-284
+            l0 = eng.pose_disc_backward_params(x6d, 0.0, bucket.dD)                        # MSE(D(opt.detach()), 0)
+            l1 = eng.pose_disc_backward_params(spin_pose, 1.0, bucket.dD)                  # MSE(D(spin), 1)
+            bucket.put(3, l0 + l1)
+        if use_sd:                                                                          # :286-293
+            l0 = eng.shape_disc_backward_params(betas, 0.0, bucket.dS)
+            l1 = eng.shape_disc_backward_params(spin_betas, 1.0, bucket.dS)
+            bucket.put(4, l0 + l1)
+        jsq = torch.zeros(B, device=device)                                                 # :300-312
+        joints_before = torch.empty(B, 17, 3, device=device)
+        eng.j_regressor_grad(x6d, betas, gt_j3d, sqerr=jsq, out=bucket.dJ, joints=joints_before)
+        bucket.put(5, jsq)
+        e_b, epa_b = utils.evaluate_sums(joints_before, gt_mm)                             # :314-315 joints of the old regressor
+        bucket.scalars[6:7].copy_(e_b.reshape(1)); bucket.scalars[7:8].copy_(epa_b.reshape(1))
+        bucket.scalars[8:10].copy_(after_sums)                                              # previous batch, after its J step
+
+        jdist.all_reduce_sum_(bucket.flat)                                                  # THE collective of the outer step
+
+        # ---- replicated Adam steps (identical on every rank) ----
         if use_pd:
-            g = torch.zeros_like(disc_flat)
-            l0 = eng.pose_disc_backward_params(x6d, 0.0, g)                                # MSE(D(opt.detach()), 0)
-            l1 = eng.pose_disc_backward_params(spin_pose, 1.0, g)                          # MSE(D(spin), 1)
-            jdist.all_reduce_sum_(g)
-            disc_opt.apply(disc_flat, g)
+            disc_opt.apply(disc_flat, bucket.dD)
             eng.set_pose_disc(disc_flat)
-            pose_d_loss = _global_mean(l0 + l1, B_global * 25)
-        # ---- shape-discriminator update (:286-293) ----
-        shape_d_loss = None
         if use_sd:
-            g = torch.zeros_like(sdisc_flat)
-            l0 = eng.shape_disc_backward_params(betas, 0.0, g)
-            l1 = eng.shape_disc_backward_params(spin_betas, 1.0, g)
-            jdist.all_reduce_sum_(g)
-            sdisc_opt.apply(sdisc_flat, g)
+            sdisc_opt.apply(sdisc_flat, bucket.dS)
             eng.set_shape_disc(sdisc_flat)
-            shape_d_loss = _global_mean(l0 + l1, B_global)
+        eng.j_step_apply(J_regressor, bucket.dJ, J_opt.m, J_opt.v, J_opt.step, J_opt.lr, mask=j_reg_mask)
+        joints_after = eng.find_joints_forward(betas, x6d=x6d)                              # :317-321 with the stepped regressor
+        e_a, epa_a = utils.evaluate_sums(joints_after, gt_mm)
+        after_sums = torch.stack([e_a, epa_a])
 
-        # ---- J_regressor step (:300-312) and before/after metrics (:314-321) ----
-        joints_before = eng.find_joints_forward(betas, x6d=x6d)
-        j_err = _j_step(eng, J_regressor, J_opt, x6d, betas, gt_j3d, j_reg_mask)
-        joints_after = eng.find_joints_forward(betas, x6d=x6d)
-        mpjpe_b, pampjpe_b = _global_evaluate(joints_before, gt_mm, B_global)
-        mpjpe_a, pampjpe_a = _global_evaluate(joints_after, gt_mm, B_global)
-        torch.cuda.synchronize()
-        rec = {'batch': it, 'joint_loss': joint_loss, 'pose_discriminated_loss': pose_discriminated_loss,
-               'shape_discriminated_loss': shape_discriminated_loss, 'pose_discriminator_loss': pose_d_loss,
-               'shape_discriminator_loss': shape_d_loss, 'j_regressor_error': j_err, 'mpjpe': mpjpe_a,
-               'pampjpe': pampjpe_a, 'mpjpe difference': mpjpe_b - mpjpe_a,
-               'pampjpe difference': pampjpe_b - pampjpe_a, 'seconds': time.perf_counter() - t0,
+        tail = bucket.tail.cpu().double().numpy()                                           # the ONE read-back of this batch
+        sc, hist_np = tail[:N_SCALARS], tail[N_SCALARS:].reshape(-1, 5)
+        if pending is not None:
+            finish(pending[0], pending[1], sc[8:10])
+        rec = {'batch': it, 'joint_loss': sc[0] / (B_global * 51),
+               'pose_discriminated_loss': sc[1] / (B_global * 25) if pose_disc_sq is not None else None,
+               'shape_discriminated_loss': sc[2] / B_global if shape_disc_sq is not None else None,
+               'pose_discriminator_loss': sc[3] / (B_global * 25) if use_pd else None,
+               'shape_discriminator_loss': sc[4] / B_global if use_sd else None,
+               'j_regressor_error': sc[5] / (B_global * 51),
+               '_mpjpe_before': sc[6] * 1000 / B_global, '_pampjpe_before': sc[7] * 1000 / B_global,
+               'loss_history': [[float(x) for x in row] for row in hist_np],                # :255-261, every 10th iteration
+               'seconds': time.perf_counter() - t0,
                'body_model': smpl.provenance, 'data': 'dataset' if args.data_root else 'synthetic'}
-        history.append(rec)
-        if rank == 0:
-            log(rec)                                                                        # :323-337 (wandb.log analogue)
-            if args.wandb_log:
-                try:
-                    import wandb
-                    wandb.log(rec)
-                except ImportError:
-                    pass
+        rec = {k: (float(x) if isinstance(x, np.floating) else x) for k, x in rec.items()}
+        pending = (rec, B_global)
 
+    if pending is not None:                 # flush: the last batch's after-the-J-step sums
+        jdist.all_reduce_sum_(after_sums)
+        finish(pending[0], pending[1], after_sums.cpu().double().numpy())
     if args.save_j_regressor and rank == 0:
         checkpoint.save_j_regressor(J_regressor, args.save_j_regressor)
     return {'history': history, 'J_regressor': J_regressor, 'disc_flat': disc_flat, 'sdisc_flat': sdisc_flat,
             'x6d': x6d, 'betas': betas, 'shard': (lo, hi)}
+
+
+def _j_step_in_loop(eng, J_regressor, J_opt, x6d, betas, gt_j3d, mask, dJ_buf) -> None:
+    """scripts/optimize.py:300-312 between two segments of the inner loop under data parallelism: local dJ, ONE
+    all-reduce of the (17,6890) gradient, replicated Adam + re-normalisation in one call; nothing is read back."""
+    eng.j_regressor_grad(x6d, betas, gt_j3d, out=dJ_buf)
+    jdist.all_reduce_sum_(dJ_buf)
+    eng.j_step_apply(J_regressor, dJ_buf, J_opt.m, J_opt.v, J_opt.step, J_opt.lr, mask=mask)
 
 
 def _synthetic_gt_j2d(eng, x6d, betas, cam, seed, lo, hi, B_global):
@@ -255,28 +339,3 @@ def _synthetic_mask(eng, x6d, betas, cam, seed, lo, hi, B_global):
     dcam = (torch.randn(B_global, 3, generator=g) * torch.tensor([0.2, 0.2, 2.0]))[lo:hi]
     cam_true = (cam + dcam.to(cam.device)).contiguous()
     return (eng.silhouette_forward(verts, cam_true) > 0).float().contiguous()
-
-
-def _global_mean(local_sum_tensor: torch.Tensor, denom: int) -> float:
-    t = local_sum_tensor.sum().reshape(1).clone()
-    jdist.all_reduce_sum_(t)
-    return float(t.item()) / denom
-
-
-def _global_evaluate(joints: torch.Tensor, gt_mm: torch.Tensor, B_global: int):
-    """utils.evaluate over the GLOBAL batch: per-pose errors are summed locally, all-reduced, divided by B_global."""
-    e, e_pa = utils.evaluate_sums(joints, gt_mm)
-    t = torch.stack([e, e_pa]).clone()
-    jdist.all_reduce_sum_(t)
-    return float(t[0].item()) * 1000 / B_global, float(t[1].item()) * 1000 / B_global
-
-
-def _j_step(eng, J_regressor, J_opt, x6d, betas, gt_j3d, mask) -> float:
-    """scripts/optimize.py:300-312: joint MSE of the detached poses w.r.t. the raw regressor, one
-    all-reduce of the (17,6890) gradient, replicated Adam, re-normalisation."""
-    sq = torch.zeros(x6d.shape[0], device=x6d.device)
-    dJ = eng.j_regressor_grad(x6d, betas, gt_j3d, sqerr=sq)
-    jdist.all_reduce_sum_(dJ)
-    J_opt.apply(J_regressor, dJ)
-    eng.set_j_regressor(J_regressor, mask)
-    return _global_mean(sq, eng.batch_norm * 51)

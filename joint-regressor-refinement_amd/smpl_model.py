@@ -114,6 +114,39 @@ def synthetic_smpl(seed: int = 1234, max_influences: int = 4) -> Dict[str, np.nd
                 lbs_weights=W.astype(np.float32), parents=SMPL_PARENTS.copy(), faces=faces)
 
 
+def shuffled_vertex_order(model: Dict[str, np.ndarray], seed: int = 5, scope: str = 'parts'):
+    """The same body with the vertex order of an arbitrary mesh FILE: vertices stay grouped by body part (their dominant
+    skinning joint, parts in order of first appearance) but are shuffled (seeded) inside each part -- what a real model
+    file looks like to the 32-vertex tiles, as opposed to the synthetic generator's ring-major order.  Every
+    per-vertex array and the face indices are permuted consistently; returns the new model and `perm` with
+    new_vertex[k] = old_vertex[perm[k]].  scope='all': one shuffle of ALL vertices (no locality left at all: only the
+    library's internal joint-sorted order makes such a file fit the joint-sparse kernels)."""
+    rng = np.random.RandomState(seed)
+    W = model['lbs_weights']
+    dom = W.argmax(1)
+    parts = []
+    for j in dom:
+        if j not in parts:
+            parts.append(int(j))
+    if scope == 'all':
+        perm = rng.permutation(NUM_VERTS).astype(np.int64)
+    else:
+        perm = np.concatenate([rng.permutation(np.nonzero(dom == j)[0]) for j in parts]).astype(np.int64)
+    assert sorted(perm.tolist()) == list(range(NUM_VERTS))
+    inv = np.empty_like(perm)
+    inv[perm] = np.arange(NUM_VERTS)
+    out = dict(model)
+    out['v_template'] = model['v_template'][perm]
+    out['shapedirs'] = model['shapedirs'][perm]
+    out['posedirs'] = np.ascontiguousarray(model['posedirs'].reshape(207, NUM_VERTS, 3)[:, perm].reshape(207, NUM_VERTS * 3))
+    out['J_regressor'] = np.ascontiguousarray(model['J_regressor'][:, perm])
+    out['lbs_weights'] = model['lbs_weights'][perm]
+    if model.get('faces') is not None:
+        out['faces'] = inv[model['faces']].astype(np.int32)
+    out['provenance'] = f"{model.get('provenance', 'synthetic')}+shuffled(seed={seed})"
+    return out, perm
+
+
 def load_smpl_model(model_dir: Optional[str], allow_synthetic: bool = True) -> Dict[str, np.ndarray]:
     """Load a real SMPL model if the user supplies one (`<dir>/SMPL_NEUTRAL.pkl` or `.npz`, the
     layout smplx expects at scripts/optimize.py:96-99).  If no model file is found: the seeded synthetic

@@ -45,8 +45,17 @@ def pytest_collection_finish(session):
     runs = {
         'w1': [sys.executable, worker, os.path.join(tmp, 'w1')] + DP_FLAGS,
         'w2': _torchrun(2, 29541, [worker, os.path.join(tmp, 'w2')] + DP_FLAGS + ['--dist_backend', 'gloo', '--single_device']),
-        'bench2': _torchrun(2, 29542, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--batch', '256',
-                                       '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded']),
+        # bench.py --gpus 2 WITHOUT torchrun: bench.py starts its own 2-rank child (what the driver's command line does)
+        'bench2': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--batch', '256',
+                   '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5',
+                   '--min_timed_ms', '50'],
+        # the same under an explicit torchrun (the README's / the contract's N > 1 command line)
+        'bench2t': _torchrun(2, 29542, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--batch', '256',
+                                        '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded',
+                                        '--no_skin_variants', '--no_config5', '--min_timed_ms', '50']),
+        # a launcher world that contradicts --gpus must fail loudly
+        'bench_mismatch': _torchrun(2, 29543, [os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
+                                               '--batch', '128', '--backend', 'gloo', '--single_device', '--no_cpu_baseline']),
     }
     DP_RUNS['dir'] = tmp
     for name, cmd in runs.items():

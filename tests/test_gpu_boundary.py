@@ -297,42 +297,6 @@ def _seeded_disc_sd():
     return _mod('discriminator').Discriminator().state_dict()
 
 
-def test_forward_reuse_across_the_j_step(smpl_hip, smpl_model_np, j_h36m_np):
-    """jrr_engine_set_forward_reuse: the iteration after a J step regresses its joints from the J step's stored vertices
-    with the NEW regressor -- same trajectory as repeating the forward (scripts/optimize.py:300-312 then :220-229)."""
-    eng_mod = _mod('engine')
-    B = 200
-    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, j_h36m_np, B, seed=71)
-    gt_c = oracle.move_pelvis(T(batch['gt_j3d'])).to(DEV).contiguous()
-    dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
-    out = []
-    for reuse in (False, True):
-        eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_POSE_DISC)
-        eng.set_forward_reuse(reuse)
-        J = T(j_h36m_np).to(DEV).clone()
-        eng.set_j_regressor(J)
-        eng.set_pose_disc(eng_mod.flatten_state_dict(dsd, eng_mod.DISC_KEYS))
-        x, b = T(batch['pose6d']).to(DEV).contiguous(), T(batch['betas']).to(DEV).contiguous()
-        m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
-        step = torch.zeros(1, dtype=torch.int32, device=DEV)
-        Jm, Jv, Js = torch.zeros_like(J), torch.zeros_like(J), torch.zeros(1, dtype=torch.int32, device=DEV)
-        sq = torch.zeros(B, device=DEV)
-        for _ in range(2):                       # two (2 inner iterations + J step) rounds
-            eng.refine_run(x, b, gt_c, m, v, step, 1e-2, 2, sqerr=sq)
-            dJ = eng.j_regressor_grad(x, b, gt_c)
-            Js += 1
-            eng_mod.adam_step(J, dJ, Jm, Jv, Js, 1e-2)
-            eng.set_j_regressor(J)
-        eng.refine_run(x, b, gt_c, m, v, step, 1e-2, 1, sqerr=sq)
-        assert int(step.item()) == 5
-        out.append((x.cpu(), b.cpu(), sq.cpu(), J.cpu()))
-    (x0, b0, s0, J0), (x1, b1, s1, J1) = out
-    assert torch.equal(J0, J1) or (J0 - J1).abs().max().item() < 2e-5
-    np.testing.assert_allclose(s1.sum().item(), s0.sum().item(), rtol=1e-4)
-    assert (x0 - x1).abs().mean().item() < 2e-7 and (x0 - x1).abs().max().item() < 6e-4
-    assert (b0 - b1).abs().max().item() < 2e-4
-
-
 def test_silhouette_gradients_where_both_rasterisers_agree(smpl_hip, smpl_model_np, j_h36m_np):
     """row f2 at a ragged batch of 67 poses: coverage agreement >= 99.98 % of the pixels, and -- with the upstream
     gradient restricted to the pixels where both rasterisers see the same face at the same distance -- vertex and camera

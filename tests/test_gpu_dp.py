@@ -66,12 +66,29 @@ def test_two_rank_driver_moved_the_regressor_only_on_its_support():
     assert not moved[J0 <= 0].any()
 
 
-def test_bench_two_ranks():
-    r = _run('bench2')
-    line = [l for l in r['out'].splitlines() if l.startswith('{')][-1]
-    j = json.loads(line)
+@pytest.mark.parametrize('name', ['bench2', 'bench2t'])
+def test_bench_two_ranks(name):
+    """`python bench.py --gpus 2` (bench.py launches its own torchrun child before touching the GPU) and the explicit
+    torchrun line both give ONE JSON line of a 2-rank run, with the evidence of the rank count in it"""
+    r = _run(name)
+    lines = [l for l in r['out'].splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r['out'][-2000:]
+    j = json.loads(lines[0])
     assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] > 0
     assert j['config']['global_batch'] == 512 and j['config']['parallelism'] == 'dp2'
     assert j['config']['j_steps_in_timed_region'] >= 1
     assert j['j_step']['allreduce_bytes'] == 17 * 6890 * 4
     assert np.isfinite(j['config']['joint_loss_last'])
+    c = j['collective']
+    assert c['world'] == 2 and len(c['ranks_seen']) == 2
+    assert sorted(rk[0] for rk in c['ranks_seen']) == [0, 1]
+    assert len({rk[3] for rk in c['ranks_seen']}) == 2                  # two processes
+    assert c['allreduce_check'] == c['allreduce_expected'] == 1.0       # sum of ranks over the collective
+    assert c['backend'] == 'gloo' and c['single_device_debug'] is True
+    assert j['cadence1']['timed_regions'] >= 5 and j['cadence1']['value'] > 0
+
+
+def test_bench_rejects_a_world_that_contradicts_gpus():
+    r = conftest.DP_RUNS.get('bench_mismatch')
+    assert r is not None and r['rc'] != 0
+    assert '--gpus 1 but the launcher started 2' in (r['out'] + r['err'])

@@ -1,0 +1,307 @@
+"""Round-3 parity rows, HIP path (through the C ABI) vs the CPU oracle (pytest -m gpu):
+  * the FUSED silhouette path of the inner loop (k_sil_raster<true>: in-kernel projection from the row-quad vertex buffer,
+    packed fixed-point adjoint, write-back into k_lbs_bwd<2>) at a ragged batch of 67 against the oracle's loop
+    (scripts/optimize.py:234-237, scripts/mesh_renderer.py:34-38,62-68), and at the benchmarked batch of 4096 against the
+    stand-alone rasteriser / adjoint (size-independent property: both paths compute the same function)
+  * all FIVE terms of scripts/optimize.py:252-253 in one run, and the loss history of scripts/optimize.py:255-261
+  * the J step inside the C call (jrr_refine_run_j_steps), the explicit forward reuse (jrr_refine_run_after_j_step) and
+    its state check, jrr_j_step_apply
+  * a body model whose vertex order is shuffled (what an arbitrary mesh file looks like): joint-sparse class through the
+    library's internal vertex order, results in FILE order
+  * Discriminator module: backward twice through one graph, restore path, bounded engine cache
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import PKG_NAME
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = 'cuda:0'
+
+
+def _mod(name):
+    return importlib.import_module(f'{PKG_NAME}.{name}')
+
+
+@pytest.fixture(scope='module')
+def smpl_hip(smpl_model_np):
+    return _mod('smpl').SMPL(model=smpl_model_np).to(DEV)
+
+
+def _sil_inputs(smpl_model_np, j_h36m_np, B, seed):
+    from oracle import silhouette_port as sp
+    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, j_h36m_np, B, seed=seed)
+    x6, betas, cam = T(batch['pose6d']), T(batch['betas']), T(batch['cam'])
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(B, 24, 3, 3)
+    verts = smpl(R[:, :1], R[:, 1:], betas).vertices
+    mask = (sp.soft_silhouette(verts, smpl_model_np['faces'], cam + torch.tensor([0.15, -0.1, 1.0]))[:, 0] > 0).float()
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    return smpl, x6, betas, cam, mask, gt_c
+
+
+def _fresh_state(B):
+    return (torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV))
+
+
+def test_fused_silhouette_loop_ragged_67(smpl_hip, smpl_model_np, j_h36m_np):
+    """BASELINE configs[4] at a ragged mid-size batch: joint loss + silhouette loss (x100) in the fused loop, 3 iterations,
+    vs oracle.refine_poses(sil_mask=...): poses / betas / camera <= 2e-3 max and <= 1e-4 mean; bitwise repeatable."""
+    eng_mod = _mod('engine')
+    B, n = 67, 3
+    smpl, x6, betas, cam0, mask, gt_c = _sil_inputs(smpl_model_np, j_h36m_np, B, 57)
+    o, p, b, hist, c = oracle.refine_poses(smpl, T(j_h36m_np), x6[:, :1], x6[:, 1:], betas, gt_c, n, cam=cam0,
+                                           sil_mask=mask[:, None], faces=smpl_model_np['faces'])
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_SILHOUETTE | eng_mod.FLAG_KEEP_VERTS)
+    eng.set_j_regressor(T(j_h36m_np))
+    md, gd = mask.to(DEV).contiguous(), gt_c.to(DEV).contiguous()
+    outs = []
+    for _ in range(2):
+        xd, bd, cd = x6.clone().to(DEV), betas.clone().to(DEV), cam0.clone().to(DEV)
+        cm, cv = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV)
+        eng.set_silhouette(md, cd, cm, cv)
+        m, v, step = _fresh_state(B)
+        eng.refine_run(xd, bd, gd, m, v, step, 1e-2, n)
+        eng.set_silhouette(None)
+        outs.append((xd.cpu(), bd.cpu(), cd.cpu()))
+    xd, bd, cd = outs[0]
+    dx = (xd - torch.cat([o, p], 1)).abs()
+    assert dx.max().item() < 2e-3 and dx.mean().item() < 1e-4, (dx.max().item(), dx.mean().item())
+    db = (bd - b).abs()
+    assert db.max().item() < 2e-3 and db.mean().item() < 1e-4, (db.max().item(), db.mean().item())
+    dc = (cd - c).abs()
+    assert dc.max().item() < 2e-3 and dc.mean().item() < 1e-4, (dc.max().item(), dc.mean().item())
+    assert (cd - cam0).abs().max().item() > 5e-3                      # the camera did move
+    assert all(torch.equal(a, b_) for a, b_ in zip(outs[0], outs[1]))  # fixed-point adjoint: bitwise reproducible
+
+
+def test_all_five_terms_together(smpl_hip, smpl_model_np, j_h36m_np):
+    """scripts/optimize.py:252-253 in ONE run: loss_j2d/100 + silhouette*100 + joint*10000 + poseD*10 + shapeD*10, batch 16,
+    3 iterations vs the oracle; the loss history (optimize.py:255-261) equals the oracle's weighted terms."""
+    eng_mod = _mod('engine')
+    B, n = 16, 3
+    smpl, x6, betas, cam0, mask, gt_c = _sil_inputs(smpl_model_np, j_h36m_np, B, 58)
+    R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(B, 24, 3, 3)
+    j0 = oracle.find_joints(smpl, betas, R[:, :1], R[:, 1:], T(j_h36m_np))
+    gen = torch.Generator().manual_seed(6)
+    gt_j2d = oracle.project_joints(j0, cam0 + torch.tensor([0.2, -0.1, 2.0]))[..., :2] + torch.randn(B, 17, 2, generator=gen) * 2.0
+    dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+    ssd = oracle.formula_state_dict(oracle.SHAPE_DISC_PARAM_SHAPES, seed=1)
+    o, p, b, hist, c = oracle.refine_poses(smpl, T(j_h36m_np), x6[:, :1], x6[:, 1:], betas, gt_c, n, disc_sd=dsd, shape_disc_sd=ssd,
+                                           gt_j2d=gt_j2d, cam=cam0, sil_mask=mask[:, None], faces=smpl_model_np['faces'])
+    flags = eng_mod.FLAG_POSE_DISC | eng_mod.FLAG_SHAPE_DISC | eng_mod.FLAG_SILHOUETTE | eng_mod.FLAG_KEEP_VERTS
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=flags)
+    eng.set_j_regressor(T(j_h36m_np))
+    eng.set_pose_disc(eng_mod.flatten_state_dict(dsd, eng_mod.DISC_KEYS))
+    eng.set_shape_disc(eng_mod.flatten_state_dict(ssd, eng_mod.SHAPE_DISC_KEYS))
+    xd, bd, cd = x6.clone().to(DEV), betas.clone().to(DEV), cam0.clone().to(DEV)
+    cm, cv = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV)
+    eng.set_reprojection(gt_j2d.to(DEV).contiguous(), cd, cm, cv)
+    eng.set_silhouette(mask.to(DEV).contiguous(), cd, cm, cv)
+    eng.set_loss_history(n, every=1)
+    m, v, step = _fresh_state(B)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, n)
+    rec = eng.loss_history().cpu()
+    eng.set_loss_history(0)
+    eng.set_reprojection(None); eng.set_silhouette(None)
+    dx = (xd.cpu() - torch.cat([o, p], 1)).abs()
+    assert dx.max().item() < 2e-3 and dx.mean().item() < 1e-4, (dx.max().item(), dx.mean().item())
+    assert (bd.cpu() - b).abs().max().item() < 2e-3
+    assert (cd.cpu() - c).abs().max().item() < 2e-3
+    assert rec.shape == (n, 5)
+    for it in range(n):
+        h = hist[it]
+        want = [h['loss_j2d'] * 0.01, h['silhouette_loss'] * 100, h['joint_loss'] * 10000, h['pose_discriminated_loss'] * 10,
+                h['shape_discriminated_loss'] * 10]
+        # the first record is the loss at identical parameters; later ones see the (Adam-amplified) trajectory difference
+        np.testing.assert_allclose(rec[it].numpy(), want, rtol=2e-4 if it == 0 else 2e-2, err_msg=f'iteration {it}')
+
+
+def test_fused_silhouette_matches_standalone_at_4096(smpl_hip, smpl_model_np, j_h36m_np):
+    """The benchmarked batch: the fused loop's silhouette kernel (jrr_silhouette_loss_grad = exactly its launch) against the
+    stand-alone rasteriser + adjoint (the pair pinned to the oracle at B = 3 and 67): per-pose squared error on ALL 4096
+    poses, vertex / camera gradient on a strided subset to 2e-3."""
+    eng_mod = _mod('engine')
+    B = 4096
+    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, j_h36m_np, B, seed=59)
+    x, b, cam = (T(batch[k]).to(DEV).contiguous() for k in ('pose6d', 'betas', 'cam'))
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_SILHOUETTE | eng_mod.FLAG_KEEP_VERTS)
+    eng.set_j_regressor(T(j_h36m_np))
+    _, verts = eng.find_joints_forward(b, x6d=x, return_verts=True)
+    mask = (eng.silhouette_forward(verts, (cam + torch.tensor([0.15, -0.1, 1.0], device=DEV)).contiguous()) > 0).float().contiguous()
+    sq_f, dv_f, dc_f = eng.silhouette_loss_grad(x, b, cam, mask)
+    sq_f2, dv_f2, dc_f2 = eng.silhouette_loss_grad(x, b, cam, mask)
+    assert torch.equal(sq_f, sq_f2) and torch.equal(dv_f, dv_f2) and torch.equal(dc_f, dc_f2)     # bitwise repeatable
+    alpha = eng.silhouette_forward(verts, cam)
+    sq_ref = ((alpha - mask) ** 2).sum((1, 2))
+    assert sq_ref.min().item() > 100.0
+    rel = ((sq_f - sq_ref).abs() / sq_ref)
+    # alpha = sigmoid(d / 1e-4) amplifies the last bits of d on the few edge pixels where the two projections round differently
+    assert rel.max().item() < 2e-3 and rel.mean().item() < 2e-5, (rel.max().item(), rel.mean().item())
+    galpha = ((alpha - mask) * (2.0 * 100.0 / (B * 224 * 224))).contiguous()
+    dv_ref, dc_ref = eng.silhouette_backward(galpha)
+    sub = slice(0, B, 16)
+    rv = ((dv_f[sub].double() - dv_ref[sub].double()).norm() / dv_ref[sub].double().norm()).item()
+    rc = ((dc_f.double() - dc_ref.double()).norm() / dc_ref.double().norm()).item()
+    assert rv < 2e-3, rv
+    assert rc < 2e-3, rc
+    # per pose, on the subset: no single pose is off (a wrong pose would hide in the norm over 256)
+    pp = ((dv_f[sub].double() - dv_ref[sub].double()).flatten(1).norm(dim=1) / dv_ref[sub].double().flatten(1).norm(dim=1))
+    assert pp.max().item() < 1e-2, pp.max().item()
+
+
+def test_j_steps_inside_the_call_and_explicit_reuse(smpl_hip, smpl_model_np, j_h36m_np):
+    """scripts/optimize.py:300-312 then :220-229.  Three ways to run (2 iterations + J step) x 2 + 1 iteration:
+      A  refine_run / j_regressor_grad / adam_step / set_j_regressor, every forward repeated
+      B  refine_run(after_j_step=True) / j_regressor_grad / j_step_apply: the iteration after a J step reuses its forward
+      C  ONE C call: refine_run_j_steps(j_every = 2) + refine_run(after_j_step=True)
+    B and C are the same launches (bit-equal); A differs by the summation order of the re-regressed joints only."""
+    eng_mod, lib_mod = _mod('engine'), _mod('_lib')
+    B = 200
+    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, j_h36m_np, B, seed=71)
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d'])).to(DEV).contiguous()
+    dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+    out = {}
+    for mode in 'ABC':
+        eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_POSE_DISC)
+        J = T(j_h36m_np).to(DEV).clone()
+        eng.set_j_regressor(J)
+        eng.set_pose_disc(eng_mod.flatten_state_dict(dsd, eng_mod.DISC_KEYS))
+        x, b = T(batch['pose6d']).to(DEV).contiguous(), T(batch['betas']).to(DEV).contiguous()
+        m, v, step = _fresh_state(B)
+        Jm, Jv, Js = torch.zeros_like(J), torch.zeros_like(J), torch.zeros(1, dtype=torch.int32, device=DEV)
+        sq = torch.zeros(B, device=DEV)
+        if mode == 'C':
+            eng.refine_run_j_steps(x, b, gt_c, m, v, step, 1e-2, 4, 2, J, Jm, Jv, Js, 1e-2, sqerr=sq)
+        else:
+            for r in range(2):
+                eng.refine_run(x, b, gt_c, m, v, step, 1e-2, 2, sqerr=sq, after_j_step=(mode == 'B' and r > 0))
+                dJ = eng.j_regressor_grad(x, b, gt_c)
+                if mode == 'A':
+                    Js += 1
+                    eng_mod.adam_step(J, dJ, Jm, Jv, Js, 1e-2)
+                    eng.set_j_regressor(J)
+                else:
+                    eng.j_step_apply(J, dJ, Jm, Jv, Js, 1e-2)
+        eng.refine_run(x, b, gt_c, m, v, step, 1e-2, 1, sqerr=sq, after_j_step=mode != 'A')
+        assert int(step.item()) == 5 and int(Js.item()) == 2
+        out[mode] = (x.cpu(), b.cpu(), sq.cpu(), J.cpu())
+        if mode == 'B':      # what the engine can check about a reuse request, it checks
+            eng.find_joints_forward(b, x6d=x)                       # any other call drops the cached forward
+            with pytest.raises(lib_mod.JrrError, match='previous call'):
+                eng.refine_run(x, b, gt_c, m, v, step, 1e-2, 1, after_j_step=True)
+            eng.j_regressor_grad(x, b, gt_c)
+            x2 = x.clone()                                           # same contents, another buffer
+            with pytest.raises(lib_mod.JrrError, match='previous call'):
+                eng.refine_run(x2, b, gt_c, m, v, step, 1e-2, 1, after_j_step=True)
+    for k in range(4):
+        assert torch.equal(out['B'][k], out['C'][k]), k
+    (x0, b0, s0, J0), (x1, b1, s1, J1) = out['A'], out['B']
+    assert (J0 - J1).abs().max().item() < 2e-5
+    np.testing.assert_allclose(s1.sum().item(), s0.sum().item(), rtol=1e-4)
+    assert (x0 - x1).abs().mean().item() < 2e-7 and (x0 - x1).abs().max().item() < 6e-4
+    assert (b0 - b1).abs().max().item() < 2e-4
+
+
+@pytest.mark.parametrize('scope,classes', [('parts', (8, 12)), ('all', (8, 12))])
+def test_shuffled_vertex_order_model(smpl_model_np, j_h36m_np, scope, classes):
+    """A body whose FILE order of the vertices is a seeded shuffle (inside body parts: what a real mesh file looks like;
+    'all': no locality at all) still runs the joint-sparse kernels -- class <= 12, for 'all' only through the library's
+    internal joint-sorted order -- and every vertex-indexed quantity comes back in FILE order: joints, vertices, dJ and a
+    3-iteration refinement against the oracle on the shuffled model."""
+    sm, eng_mod = _mod('smpl_model'), _mod('engine')
+    model, perm = sm.shuffled_vertex_order(smpl_model_np, seed=5, scope=scope)
+    Jh = np.ascontiguousarray(j_h36m_np[:, perm])
+    B = 37
+    batch = sm.synthetic_batch(model, Jh, B, seed=91)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    smpl = oracle.OracleSMPL(model)
+    R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(B, 24, 3, 3)
+    j_ref, v_ref = oracle.find_joints(smpl, betas, R[:, :1], R[:, 1:], T(Jh), return_verts=True)
+    dm = eng_mod.DeviceModel(model, DEV)
+    eng = eng_mod.RefineEngine(dm, B, flags=eng_mod.FLAG_KEEP_VERTS)
+    assert eng.info['joint_sparse'] in classes, eng.info
+    eng.set_j_regressor(T(Jh))
+    xd, bd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous()
+    j, vv = eng.find_joints_forward(bd, x6d=xd, return_verts=True)
+    assert (j.cpu() - j_ref).abs().max().item() < 2e-5
+    assert (vv.cpu() - v_ref).abs().max().item() < 5e-6
+    # the same poses on the un-shuffled model: identical function up to the summation order
+    eng0 = eng_mod.RefineEngine(eng_mod.DeviceModel(smpl_model_np, DEV), B, flags=eng_mod.FLAG_KEEP_VERTS)
+    eng0.set_j_regressor(T(j_h36m_np))
+    _, v0 = eng0.find_joints_forward(bd, x6d=xd, return_verts=True)
+    assert (vv.cpu() - v0.cpu()[:, perm]).abs().max().item() < 5e-6
+    # J gradient in file order
+    _, dJ_ref, _ = oracle.j_regressor_loss_and_grad(smpl, T(Jh), x6[:, :1], x6[:, 1:], betas, gt_c)
+    dJ = eng.j_regressor_grad(xd, bd, gt_c.to(DEV).contiguous()).cpu()
+    assert ((dJ - dJ_ref).abs().max() / dJ_ref.abs().max()).item() < 5e-4
+    assert torch.equal(dJ != 0, dJ_ref != 0)
+    # refinement
+    o, p, b_, hist = oracle.refine_poses(smpl, T(Jh), x6[:, :1], x6[:, 1:], betas, gt_c, 3)
+    m, v, step = _fresh_state(B)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, 3)
+    d = (xd.cpu() - torch.cat([o, p], 1)).abs()
+    assert d.max().item() < 6e-4 and d.mean().item() < 5e-6
+    assert (bd.cpu() - b_).abs().max().item() < 3e-4
+
+
+def test_discriminator_module_backward_twice_and_restore(smpl_model_np):
+    """backward twice through one graph (retain_graph) must give the same dx and dparams both times (the
+    weight-gradient pass leaves ROW-MAJOR activations behind, the input-gradient pass reads quads), and a restore of
+    older weights by a deferred backward must not leave the module's next forward on stale weights."""
+    disc = _mod('discriminator')
+    torch.manual_seed(3)
+    D = disc.Discriminator().to(DEV)
+    ref_sd = {k: v.detach().cpu().clone() for k, v in D.state_dict().items()}
+    B = 70
+    gen = torch.Generator().manual_seed(8)
+    x = torch.randn(B, 24, 6, generator=gen)
+    xr = x.clone().requires_grad_(True)
+    sd = {k: v.clone().requires_grad_(True) for k, v in ref_sd.items()}
+    out_ref = oracle.discriminator_forward(sd, xr)
+    w = torch.randn(B, 25, 1, generator=gen)
+    (out_ref * w).sum().backward()
+    xd = x.to(DEV).requires_grad_(True)
+    out = D(xd)
+    loss = (out * w.to(DEV)).sum()
+    grads = []
+    for k in range(2):
+        D.zero_grad()
+        xd.grad = None
+        loss.backward(retain_graph=True)
+        grads.append((xd.grad.cpu().clone(), {n: p.grad.cpu().clone() for n, p in D.named_parameters()}))
+    for gx, gp in grads:
+        assert ((gx - xr.grad).abs().max() / xr.grad.abs().max()).item() < 5e-4
+        for n in gp:
+            assert ((gp[n] - sd[n].grad).abs().max() / sd[n].grad.abs().max().clamp_min(1e-20)).item() < 2e-3, n
+    assert torch.equal(grads[0][0], grads[1][0])
+    # deferred backward after the weights moved: graph of the OLD weights, then a forward with the NEW ones
+    out_old = D(xd)
+    with torch.no_grad():
+        for p in D.parameters():
+            p.mul_(1.01)
+    out_mid = D(xd.detach())                              # uploads the new weights, moves the engine's generation
+    (out_old * w.to(DEV)).sum().backward()                # restore path: re-uploads the OLD weights
+    out_new = D(xd.detach())                              # must run on the NEW weights again
+    assert torch.equal(out_new, out_mid)
+    assert not torch.equal(out_new, out_old.detach())
+    # bounded engine cache
+    for bsz in (3, 5, 7, 9, 11, 13):
+        D(torch.randn(bsz, 24, 6, device=DEV))
+    assert len(D._jrr.engines) <= D._jrr.MAX_ENGINES
+
+
+def test_model_less_engine_workspace():
+    """a discriminator-only engine does not carve the SMPL sections (~230 KB per pose)"""
+    eng_mod, lib = _mod('engine'), _mod('_lib').load()
+    full = lib.jrr_engine_workspace_bytes(4096, eng_mod.FLAG_SHAPE_DISC)
+    small = lib.jrr_engine_workspace_bytes(4096, eng_mod.FLAG_SHAPE_DISC | eng_mod.FLAG_NO_MODEL)
+    assert full > 800 * 2 ** 20 and small < 4 * 2 ** 20, (full, small)
+    e = eng_mod.RefineEngine(None, 4096, flags=eng_mod.FLAG_SHAPE_DISC, device=DEV)
+    assert e.workspace.numel() < 4 * 2 ** 20

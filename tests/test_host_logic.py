@@ -190,3 +190,25 @@ def test_pixel_centre_f64_product_equals_fp32_division():
     got = np.float32(1) - ((2 * i + 1).astype(np.float64) * (1.0 / 224.0)).astype(np.float32)
     assert ref.dtype == np.float32 and got.dtype == np.float32
     assert np.array_equal(ref, got)
+
+
+def test_shared_bucket_layout():
+    """the flat all-reduce bucket of the outer step: [dJ | dD | dShapeD | sums | history], every section
+    256-byte aligned (the C ABI takes 16-byte aligned pointers), one contiguous tail to read back"""
+    opt = _mod('optimize')
+    eng = _mod('engine')
+    b = opt.SharedBucket('cpu', True, True, 10)
+    assert b.dJ.shape == (17, 6890) and b.dD.numel() == eng.DISC_PARAMS and b.dS.numel() == eng.SHAPE_DISC_PARAMS
+    base = b.flat.data_ptr()
+    for t in (b.dJ, b.dD, b.dS):
+        assert (t.data_ptr() - base) % 256 == 0 and t.is_contiguous()
+    assert b.tail.numel() == opt.N_SCALARS + 50 and b.hist.shape == (10, 5)
+    assert 7.8e6 < b.nbytes < 7.9e6                              # section 8e: 7.83 MB
+    b.put(3, torch.arange(5.0))
+    b.hist[2, 1] = 7.0
+    tail = b.tail.numpy()
+    assert tail[3] == 10.0 and tail[opt.N_SCALARS + 2 * 5 + 1] == 7.0
+    b.dD[5] = 2.0                                               # views alias the flat buffer
+    assert b.flat[(b.dD.data_ptr() - base) // 4 + 5] == 2.0
+    nb = opt.SharedBucket('cpu', False, False, 0)
+    assert nb.dD.numel() == 0 and nb.dS.numel() == 0 and nb.tail.numel() == opt.N_SCALARS
