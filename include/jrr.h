@@ -217,6 +217,10 @@ int jrr_silhouette_forward(jrr_engine_t* e, const float* verts_dev, const float*
  * float atomics: summation order (last bits) varies between runs.                                    */
 int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha_dev, float* dverts_dev, float* dcam_dev,
                             void* stream);
+/* pix_to_face of the most recent rasterisation on this engine (jrr_silhouette_forward, jrr_silhouette_loss_grad or the
+ * last silhouette iteration of jrr_refine_run): the pytorch3d rasteriser's Fragments.pix_to_face at faces_per_pixel = 1
+ * (scripts/mesh_renderer.py:34-38,59-63): (B,224,224) int32, -1 = background, else the index of the nearest face.      */
+int jrr_silhouette_pix_to_face(jrr_engine_t* e, int32_t* pix_to_face_dev, void* stream);
 /* Enable (mask_dev != NULL, (B,224,224)) / disable the term 100 * mean((silhouette - mask)^2) of the inner
  * loop (scripts/optimize.py:234-237,252); shares the camera parameter with jrr_engine_set_reprojection.
  * The engine caches sum(mask^2) per pose at the next jrr_refine_run: call this again after changing the mask's contents. */

@@ -57,6 +57,7 @@ SIGNATURES = {
     'jrr_silhouette_forward': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_silhouette_backward': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_silhouette_loss_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
+    'jrr_silhouette_pix_to_face': (c_int, [_P, _P, _P]),
     'jrr_engine_set_silhouette': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_refine_run': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),
     'jrr_j_regressor_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),

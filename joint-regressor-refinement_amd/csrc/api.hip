@@ -1016,6 +1016,15 @@ extern "C" int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha, flo
   return JRR_OK;
 }
 
+extern "C" int jrr_silhouette_pix_to_face(jrr_engine_t* e, int32_t* p2f, void* stream) {
+  if (!e || !p2f) return JRR_ERR_ARG;
+  int rc = sil_check(e);
+  if (rc) return rc;
+  launch_sil_pix_to_face(e->cover, e->ncover, p2f, e->B, (hipStream_t)stream);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
 extern "C" int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask, float* cam, float* cam_m, float* cam_v) {
   if (!e) return JRR_ERR_ARG;
   e->fwd_cached = false;

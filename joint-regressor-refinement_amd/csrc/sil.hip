@@ -518,6 +518,25 @@ int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s) {
   return 0;
 }
 
+// pix_to_face of the last rasterisation (pytorch3d Fragments.pix_to_face, faces_per_pixel = 1): -1 = background, else the
+// winning face, from the per-pose covered-pixel lists
+__global__ void k_sil_pix_to_face(const unsigned* __restrict__ cover, const int* __restrict__ ncover, int* __restrict__ p2f) {
+  const int b = blockIdx.x;
+  int* out = p2f + (size_t)b * SIL * SIL;
+  for (int i = threadIdx.x; i < SIL * SIL; i += blockDim.x) out[i] = -1;
+  __syncthreads();
+  const unsigned* lst = cover + (size_t)b * SIL * SIL;
+  const int n = ncover[b];
+  for (int i = threadIdx.x; i < n; i += blockDim.x) {
+    const unsigned e = lst[i];
+    out[e >> SIL_FBITS] = (int)(e & ((1u << SIL_FBITS) - 1));
+  }
+}
+int launch_sil_pix_to_face(const unsigned* cover, const int* ncover, int* p2f, int B, hipStream_t s) {
+  hipLaunchKernelGGL(k_sil_pix_to_face, dim3(B), dim3(1024), 0, s, cover, ncover, p2f);
+  return 0;
+}
+
 static bool g_sil_attr = false;
 static void sil_attrs() {
   if (g_sil_attr) return;

@@ -299,6 +299,12 @@ class RefineEngine:
         check(self.lib.jrr_silhouette_backward(self.handle, ptr(galpha), ptr(dverts), ptr(dcam), self._s()), 'silhouette_backward')
         return dverts, dcam
 
+    def silhouette_pix_to_face(self) -> torch.Tensor:
+        """(B,224,224) int32 nearest-face index per pixel (-1 = background) of the most recent rasterisation"""
+        p2f = torch.empty(self.batch, SIL, SIL, dtype=torch.int32, device=self.device)
+        check(self.lib.jrr_silhouette_pix_to_face(self.handle, ptr(p2f), self._s()), 'silhouette_pix_to_face')
+        return p2f
+
     def silhouette_loss_grad(self, x6d, betas, cam, mask, want_dverts=True):
         """the silhouette term as the fused loop evaluates it: per-pose sum (silhouette - mask)^2, d/dverts (B,6890,3) and
         d/dcam (B,3) of 100 * mean((silhouette - mask)^2)  (jrr_silhouette_loss_grad)"""
