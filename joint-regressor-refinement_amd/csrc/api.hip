@@ -42,7 +42,8 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nDq = nDn, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
   const size_t nJt = 72 + 24, nJS = 720 + 16;   // padded to keep 16-byte alignment of what follows
   const size_t nWc = (size_t)(VT + 1) * KJS_MAX * 32, nJl = (size_t)VT * KJS_MAX, nPerm = (size_t)VP + 6912;   // p2v [VP], v2p [V] padded
-  std::vector<float> h(nDk + nDn + nDq + nWjv + nWvj + nJt + nJS + nWc + nJl + nPerm, 0.f);
+  const size_t nW16 = (size_t)VT * 16 * 36, nSeg = (size_t)VT * 32;                      // segid [VT] (padded to 16 per tile), segj [VT][16]
+  std::vector<float> h(nDk + nDn + nDq + nWjv + nWvj + nJt + nJS + nWc + nJl + nPerm + nW16 + nSeg, 0.f);
   float* Dk = h.data();
   float* Dn = Dk + nDk;
   float* Dq = Dn + nDn;
@@ -54,6 +55,9 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   int32_t* Jl = reinterpret_cast<int32_t*>(Wc + nWc);
   int32_t* P2V = Jl + nJl;
   int32_t* V2P = P2V + VP;
+  float* W16 = reinterpret_cast<float*>(P2V + nPerm);
+  int32_t* SegId = reinterpret_cast<int32_t*>(W16 + nW16);
+  int32_t* SegJ = SegId + (size_t)VT * 16;
   // ---- internal vertex order (jrr_common.h): the file order unless it does not fit the joint-sparse kernels and the
   //      joint-sorted order does (or JRR_VERTEX_ORDER=sorted asks for it: tests) ----
   auto tile_joints = [&](const std::vector<int>& order) {      // most joints any 32-row tile touches
@@ -133,6 +137,31 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
     // JRR_DENSE_SKINNING=1 forces the dense kernels, JRR_SKIN_JOINTS=12 the 12-joint variant (verification: tests)
     { const char* dense = getenv("JRR_DENSE_SKINNING"); if (dense && dense[0] == '1') kjs = 0; }
     { const char* kj = getenv("JRR_SKIN_JOINTS"); if (kj && atoi(kj) == 12 && kjs == 8) kjs = 12; }
+    // segments for the backward kernel's 16-row dA windows: greedy runs of tiles whose joint union stays <= 16
+    if (kjs) {
+      int seg = 0;
+      std::vector<int> win;      // joints of the current segment, in order of first appearance
+      std::vector<int> first_tile{0};
+      for (int t = 0; t < VT; ++t) {
+        std::vector<int> grown(win);
+        for (int j : lists[t]) if (std::find(grown.begin(), grown.end(), j) == grown.end()) grown.push_back(j);
+        if (grown.size() > 16) {   // close the segment: its window is final
+          for (int u = first_tile[seg]; u < t; ++u) for (int n = 0; n < 16; ++n) SegJ[u * 16 + n] = n < (int)win.size() ? win[n] : -1;
+          ++seg; first_tile.push_back(t);
+          win = lists[t];
+        } else win = grown;
+        SegId[t] = seg;
+      }
+      for (int u = first_tile[seg]; u < VT; ++u) for (int n = 0; n < 16; ++n) SegJ[u * 16 + n] = n < (int)win.size() ? win[n] : -1;
+      for (int t = 0; t < VT; ++t)
+        for (int n = 0; n < 16; ++n) {
+          const int j = SegJ[t * 16 + n];
+          for (int vv = 0; vv < 32; ++vv) {
+            const int p_ = t * 32 + vv;
+            W16[((size_t)t * 16 + n) * 36 + vv] = (j >= 0 && p_ < V) ? W[(size_t)order[p_] * NJ + j] : 0.f;
+          }
+        }
+    }
     for (int t = 0; t < VT && kjs; ++t) {
       for (int n = 0; n < kjs; ++n) {
         const int j = n < (int)lists[t].size() ? lists[t][n] : 0;      // padding: joint 0 with zero weights
@@ -180,6 +209,9 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   if (permuted) { m->v2p_host = new int[V]; memcpy(m->v2p_host, V2P, (size_t)V * sizeof(int)); }
   m->d.p2v = permuted ? reinterpret_cast<int*>(m->d.jl + nJl) : nullptr;
   m->d.v2p = permuted ? m->d.p2v + VP : nullptr;
+  m->d.W16 = reinterpret_cast<float*>(reinterpret_cast<int*>(m->d.jl + nJl) + nPerm);
+  m->d.segid = reinterpret_cast<int*>(m->d.W16 + nW16);
+  m->d.segj = m->d.segid + (size_t)VT * 16;
   m->d.parents.maxd = 0;
   m->d.faces = nullptr;
   m->d.faces_int = nullptr;

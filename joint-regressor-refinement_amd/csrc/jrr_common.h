@@ -136,6 +136,14 @@ struct Model {
   float* Wc;    // [VT][kjs][32] (+ one tile of slack)
   int* jl;      // [VT][kjs]
   int kjs;
+  // Joint WINDOWS of the backward kernel's dA products (kjs > 0).  dA_{r,c}[j][pose] = sum_v W[v][j] (...) only has
+  // non-zero rows for the joints that skin the tile; it is accumulated over the tiles of a vertex chunk, so the rows must
+  // mean the same joints from tile to tile: consecutive tiles are grouped (greedily, at model upload) into SEGMENTS whose
+  // joint union is <= 16, the product runs over the segment's 16-row window (v_mfma_f32_16x16x1_4b_f32: half the issue
+  // time of 32 padded joint rows), and a workgroup adds its accumulators into its dA slab when the segment changes.
+  float* W16;   // [VT][16][36]      W[v][window joint n] of the tile's segment, [n][v] with rows padded to 36 floats
+  int* segid;   // [VT]              segment of each tile
+  int* segj;    // [VT][16]          the window of the tile's segment: joint of row n, -1 = unused row
   // Internal vertex order.  Nothing inside the LBS path depends on WHICH vertex sits in which row (every consumer sums
   // over vertices), so jrr_model_create may store the vertices in an order that makes the tiles joint-coherent (sorted
   // by their influencing joints) when the file order does not fit kjs.  p2v / v2p are NULL for the identity; otherwise

@@ -45,6 +45,14 @@ constexpr int NSTAGE = NKCH + 6;                  // 13
 constexpr int LBS_FWD_MFMA_PER_TILE = (KF / 2) * 3 + 6 * 24 + 3 * 16;
 // per-tile operand record of the backward kernel: [Jn 18x32 | W^T 24x32 | W 32x32(j) | pad] = 10 KB
 constexpr int TB_JN = 0, TB_WJV = NHP * 32, TB_WVJ = TB_WJV + W_FLOATS, TB_FLOATS = 2560;
+// joint-sparse variants: the W block holds the segment-window weights W16 [16 n][36] (576 floats, jrr_common.h) instead of
+// [32 v][32 j]; the record then ends at 1920 floats: 8 of the 10 DMA pieces
+constexpr int TB_W16_FLOATS = 16 * 36, TB_PIECES_SPARSE = 8;
+// v_mfma_f32_16x16x1_4b_f32: four independent 16x16 outer products per instruction (block = lane / 16), 8 passes = half the
+// issue time of v_mfma_f32_32x32x2_f32 (33 vs 64 clocks measured, tools/probe/mfma16_probe.hip):
+//   A: lane l holds A_blk[row l % 16],  B: lane l holds B_blk[col l % 16],  blk = l / 16
+//   D: register 4 blk + i of lane l holds D_blk[row 4 (l / 16) + i][col l % 16]
+__device__ __forceinline__ f32x16 mfma16(float a, float b, f32x16 c) { return __builtin_amdgcn_mfma_f32_16x16x1f32(a, b, c, 0, 0, 0); }
 
 // one wave-instruction: 64 lanes x 16 B from per-lane global addresses into LDS [dst, dst + 1 KB)
 __device__ __forceinline__ void dma16(const float* gsrc_lane, float* lds_dst_wave) {
@@ -378,7 +386,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
                                                     const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                     const float* __restrict__ dVT, float* __restrict__ DVP,
                                                     float* __restrict__ dATp, int BP, int nvc, int n_bt,
-                                                    const int* __restrict__ jl) {
+                                                    const int* __restrict__ jl, const int* __restrict__ segid,
+                                                    const int* __restrict__ segj) {
   constexpr bool SPARSE = KJ > 0;
   constexpr int KJS = SPARSE ? KJ : 8;
   __shared__ __attribute__((aligned(16))) float lds[BWD_RING * TB_FLOATS + DVBUF_FLOATS + 3 * 36 * 64 + 27 * 64];
@@ -405,7 +414,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
       const int o = wv + 4 * i;
-      if (o < TB_FLOATS / 256) dma16u(src + o * 256, lane_ln, dst + o * 256);
+      if (o < (SPARSE ? TB_PIECES_SPARSE : TB_FLOATS / 256)) dma16u(src + o * 256, lane_ln, dst + o * 256);
     }
   };
   // The two roles are two separate code paths (each with its own accumulators: the register allocation is the larger
@@ -414,8 +423,45 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
   if (t_begin + 1 < t_end) issue(t_begin + 1, 1);
 
   if (plane) {
-    // ================= plane wave c: T_{r,c}, dvp_c, dA_{r,c} =================
+    // ================= plane wave c: T_{r,c}, dvp_c, dA_{r,c} (joint-sparse: + dA_{c,3}) =================
     f32x16 acc3[3] = {zero16(), zero16(), zero16()};
+    // joint-sparse: the four products (0,c), (1,c), (2,c), (c,3) over the segment's 16-row joint window, as block
+    // accumulators of v_mfma_f32_16x16x1_4b_f32 (blocks 0 + 2 = pose columns 0..15, blocks 1 + 3 = 16..31)
+    f32x16 acc4 = zero16();
+    int cur_seg = SPARSE ? segid[t_begin] : 0;
+    int seg_tile = t_begin;                  // a tile of the open segment (its window is segj[seg_tile])
+    unsigned seen = 0u;                      // joints whose slab rows this wave has written
+    // close a segment: add its accumulators into this workgroup's dA slab (first touch of a joint stores, later ones add;
+    // the slab rows belong to this wave alone) and start the next one
+    auto flush_window = [&]() {
+      if constexpr (SPARSE) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // earlier slab stores of this wave have landed
+        const int* sj = segj + seg_tile * 16;
+        const int col = b0 + (lane & 15);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int j = sj[4 * (lane >> 4) + i];
+          if (j >= 0) {
+            const bool add = (seen >> j) & 1u;
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+              const f32x16& a = p == 0 ? acc3[0] : p == 1 ? acc3[1] : p == 2 ? acc3[2] : acc4;
+              const int e = p < 3 ? p * 4 + c : c * 4 + 3;
+              float* dst = dATp + ((size_t)(vc * 12 + e) * NJ + j) * BP + col;
+              float lo = a[i] + a[8 + i], hi = a[4 + i] + a[12 + i];
+              if (add) { lo += dst[0]; hi += dst[16]; }
+              dst[0] = lo; dst[16] = hi;
+            }
+          }
+        }
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+          const int j = sj[n];                                       // wave-uniform
+          if (j >= 0) seen |= 1u << j;
+        }
+        acc3[0] = zero16(); acc3[1] = zero16(); acc3[2] = zero16(); acc4 = zero16();
+      }
+    };
     // this wave's A^T operand vectors (r, j-pair) -> LDS, once
 #pragma unroll
     for (int r = 0; r < 3; ++r)
@@ -503,19 +549,42 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
         }
         *quad_ptr(DVP, (size_t)c * (VP / 4) + vt * 8, g, BP, qoff) = t;
       }
-      const float* wvp = tab + TB_WVJ + l31;
-      float wn = wvp[acc_row(0, half) * 32];
+      if constexpr (SPARSE) {
+        // dA over the segment's 16-row joint window.  A operand: W16[n = lane % 16][v = acc_row(q, half)], four 16-byte
+        // reads per tile (rows padded to 36 floats: conflict-free); B operand: this lane's register q of the accumulator
+        // layout; one 4-block instruction adds rows acc_row(q, 0) and acc_row(q, 1) for all 32 pose columns.
+        const int sg = segid[vt];                                    // wave-uniform
+        if (sg != cur_seg) { flush_window(); cur_seg = sg; }
+        seg_tile = vt;
+        const f32x4* w16 = reinterpret_cast<const f32x4*>(tab + TB_WVJ + (lane & 15) * 36 + 4 * half);
+        f32x4 wq[4];
 #pragma unroll
-      for (int q = 0; q < 16; ++q) {
-        const float wvj = wn;
-        const float p0 = dv[0][q] * vpc[q], p1 = dv[1][q] * vpc[q], p2 = dv[2][q] * vpc[q];
-        __builtin_amdgcn_sched_barrier(0);
-        acc3[0] = mfma(wvj, p0, acc3[0]);
-        __builtin_amdgcn_sched_barrier(0);
-        if (q + 1 < 16) wn = wvp[acc_row(q + 1, half) * 32];
-        __builtin_amdgcn_sched_barrier(0);
-        acc3[1] = mfma(wvj, p1, acc3[1]);
-        acc3[2] = mfma(wvj, p2, acc3[2]);
+        for (int g = 0; g < 4; ++g) wq[g] = w16[2 * g];
+        const f32x16& dvc = c == 0 ? dv[0] : c == 1 ? dv[1] : dv[2];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float wvj = wq[q >> 2][q & 3];
+          const float p0 = dv[0][q] * vpc[q], p1 = dv[1][q] * vpc[q], p2 = dv[2][q] * vpc[q];
+          acc3[0] = mfma16(wvj, p0, acc3[0]);
+          acc3[1] = mfma16(wvj, p1, acc3[1]);
+          acc3[2] = mfma16(wvj, p2, acc3[2]);
+          acc4 = mfma16(wvj, dvc[q], acc4);
+        }
+      } else {
+        const float* wvp = tab + TB_WVJ + l31;
+        float wn = wvp[acc_row(0, half) * 32];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+          const float wvj = wn;
+          const float p0 = dv[0][q] * vpc[q], p1 = dv[1][q] * vpc[q], p2 = dv[2][q] * vpc[q];
+          __builtin_amdgcn_sched_barrier(0);
+          acc3[0] = mfma(wvj, p0, acc3[0]);
+          __builtin_amdgcn_sched_barrier(0);
+          if (q + 1 < 16) wn = wvp[acc_row(q + 1, half) * 32];
+          __builtin_amdgcn_sched_barrier(0);
+          acc3[1] = mfma(wvj, p1, acc3[1]);
+          acc3[2] = mfma(wvj, p2, acc3[2]);
+        }
       }
       slot = slot1;
     };
@@ -523,12 +592,25 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
       tile(vt, vpA, vpB);
       if (vt + 1 < t_end) tile(vt + 1, vpB, vpA);
     }
+    if constexpr (SPARSE) {
+      flush_window();
+      // joints no tile of this chunk touches: their slab rows are zero
+#pragma unroll 1
+      for (int j = 0; j < NJ; ++j) {
+        if ((seen >> j) & 1u) continue;
+        if (lane < 32) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int j = acc_row(q, half);
-      if (j < NJ) {
+          for (int p = 0; p < 4; ++p) dATp[((size_t)(vc * 12 + (p < 3 ? p * 4 + c : c * 4 + 3)) * NJ + j) * BP + bcol] = 0.f;
+        }
+      }
+    } else {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) dATp[((size_t)(vc * 12 + r * 4 + c) * NJ + j) * BP + bcol] = acc3[r][q];
+      for (int q = 0; q < 16; ++q) {
+        const int j = acc_row(q, half);
+        if (j < NJ) {
+#pragma unroll
+          for (int r = 0; r < 3; ++r) dATp[((size_t)(vc * 12 + r * 4 + c) * NJ + j) * BP + bcol] = acc3[r][q];
+        }
       }
     }
   } else {
@@ -603,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
     __syncthreads();                                  // records of the first two tiles landed
     compute_dv(t_begin, ring);
     publish_dv();
-    accumulate_dA3(ring);
+    if constexpr (!SPARSE) accumulate_dA3(ring);      // joint-sparse: the plane waves take dA_{c,3} (16-row products)
     int slot = 0;
     for (int vt = t_begin; vt < t_end; ++vt) {
       barrier_keep_vm<0>();                           // nothing younger than this wave's record copies is in flight
@@ -613,16 +695,18 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
       if (vt + 1 < t_end) {      // this wave's whole tile (27 + 48 MFMA) runs beside the plane waves' 84
         compute_dv(vt + 1, ring + slot1 * TB_FLOATS);
         publish_dv();
-        accumulate_dA3(ring + slot1 * TB_FLOATS);
+        if constexpr (!SPARSE) accumulate_dA3(ring + slot1 * TB_FLOATS);
       }
       slot = slot1;
     }
+    if constexpr (!SPARSE) {
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int j = acc_row(q, half);
-      if (j < NJ) {
+      for (int q = 0; q < 16; ++q) {
+        const int j = acc_row(q, half);
+        if (j < NJ) {
 #pragma unroll
-        for (int r = 0; r < 3; ++r) dATp[((size_t)(vc * 12 + r * 4 + 3) * NJ + j) * BP + bcol] = acc3[r][q];
+          for (int r = 0; r < 3; ++r) dATp[((size_t)(vc * 12 + r * 4 + 3) * NJ + j) * BP + bcol] = acc3[r][q];
+        }
       }
     }
   }
@@ -631,13 +715,16 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 // static (W) parts of the per-tile backward operand records
 // (Wc != NULL: the W^T block takes the kjs compacted rows of the joint-sparse path, zeros behind them)
 __global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __restrict__ Wvj, float* __restrict__ Tb,
-                                 const float* __restrict__ Wc, int kjs) {
+                                 const float* __restrict__ Wc, int kjs, const float* __restrict__ W16) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over VT * 2048
   if (idx >= VT * 2048) return;
   const int vt = idx >> 11, k = idx & 2047;
   float* dst = Tb + (size_t)vt * TB_FLOATS;
   if (k < W_FLOATS) dst[TB_WJV + k] = Wc ? (k < kjs * 32 ? Wc[(size_t)vt * kjs * 32 + k] : 0.f) : Wjv[(size_t)vt * W_FLOATS + k];
-  else if (k < W_FLOATS + 1024) dst[TB_WVJ + (k - W_FLOATS)] = Wvj[(size_t)vt * 1024 + (k - W_FLOATS)];
+  else if (k < W_FLOATS + 1024) {
+    const int kk = k - W_FLOATS;
+    dst[TB_WVJ + kk] = Wc ? (kk < TB_W16_FLOATS ? W16[(size_t)vt * TB_W16_FLOATS + kk] : 0.f) : Wvj[(size_t)vt * 1024 + kk];
+  }
   else if (k - W_FLOATS - 1024 < TB_FLOATS - TB_WVJ - 1024) dst[TB_WVJ + 1024 + (k - W_FLOATS - 1024)] = 0.f;
 }
 
@@ -818,11 +905,11 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
 #define JRR_LBS_BWD(DVM)                                                                                                        \
   do {                                                                                                                          \
     if (m.kjs == 8)                                                                                                             \
-      hipLaunchKernelGGL((k_lbs_bwd<DVM, 8>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl);        \
+      hipLaunchKernelGGL((k_lbs_bwd<DVM, 8>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl, m.segid, m.segj);        \
     else if (m.kjs == 12)                                                                                                       \
-      hipLaunchKernelGGL((k_lbs_bwd<DVM, 12>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl);       \
+      hipLaunchKernelGGL((k_lbs_bwd<DVM, 12>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl, m.segid, m.segj);       \
     else                                                                                                                        \
-      hipLaunchKernelGGL((k_lbs_bwd<DVM, 0>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl);        \
+      hipLaunchKernelGGL((k_lbs_bwd<DVM, 0>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl, m.segid, m.segj);        \
   } while (0)
   if (dVT && dJT) JRR_LBS_BWD(2);
   else if (dVT) JRR_LBS_BWD(1);
@@ -844,7 +931,7 @@ int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, floa
 }
 
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s) {
-  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb, m.kjs ? m.Wc : nullptr, m.kjs);
+  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb, m.kjs ? m.Wc : nullptr, m.kjs, m.W16);
   return 0;
 }
 
