@@ -212,6 +212,7 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   m->d.W16 = reinterpret_cast<float*>(reinterpret_cast<int*>(m->d.jl + nJl) + nPerm);
   m->d.segid = reinterpret_cast<int*>(m->d.W16 + nW16);
   m->d.segj = m->d.segid + (size_t)VT * 16;
+  { const char* b16 = getenv("JRR_BWD16"); m->d.bwd16 = (kjs && !(b16 && b16[0] == '0')) ? 1 : 0; }
   m->d.parents.maxd = 0;
   m->d.faces = nullptr;
   m->d.faces_int = nullptr;
@@ -318,10 +319,11 @@ static int pick_chunks(int wg_per_chunk, int max_chunks) {
   return best;
 }
 
-static void plan_geometry(int BP, int& nvc, int& nvcb, int& nsplit, int& nsplitJ) {
+static void plan_geometry(int BP, int& nvc, int& nvcb, int& nvcb16, int& nsplit, int& nsplitJ) {
   const int nbg = BP / BG;
   nvc = pick_chunks(nbg, 54);                       // forward: one workgroup per (128 poses, chunk)
-  nvcb = pick_chunks(BP / BT, 36);                  // backward: one workgroup per (32 poses, chunk)
+  nvcb = pick_chunks(BP / BT, 36);                  // backward, role kernel: one workgroup per (32 poses, chunk)
+  nvcb16 = pick_chunks(BP / 64, 36);                // backward, k_lbs_bwd16: one workgroup per (64 poses, chunk)
   nsplit = (512 + nbg - 1) / nbg;
   if (nsplit > 32) nsplit = 32;
   if (nsplit < 1) nsplit = 1;
@@ -340,8 +342,8 @@ struct Carver {
 
 static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   const int BP = (int)round_up((size_t)B, BG);
-  int nvc, nvcb, nsplit, nsplitJ;
-  plan_geometry(BP, nvc, nvcb, nsplit, nsplitJ);
+  int nvc, nvcb, nvcb16, nsplit, nsplitJ;
+  plan_geometry(BP, nvc, nvcb, nvcb16, nsplit, nsplitJ);
   Carver c{(char*)ws, 0};
   jrr_engine tmp;
   jrr_engine* t = e ? e : &tmp;
@@ -360,7 +362,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->JP = c.take((size_t)nvc * 3 * NH * BP);
     t->dJT = c.take((size_t)3 * NHP * BP);
     t->DVP = c.take((size_t)3 * VP * BP);
-    t->dATp = c.take((size_t)nvcb * 12 * NJ * BP);
+    t->dATp = c.take((size_t)(nvcb > nvcb16 ? nvcb : nvcb16) * 12 * NJ * BP);     // slabs of either backward kernel
     t->dFTp = c.take((size_t)nsplit * KFP * BP);
     t->Jsum = c.take((size_t)3 * NH * BP);
     t->dA = c.take((size_t)12 * NJ * BP);
@@ -430,7 +432,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->dJraw = c.take((size_t)NH * V);
   }
   if (e) {
-    e->BP = BP; e->nvc = nvc; e->nvcb = nvcb; e->nsplit = nsplit; e->nsplitJ = nsplitJ;
+    e->BP = BP; e->nvc = nvc; e->nvcb = (e->has_model && e->m.kjs && e->m.bwd16) ? nvcb16 : nvcb; e->nsplit = nsplit; e->nsplitJ = nsplitJ;
   }
   return c.off;
 }
@@ -580,7 +582,8 @@ extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   e->have_mask = mask != nullptr;
   if (!e->tab_static) { launch_bwd_tab_static(e->m, e->Jn_iv, s); e->tab_static = true; }   // model-only: once per engine
-  launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, e->Jn_q, e->m.p2v, s);
+  launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, e->Jn_q, e->m.p2v, s,
+                        (e->m.kjs && e->m.bwd16) ? 1 : 0);
   e->fold_valid = false;
   if (e->folded) {
     int rc = fold_rebuild(e, s);
@@ -657,7 +660,7 @@ extern "C" int jrr_rodrigues_backward(const float* aa, const float* dR, float* d
 // by their consumers (k_joints_loss, k_chain_bwd: a few pose-contiguous loads per thread); the 16 split-K slabs of
 // dF^T (58 MB at 4096 poses) keep a wide reduction kernel of their own -- and so do the dA slabs when there are many of
 // them (small batches: 16 slabs at 1024 poses, where k_chain_bwd has only 32 blocks to sum them with).
-constexpr int MAX_SLABS_IN_CONSUMER = 4;
+constexpr int MAX_SLABS_IN_CONSUMER = 8;
 // conv_x6d != NULL (fused loop with the pose discriminator): the per-joint MLP adjoint shares the launch of the dF^T sum.
 static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s, const float* conv_x6d = nullptr, float dscale = 0.f) {
   if (conv_x6d)

@@ -144,6 +144,8 @@ struct Model {
   float* W16;   // [VT][16][36]      W[v][window joint n] of the tile's segment, [n][v] with rows padded to 36 floats
   int* segid;   // [VT]              segment of each tile
   int* segj;    // [VT][16]          the window of the tile's segment: joint of row n, -1 = unused row
+  int bwd16;    // kjs > 0: run the symmetric 16-pose backward kernel k_lbs_bwd16 (0 with JRR_BWD16=0 in the environment
+                // of jrr_model_create: the role kernel k_lbs_bwd<., kjs>)
   // Internal vertex order.  Nothing inside the LBS path depends on WHICH vertex sits in which row (every consumer sums
   // over vertices), so jrr_model_create may store the vertices in an order that makes the tiles joint-coherent (sorted
   // by their influencing joints) when the file order does not fit kjs.  p2v / v2p are NULL for the identity; otherwise

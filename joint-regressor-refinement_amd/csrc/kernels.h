@@ -87,7 +87,7 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s);
 int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s, const int* p2v = nullptr);
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv, float* Jn_q,
-                          const int* p2v, hipStream_t s);
+                          const int* p2v, hipStream_t s, int r16 = 0);
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
                     float* dJ, const int* v2p, hipStream_t s);
 

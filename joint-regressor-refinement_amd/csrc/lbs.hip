@@ -48,6 +48,8 @@ constexpr int TB_JN = 0, TB_WJV = NHP * 32, TB_WVJ = TB_WJV + W_FLOATS, TB_FLOAT
 // joint-sparse variants: the W block holds the segment-window weights W16 [16 n][36] (576 floats, jrr_common.h) instead of
 // [32 v][32 j]; the record then ends at 1920 floats: 8 of the 10 DMA pieces
 constexpr int TB_W16_FLOATS = 16 * 36, TB_PIECES_SPARSE = 8;
+// record of k_lbs_bwd16 (below): JN | WT | WD | JL, 7 DMA pieces
+constexpr int R16_JN = 0, R16_WT = 640, R16_WD = 1024, R16_JL = 1536, R16_FLOATS = 1792, R16_PIECES = 7;
 // v_mfma_f32_16x16x1_4b_f32: four independent 16x16 outer products per instruction (block = lane / 16), 8 passes = half the
 // issue time of v_mfma_f32_32x32x2_f32 (33 vs 64 clocks measured, tools/probe/mfma16_probe.hip):
 //   A: lane l holds A_blk[row l % 16],  B: lane l holds B_blk[col l % 16],  blk = l / 16
@@ -712,14 +714,249 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// backward, joint-sparse models: FOUR SYMMETRIC WAVES, each alone with 16 poses
+//   The role kernel above splits a 32-pose tile over three plane waves and a vertex-adjoint wave: one wave is always late,
+//   and two barriers per tile tie the four together.  With 16x16 matrix tiles (v_mfma_f32_16x16x4_f32, the same FLOP per clock
+//   as 32x32x2) a (32 vertices x 16 poses) tile is 8 registers instead of 16 per lane, the twelve dA accumulators of a
+//   16-row joint window are 48 registers instead of 192 -- and ONE wave can hold everything for its own 16 poses: vertex
+//   adjoint, T recompute, dvp, all twelve dA products.  No roles, no hand-off through LDS, no imbalance; the four waves of a
+//   workgroup (64 poses) only share the per-tile operand records (LDS-DMA ring, ONE barrier per tile).
+//   16x16x4:  A: lane l holds A[m = l % 16][k = l / 16]   B: lane l holds B[k = l / 16][n = l % 16]
+//             D: register i of lane l holds D[row 4 (l / 16) + i][col l % 16]
+//   so register i of a lane group g = l / 16 is vertex row 16 blk + 4 g + i of its pose column: four consecutive rows = one
+//   16-byte row quad of VPb / DVP (one dwordx4 per (plane, blk)), and -- as the B operand of a product that sums over the
+//   tile's rows -- K index g of the step (blk, i), whose A operand therefore is W16[n][16 blk + 4 g + i].
+//   Record R16 of a tile (k_jreg_tiles / k_bwd_tab_static write it in place of the role kernel's):
+//     JN [blk][s < 5][64 lanes]   Jn[i = 4 s + g][16 blk + m]            A operands of dverts  (i >= 17: 0)
+//     WT [blk][s < 3][64 lanes]   W[16 blk + m][joint slot 4 s + g]       A operands of T       (slots >= KJ: 0)
+//     WD [blk][g][n][4]           W16[n][16 blk + 4 g + 0..3]             A operands of dA, one ds_read_b128 per blk
+//     JL [16]                     16 * joint of slot k (ints)              row offsets into the wave's A^T slice
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+template <int DV, int KJ>
+__global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ Tb, const float* __restrict__ AT,
+                                                      const float* __restrict__ VPb, const float* __restrict__ dJT,
+                                                      const float* __restrict__ dVT, float* __restrict__ DVP,
+                                                      float* __restrict__ dATp, int BP, int nvc, int n_bt,
+                                                      const int* __restrict__ segid, const int* __restrict__ segj) {
+  constexpr int S = KJ / 4;                          // K steps of the T product (4 joint slots each)
+  constexpr int ASL = 9 * NJ * 16;                   // floats of one wave's A^T slice [(r,c)][24 joints][16 poses]
+  __shared__ __attribute__((aligned(16))) float lds[BWD_RING * R16_FLOATS + 4 * ASL];
+  float* const ring = lds;
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, n = lane & 15, g = lane >> 4;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  float* const ldsA = lds + BWD_RING * R16_FLOATS + wv * ASL;
+  const int L = xcd_remap(blockIdx.x, gridDim.x);
+  const int vc = L / n_bt, bt = L % n_bt;
+  const int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
+  const size_t bcol = (size_t)bt * 64 + wv * 16 + n;          // this lane's pose column
+  const unsigned lane_ln = (unsigned)lane * 4u;
+
+  auto issue = [&](int vt, int slot) {
+    const float* src = Tb + (size_t)vt * TB_FLOATS;
+    float* dst = ring + slot * R16_FLOATS;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int o = wv + 4 * i;
+      if (o < R16_PIECES) dma16u(src + o * 256, lane_ln, dst + o * 256);
+    }
+  };
+  issue(t_begin, 0);
+  if (t_begin + 1 < t_end) issue(t_begin + 1, 1);
+
+  // this wave's A^T slice (the 3x3 rotation part; the translation column is not needed for T) -> LDS, once
+#pragma unroll
+  for (int rc = 0; rc < 9; ++rc)
+#pragma unroll
+    for (int jj = 0; jj < NJ / 4; ++jj) {
+      const int j = 4 * jj + g;
+      ldsA[(rc * NJ + j) * 16 + n] = AT[(size_t)(((rc / 3) * 4 + rc % 3) * NJ + j) * BP + bcol];
+    }
+  // joint adjoint as B operands of the vertex-adjoint product: dj[r][s] = dJ^T[r][i = 4 s + g][pose]
+  float dj[3][5];
+#pragma unroll
+  for (int r = 0; r < 3; ++r)
+#pragma unroll
+    for (int s5 = 0; s5 < 5; ++s5) {
+      const int i = 4 * s5 + g;
+      dj[r][s5] = (DV != 1 && i < NHP) ? dJT[(size_t)(r * NHP + i) * BP + bcol] : 0.f;
+    }
+
+  // row quad (plane, tile, blk) of this lane: rows 32 vt + 16 blk + 4 g + 0..3 of its pose
+  auto qidx = [&](int plane, int vt, int blk) { return ((size_t)plane * (VP / 4) + vt * 8 + 4 * blk + g) * BP + bcol; };
+  const f32x4* const VP4 = reinterpret_cast<const f32x4*>(VPb);
+  const f32x4* const dV4 = reinterpret_cast<const f32x4*>(dVT);
+  f32x4* const DVP4 = reinterpret_cast<f32x4*>(DVP);
+  auto load_vp = [&](int vt, f32x4 (&dst)[3][2]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int c = 0; c < 3; ++c)
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) dst[c][blk] = VP4[qidx(c, vt, blk)];
+  };
+
+  f32x4 acc[12];                                   // dA_{r,c} at 3 r + c (c < 3), dA_{r,3} at 9 + r: 16 window rows x 16 poses
+#pragma unroll
+  for (int e = 0; e < 12; ++e) acc[e] = zero4();
+  int cur_seg = segid[t_begin];
+  int seg_tile = t_begin;
+  unsigned seen = 0u;
+  // close a segment: add the accumulators into this workgroup's dA slab (first touch of a joint stores, later ones add;
+  // the 16 pose columns belong to this wave alone)
+  auto flush_window = [&]() __attribute__((always_inline)) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int* sj = segj + seg_tile * 16;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int j = sj[4 * g + i];
+      if (j >= 0) {
+        const bool add = (seen >> j) & 1u;
+#pragma unroll
+        for (int e = 0; e < 12; ++e) {
+          const int ent = e < 9 ? (e / 3) * 4 + e % 3 : (e - 9) * 4 + 3;
+          float* dst = dATp + ((size_t)(vc * 12 + ent) * NJ + j) * BP + bcol;
+          float val = acc[e][i];
+          if (add) val += dst[0];
+          dst[0] = val;
+        }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      const int j = sj[k];
+      if (j >= 0) seen |= 1u << j;
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = zero4();
+  };
+
+  f32x4 vpA[3][2], vpB[3][2];
+  load_vp(t_begin, vpA);
+  int slot = 0;
+  auto tile = [&](int vt, const f32x4 (&vpc)[3][2], f32x4 (&vpn)[3][2]) __attribute__((always_inline)) {
+    // record vt has landed (it was issued two tiles ago: older than the 6 prefetch loads and the 6 dvp stores of the previous
+    // tile, which stay in flight) and every wave is done with the slot the next copy overwrites
+    barrier_keep_vm<12>();
+    const int slot1 = (slot + 1 == BWD_RING) ? 0 : slot + 1, slot2 = (slot1 + 1 == BWD_RING) ? 0 : slot1 + 1;
+    if (vt + 2 < t_end) issue(vt + 2, slot2);
+    __builtin_amdgcn_sched_barrier(0);
+    const float* tab = ring + slot * R16_FLOATS;
+    if (vt + 1 < t_end) load_vp(vt + 1, vpn);
+    // ---- vertex adjoint of the tile: dverts_r = Jn^T dj_r and / or the caller's ----
+    f32x4 dv[3][2];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) dv[r][blk] = (DV != 0) ? dV4[qidx(r, vt, blk)] : zero4();
+    if (DV != 1) {
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+          const float a = tab[R16_JN + (blk * 5 + s5) * 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) dv[r][blk] = mfma4(a, dj[r][s5], dv[r][blk]);
+        }
+    }
+    // ---- operands shared by the planes: W^T (A of T), W16 (A of dA), the A^T row offsets of the tile's joint slots ----
+    float wt[2][S];
+    int jo[S];
+#pragma unroll
+    for (int s = 0; s < S; ++s) {
+      jo[s] = reinterpret_cast<const int*>(tab + R16_JL)[4 * s + g];
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) wt[blk][s] = tab[R16_WT + (blk * 3 + s) * 64 + lane];
+    }
+    f32x4 wd[2];
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk) wd[blk] = *reinterpret_cast<const f32x4*>(tab + R16_WD + ((blk * 4 + g) * 16 + n) * 4);
+    const int sg = segid[vt];                                      // wave-uniform
+    if (sg != cur_seg) { flush_window(); cur_seg = sg; }
+    seg_tile = vt;
+    // ---- translation column: dA_{r,3} += W16^T dverts_r ----
+#pragma unroll
+    for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) acc[9 + r] = mfma4(wd[blk][i], dv[r][blk][i], acc[9 + r]);
+    // ---- per plane c: T_{r,c} (recomputed), dvp_c = sum_r T_{r,c} dverts_r, dA_{r,c} += W16^T (dverts_r * vp_c) ----
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      f32x4 T[3][2];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) { T[r][0] = zero4(); T[r][1] = zero4(); }
+#pragma unroll
+      for (int s = 0; s < S; ++s)
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+          const float at = ldsA[(r * 3 + c) * (NJ * 16) + jo[s] + n];
+          T[r][0] = mfma4(wt[0][s], at, T[r][0]);
+          T[r][1] = mfma4(wt[1][s], at, T[r][1]);
+        }
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk) {
+        f32x4 t;
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+          t[i] = fmaf(T[2][blk][i], dv[2][blk][i], fmaf(T[1][blk][i], dv[1][blk][i], T[0][blk][i] * dv[0][blk][i]));
+        DVP4[qidx(c, vt, blk)] = t;
+      }
+#pragma unroll
+      for (int blk = 0; blk < 2; ++blk)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float v = vpc[c][blk][i];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) acc[3 * r + c] = mfma4(wd[blk][i], dv[r][blk][i] * v, acc[3 * r + c]);
+        }
+    }
+    slot = slot1;
+  };
+  for (int vt = t_begin; vt < t_end; vt += 2) {
+    tile(vt, vpA, vpB);
+    if (vt + 1 < t_end) tile(vt + 1, vpB, vpA);
+  }
+  flush_window();
+  // joints no tile of this chunk touches: zero rows
+#pragma unroll 1
+  for (int j = 0; j < NJ; ++j) {
+    if ((seen >> j) & 1u) continue;
+    if (lane < 16) {
+#pragma unroll
+      for (int ent = 0; ent < 12; ++ent) dATp[((size_t)(vc * 12 + ent) * NJ + j) * BP + bcol] = 0.f;
+    }
+  }
+}
+
 // static (W) parts of the per-tile backward operand records
 // (Wc != NULL: the W^T block takes the kjs compacted rows of the joint-sparse path, zeros behind them)
 __global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __restrict__ Wvj, float* __restrict__ Tb,
-                                 const float* __restrict__ Wc, int kjs, const float* __restrict__ W16) {
+                                 const float* __restrict__ Wc, int kjs, const float* __restrict__ W16,
+                                 const int* __restrict__ jl, int r16) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over VT * 2048
   if (idx >= VT * 2048) return;
   const int vt = idx >> 11, k = idx & 2047;
   float* dst = Tb + (size_t)vt * TB_FLOATS;
+  if (r16) {      // record R16 of k_lbs_bwd16 (everything but its JN block, which k_jreg_tiles writes)
+    if (k >= R16_FLOATS - R16_WT) return;
+    const int o = R16_WT + k;
+    if (o < R16_WD) {               // WT [blk][s < 3][g][m] = W[16 blk + m][slot 4 s + g]
+      const int q = o - R16_WT, blk = q / 192, s = (q / 64) % 3, g = (q >> 4) & 3, m = q & 15;
+      const int slot = 4 * s + g;
+      dst[o] = slot < kjs ? Wc[((size_t)vt * kjs + slot) * 32 + 16 * blk + m] : 0.f;
+    } else if (o < R16_JL) {        // WD [blk][g][n][i] = W16[n][16 blk + 4 g + i]
+      const int q = o - R16_WD, blk = q >> 8, g = (q >> 6) & 3, n = (q >> 2) & 15, i = q & 3;
+      dst[o] = W16[(size_t)vt * TB_W16_FLOATS + n * 36 + 16 * blk + 4 * g + i];
+    } else {                        // JL [16]: 16 * joint of slot k (row offset into a wave's A^T slice), as an int
+      const int q = o - R16_JL;
+      reinterpret_cast<int*>(dst)[o] = (q < kjs) ? 16 * jl[vt * kjs + q] : 0;
+    }
+    return;
+  }
   if (k < W_FLOATS) dst[TB_WJV + k] = Wc ? (k < kjs * 32 ? Wc[(size_t)vt * kjs * 32 + k] : 0.f) : Wjv[(size_t)vt * W_FLOATS + k];
   else if (k < W_FLOATS + 1024) {
     const int kk = k - W_FLOATS;
@@ -827,7 +1064,7 @@ __global__ __launch_bounds__(JREG_THREADS) void k_jreg_rowsum(const float* __res
 
 __global__ void k_jreg_tiles(const float* __restrict__ J, const float* __restrict__ mask,
                              const float* __restrict__ rowsum, float* __restrict__ Jn, float* __restrict__ Jn_vi,
-                             float* __restrict__ Jn_iv, float* __restrict__ Jn_q, const int* __restrict__ p2v) {
+                             float* __restrict__ Jn_iv, float* __restrict__ Jn_q, const int* __restrict__ p2v, int r16) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over VT*32*32 (tile, vv, i)
   if (idx >= VT * 1024) return;
   const int vt = idx >> 10, vv = (idx >> 5) & 31, i = idx & 31;
@@ -842,7 +1079,9 @@ __global__ void k_jreg_tiles(const float* __restrict__ J, const float* __restric
   }
   Jn_vi[(size_t)vt * 1024 + vv * 32 + i] = val;
   Jn_q[((size_t)(v >> 2) * 32 + i) * 4 + (v & 3)] = val;      // vertex quads [VP/4][32][4]: A operand of k_gemm_q32
-  if (i < NHP) Jn_iv[(size_t)vt * TB_FLOATS + TB_JN + i * 32 + vv] = val;   // backward operand record
+  // backward operand record: the role kernel's [i][32 v], or R16's JN [blk][s = i / 4][g = i % 4][m] (k_lbs_bwd16)
+  if (r16) { if (i < 20) Jn_iv[(size_t)vt * TB_FLOATS + R16_JN + ((vv >> 4) * 5 + (i >> 2)) * 64 + (i & 3) * 16 + (vv & 15)] = val; }
+  else if (i < NHP) Jn_iv[(size_t)vt * TB_FLOATS + TB_JN + i * 32 + vv] = val;
 }
 
 // dJ_raw = mask * relu'(J*mask) * (dJn - sum_v(dJn*Jn)) / rowsum      (dJn given as [17][ldn])
@@ -900,6 +1139,22 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
 
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s) {
+  if (m.kjs && m.bwd16) {                       // four symmetric waves of 16 poses: one workgroup per (64 poses, vertex chunk)
+    const int n_bt16 = BP / 64;
+    dim3 grid16(n_bt16 * nvc), block16(256);
+#define JRR_LBS_BWD16(DVM)                                                                                                      \
+  do {                                                                                                                          \
+    if (m.kjs == 8)                                                                                                             \
+      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 8>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj);  \
+    else                                                                                                                        \
+      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 12>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj); \
+  } while (0)
+    if (dVT && dJT) JRR_LBS_BWD16(2);
+    else if (dVT) JRR_LBS_BWD16(1);
+    else JRR_LBS_BWD16(0);
+#undef JRR_LBS_BWD16
+    return 0;
+  }
   const int n_bt = BP / BT;                     // one workgroup per (pose tile, vertex chunk)
   dim3 grid(n_bt * nvc), block(256);
 #define JRR_LBS_BWD(DVM)                                                                                                        \
@@ -924,14 +1179,15 @@ int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int
 }
 
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv,
-                          float* Jn_q, const int* p2v, hipStream_t s) {
+                          float* Jn_q, const int* p2v, hipStream_t s, int r16) {
   hipLaunchKernelGGL(k_jreg_rowsum, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, rowsum);
-  hipLaunchKernelGGL(k_jreg_tiles, dim3(VT * 1024 / 256), dim3(256), 0, s, J, mask, rowsum, Jn, Jn_vi, Jn_iv, Jn_q, p2v);
+  hipLaunchKernelGGL(k_jreg_tiles, dim3(VT * 1024 / 256), dim3(256), 0, s, J, mask, rowsum, Jn, Jn_vi, Jn_iv, Jn_q, p2v, r16);
   return 0;
 }
 
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s) {
-  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb, m.kjs ? m.Wc : nullptr, m.kjs, m.W16);
+  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb, m.kjs ? m.Wc : nullptr, m.kjs, m.W16, m.jl,
+                     (m.kjs && m.bwd16) ? 1 : 0);
   return 0;
 }
 
