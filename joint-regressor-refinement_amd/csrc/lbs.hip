@@ -169,9 +169,37 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     }
   };
 
+  // H36M joints 0..15 as block accumulators of v_mfma_f32_16x16x1_4b_f32 (17 joint rows in a 32-row product waste 47 % of
+  // it; 16 rows on the four-block instruction take half the issue time), joint 16 as a per-lane partial on the vector ALU
   f32x16 jacc[3] = {zero16(), zero16(), zero16()};
+  float j16[3] = {0.f, 0.f, 0.f};
   f32x16 vp[3];
   f32x16 vr;
+
+  // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b] for the tile in `vr`: A operand Jn[i = lane % 16][v = acc_row(q, half)]
+  // (the [v][32 i] tile of the record, read with i = lane % 16), B operand register q of the vertex tile; one four-block
+  // instruction adds the two rows acc_row(q, 0), acc_row(q, 1) for all 32 pose columns (blocks 0 + 2: columns 0..15,
+  // 1 + 3: 16..31).  Operands four steps ahead (an instruction is 32 clocks).
+  auto regress = [&](auto R_, const float* ldsJ) __attribute__((always_inline)) {
+    constexpr int r = decltype(R_)::value;
+    const float* jp = ldsJ + half * 128 + (lane & 15);              // row acc_row(q, half) = acc_row_u(q) + 4 half
+    float a0 = jp[acc_row_u(0) * 32], a1 = jp[acc_row_u(1) * 32], a2 = jp[acc_row_u(2) * 32], a3 = jp[acc_row_u(3) * 32];
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const float ac = a0;
+      a0 = a1; a1 = a2; a2 = a3;
+      __builtin_amdgcn_sched_barrier(0);
+      jacc[r] = mfma16(ac, vr[q], jacc[r]);
+      __builtin_amdgcn_sched_barrier(0);
+      if (q + 4 < 16) a3 = jp[acc_row_u(q + 4) * 32];
+    }
+    // joint 16 on the vector ALU: Jn[16][v] verts[v][b] over this lane's rows (the two lane halves are summed at the end)
+    const float* sp = ldsJ + half * 128 + 16;
+    float p16 = 0.f;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) p16 = fmaf(sp[acc_row_u(q) * 32], vr[q], p16);
+    j16[r] += p16;
+  };
 
   if (t_begin < t_end) issue(t_begin, 0, 0);
   int g = 0;   // global stage counter: ring slot = g & 1
@@ -269,18 +297,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
             *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g4, BP, qoff) = t;
           }
         }
-        {   // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b]; three steps ahead: one MFMA per step
-          float j0 = ldsJ[acc_row(0, half) * 32 + l31], j1 = ldsJ[acc_row(1, half) * 32 + l31], j2 = ldsJ[acc_row(2, half) * 32 + l31];
-#pragma unroll
-          for (int q = 0; q < 16; ++q) {
-            const float jc = j0;
-            j0 = j1; j1 = j2;
-            __builtin_amdgcn_sched_barrier(0);
-            jacc[r] = mfma(jc, vr[q], jacc[r]);
-            __builtin_amdgcn_sched_barrier(0);
-            if (q + 3 < 16) j2 = ldsJ[acc_row(q + 3, half) * 32 + l31];
-          }
-        }
+        regress(std::integral_constant<int, r>{}, ldsJ);
       } else {
         constexpr int h = s - NKCH, r = h >> 1;
         if (STORE_VP) {   // spread the v_posed stores over the six skinning stages: two 16-byte row quads each
@@ -326,19 +343,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
               *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g, BP, qoff) = t;
             }
           }
-          // joints^T[i, b] += sum_v Jn[i, v] verts_r[v, b]
-          {   // three steps ahead: one MFMA per step
-            float j0 = ldsJ[acc_row(0, half) * 32 + l31], j1 = ldsJ[acc_row(1, half) * 32 + l31], j2 = ldsJ[acc_row(2, half) * 32 + l31];
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-              const float jc = j0;
-              j0 = j1; j1 = j2;
-              __builtin_amdgcn_sched_barrier(0);
-              jacc[r] = mfma(jc, vr[q], jacc[r]);
-              __builtin_amdgcn_sched_barrier(0);
-              if (q + 3 < 16) j2 = ldsJ[acc_row(q + 3, half) * 32 + l31];
-            }
-          }
+          regress(std::integral_constant<int, r>{}, ldsJ);
         }
       }
       ++g;
@@ -347,10 +352,17 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int i = acc_row(q, half);
-      if (i < NH) JP[((size_t)(vc * 3 + r) * NH + i) * BP + bcol] = jacc[r][q];
+    for (int u = 0; u < 4; ++u) {        // block layout: register 4 blk + u = joint 4 (lane / 16) + u, pose column lane % 16 (+ 16)
+      const int i = 4 * (lane >> 4) + u;
+      float* dst = JP + ((size_t)(vc * 3 + r) * NH + i) * BP + (size_t)b0 + (lane & 15);
+      dst[0] = jacc[r][u] + jacc[r][8 + u];
+      dst[16] = jacc[r][4 + u] + jacc[r][12 + u];
     }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {          // joint 16: the two lane halves hold the partial sums over their rows
+    const float t = j16[r] + __shfl_xor(j16[r], 32);
+    if (lane < 32) JP[((size_t)(vc * 3 + r) * NH + 16) * BP + bcol] = t;
+  }
   if (probe && blockIdx.x == 0 && tid == 0) {
     probe[0] = clock64() - probe_t0;                 // shader clocks this wave was resident
     probe[1] = (long long)(t_end - t_begin) * (SPARSE ? (KF / 2) * 3 + 3 * 2 * KJS + 3 * 16 : LBS_FWD_MFMA_PER_TILE);   // MFMA instructions it issued
