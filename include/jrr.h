@@ -44,7 +44,8 @@ enum {
   JRR_NUM_BETAS = 10,
   JRR_POSE6D = 144,        /* 24 joints x 6 */
   JRR_DISC_PARAMS = 1840153,
-  JRR_SHAPE_DISC_PARAMS = 171
+  JRR_SHAPE_DISC_PARAMS = 171,
+  JRR_SIL_SIZE = 224       /* silhouette image size (square); see jrr_silhouette_forward */
 };
 
 /* engine flags */
@@ -210,7 +211,11 @@ int jrr_camera_prefit(jrr_engine_t* e, const float* x6d_dev, const float* betas_
 /* ---- soft silhouette (BASELINE configs[4]) ---------------------------
  * render_mesh(...) = Mesh_Renderer(224)(batch, verts*[-2,-2,2])[:, 3], scripts/optimize.py:77-85 +
  * scripts/mesh_renderer.py:23-79 (pytorch3d 0.3.0 rasteriser, blur_radius 0, 1 face per pixel,
- * SoftSilhouetteShader sigma 1e-4).  verts (B,6890,3), cam (B,3) -> alpha (B,224,224).              */
+ * SoftSilhouetteShader sigma 1e-4).  verts (B,6890,3), cam (B,3) -> alpha (B,224,224).
+ * The image size is FIXED at 224 (JRR_SIL_SIZE): the only size the reference's loop instantiates (scripts/optimize.py:110
+ * `Mesh_Renderer(image_size=224)`; the constructor's own default of 256, scripts/mesh_renderer.py:25, is never used by the
+ * reference).  The z-buffer strips, the pixel-index packing of the covered-pixel lists and the LDS budget of the rasteriser
+ * are built for it; the host mirror's Mesh_Renderer(image_size != 224) raises NotImplementedError naming this line.   */
 int jrr_silhouette_forward(jrr_engine_t* e, const float* verts_dev, const float* cam_dev, float* alpha_dev,
                            void* stream);
 /* adjoint for the SAME inputs (must follow the forward): galpha (B,224,224) -> dverts (B,6890,3), dcam (B,3);

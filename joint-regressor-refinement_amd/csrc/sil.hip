@@ -293,11 +293,16 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   // 32-bit fixed-point integers in ONE 64-bit word, value = (ix << 32) + iy as a signed 64-bit sum, added with one
   // ds_add_u64 -- 2 atomics per covered pixel (6 in world space, 4 with float pairs; 10.5 of the pass's 19.7 us were
   // atomics).  Integer addition is associative: the adjoint is bitwise reproducible, which the float version was not.
-  // Quantum q = scale * 2^-19: one contribution is at most 86 scale (|c| <= 2 * 1e4 scale * |alpha - mask| * max_x
-  // e^-x sqrt(x) * 0.01), twenty of one sign on a vertex stay below 2^31 q; the rounding error per contribution,
-  // q / 2 = 1e-6 scale, is 1e-5 .. 1e-8 of the contributions that matter.
+  // Quantum q = scale * 2^-17.  One contribution is at most 86 scale (|c| <= 2 * 1e4 scale * |alpha - mask| * max_x
+  // e^-x sqrt(x) * 0.01) = 2^23.4 q, so ~190 maximal contributions of one sign on a vertex stay below 2^31 q (a carry from
+  // the low word into the high one would corrupt BOTH components silently).  Only pixels within ~2 px of an edge
+  // contribute noticeably (alpha (1 - alpha) decays like e^(-d / sigma), sqrt(sigma) = 1.1 px), about 0.6 L maximal
+  // contributions for an edge L px long, shared by its two end points: with six edges per vertex the margin holds up to
+  // edges of ~100 px -- a whole-frame close-up of a mesh of this resolution (tested: tests/test_gpu_round3.py, camera at a
+  // third of the distance).  Rounding error per contribution q / 2 = 4e-6 scale: 4e-5 .. 4e-8 of the contributions that
+  // matter.  (Round 2 used 2^-19: 4 x finer and 4 x less head-room, ~47 contributions.)
   unsigned long long* acc = reinterpret_cast<unsigned long long*>(zb);
-  const float fq = scale * (1.f / 524288.f), fqi = (scale > 0.f) ? 524288.f / scale : 0.f;
+  const float fq = scale * (1.f / 131072.f), fqi = (scale > 0.f) ? 131072.f / scale : 0.f;
   auto pack2 = [&](float gx, float gy) {
     const long long ix = (long long)__float2int_rn(gx * fqi), iy = (long long)__float2int_rn(gy * fqi);
     return (unsigned long long)((ix << 32) + iy);

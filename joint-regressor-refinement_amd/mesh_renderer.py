@@ -42,7 +42,9 @@ class Mesh_Renderer(nn.Module):
     def __init__(self, image_size: int = 224, smpl=None):
         super().__init__()
         if image_size != 224:
-            raise NotImplementedError('the HIP rasteriser is built for the 224x224 image of scripts/optimize.py:110')
+            raise NotImplementedError(f'Mesh_Renderer(image_size={image_size}): the HIP rasteriser is built for the 224x224 image of '
+                                      'scripts/optimize.py:110 only (include/jrr.h, JRR_SIL_SIZE / jrr_silhouette_forward); the '
+                                      'reference constructor\'s default of 256 is never instantiated by the reference')
         self.image_size = image_size
         self.smpl = smpl
         self._engines = {}

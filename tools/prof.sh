@@ -6,8 +6,8 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # kernel trace: the default bench command itself (100 timed steps); PMC passes: a short run (counters serialise kernels)
-FULL="python3 $PWD/bench.py --no_cpu_baseline"
-CMD="python3 $PWD/bench.py --steps 5 --warmup 2 --no_cpu_baseline"
+FULL="python3 $PWD/bench.py --no_cpu_baseline --min_timed_ms 600"
+CMD="python3 $PWD/bench.py --steps 5 --warmup 2 --no_cpu_baseline --min_timed_ms 1 --no_skin_variants --no_folded"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $FULL > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
@@ -41,6 +41,12 @@ w = pick(out['pmc_write'], 'k_lbs_fwd<true, false').get('WRITE_SIZE')
 if f is not None and w is not None:
     out['traffic'] = {'k_lbs_fwd_hbm_bytes_per_launch': int((2 * f + w) * 1024), 'FETCH_SIZE_KB': f, 'WRITE_SIZE_KB': w,
                       'correction': 'bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 (gfx950: FETCH_SIZE counts 64 B per 128-B request)'}
+    for key, name in (('k_lbs_bwd', 'k_lbs_bwd'), ('k_blend_adjoint', 'k_blend_adjoint'), ('k_sil_raster<true', 'k_sil_raster_adj')):
+        ff, ww = pick(out['pmc_fetch'], key).get('FETCH_SIZE'), pick(out['pmc_write'], key).get('WRITE_SIZE')
+        if ff is not None and ww is not None:
+            out['traffic'][name + '_hbm_bytes_per_launch'] = int((2 * ff + ww) * 1024)
+            out['traffic'][name + '_FETCH_SIZE_KB'] = ff
+            out['traffic'][name + '_WRITE_SIZE_KB'] = ww
     json.dump(out['traffic'], open('pmc_traffic.json', 'w'), indent=1)
 json.dump(out, open('summary.json', 'w'), indent=1)
 for r in out.get('kernel_stats', []):
