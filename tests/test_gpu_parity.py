@@ -573,7 +573,7 @@ def test_joint_sparse_skinning_matches_the_dense_kernels(eng_mod, dmodel, smpl_m
     skipped terms are exact zeros, so joints / vertices / gradients agree to fp32 round-off of the re-grouped K pairs;
     a model whose first tile is skinned by all 24 joints must fall back to the dense kernels by itself."""
     import os
-    if any(k in os.environ for k in ('JRR_DENSE_SKINNING', 'JRR_SKIN_JOINTS', 'JRR_VERTEX_ORDER')):
+    if any(k in os.environ for k in ('JRR_DENSE_SKINNING', 'JRR_SKIN_JOINTS', 'JRR_VERTEX_ORDER', 'JRR_BWD16')):
         pytest.skip('the suite itself runs under a forced skinning variant')
     B = 130
     b = _batch(smpl_model_np, j_h36m_np, B, seed=77)
@@ -589,8 +589,19 @@ def test_joint_sparse_skinning_matches_the_dense_kernels(eng_mod, dmodel, smpl_m
         model12 = eng_mod.DeviceModel(smpl_model_np, DEV)
     finally:
         del os.environ['JRR_SKIN_JOINTS']
+    # the backward pass of a joint-sparse model runs k_lbs_bwd16 (four symmetric 16-pose waves); JRR_BWD16=0 at upload keeps the
+    # round-2 role kernel (three plane waves + a vertex-adjoint wave, 16-row dA windows): both ship, both are compared here
+    os.environ['JRR_BWD16'] = '0'
+    try:
+        roles8 = eng_mod.DeviceModel(smpl_model_np, DEV)
+        os.environ['JRR_SKIN_JOINTS'] = '12'
+        roles12 = eng_mod.DeviceModel(smpl_model_np, DEV)
+    finally:
+        del os.environ['JRR_BWD16']
+        os.environ.pop('JRR_SKIN_JOINTS', None)
     outs = {}
-    for name, dm, kjs in (('sparse', dmodel, 8), ('sparse12', model12, 12), ('dense', dense_model, 0)):
+    for name, dm, kjs in (('sparse', dmodel, 8), ('sparse12', model12, 12), ('roles8', roles8, 8), ('roles12', roles12, 12),
+                          ('dense', dense_model, 0)):
         eng = eng_mod.RefineEngine(dm, B, flags=eng_mod.FLAG_KEEP_VERTS)
         assert eng.info['joint_sparse'] == kjs
         eng.set_j_regressor(T(j_h36m_np))
@@ -605,7 +616,7 @@ def test_joint_sparse_skinning_matches_the_dense_kernels(eng_mod, dmodel, smpl_m
         outs[name] = [t.cpu() for t in (joints, verts, dx, db, xs, bs)]
     names = ['joints', 'verts', 'dx6d', 'dbetas', 'x6d after 3 iterations', 'betas after 3 iterations']
     tol = [2e-6, 2e-6, None, None, 6e-4, 6e-4]
-    for variant in ('sparse', 'sparse12'):
+    for variant in ('sparse', 'sparse12', 'roles8', 'roles12'):
         for n, a, c, t in zip(names, outs[variant], outs['dense'], tol):
             if t is None:
                 assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item() + 1e-9, (variant, n)
