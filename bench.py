@@ -542,6 +542,12 @@ def main():
                      if probe[4] else None,
                      'first_workgroup_resident_frac': round(probe[4] * 1e-6 / dom_ms, 3) if probe[4] and dom_ms > 0 else None},
         'kernels_ms': {k: round(t, 4) for k, (t, n) in prof.items() if n},
+        # the other matrix-core launches of the iteration against the same peak, each on the FLOP of the formulation it runs
+        'kernels_roofline': {name: {'flop_per_launch': fl * B, 'achieved_tflops': round(fl * B / (prof[cls][0] * 1e-3) / 1e12, 2),
+                                    'frac': round(fl * B / (prof[cls][0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
+                             for name, cls, fl in (('k_lbs_bwd', 'k_lbs_bwd', flop_bwd), ('k_blend_adjoint', 'k_gemm_tn_blend_adjoint', FLOP_BLEND_ADJ_PER_POSE),
+                                                   ('pose_disc_gemms (4 launches)', 'pose_disc_gemms', FLOP_DISC_PER_POSE))
+                             if prof.get(cls, (0, 0))[1] and prof[cls][0] > 0},
         'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
                    'allreduce_bytes': 17 * 6890 * 4, 'in_timed_region': nj_region, 'host_calls': 2 + (1 if dist is not None else 0)},
         'cadence1': {'value': round(a.steps / c1_el * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(c1_ms, 4),
