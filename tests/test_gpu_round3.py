@@ -302,6 +302,46 @@ def test_j_steps_inside_the_call_and_explicit_reuse(smpl_hip, smpl_model_np, j_h
     assert (b0 - b1).abs().max().item() < 2e-4
 
 
+@pytest.mark.parametrize('B', [1, 65])
+def test_j_steps_in_call_vs_oracle_at_edge_batches(smpl_hip, smpl_model_np, j_h36m_np, B):
+    """the new entry points at a batch of ONE pose and at 65 (one full 64-pose workgroup of the backward kernel + one pose):
+    2 iterations, J step (oracle: j_regressor_loss_and_grad + torch Adam + renormalisation), 2 more iterations"""
+    eng_mod = _mod('engine')
+    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, j_h36m_np, B, seed=300 + B)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    J0 = T(j_h36m_np)
+    # oracle: 2 iterations with a FRESH per-pose Adam would restart the moments; emulate the continuing optimiser by hand
+    orient = x6[:, :1].clone().requires_grad_(True); pose = x6[:, 1:].clone().requires_grad_(True); bt = betas.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pose, orient, bt], lr=1e-2)
+    J = J0.clone().requires_grad_(True)
+    optJ = torch.optim.Adam([J], lr=1e-2)
+    mask = oracle.find_j_reg_mask(J0)
+
+    def inner(n):
+        for _ in range(n):
+            loss, _, _ = oracle.inner_losses(smpl, J.detach(), mask, orient, pose, bt, gt_c)
+            opt.zero_grad(); loss.backward(); opt.step()
+    inner(2)
+    _, gJ, _ = oracle.j_regressor_loss_and_grad(smpl, J.detach(), orient.detach(), pose.detach(), bt.detach(), gt_c)
+    optJ.zero_grad(); J.grad = gJ; optJ.step()
+    inner(2)
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_KEEP_VERTS)
+    Jd = J0.to(DEV).clone()
+    eng.set_j_regressor(Jd)
+    xd, bd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous()
+    m, v, step = _fresh_state(B)
+    Jm, Jv, Js = torch.zeros_like(Jd), torch.zeros_like(Jd), torch.zeros(1, dtype=torch.int32, device=DEV)
+    eng.refine_run_j_steps(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, 2, 2, Jd, Jm, Jv, Js, 1e-2)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, 2, after_j_step=True)
+    assert int(step.item()) == 4 and int(Js.item()) == 1
+    assert (Jd.cpu() - J.detach()).abs().max().item() < 2e-5
+    d = (xd.cpu() - torch.cat([orient.detach(), pose.detach()], 1)).abs()
+    assert d.max().item() < 6e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+    assert (bd.cpu() - bt.detach()).abs().max().item() < 3e-4
+
+
 @pytest.mark.parametrize('scope,classes', [('parts', (8, 12)), ('all', (8, 12))])
 def test_shuffled_vertex_order_model(smpl_model_np, j_h36m_np, scope, classes):
     """A body whose FILE order of the vertices is a seeded shuffle (inside body parts: what a real mesh file looks like;
