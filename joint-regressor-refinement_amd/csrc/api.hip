@@ -324,6 +324,9 @@ static void plan_geometry(int BP, int& nvc, int& nvcb, int& nvcb16, int& nsplit,
   nvc = pick_chunks(nbg, 54);                       // forward: one workgroup per (128 poses, chunk)
   nvcb = pick_chunks(BP / BT, 36);                  // backward, role kernel: one workgroup per (32 poses, chunk)
   nvcb16 = pick_chunks(BP / 64, 36);                // backward, k_lbs_bwd16: one workgroup per (64 poses, chunk)
+  // ... but exactly one round of 512 workgroups with an even chunk count lets the kernel pair the two workgroups of a CU on
+  // one pose group (lbs.hip), which is worth more than the last per cent of tile balance
+  if (512 % (BP / 64) == 0 && 512 / (BP / 64) <= 36 && ((512 / (BP / 64)) & 1) == 0 && 32 % (512 / (BP / 64) / 2) == 0) nvcb16 = 512 / (BP / 64);
   nsplit = (512 + nbg - 1) / nbg;
   if (nsplit > 32) nsplit = 32;
   if (nsplit < 1) nsplit = 1;

@@ -13,6 +13,8 @@
 // product both produce (vertex, pose) tiles, the per-element affine combine is plain VALU on
 // matching registers, and the regressor product consumes the vertex tile as its B operand
 // (it sums over the tile's ROW index, guide section 3 "accumulator tile as the next operand").
+#include <cstdlib>
+
 #include "jrr_common.h"
 #include "kernels.h"
 
@@ -111,7 +113,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     const int vcp = p % npair;
     vc = 2 * vcp + slot;
     const int P0 = (int)((long)VT * vcp / npair), P1 = (int)((long)VT * (vcp + 1) / npair);
-    const int mid = P0 + ((P1 - P0) * 5 + 4) / 9;
+    const int mid = P0 + ((P1 - P0) * paired + 500) / 1000;      // `paired` = the first workgroup's share in thousandths
     t_begin = slot ? mid : P0;
     t_end = slot ? P1 : mid;
   }
@@ -753,7 +755,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
                                                       const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                       const float* __restrict__ dVT, float* __restrict__ DVP,
                                                       float* __restrict__ dATp, int BP, int nvc, int n_bt,
-                                                      const int* __restrict__ segid, const int* __restrict__ segj) {
+                                                      const int* __restrict__ segid, const int* __restrict__ segj, int paired) {
   constexpr int S = KJ / 4;                          // K steps of the T product (4 joint slots each)
   constexpr int ASL = 9 * NJ * 16;                   // floats of one wave's A^T slice [(r,c)][24 joints][16 poses]
   __shared__ __attribute__((aligned(16))) float lds[BWD_RING * R16_FLOATS + 4 * ASL];
@@ -763,8 +765,27 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   float* const ldsA = lds + BWD_RING * R16_FLOATS + wv * ASL;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
-  const int vc = L / n_bt, bt = L % n_bt;
-  const int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
+  // default mapping: an XCD's contiguous range of L = one vertex chunk x all pose groups (paired == -2: chunk-major inside a
+  // pose group instead; measured equal or slower: 0.200 vs 0.203 ms at B = 4096, 0.069 vs 0.066 ms at B = 1024)
+  int vc = (paired == -2) ? L % nvc : L / n_bt, bt = (paired == -2) ? L / nvc : L % n_bt;
+  int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
+  if (paired > 0) {
+    // Exactly one round of two workgroups per CU (k_lbs_fwd's geometry, see there): the two workgroups of a CU -- dispatch
+    // slots j and j + per_xcd / 2 of an XCD -- take the two halves of a PAIR of vertex chunks of the SAME pose group.
+    // Measured (B = 4096): 0.204 -> 0.184 ms; what matters is that the two share the pose group (the chunk-major mapping
+    // without pairing gains nothing), the split itself is flat around even: `paired` = the first-dispatched workgroup's
+    // share of the pair's tiles in thousandths, 480 (26 : 28 tiles) measured best by 1 %.  Static: bitwise reproducible.
+    const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
+    const int p = j % (per_xcd / 2), slot_ = j / (per_xcd / 2);
+    const int npair = nvc / 2, bt_per_xcd = (per_xcd / 2) / npair;
+    bt = xcd * bt_per_xcd + p / npair;
+    const int vcp = p % npair;
+    vc = 2 * vcp + slot_;
+    const int P0 = (int)((long)VT * vcp / npair), P1 = (int)((long)VT * (vcp + 1) / npair);
+    const int mid = P0 + ((P1 - P0) * paired + 500) / 1000;       // `paired` = the first workgroup's share in thousandths
+    t_begin = slot_ ? mid : P0;
+    t_end = slot_ ? P1 : mid;
+  }
   const size_t bcol = (size_t)bt * 64 + wv * 16 + n;          // this lane's pose column
   const unsigned lane_ln = (unsigned)lane * 4u;
 
@@ -1128,7 +1149,8 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
                    float* verts, int B, int BP, int nvc, hipStream_t s, long long* probe) {
   dim3 grid((BP / BG) * nvc), block(256);
   // exactly one round of two workgroups per CU, an even number of chunks and whole pose groups per XCD
-  const int paired = (grid.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? 1 : 0;
+  static const int fwd_split = [] { const char* e = getenv("JRR_FWD_SPLIT"); return e ? atoi(e) : 556; }();   // 5/9 (15 : 12 tiles at B = 4096)
+  const int paired = (grid.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? fwd_split : 0;
 #define JRR_LBS_FWD(SVP, SVT)                                                                                                     \
   do {                                                                                                                            \
     if (m.kjs == 8)                                                                                                               \
@@ -1154,12 +1176,16 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
   if (m.kjs && m.bwd16) {                       // four symmetric waves of 16 poses: one workgroup per (64 poses, vertex chunk)
     const int n_bt16 = BP / 64;
     dim3 grid16(n_bt16 * nvc), block16(256);
+    // JRR_BWD16_PAIRED (experiments): share of the first-dispatched workgroup of a CU in thousandths (default 480), 0 = no
+    // pairing, -2 = chunk-major mapping without pairing
+    static const int pair_env = [] { const char* e = getenv("JRR_BWD16_PAIRED"); return e ? atoi(e) : 480; }();
+    const int paired16 = (pair_env > 0) ? ((grid16.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? pair_env : 0) : pair_env;
 #define JRR_LBS_BWD16(DVM)                                                                                                      \
   do {                                                                                                                          \
     if (m.kjs == 8)                                                                                                             \
-      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 8>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj);  \
+      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 8>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj, paired16);  \
     else                                                                                                                        \
-      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 12>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj); \
+      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 12>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj, paired16); \
   } while (0)
     if (dVT && dJT) JRR_LBS_BWD16(2);
     else if (dVT) JRR_LBS_BWD16(1);
