@@ -322,6 +322,8 @@ static int pick_chunks(int wg_per_chunk, int max_chunks) {
 static void plan_geometry(int BP, int& nvc, int& nvcb, int& nvcb16, int& nsplit, int& nsplitJ) {
   const int nbg = BP / BG;
   nvc = pick_chunks(nbg, 54);                       // forward: one workgroup per (128 poses, chunk)
+  // exactly one round of 512 workgroups with an even chunk count lets k_lbs_fwd pair the two workgroups of a CU (lbs.hip)
+  { const char* e = getenv("JRR_FWD_ROUND"); if (!(e && e[0] == '0') && 512 % nbg == 0 && 512 / nbg <= 64 && ((512 / nbg) & 1) == 0 && 32 % (512 / nbg / 2) == 0) nvc = 512 / nbg; }
   nvcb = pick_chunks(BP / BT, 36);                  // backward, role kernel: one workgroup per (32 poses, chunk)
   nvcb16 = pick_chunks(BP / 64, 36);                // backward, k_lbs_bwd16: one workgroup per (64 poses, chunk)
   // ... but exactly one round of 512 workgroups with an even chunk count lets the kernel pair the two workgroups of a CU on
