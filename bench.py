@@ -444,6 +444,21 @@ def main():
     if not a.no_config5 and not use_sil and use_disc:
         config5 = side_run(eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_POSE_DISC | eng_mod.FLAG_SILHOUETTE, silhouette_setup)
         config5['workload'] = 'BASELINE configs[4]: configs[2] + soft-silhouette loss (224x224 rasteriser as HIP kernel) in the inner loop'
+        # the rasteriser is integer / vector-ALU work, not a GEMM: its line is the VALU issue rate (wave-instructions per launch
+        # from the PMC pass of tools/prof_c5.sh, static) over the live duration, against 1 wave-instruction per SIMD per 2 clocks
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('k_sil_raster_adj_pmc_per_launch_b4096') if B == 4096 else None
+        except Exception:
+            pm = None
+        ras_ms = config5.get('kernels_ms', {}).get('silhouette_fwd_bwd')
+        if pm and ras_ms:
+            peak = 256 * 4 * 2.4e9 / 2
+            config5['rasteriser_issue'] = {'bound': 'valu issue', 'valu_wave_insts_per_launch': pm['SQ_INSTS_VALU'],
+                                           'valu_wave_insts_per_pose': round(pm['SQ_INSTS_VALU'] / B), 'avg_launch_ms': ras_ms,
+                                           'achieved_ginst_s': round(pm['SQ_INSTS_VALU'] / (ras_ms * 1e-3) / 1e9, 1), 'peak_ginst_s': round(peak / 1e9, 1),
+                                           'frac': round(pm['SQ_INSTS_VALU'] / (ras_ms * 1e-3) / peak, 4),
+                                           'parked_wave_cycle_frac': round(pm['SQ_WAIT_ANY'] / pm['SQ_WAVE_CYCLES'], 3),
+                                           'source': 'profiles/pmc_traffic.json (static PMC counts, live duration)'}
     # ---- what a body model with a less coherent vertex order runs: the 12-joint-per-tile kernels and the dense kernels
     #      (the synthetic body's ring-major vertex order is what lets the headline use the 8-joint kernels) ----
     skin_variants = None
