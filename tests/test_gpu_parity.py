@@ -423,7 +423,10 @@ def test_folded_mode_matches_dense_and_oracle(eng_mod, dmodel, smpl_model_np, j_
         assert (res[mode][0] - ref).abs().max().item() < 6e-4, mode      # Adam amplifies ~0 gradients (same bound as the other trajectory tests)
         assert (res[mode][1] - b).abs().max().item() < 6e-4, mode
         np.testing.assert_allclose(float(res[mode][2].sum()) / (B * 51), hist[-1]['joint_loss'], rtol=2e-3)
-    assert (res['dense'][0] - res['folded'][0]).abs().max().item() < 3e-4
+    # two different algorithms for the same function: the bound of the other trajectory comparisons (max: one Adam-amplified
+    # near-zero gradient entry; mean: everything else)
+    d = (res['dense'][0] - res['folded'][0]).abs()
+    assert d.max().item() < 6e-4 and d.mean().item() < 2e-6, (d.max().item(), d.mean().item())
 
 
 # ---- round 2: the benchmarked configuration at its own size, config 2's geometry, KATs on the kernels ------------
