@@ -39,7 +39,9 @@ class Mesh_Renderer(nn.Module):
     space first (an exact sign flip and halving).  Channels 0-2 are 1 as pytorch3d's SoftSilhouetteShader returns
     them (sigmoid_alpha_blend of all-ones colours), independent of the textures."""
 
-    def __init__(self, image_size: int = 224, smpl=None):
+    def __init__(self, image_size: int = 256, smpl=None):
+        # the default is the reference constructor's (scripts/mesh_renderer.py:25); like every size but 224 it is rejected below --
+        # loudly, rather than silently rendering at another size than the caller's code assumes
         super().__init__()
         if image_size != 224:
             raise NotImplementedError(f'Mesh_Renderer(image_size={image_size}): the HIP rasteriser is built for the 224x224 image of '
