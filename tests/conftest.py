@@ -45,8 +45,14 @@ def pytest_collection_finish(session):
     runs = {
         'w1': [sys.executable, worker, os.path.join(tmp, 'w1')] + DP_FLAGS,
         'w2': _torchrun(2, 29541, [worker, os.path.join(tmp, 'w2')] + DP_FLAGS + ['--dist_backend', 'gloo', '--single_device']),
+        # the node's world size (BASELINE configs[3]: 8 ranks), 32 poses per rank, still on one GPU over gloo
+        'w8': _torchrun(8, 29544, [worker, os.path.join(tmp, 'w8')] + DP_FLAGS + ['--dist_backend', 'gloo', '--single_device']),
         # bench.py --gpus 2 WITHOUT torchrun: bench.py starts its own 2-rank child (what the driver's command line does)
         'bench2': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--batch', '256',
+                   '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5',
+                   '--min_timed_ms', '50'],
+        # ... and at the node's world size
+        'bench8': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '1', '--batch', '128',
                    '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5',
                    '--min_timed_ms', '50'],
         # the same under an explicit torchrun (the README's / the contract's N > 1 command line)

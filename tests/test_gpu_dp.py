@@ -55,6 +55,26 @@ def test_two_rank_driver_equals_single_process():
         np.testing.assert_allclose(h2[k], h1[k], rtol=2e-3, err_msg=k)
 
 
+def test_eight_rank_driver_equals_single_process():
+    """world size 8 (the node of BASELINE configs[3]) on the same global batch of 256: eight contiguous shards of 32 poses"""
+    _run('w1'); _run('w8')
+    (one,) = _load('w1', 1)
+    eight = _load('w8', 8)
+    assert [(int(r['lo']), int(r['hi'])) for r in eight] == [(32 * k, 32 * k + 32) for k in range(8)]
+    x8 = np.concatenate([r['x6d'] for r in eight])
+    b8 = np.concatenate([r['betas'] for r in eight])
+    assert np.abs(x8 - one['x6d']).max() < 2e-4 and np.abs(b8 - one['betas']).max() < 2e-4
+    for k in ('J', 'disc', 'sdisc'):
+        for r in eight[1:]:
+            assert np.array_equal(eight[0][k], r[k]), k              # replicated Adam after the ONE all-reduce: bit-identical
+        assert np.abs(eight[0][k] - one[k]).max() < 5e-5, k
+    h1, h8 = json.loads(str(one['history']))[0], json.loads(str(eight[0]['history']))[0]
+    for k in ('joint_loss', 'pose_discriminated_loss', 'shape_discriminated_loss', 'pose_discriminator_loss',
+              'shape_discriminator_loss', 'j_regressor_error', 'mpjpe', 'pampjpe'):
+        np.testing.assert_allclose(h8[k], h1[k], rtol=2e-3, err_msg=k)
+    np.testing.assert_allclose(np.array(h8['loss_history']), np.array(h1['loss_history']), rtol=2e-3, atol=1e-6)
+
+
 def test_two_rank_driver_moved_the_regressor_only_on_its_support():
     _run('w2')
     two = _load('w2', 2)
@@ -66,24 +86,24 @@ def test_two_rank_driver_moved_the_regressor_only_on_its_support():
     assert not moved[J0 <= 0].any()
 
 
-@pytest.mark.parametrize('name', ['bench2', 'bench2t'])
-def test_bench_two_ranks(name):
-    """`python bench.py --gpus 2` (bench.py launches its own torchrun child before touching the GPU) and the explicit
-    torchrun line both give ONE JSON line of a 2-rank run, with the evidence of the rank count in it"""
+@pytest.mark.parametrize('name,world,batch', [('bench2', 2, 256), ('bench2t', 2, 256), ('bench8', 8, 128)])
+def test_bench_n_ranks(name, world, batch):
+    """`python bench.py --gpus N` (bench.py launches its own torchrun child before touching the GPU) and the explicit
+    torchrun line both give ONE JSON line of an N-rank run, with the evidence of the rank count in it"""
     r = _run(name)
     lines = [l for l in r['out'].splitlines() if l.startswith('{')]
     assert len(lines) == 1, r['out'][-2000:]
     j = json.loads(lines[0])
-    assert j['n_gpus'] == 2 and j['scaling'] == 'weak' and j['value'] > 0
-    assert j['config']['global_batch'] == 512 and j['config']['parallelism'] == 'dp2'
+    assert j['n_gpus'] == world and j['scaling'] == 'weak' and j['value'] > 0
+    assert j['config']['global_batch'] == world * batch and j['config']['parallelism'] == f'dp{world}'
     assert j['config']['j_steps_in_timed_region'] >= 1
     assert j['j_step']['allreduce_bytes'] == 17 * 6890 * 4
     assert np.isfinite(j['config']['joint_loss_last'])
     c = j['collective']
-    assert c['world'] == 2 and len(c['ranks_seen']) == 2
-    assert sorted(rk[0] for rk in c['ranks_seen']) == [0, 1]
-    assert len({rk[3] for rk in c['ranks_seen']}) == 2                  # two processes
-    assert c['allreduce_check'] == c['allreduce_expected'] == 1.0       # sum of ranks over the collective
+    assert c['world'] == world and len(c['ranks_seen']) == world
+    assert sorted(rk[0] for rk in c['ranks_seen']) == list(range(world))
+    assert len({rk[3] for rk in c['ranks_seen']}) == world             # that many processes
+    assert c['allreduce_check'] == c['allreduce_expected'] == world * (world - 1) / 2     # sum of ranks over the collective
     assert c['backend'] == 'gloo' and c['single_device_debug'] is True
     assert j['cadence1']['timed_regions'] >= 5 and j['cadence1']['value'] > 0
 
