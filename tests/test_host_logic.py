@@ -218,12 +218,12 @@ def test_bench_gpus_n_starts_n_ranks_before_touching_the_gpu():
     """`python bench.py --gpus 2` outside torchrun becomes a torchrun CHILD of two rank processes (the driver's command line for
     N > 1); here, without a GPU, each rank stops at the availability check -- which it reaches only as a rank of a world of 2,
     i.e. after the launch -- and the parent relays the failure (exit status != 0, no JSON line)."""
+    if torch.cuda.device_count() > 0:       # (counting devices does not initialise the GPU)
+        pytest.skip('a GPU is present: the N-rank launch itself is exercised by tests/test_gpu_dp.py')
     env = dict(os.environ, MASTER_ADDR='127.0.0.1')
     env.pop('WORLD_SIZE', None); env.pop('RANK', None); env.pop('LOCAL_RANK', None)
     r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--backend', 'gloo', '--steps', '2', '--warmup', '1'],
                        env=env, cwd=ROOT, capture_output=True, text=True, timeout=300)
-    if torch.cuda.is_available():
-        pytest.skip('a GPU is present: the N-rank launch itself is exercised by tests/test_gpu_dp.py')
     assert r.returncode != 0
     assert r.stderr.count('bench.py needs an MI355X') == 2, r.stderr[-1500:]      # two ranks got as far as the check
     assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
