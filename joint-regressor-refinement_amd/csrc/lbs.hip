@@ -465,7 +465,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
               const int e = p < 3 ? p * 4 + c : c * 4 + 3;
               float* dst = dATp + ((size_t)(vc * 12 + e) * NJ + j) * BP + col;
               float lo = a[i] + a[8 + i], hi = a[4 + i] + a[12 + i];
-              if (add) { lo += dst[0]; hi += dst[16]; }
+              if (add) {      // agent-scope loads (L1 bypassed): what an earlier flush of this wave stored, whichever lane stored it
+                lo += __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                hi += __hip_atomic_load(dst + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              }
               dst[0] = lo; dst[16] = hi;
             }
           }
@@ -852,7 +855,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
           const int ent = e < 9 ? (e / 3) * 4 + e % 3 : (e - 9) * 4 + 3;
           float* dst = dATp + ((size_t)(vc * 12 + ent) * NJ + j) * BP + bcol;
           float val = acc[e][i];
-          if (add) val += dst[0];
+          if (add) val += __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L1 bypassed: an earlier flush of this wave stored it, possibly from another lane
           dst[0] = val;
         }
       }

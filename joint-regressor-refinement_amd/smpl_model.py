@@ -128,7 +128,21 @@ def shuffled_vertex_order(model: Dict[str, np.ndarray], seed: int = 5, scope: st
     for j in dom:
         if j not in parts:
             parts.append(int(j))
-    if scope == 'all':
+    if scope == 'interleaved':
+        # joint-sorted order cut into 32-vertex tiles, tiles dealt round-robin from three distant thirds of the body: every tile
+        # is coherent (few joints) but CONSECUTIVE tiles share no joints, so the backward kernel's 16-joint segments (jrr_common.h)
+        # last one or two tiles and every joint's slab rows are revisited many times -- the stress case of its flush path
+        keys = []
+        for v in range(NUM_VERTS):
+            nz = np.nonzero(W[v])[0]
+            o = nz[np.argsort(-W[v][nz], kind='stable')]
+            keys.append(tuple(list(o) + [NUM_JOINTS] * (4 - len(o)))[:4] + (v,))
+        srt = np.array(sorted(range(NUM_VERTS), key=lambda v: keys[v]), dtype=np.int64)
+        ntile = (NUM_VERTS + 31) // 32
+        third = (ntile + 2) // 3
+        tiles = [t for k in range(third) for t in (k, k + third, k + 2 * third) if t < ntile]
+        perm = np.concatenate([srt[32 * t:32 * t + 32] for t in tiles])
+    elif scope == 'all':
         perm = rng.permutation(NUM_VERTS).astype(np.int64)
     else:
         perm = np.concatenate([rng.permutation(np.nonzero(dom == j)[0]) for j in parts]).astype(np.int64)

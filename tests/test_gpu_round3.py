@@ -342,10 +342,11 @@ def test_j_steps_in_call_vs_oracle_at_edge_batches(smpl_hip, smpl_model_np, j_h3
     assert (bd.cpu() - bt.detach()).abs().max().item() < 3e-4
 
 
-@pytest.mark.parametrize('scope,classes', [('parts', (8, 12)), ('all', (8, 12))])
+@pytest.mark.parametrize('scope,classes', [('parts', (8, 12)), ('all', (8, 12)), ('interleaved', (8, 12))])
 def test_shuffled_vertex_order_model(smpl_model_np, j_h36m_np, scope, classes):
     """A body whose FILE order of the vertices is a seeded shuffle (inside body parts: what a real mesh file looks like;
-    'all': no locality at all) still runs the joint-sparse kernels -- class <= 12, for 'all' only through the library's
+    'all': no locality at all; 'interleaved': coherent tiles whose neighbours share no joints -- the backward kernel's 16-joint
+    segments then change at almost every tile and its slab flush runs dozens of times per workgroup) still runs the joint-sparse kernels -- class <= 12, for 'all' only through the library's
     internal joint-sorted order -- and every vertex-indexed quantity comes back in FILE order: joints, vertices, dJ and a
     3-iteration refinement against the oracle on the shuffled model."""
     sm, eng_mod = _mod('smpl_model'), _mod('engine')
