@@ -388,6 +388,47 @@ def test_shuffled_vertex_order_model(smpl_model_np, j_h36m_np, scope, classes):
     assert (bd.cpu() - b_).abs().max().item() < 3e-4
 
 
+def test_backward_flush_path_at_4096(smpl_model_np, j_h36m_np):
+    """At the benchmarked batch a workgroup of the backward kernel walks 27 tiles; on the 'interleaved' model its 16-joint
+    segment changes several times on the way and every joint's slab rows are stored once and then ADDED to (read-modify-write
+    by whichever lane holds the joint in the new window).  d/d(pose, betas) of a random joint adjoint: all 4096 poses equal the
+    dense kernels on the same model (no windows, no flush) to fp32 regrouping, and a strided subset equals the oracle's autograd."""
+    import os
+    if any(k in os.environ for k in ('JRR_DENSE_SKINNING', 'JRR_SKIN_JOINTS', 'JRR_VERTEX_ORDER')):
+        pytest.skip('the suite itself runs under a forced skinning variant')
+    sm, eng_mod = _mod('smpl_model'), _mod('engine')
+    model, perm = sm.shuffled_vertex_order(smpl_model_np, seed=5, scope='interleaved')
+    Jh = np.ascontiguousarray(j_h36m_np[:, perm])
+    B = 4096
+    batch = sm.synthetic_batch(model, Jh, B, seed=93)
+    xd, bd = T(batch['pose6d']).to(DEV).contiguous(), T(batch['betas']).to(DEV).contiguous()
+    dj = torch.randn(B, 17, 3, generator=torch.Generator().manual_seed(9))
+    outs = {}
+    for name, env in (('sparse', {}), ('dense', {'JRR_DENSE_SKINNING': '1'})):
+        os.environ.update(env)
+        try:
+            dm = eng_mod.DeviceModel(model, DEV)
+        finally:
+            for k in env:
+                del os.environ[k]
+        eng = eng_mod.RefineEngine(dm, B, flags=0)
+        assert (eng.info['joint_sparse'] > 0) == (name == 'sparse')
+        eng.set_j_regressor(T(Jh))
+        eng.find_joints_forward(bd, x6d=xd)
+        dx, db, _ = eng.find_joints_backward(bd, dj.to(DEV).contiguous(), x6d=xd)
+        outs[name] = (dx.cpu(), db.cpu())
+    for a, c in zip(outs['sparse'], outs['dense']):
+        assert (a - c).abs().max().item() <= 2e-5 * c.abs().max().item(), (a - c).abs().max().item()
+    sub = slice(0, B, 128)
+    xs = T(batch['pose6d'])[sub].clone().requires_grad_(True)
+    bs = T(batch['betas'])[sub].clone().requires_grad_(True)
+    R = oracle.rot6d_to_rotmat(xs.reshape(-1, 6)).view(-1, 24, 3, 3)
+    j = oracle.find_joints(oracle.OracleSMPL(model), bs, R[:, :1], R[:, 1:], T(Jh))
+    (j * dj[sub]).sum().backward()
+    assert ((outs['sparse'][0][sub] - xs.grad).abs().max() / xs.grad.abs().max()).item() < 5e-4
+    assert ((outs['sparse'][1][sub] - bs.grad).abs().max() / bs.grad.abs().max()).item() < 5e-4
+
+
 def test_discriminator_module_backward_twice_and_restore(smpl_model_np):
     """backward twice through one graph (retain_graph) must give the same dx and dparams both times (the
     weight-gradient pass leaves ROW-MAJOR activations behind, the input-gradient pass reads quads), and a restore of
