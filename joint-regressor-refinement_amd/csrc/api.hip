@@ -290,6 +290,7 @@ struct jrr_engine {
   // entry point that overwrites FT / AT / VPb / VTb or may run between the two calls (drop_cached_forward)
   bool fwd_cached; const float *fc_x6d, *fc_betas;
   float* dJraw;                                      // (17,6890) gradient scratch of the in-call J steps (jrr_refine_run_j_steps)
+  JSupport jsup; bool have_jsup;                     // support lists of the normalised regressor (KEEP_VERTS engines; lbs.hip)
   float* hist; int hist_cap, hist_every, hist_n; long long hist_iter;   // loss history (jrr_engine_set_loss_history)
   float *VTb;       // [3][VP][BP] vertices / transposed vertex adjoint (KEEP_VERTS or SILHOUETTE)
   float *dVTb, *dJnp, *dJn;   // transposed external vertex adjoint [3][VP][BP]; J-gradient partial slabs [3*nsplitJ][32][VP]
@@ -435,6 +436,10 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->dJnp = c.take((size_t)3 * nsplitJ * 32 * VP);
     t->dJn = c.take((size_t)NH * VP);
     t->dJraw = c.take((size_t)NH * V);
+    t->jsup.flag = (int*)c.take(64);
+    t->jsup.cnt = (int*)c.take(64);
+    t->jsup.col = (int*)c.take((size_t)NH * JSUP_CAP);
+    t->jsup.val = c.take((size_t)NH * JSUP_CAP);
   }
   if (e) {
     e->BP = BP; e->nvc = nvc; e->nvcb = (e->has_model && e->m.kjs && e->m.bwd16) ? nvcb16 : nvcb; e->nsplit = nsplit; e->nsplitJ = nsplitJ;
@@ -466,6 +471,7 @@ extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_
   e->bnorm = batch_norm > 0 ? batch_norm : batch;
   e->flags = flags;
   carve(e, ws, batch, flags);
+  e->have_jsup = (flags & JRR_FLAG_KEEP_VERTS) != 0;
   *out = e;
   return JRR_OK;
 }
@@ -586,9 +592,13 @@ extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const
   JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   e->have_mask = mask != nullptr;
-  if (!e->tab_static) { launch_bwd_tab_static(e->m, e->Jn_iv, s); e->tab_static = true; }   // model-only: once per engine
+  if (!e->tab_static) {                                                                     // model-only: once per engine
+    launch_bwd_tab_static(e->m, e->Jn_iv, s); e->tab_static = true;
+    // the support-restricted J step writes dJn on the support only: everything else must be finite (it meets Jn = 0)
+    if (e->have_jsup) JRR_HIP(hipMemsetAsync(e->dJn, 0, (size_t)NH * VP * sizeof(float), s));
+  }
   launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, e->Jn_q, e->m.p2v, s,
-                        (e->m.kjs && e->m.bwd16) ? 1 : 0);
+                        (e->m.kjs && e->m.bwd16) ? 1 : 0, e->m.v2p, e->have_jsup ? &e->jsup : nullptr);
   e->fold_valid = false;
   if (e->folded) {
     int rc = fold_rebuild(e, s);
@@ -1107,9 +1117,12 @@ extern "C" int jrr_silhouette_loss_grad(jrr_engine_t* e, const float* x6d, const
 // joints^T partials from the STORED vertices: JPv[split][r][32][BP] = sum_{v in split} Jn[i,v] verts_r[v,b]
 // (both operands in vertex quads: Jn_q [VP/4][32][4], VTb [3][VP/4][BP][4]; rows i >= 17 of Jn_q are zero)
 static int joints_from_stored_verts(jrr_engine* e, hipStream_t s) {
-  // slab layout [split][plane][32][BP], what k_joints_loss reads with jp_rows = 32
+  // slab layout [split][plane][32][BP], what k_joints_loss reads with jp_rows = 32.  The support-restricted kernel writes ONE
+  // complete slab (slab 0) when the regressor's support lists fit (device flag jsup.flag, which k_joints_loss also reads to
+  // sum one slab only); otherwise it returns at once and the dense product below does the work -- and vice versa.
+  if (e->have_jsup) launch_rejoints_sparse(e->jsup, e->VTb, e->dFTp, e->BP, s);
   return launch_gemm_q32(e->Jn_q, 32, 0, e->VTb, e->BP, (size_t)VP * e->BP, e->dFTp, e->BP, (size_t)3 * 32 * e->BP,
-                         (size_t)32 * e->BP, e->BP, VP, 3, e->nsplit, s);
+                         (size_t)32 * e->BP, e->BP, VP, 3, e->nsplit, s, e->have_jsup ? e->jsup.flag : nullptr);
 }
 
 // =============================================================================================
@@ -1217,7 +1230,8 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     prof_mark(e, 2, s);
     ReprojLaunch rl{e->gt_j2d, e->cam, e->gcam, e->sq2d, (float)(2.0 * 0.01 / ((double)e->bnorm * 34.0))};   // weight 1/100
     launch_joints_loss(reuse ? e->dFTp : folded ? e->Jsum : e->JP, reuse ? e->nsplit : folded ? 1 : e->nvc, gt_mm, nullptr, jscale,
-                       e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s, e->gt_j2d ? &rl : nullptr, reuse ? 32 : NH);
+                       e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s, e->gt_j2d ? &rl : nullptr, reuse ? 32 : NH,
+                       (reuse && e->have_jsup) ? e->jsup.flag : nullptr);
     prof_mark(e, 2, s);
     int rc = 0;
     const bool sil = e->sil_mask != nullptr && !folded;
@@ -1316,7 +1330,8 @@ extern "C" int jrr_refine_run_j_steps(jrr_engine_t* e, float* x6d, float* betas,
 // J step (scripts/optimize.py:300-312)
 // =============================================================================================
 // dJn[i][v] = sum over the (plane, pose-split) slabs P[s][i][v]
-__global__ void k_djn_reduce(const float* __restrict__ P, int nslab, float* __restrict__ dJn) {
+__global__ void k_djn_reduce(const float* __restrict__ P, int nslab, float* __restrict__ dJn, const int* __restrict__ skip) {
+  if (skip && *skip) return;                   // the support-restricted product wrote dJn itself
   int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= NH * VP) return;
   int i = idx / VP, v = idx % VP;
@@ -1328,9 +1343,12 @@ __global__ void k_djn_reduce(const float* __restrict__ P, int nslab, float* __re
 // dJ from the joint adjoint dJT [3][18][BP] (already in the engine) and the stored vertices VTb [3][VP][BP]
 static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s) {
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("dJ requires an engine created with JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
-  int rc = launch_jgrad_q(e->dJT, e->VTb, e->dJnp, e->BP, e->nsplitJ, s);
+  // over the regressor's support when its lists fit (lbs.hip, "J step over the regressor's SUPPORT"), else the dense product
+  const int* sflag = e->have_jsup ? e->jsup.flag : nullptr;
+  if (e->have_jsup) launch_jgrad_sparse(e->jsup, e->dJT, e->VTb, e->dJn, e->BP, s);
+  int rc = launch_jgrad_q(e->dJT, e->VTb, e->dJnp, e->BP, e->nsplitJ, s, sflag);
   if (rc) return rc;
-  hipLaunchKernelGGL(k_djn_reduce, dim3((NH * VP + 255) / 256), dim3(256), 0, s, e->dJnp, 3 * e->nsplitJ, e->dJn);
+  hipLaunchKernelGGL(k_djn_reduce, dim3((NH * VP + 255) / 256), dim3(256), 0, s, e->dJnp, 3 * e->nsplitJ, e->dJn, sflag);
   launch_jreg_bwd(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->Jn, e->rowsum, e->dJn, VP, dJ, e->m.v2p, s);
   CHECK_LAUNCH();
   return JRR_OK;

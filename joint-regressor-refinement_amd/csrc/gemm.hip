@@ -199,8 +199,10 @@ struct Q32Args {
   const float* Bm; int ldB; size_t planeB;    // B quads [K/4][ldB][4]
   float* Out; int ldo; size_t ks_stride, plane_stride;   // tile (k-split ks, plane c) at Out + ks*ks_stride + c*plane_stride
   int K, ksplit;
+  const int* skip;                            // nullable: *skip != 0 -> nothing to do
 };
 __global__ __launch_bounds__(256) void k_gemm_q32(Q32Args g) {
+  if (g.skip && *g.skip) return;
   // 16-deep chunks (4 k-quads): A 2 KB + B 8 KB per slot, 4-deep ring (three chunks in flight: the product is a
   // stream over the 340 MB vertex buffer, 32 MFMA-rows of work per 128-byte column -- bytes in flight are what counts)
   constexpr int SA = 4 * 32 * 4, SB = 4 * 128 * 4, SLOT = SA + SB, RING = 4;
@@ -265,12 +267,13 @@ __global__ __launch_bounds__(256) void k_gemm_q32(Q32Args g) {
 }
 
 int launch_gemm_q32(const float* A, int ldA, size_t planeA, const float* Bm, int ldB, size_t planeB, float* Out, int ldo,
-                    size_t ks_stride, size_t plane_stride, int N, int K, int nplanes, int ksplit, hipStream_t s) {
+                    size_t ks_stride, size_t plane_stride, int N, int K, int nplanes, int ksplit, hipStream_t s,
+                    const int* skip_flag) {
   if (N % 128 != 0 || K % 16 != 0 || ldA < 32 || ldB < N) {
     jrr_set_error("gemm_q32: unsupported shape N=%d K=%d ldA=%d ldB=%d", N, K, ldA, ldB);
     return JRR_ERR_ARG;
   }
-  Q32Args g{A, ldA, planeA, Bm, ldB, planeB, Out, ldo, ks_stride, plane_stride, K, ksplit};
+  Q32Args g{A, ldA, planeA, Bm, ldB, planeB, Out, ldo, ks_stride, plane_stride, K, ksplit, skip_flag};
   hipLaunchKernelGGL(k_gemm_q32, dim3(N / 128, nplanes * ksplit), dim3(256), 0, s, g);
   return 0;
 }
@@ -280,9 +283,11 @@ struct JgArgs {
   const float* VTq;    // [3][VP/4][BP][4]
   float* Out;          // [3 * ksplit][32][VP] partial slabs
   int BP, ksplit;
+  const int* skip;     // nullable: *skip != 0 -> nothing to do
 };
 constexpr int JG_SB = 32 * 32 * 4, JG_SA = 8 * 32 * 4, JG_SLOT = JG_SB + JG_SA, JG_RING = 4;   // 16 KB + 4 KB per slot
 __global__ __launch_bounds__(256, 2) void k_jgrad_q(JgArgs g) {
+  if (g.skip && *g.skip) return;
   __shared__ __attribute__((aligned(16))) float lds[JG_RING * JG_SLOT];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
@@ -374,9 +379,9 @@ __global__ __launch_bounds__(256, 2) void k_jgrad_q(JgArgs g) {
     *reinterpret_cast<f32x4*>(out + (size_t)acc_row(wave * 4 + qq, half) * VP + (size_t)(vq0 + l31) * 4) = o[qq];
 }
 
-int launch_jgrad_q(const float* dJT, const float* VTq, float* Out, int BP, int ksplit, hipStream_t s) {
+int launch_jgrad_q(const float* dJT, const float* VTq, float* Out, int BP, int ksplit, hipStream_t s, const int* skip_flag) {
   if (BP % 32 != 0 || ksplit < 1 || ksplit > BP / 32) { jrr_set_error("jgrad_q: unsupported shape BP=%d ksplit=%d", BP, ksplit); return JRR_ERR_ARG; }
-  JgArgs g{dJT, VTq, Out, BP, ksplit};
+  JgArgs g{dJT, VTq, Out, BP, ksplit, skip_flag};
   hipLaunchKernelGGL(k_jgrad_q, dim3(VP / 128, 3 * ksplit), dim3(256), 0, s, g);
   return 0;
 }

@@ -65,7 +65,7 @@ int launch_dconv_bwd_reduce(const float* img, const float* x6d, const float* dH2
                             hipStream_t s);
 int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float* djoints_in, float scale,
                        float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s,
-                       const ReprojLaunch* r = nullptr, int jp_rows = NH);
+                       const ReprojLaunch* r = nullptr, int jp_rows = NH, const int* one_slab_flag = nullptr);
 int launch_step_inc(int32_t* step, hipStream_t s);
 int launch_project_joints(const float* joints, const float* cam, float* out, int B, hipStream_t s);
 int launch_camera_fit(const float* joints, const float* gt_j2d, float* cam, float scale2d, int nsteps, float lr, float* sq2d,
@@ -86,8 +86,18 @@ int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s);
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s);
 int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s, const int* p2v = nullptr);
+// Support of the normalised regressor (the J step's products only need it: ReLU' makes dJ exactly zero elsewhere).
+// JSupport lives in the engine workspace: cnt[i] positive entries of row i, their internal vertex rows / weights in ascending
+// vertex order, flag[0] = 1 when every row has at most JSUP_CAP of them (else the dense products run).
+constexpr int JSUP_CAP = 128;
+struct JSupport { int* flag; int* cnt; int* col; float* val; };     // flag[1], cnt[32], col[17][JSUP_CAP], val[17][JSUP_CAP]
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv, float* Jn_q,
-                          const int* p2v, hipStream_t s, int r16 = 0);
+                          const int* p2v, hipStream_t s, int r16 = 0, const int* v2p = nullptr, const JSupport* sup = nullptr);
+// dJn[i][row] = sum_{b, r} dj_r[i][b] verts_r[row][b] for the support entries only (sup.flag != 0; the other entries of dJn keep
+// whatever finite value they hold: they meet Jn = 0 and relu' = 0 in k_jreg_bwd)
+int launch_jgrad_sparse(const JSupport& sup, const float* dJT, const float* VTq, float* dJn, int BP, hipStream_t s);
+// joints of the stored vertices with the current regressor, one slab [3][32][BP] (rows i < 17), support entries only
+int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, int BP, hipStream_t s);
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
                     float* dJ, const int* v2p, hipStream_t s);
 
@@ -100,9 +110,11 @@ int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 // blend-basis adjoint dF^T[split][224][BP] = sum_{c, v in split} D_c[v][.] dvp_c[v][.], both operands in vertex quads
 int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s);
+// skip_flag (device, nullable): the launch returns at once when *skip_flag != 0 (the support-restricted kernels did the work)
 int launch_gemm_q32(const float* A, int ldA, size_t planeA, const float* Bm, int ldB, size_t planeB, float* Out, int ldo,
-                    size_t ks_stride, size_t plane_stride, int N, int K, int nplanes, int ksplit, hipStream_t s);
-int launch_jgrad_q(const float* dJT, const float* VTq, float* Out, int BP, int ksplit, hipStream_t s);
+                    size_t ks_stride, size_t plane_stride, int N, int K, int nplanes, int ksplit, hipStream_t s,
+                    const int* skip_flag = nullptr);
+int launch_jgrad_q(const float* dJT, const float* VTq, float* Out, int BP, int ksplit, hipStream_t s, const int* skip_flag = nullptr);
 
 // sil.hip
 int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s);

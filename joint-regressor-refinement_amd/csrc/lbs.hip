@@ -1080,9 +1080,10 @@ __global__ void k_dverts_transpose(const float* __restrict__ dverts, int ldv, fl
 // ------------------------------------------------------------------------------------------
 constexpr int JREG_THREADS = 1024;     // one block per regressor row: 6890 columns, 7 per thread
 __global__ __launch_bounds__(JREG_THREADS) void k_jreg_rowsum(const float* __restrict__ J, const float* __restrict__ mask,
-                                                               float* __restrict__ rowsum) {
+                                                               float* __restrict__ rowsum, int* __restrict__ sup_flag) {
   __shared__ float red[JREG_THREADS];
   const int i = blockIdx.x;
+  if (sup_flag && i == 0 && threadIdx.x == 0) *sup_flag = 1;      // k_jreg_support (two launches later) may clear it
   float acc = 0.f;
   for (int v = threadIdx.x; v < V; v += blockDim.x) {
     float x = J[(size_t)i * V + v];
@@ -1118,6 +1119,92 @@ __global__ void k_jreg_tiles(const float* __restrict__ J, const float* __restric
   // backward operand record: the role kernel's [i][32 v], or R16's JN [blk][s = i / 4][g = i % 4][m] (k_lbs_bwd16)
   if (r16) { if (i < 20) Jn_iv[(size_t)vt * TB_FLOATS + R16_JN + ((vv >> 4) * 5 + (i >> 2)) * 64 + (i & 3) * 16 + (vv & 15)] = val; }
   else if (i < NHP) Jn_iv[(size_t)vt * TB_FLOATS + TB_JN + i * 32 + vv] = val;
+}
+
+// ------------------------------------------------------------------------------------------
+// J step over the regressor's SUPPORT (scripts/optimize.py:300-312).  dJ_raw = mask relu'(J mask) (dJn - <dJn, Jn>) / rowsum is
+// exactly zero wherever J mask <= 0, and <dJn, Jn> only meets dJn where Jn > 0: the J step needs dJn -- a (17 x 6890) x B product
+// over the 340 MB of stored vertices -- on the positive entries of J only (62 of 117 130 for the shipped checkpoint, and Adam
+// never re-activates an entry: its gradient is zero while it is <= 0).  The same holds for the re-regression of the joints with
+// the stepped regressor.  Both become gathers of a few vertex rows; rows with more than JSUP_CAP positive entries switch the
+// whole step back to the dense products (flag = 0, decided on the device: no host synchronisation).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(JREG_THREADS) void k_jreg_support(const float* __restrict__ Jn, const int* __restrict__ v2p, JSupport sup) {
+  __shared__ int wcount[JREG_THREADS / 64];
+  __shared__ int base;
+  const int i = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (threadIdx.x == 0) base = 0;
+  __syncthreads();
+  for (int v0 = 0; v0 < V; v0 += JREG_THREADS) {            // ascending vertex order: deterministic lists
+    const int v = v0 + threadIdx.x;
+    const float w = (v < V) ? Jn[(size_t)i * V + v] : 0.f;
+    const bool on = w > 0.f;
+    const unsigned long long bal = __ballot(on);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int q = 0; q < wave; ++q) off += wcount[q];
+    off += __popcll(bal & ((1ull << lane) - 1ull));
+    if (on && off < JSUP_CAP) { sup.col[i * JSUP_CAP + off] = v2p ? v2p[v] : v; sup.val[i * JSUP_CAP + off] = w; }
+    __syncthreads();
+    if (threadIdx.x == 0) { int t = 0; for (int q = 0; q < JREG_THREADS / 64; ++q) t += wcount[q]; base += t; }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    sup.cnt[i] = base < JSUP_CAP ? base : JSUP_CAP;
+    if (base > JSUP_CAP) atomicMin(sup.flag, 0);            // (flag is set to 1 by k_jreg_rowsum, the launch before)
+  }
+}
+
+// one workgroup per (row i, entry slot): dJn[i][row] = sum_b sum_r dj_r[i][b] verts_r[row][b]; fixed-order sums
+__global__ __launch_bounds__(256) void k_jgrad_sparse(JSupport sup, const float* __restrict__ dJT, const float* __restrict__ VTq,
+                                                      float* __restrict__ dJn, int BP) {
+  if (*sup.flag == 0) return;
+  __shared__ float red[256];
+  const int i = blockIdx.x;
+  for (int e = blockIdx.y; e < sup.cnt[i]; e += gridDim.y) {
+    const int row = sup.col[i * JSUP_CAP + e];
+    float acc = 0.f;
+    for (int b = threadIdx.x; b < BP; b += 256) {          // padded poses carry dj = 0
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+        acc = fmaf(dJT[(size_t)(r * NHP + i) * BP + b], VTq[(((size_t)r * (VP / 4) + (row >> 2)) * BP + b) * 4 + (row & 3)], acc);
+    }
+    red[threadIdx.x] = acc;
+    __syncthreads();
+    for (int w = 128; w > 0; w >>= 1) {
+      if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) dJn[(size_t)i * VP + row] = red[0];
+    __syncthreads();
+  }
+}
+
+// joints^T slab [3][32][BP] (rows i < 17) of the stored vertices with the current regressor: one thread per (pose, row i)
+__global__ __launch_bounds__(256) void k_rejoints_sparse(JSupport sup, const float* __restrict__ VTq, float* __restrict__ out, int BP) {
+  if (*sup.flag == 0) return;
+  const int b = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+  if (b >= BP) return;
+  float acc[3] = {0.f, 0.f, 0.f};
+  const int n = sup.cnt[i];
+  for (int e = 0; e < n; ++e) {
+    const int row = sup.col[i * JSUP_CAP + e];
+    const float w = sup.val[i * JSUP_CAP + e];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) acc[r] = fmaf(w, VTq[(((size_t)r * (VP / 4) + (row >> 2)) * BP + b) * 4 + (row & 3)], acc[r]);
+  }
+#pragma unroll
+  for (int r = 0; r < 3; ++r) out[(size_t)(r * 32 + i) * BP + b] = acc[r];
+}
+
+int launch_jgrad_sparse(const JSupport& sup, const float* dJT, const float* VTq, float* dJn, int BP, hipStream_t s) {
+  hipLaunchKernelGGL(k_jgrad_sparse, dim3(NH, 16), dim3(256), 0, s, sup, dJT, VTq, dJn, BP);
+  return 0;
+}
+int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, int BP, hipStream_t s) {
+  hipLaunchKernelGGL(k_rejoints_sparse, dim3(BP / 256 > 0 ? BP / 256 : 1, NH), dim3(256), 0, s, sup, VTq, out, BP);
+  return 0;
 }
 
 // dJ_raw = mask * relu'(J*mask) * (dJn - sum_v(dJn*Jn)) / rowsum      (dJn given as [17][ldn])
@@ -1220,9 +1307,10 @@ int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int
 }
 
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv,
-                          float* Jn_q, const int* p2v, hipStream_t s, int r16) {
-  hipLaunchKernelGGL(k_jreg_rowsum, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, rowsum);
+                          float* Jn_q, const int* p2v, hipStream_t s, int r16, const int* v2p, const JSupport* sup) {
+  hipLaunchKernelGGL(k_jreg_rowsum, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, rowsum, sup ? sup->flag : nullptr);
   hipLaunchKernelGGL(k_jreg_tiles, dim3(VT * 1024 / 256), dim3(256), 0, s, J, mask, rowsum, Jn, Jn_vi, Jn_iv, Jn_q, p2v, r16);
+  if (sup) hipLaunchKernelGGL(k_jreg_support, dim3(NH), dim3(JREG_THREADS), 0, s, Jn, v2p, *sup);
   return 0;
 }
 

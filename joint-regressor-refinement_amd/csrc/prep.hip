@@ -409,8 +409,10 @@ __global__ __launch_bounds__(PP * NH) void k_joints_loss(const float* __restrict
                                                          const float* __restrict__ gt_mm,
                                                          const float* __restrict__ djoints_in, float scale,
                                                          float* __restrict__ joints_out, float* __restrict__ sqerr,
-                                                         float* __restrict__ dJT, Reproj rp, int B, int BP) {
+                                                         float* __restrict__ dJT, Reproj rp, int B, int BP,
+                                                         const int* __restrict__ one_slab_flag) {
   // one thread per (pose, H36M joint): block = 32 poses x 17 joints, lanes over poses
+  if (one_slab_flag && *one_slab_flag) nvc = 1;       // the support-restricted re-regression wrote ONE complete slab
   __shared__ float red[NH][8][PP];   // per-joint partials: 0..2 g, 3 err, 4 e2d, 5..7 gcam
   __shared__ float pel[3][PP];
   const int bl = threadIdx.x & (PP - 1), i = threadIdx.x / PP;
@@ -954,12 +956,12 @@ int launch_prep_fwd_dconv(const Model& m, const float* x6d, const float* betas, 
 
 int launch_joints_loss(const float* JP, int nvc, const float* gt_mm, const float* djoints_in, float scale,
                        float* joints_out, float* sqerr, float* dJT, int B, int BP, hipStream_t s, const ReprojLaunch* r,
-                       int jp_rows) {
+                       int jp_rows, const int* one_slab_flag) {
   Reproj rp;
   rp.gt_j2d = r ? r->gt_j2d : nullptr; rp.cam = r ? r->cam : nullptr; rp.gcam = r ? r->gcam : nullptr;
   rp.sq2d = r ? r->sq2d : nullptr; rp.scale2d = r ? r->scale2d : 0.f;
   hipLaunchKernelGGL(k_joints_loss, dim3(BP / PP), dim3(PP * NH), 0, s, JP, nvc, jp_rows, gt_mm, djoints_in, scale, joints_out,
-                     sqerr, dJT, rp, B, BP);
+                     sqerr, dJT, rp, B, BP, one_slab_flag);
   return 0;
 }
 

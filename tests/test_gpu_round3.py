@@ -429,6 +429,46 @@ def test_backward_flush_path_at_4096(smpl_model_np, j_h36m_np):
     assert ((outs['sparse'][1][sub] - bs.grad).abs().max() / bs.grad.abs().max()).item() < 5e-4
 
 
+@pytest.mark.parametrize('npos', [128, 129])
+def test_j_step_support_lists_at_their_capacity(smpl_hip, smpl_model_np, j_h36m_np, npos):
+    """The J step's two products run over the regressor's support (dJ is exactly zero where J <= 0) while every row has at most
+    128 positive entries, and switch to the dense products on the device otherwise: a row with exactly 128 / 129 positives,
+    dJ and the re-regressed joints after a J step against the oracle either way."""
+    eng_mod = _mod('engine')
+    B = 96
+    rng = np.random.RandomState(npos)
+    Jnp = j_h36m_np.copy()
+    cols = rng.choice(6890, size=npos, replace=False)
+    Jnp[5, :] = 0.0
+    Jnp[5, cols] = rng.uniform(0.05, 1.0, size=npos).astype(np.float32)
+    Jnp[7, rng.choice(6890, size=40, replace=False)] = -0.3          # negatives: never in a list, never a gradient
+    batch = _mod('smpl_model').synthetic_batch(smpl_model_np, Jnp, B, seed=400 + npos)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    _, dJ_ref, _ = oracle.j_regressor_loss_and_grad(smpl, T(Jnp), x6[:, :1], x6[:, 1:], betas, gt_c)
+    eng = eng_mod.RefineEngine(smpl_hip.device_model, B, flags=eng_mod.FLAG_KEEP_VERTS)
+    Jd = T(Jnp).to(DEV).clone()
+    eng.set_j_regressor(Jd)
+    xd, bd, gd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous(), gt_c.to(DEV).contiguous()
+    dJ = eng.j_regressor_grad(xd, bd, gd)
+    assert ((dJ.cpu() - dJ_ref).abs().max() / dJ_ref.abs().max()).item() < 5e-4
+    assert torch.equal(dJ.cpu() != 0, dJ_ref != 0)
+    # step the regressor, then ONE inner iteration that re-regresses the joints from the J step's vertices
+    Jm, Jv, Js = torch.zeros_like(Jd), torch.zeros_like(Jd), torch.zeros(1, dtype=torch.int32, device=DEV)
+    eng.j_step_apply(Jd, dJ, Jm, Jv, Js, 1e-2)
+    m, v, step = _fresh_state(B)
+    sq = torch.zeros(B, device=DEV)
+    x1, b1 = xd.clone(), bd.clone()
+    # (the reuse claim is about buffers: run the iteration on the J step's own buffers)
+    eng.j_regressor_grad(xd, bd, gd)
+    eng.refine_run(xd, bd, gd, m, v, step, 1e-2, 1, sqerr=sq, after_j_step=True)
+    R = oracle.rot6d_to_rotmat(x1.cpu().reshape(-1, 6)).view(B, 24, 3, 3)
+    j_new = oracle.find_joints(smpl, b1.cpu(), R[:, :1], R[:, 1:], Jd.cpu())
+    want = ((oracle.move_pelvis(j_new) - gt_c / 1000) ** 2).sum((1, 2))
+    np.testing.assert_allclose(sq.cpu().numpy(), want.numpy(), rtol=2e-4, atol=1e-9)
+
+
 def test_discriminator_module_backward_twice_and_restore(smpl_model_np):
     """backward twice through one graph (retain_graph) must give the same dx and dparams both times (the
     weight-gradient pass leaves ROW-MAJOR activations behind, the input-gradient pass reads quads), and a restore of
