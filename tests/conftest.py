@@ -63,6 +63,11 @@ def pytest_collection_finish(session):
         'bench_mismatch': _torchrun(2, 29543, [os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
                                                '--batch', '128', '--backend', 'gloo', '--single_device', '--no_cpu_baseline']),
     }
+    if torch.cuda.device_count() >= 2:
+        # a box with two or more GPUs: the SAME runs with one rank per GPU over RCCL (backend nccl), no --single_device
+        runs['w2n'] = _torchrun(2, 29545, [worker, os.path.join(tmp, 'w2n')] + DP_FLAGS[:-2] + ['--dist_backend', 'nccl'])
+        runs['bench2n'] = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--batch', '256',
+                           '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5', '--min_timed_ms', '50']
     DP_RUNS['dir'] = tmp
     for name, cmd in runs.items():
         try:

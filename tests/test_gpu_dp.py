@@ -112,3 +112,31 @@ def test_bench_rejects_a_world_that_contradicts_gpus():
     r = conftest.DP_RUNS.get('bench_mismatch')
     assert r is not None and r['rc'] != 0
     assert '--gpus 1 but the launcher started 2' in (r['out'] + r['err'])
+
+
+def _multi_gpu():
+    import torch
+    return torch.cuda.device_count() >= 2          # (counting devices does not initialise the GPU)
+
+
+@pytest.mark.skipif(not _multi_gpu(), reason='needs two GPUs: one rank per GPU over RCCL (the 1-GPU boxes run the gloo stand-in above)')
+def test_two_rank_driver_over_rccl_equals_single_process():
+    """one rank per GPU, backend nccl (= RCCL over xGMI): the flat all-reduce of the outer step, the in-loop J step"""
+    _run('w1'); _run('w2n')
+    (one,) = _load('w1', 1)
+    two = _load('w2n', 2)
+    x2 = np.concatenate([two[0]['x6d'], two[1]['x6d']])
+    assert np.abs(x2 - one['x6d']).max() < 2e-4
+    for k in ('J', 'disc', 'sdisc'):
+        assert np.array_equal(two[0][k], two[1][k]), k
+        assert np.abs(two[0][k] - one[k]).max() < 5e-5, k
+
+
+@pytest.mark.skipif(not _multi_gpu(), reason='needs two GPUs')
+def test_bench_two_ranks_over_rccl():
+    r = _run('bench2n')
+    j = json.loads([l for l in r['out'].splitlines() if l.startswith('{')][-1])
+    c = j['collective']
+    assert j['n_gpus'] == 2 and c['world'] == 2 and c['backend'].startswith('nccl')
+    assert sorted(rk[1] for rk in c['ranks_seen']) == [0, 1]            # two different devices
+    assert c['allreduce_check'] == 1.0 and c['single_device_debug'] is False
