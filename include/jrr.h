@@ -261,7 +261,9 @@ int jrr_refine_aux_losses(jrr_engine_t* e, float* pose_disc_sq_dev, float* shape
 /* J step, scripts/optimize.py:300-312: gradient of mean((move_pelvis(joints)-gt/1000)^2) w.r.t.
  * the raw J_regressor for the current (detached) poses; dJ_dev (17,6890).  sqerr_dev (B, nullable): per-pose squared
  * joint error; joints_dev (B,17,3, nullable): the joints of this forward, i.e. of the regressor BEFORE its step (what
- * utils.evaluate reads at scripts/optimize.py:314-315).                                                        */
+ * utils.evaluate reads at scripts/optimize.py:314-315).  The product behind it runs over the POSITIVE entries of
+ * J*mask only (dJ is exactly zero elsewhere: relu'); rows with more than 128 of them switch to the dense product by
+ * themselves (device-side decision, no synchronisation).                                                         */
 int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev,
                          const float* gt_centred_mm_dev, float* dJ_dev, float* sqerr_dev, float* joints_dev, void* stream);
 
@@ -326,7 +328,9 @@ int jrr_engine_profile_read(jrr_engine_t* e, float* ms_host, int32_t* counts_hos
  * of the last launch inside jrr_refine_run: out[0] = shader clocks the wave was resident (s_memtime),
  * out[1] = MFMA instructions it issued, out[2] = waves resident per SIMD, out[3] = issue clocks per MFMA,
  * out[4] = the same interval in ns (s_memrealtime).  MFMA-pipe occupancy = out[1]*out[2]*out[3]/out[0];
- * sustained shader clock = out[0]/out[4] GHz.  out_host holds 5 values.  Synchronous (device -> host copy). */
+ * sustained shader clock = out[0]/out[4] GHz.  out_host holds 5 values.  Synchronous (device -> host copy).
+ * (48 of the 423 instructions per tile of the joint-sparse kernel are the 33-clock four-block form v_mfma_f32_16x16x1_4b_f32:
+ * the occupancy formula, which prices every instruction at out[3] = 64 clocks, reads ~5 % high for it.)               */
 int jrr_engine_probe_read(jrr_engine_t* e, int64_t* out_host);
 
 #ifdef __cplusplus
