@@ -84,7 +84,9 @@ int jrr_model_set_faces(jrr_model_t* m, const int32_t* faces_host, int n_faces);
 /* ---- engine -------------------------------------------------------------------------------
  * `batch` = poses on this device; `batch_norm` = divisor batch of the MSE means
  * (== batch single-GPU; == global batch under data parallelism so that a sharded run equals
- * the single-process run).  The caller owns `workspace_dev`.
+ * the single-process run).  The caller owns `workspace_dev`: jrr_engine_workspace_bytes bytes,
+ * 256-byte aligned and ZERO-FILLED at creation (padding rows / columns of several sections are operands of the matrix
+ * kernels and are never written).
  * `model` may be NULL for an engine that serves the discriminators only (flags within
  * JRR_FLAG_POSE_DISC | JRR_FLAG_SHAPE_DISC): Discriminator / Shape_Discriminator modules need no body model. */
 size_t jrr_engine_workspace_bytes(int batch, int flags);
