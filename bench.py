@@ -48,11 +48,33 @@ FLOP_LBS_BWD_PER_POSE = 2 * 17 * 6890 * 3 + 2 * 6890 * 24 * 9 + 2 * 6890 * 9 + 2
 FLOP_BLEND_ADJ_PER_POSE = 2 * 217 * 20670                                                             # dF = D . dvp
 FLOP_DISC_PER_POSE = 2 * 2 * (24 * (192 + 1024) + 786432 + 1048576 + 1024 + 768)                     # fwd + input-grad
 # Joint-sparse skinning (engine info `joint_sparse`): every SMPL vertex has <= 4 skinning influences and a
-# tile of 32 consecutive vertices few joints in total, so the skinning products run over 8 (or 12) joints per tile instead of 24.  The
-# roofline counts the FLOP of the formulation that actually runs; the dense-formulation rate is printed beside it (it may
-# exceed the MFMA peak: the skipped multiplications are by structural zeros).
-def flop_lbs_fwd_sparse(kjs): return FLOP_LBS_FWD_PER_POSE - 2 * 6890 * (24 - kjs) * 12
-def flop_lbs_bwd_sparse(kjs): return FLOP_LBS_BWD_PER_POSE - 2 * 6890 * (24 - kjs) * 9
+# tile of 32 consecutive vertices few joints in total, so the skinning products run over the tile's own joint SLOTS instead of 24.
+# ONE rule for every roofline figure of this file: the FLOP of the formulation that actually RUNS -- multiplications the kernels
+# skip (structural zeros) are not counted, padded rows that they do multiply are not counted either (17 joint rows, not 32):
+#   forward   skin blend over `slots` joint slots per tile (8 or 12 per pass; a WIDE tile runs two passes)
+#   backward  T recompute over the tile's K steps of 4 slots; dA over the 16-row joint WINDOWS (not 24 joints) of both
+#             joint-sparse backward kernels (k_lbs_bwd16 and the role kernel under JRR_BWD16=0)
+# The dense-formulation rate is printed beside it (it may exceed the MFMA peak: the skipped multiplications are by zeros).
+def skin_slots(model_info):
+    """(mean forward slots, mean backward slots) per 32-vertex tile from the model's tile histogram (jrr_model_info)"""
+    kjs, hist = model_info['joint_slots'], model_info['tile_joint_histogram']
+    if not kjs:
+        return 24.0, 24.0
+    nt = sum(hist)
+    fwd = sum(n * (kjs if k <= kjs else 2 * kjs) for k, n in enumerate(hist)) / nt
+    bwd = sum(n * 4 * max(kjs // 4, (k + 3) // 4) for k, n in enumerate(hist)) / nt
+    return fwd, bwd
+def flop_lbs_fwd(model_info):
+    return FLOP_LBS_FWD_PER_POSE - 2 * 6890 * 12 * (24 - skin_slots(model_info)[0])
+def flop_lbs_bwd(model_info):
+    if not model_info['joint_slots']:
+        return FLOP_LBS_BWD_PER_POSE
+    return 2 * 17 * 6890 * 3 + 2 * 6890 * skin_slots(model_info)[1] * 9 + 2 * 6890 * 9 + 2 * 6890 * 16 * 12   # dverts, T, dvp, dA (16-row windows)
+# matrix instructions per (32-vertex tile x 32 poses) of the forward kernel, for the pipe-busy figure: 327 blend K-pairs x 3
+# planes + 2 x slots x 3 rows on v_mfma_f32_32x32x2_f32 (64 clocks) and 48 four-block regressor instructions (33 clocks measured)
+def fwd_pipe_clocks_per_tile(model_info):
+    slots = skin_slots(model_info)[0]
+    return (327 + 6 * slots) * 64 + 48 * 33 if model_info['joint_slots'] else 519 * 64
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
 
 
@@ -74,6 +96,7 @@ def parse():
     ap.add_argument('--cpu_seconds', type=float, default=8.0, help='time budget per cpu_baseline variant')
     ap.add_argument('--no_folded', action='store_true', help='skip the separately reported folded-regressor mode')
     ap.add_argument('--no_config5', action='store_true', help='skip the separately reported BASELINE configs[4] block')
+    ap.add_argument('--no_config2', action='store_true', help='skip the separately reported BASELINE configs[1] block (batch 1024, joint loss only)')
     ap.add_argument('--no_skin_variants', action='store_true',
                     help='skip the separately reported 12-joint / dense skinning runs (what a body model with a less coherent vertex order runs)')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL); gloo for debugging')
@@ -234,6 +257,7 @@ def main():
     J_np = sm.default_h36m_regressor()
     batch_np = sm.synthetic_batch(model_np, J_np, B, seed=1000 + rank)
     dmodel = eng_mod.DeviceModel(model_np, dev)
+    jd = importlib.import_module(PKG + '.dist')
     flags = eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0) | (eng_mod.FLAG_SILHOUETTE if use_sil else 0)
     eng = eng_mod.RefineEngine(dmodel, B, batch_norm=B * world, flags=flags)
     J = torch.from_numpy(J_np).to(dev).contiguous()
@@ -269,37 +293,46 @@ def main():
     dJ = torch.zeros_like(J)          # the all-reduce bucket of the J step: allocated once
     after_j = [False]                 # the previous engine call was a J step on (x6d, betas): the next iteration reuses its forward
 
+    # The J step between two segments of the loop when the host drives it (N > 1): local gradient -> ONE all-reduce -> replicated
+    # Adam + re-normalisation.  The payload is the regressor's support (17 x 128 floats = 8 704 B) when it fits the engine's lists,
+    # the dense (17,6890) gradient otherwise (dist.JStepExchange; asked once, here).
+    xch = jd.JStepExchange(eng, dJ, compact=True, reduce=(lambda t: dist.all_reduce(t)) if dist is not None else (lambda t: t))
+
     def j_step():
-        """scripts/optimize.py:300-312 data-parallel: local dJ (normalised by the global batch), ONE RCCL all-reduce,
-        replicated Adam(lr=args.j_reg_lr=1e-2) + re-normalisation (one call); no allocation, nothing read back."""
-        eng.j_regressor_grad(x6d, betas, gt_c, out=dJ)
-        if dist is not None:
-            dist.all_reduce(dJ)
-        eng.j_step_apply(J, dJ, Jm, Jv, Jstep, 1e-2)
+        """scripts/optimize.py:300-312 data-parallel; no allocation, nothing read back"""
+        xch.step(J, Jm, Jv, Jstep, 1e-2, x6d, betas, gt_c)
         after_j[0] = not use_sil
 
-    def run(n, cadence):
-        """n inner iterations with a J step after every `cadence`-th one (counted from the start of the call).
-        One process: ONE C call for everything (jrr_refine_run_j_steps).  N > 1: the all-reduce sits between the two
-        halves of each J step, so the host issues refine_run / j_regressor_grad / all_reduce / j_step_apply per segment."""
-        nj = n // cadence
-        if dist is None:
-            if nj:
-                eng.refine_run_j_steps(x6d, betas, gt_c, m, v, step, 1e-2, nj * cadence, cadence, J, Jm, Jv, Jstep, 1e-2, sqerr=sq,
-                                       after_j_step=after_j[0])
-                after_j[0] = not use_sil
-            if n - nj * cadence:
-                eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, n - nj * cadence, sqerr=sq, after_j_step=after_j[0])
-                after_j[0] = False
-            return nj
-        left = n
+    def run_host_driven(n, cadence, reuse=True):
+        """what N > 1 ranks execute: the host issues refine_run / j_regressor_grad / all_reduce / j_step_apply per J step"""
+        left, nj = n, 0
         while left > 0:
             seg = min(left, cadence)
-            eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, seg, sqerr=sq, after_j_step=after_j[0])
+            eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, seg, sqerr=sq, after_j_step=after_j[0] and reuse)
             after_j[0] = False
             left -= seg
             if seg == cadence:
                 j_step()
+                nj += 1
+        return nj
+
+    def run(n, cadence, reuse=False):
+        """n inner iterations with a J step after every `cadence`-th one (counted from the start of the call).
+        One process: ONE C call for everything (jrr_refine_run_j_steps).  N > 1: the all-reduce sits between the two
+        halves of each J step, so the host drives the segments (run_host_driven).
+        reuse: the iteration after a J step re-regresses its joints from the J step's stored vertices instead of repeating the
+        SMPL forward.  The reference draws a NEW batch after every J step (scripts/optimize.py:144-148, 300-312), so the headline
+        runs with reuse=False; only `cadence1` (a J step after every iteration on the same poses) uses it."""
+        if dist is not None:
+            return run_host_driven(n, cadence, reuse)
+        nj = n // cadence
+        if nj:
+            eng.refine_run_j_steps(x6d, betas, gt_c, m, v, step, 1e-2, nj * cadence, cadence, J, Jm, Jv, Jstep, 1e-2, sqerr=sq,
+                                   after_j_step=after_j[0] and reuse, reuse_forward=reuse)
+            after_j[0] = (not use_sil) and reuse
+        if n - nj * cadence:
+            eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, n - nj * cadence, sqerr=sq, after_j_step=after_j[0] and reuse)
+            after_j[0] = False
         return nj
 
     def barrier():
@@ -341,11 +374,21 @@ def main():
 
     # ---- BASELINE configs[3] "all-reduce on the J_regressor gradient EACH step": J step after every iteration,
     #      timed like `value` (median of >= 5 regions) ----
-    timed_region(a.steps, 1)       # untimed warm-up region
-    c1_regions = [timed_region(a.steps, 1)[0]]
+    run_c1 = lambda n, c: run(n, c, reuse=True)      # noqa: E731
+    timed_region(a.steps, 1, run_c1)       # untimed warm-up region
+    c1_regions = [timed_region(a.steps, 1, run_c1)[0]]
     for _ in range(max(4, min(repeats_for(c1_regions[0]), 10) - 1)):
-        c1_regions.append(timed_region(a.steps, 1)[0])
+        c1_regions.append(timed_region(a.steps, 1, run_c1)[0])
     c1_el = statistics.median(c1_regions)
+    # ---- the same cadence through the call sequence N > 1 ranks execute (host-driven segments, the support-sized payload, a
+    #      no-op in place of the collective at world size 1): bounds the multi-GPU cadence-1 cost before any 8-GPU box sees it ----
+    c1h_el, c1h_regions = None, []
+    if dist is None:
+        run_c1h = lambda n, c: run_host_driven(n, c, reuse=True)      # noqa: E731
+        timed_region(a.steps, 1, run_c1h)
+        c1h_regions = [timed_region(a.steps, 1, run_c1h)[0] for _ in range(5)]
+        c1h_el = statistics.median(c1h_regions)
+        after_j[0] = False
 
     # ---- the inner iteration ALONE (no J step in the region, no forward reuse): the denominator of roofline.whole_step ----
     def run_inner(n, _cadence):
@@ -403,30 +446,34 @@ def main():
         d_ms = (time.perf_counter() - td) / nj * 1e3
         eng.set_pose_disc(disc_flat.to(dev))
 
-    def side_run(flags_, setup=None, model=None):
-        """a separately reported mode on a fresh copy of the same batch: warm-up, then --steps timed iterations (median of 3)"""
-        e2 = eng_mod.RefineEngine(model or dmodel, B, batch_norm=B * world, flags=flags_)
+    def side_run(flags_, setup=None, model=None, Bs=None, disc=None):
+        """a separately reported mode on a fresh copy of the same batch (its first Bs poses): warm-up, then --steps timed
+        iterations (median of 3)"""
+        Bs = Bs or B
+        disc = use_disc if disc is None else disc
+        e2 = eng_mod.RefineEngine(model or dmodel, Bs, batch_norm=Bs * world, flags=flags_)
         if flags_ & eng_mod.FLAG_FOLDED:
             e2.set_folded(True)
         e2.set_j_regressor(J)
-        if use_disc:
+        if disc:
             e2.set_pose_disc(disc_flat.to(dev))
-        fx = torch.from_numpy(batch_np['pose6d']).to(dev).contiguous()
-        fb = torch.from_numpy(batch_np['betas']).to(dev).contiguous()
+        fx = torch.from_numpy(batch_np['pose6d'][:Bs]).to(dev).contiguous()
+        fb = torch.from_numpy(batch_np['betas'][:Bs]).to(dev).contiguous()
+        fgt = gt_c[:Bs].contiguous()
         refs = setup(e2, fx, fb) if setup else None      # noqa: F841
-        fm, fv = torch.zeros(B, 154, device=dev), torch.zeros(B, 154, device=dev)
+        fm, fv = torch.zeros(Bs, 154, device=dev), torch.zeros(Bs, 154, device=dev)
         fstep = torch.zeros(1, dtype=torch.int32, device=dev)
-        e2.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, a.warmup)
+        e2.refine_run(fx, fb, fgt, fm, fv, fstep, 1e-2, a.warmup)
 
         def go(n, _c):
-            e2.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, n)
+            e2.refine_run(fx, fb, fgt, fm, fv, fstep, 1e-2, n)
             return 0
         fel = statistics.median([timed_region(a.steps, 0, go)[0] for _ in range(3)])
-        out_ = {'value': round(a.steps / fel * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(fel / a.steps * 1e3, 4),
+        out_ = {'value': round(a.steps / fel * world, 3), 'unit': f'it/s (x{Bs} poses)', 'ms_per_step': round(fel / a.steps * 1e3, 4),
                 'joint_sparse': int(e2.info.get('joint_sparse') or 0)}
-        if setup is silhouette_setup:
+        if setup is silhouette_setup or Bs != B:
             e2.set_profiling(True)
-            e2.refine_run(fx, fb, gt_c, fm, fv, fstep, 1e-2, max(2, min(a.steps, 10)))
+            e2.refine_run(fx, fb, fgt, fm, fv, fstep, 1e-2, max(2, min(a.steps, 10)))
             pr = e2.profile_read()
             e2.set_profiling(False)
             out_['kernels_ms'] = {k: round(t, 4) for k, (t, n) in pr.items() if n}
@@ -459,16 +506,29 @@ def main():
                                            'frac': round(pm['SQ_INSTS_VALU'] / (ras_ms * 1e-3) / peak, 4),
                                            'parked_wave_cycle_frac': round(pm['SQ_WAIT_ANY'] / pm['SQ_WAVE_CYCLES'], 3),
                                            'source': 'profiles/pmc_traffic.json (static PMC counts, live duration)'}
+    # ---- BASELINE configs[1]: batch 1024, 3D-joint loss only, separately timed with its own roofline fraction ----
+    config2 = None
+    if not a.no_config2 and a.config == 3 and B >= 1024:
+        config2 = side_run(eng_mod.FLAG_KEEP_VERTS, Bs=1024, disc=False)
+        fl2 = flop_lbs_fwd(dmodel.info) + flop_lbs_bwd(dmodel.info) + FLOP_BLEND_ADJ_PER_POSE
+        config2.update({'workload': 'BASELINE configs[1]: batch=1024 pose optimisation, 3D-joint L2 loss only',
+                        'whole_step': {'flop_per_pose_iter': fl2, 'achieved': round(fl2 * 1024 / (config2['ms_per_step'] * 1e-3) / 1e12, 2),
+                                       'frac': round(fl2 * 1024 / (config2['ms_per_step'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                       'dense_formulation_flop_per_pose_iter': FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE}})
     # ---- what a body model with a less coherent vertex order runs: the 12-joint-per-tile kernels and the dense kernels
     #      (the synthetic body's ring-major vertex order is what lets the headline use the 8-joint kernels) ----
     skin_variants = None
     if not a.no_skin_variants and not use_sil:
         skin_variants = {}
-        for name, env in (('skin12', {'JRR_SKIN_JOINTS': '12'}), ('dense', {'JRR_DENSE_SKINNING': '1'})):
+        variants = [('skin12', {'JRR_SKIN_JOINTS': '12'}, model_np), ('dense', {'JRR_DENSE_SKINNING': '1'}, model_np),
+                    # a body whose FILE order means nothing to the tiles (seeded random): the library's joint-sorted order + per-tile
+                    # classes decide; a few tiles are wide and pay a second pass themselves
+                    ('capsules_random_file_order', {}, sm.synthetic_smpl(1234, kind='capsules'))]
+        for name, env, mnp in variants:
             old = {k: os.environ.get(k) for k in env}
             os.environ.update(env)                       # read by jrr_model_create
             try:
-                mdl = eng_mod.DeviceModel(model_np, dev)
+                mdl = eng_mod.DeviceModel(mnp, dev)
             finally:
                 for k, vv in old.items():
                     if vv is None:
@@ -476,12 +536,10 @@ def main():
                     else:
                         os.environ[k] = vv
             r = side_run(eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0), model=mdl)
-            kj = r['joint_sparse']
-            fl = ((flop_lbs_fwd_sparse(kj) + flop_lbs_bwd_sparse(kj)) if kj else (FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE)) \
-                + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
+            fl = flop_lbs_fwd(mdl.info) + flop_lbs_bwd(mdl.info) + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
             r.update({'flop_per_pose_iter': fl, 'achieved_tflops': round(fl * B / (r['ms_per_step'] * 1e-3) / 1e12, 2),
                       'frac_of_f32_mfma_peak': round(fl * B / (r['ms_per_step'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                      'forced_by': env})
+                      'forced_by': env, 'model': mdl.info})
             skin_variants[name] = r
             del mdl
 
@@ -493,18 +551,30 @@ def main():
     ms_per_step = elapsed / a.steps * 1e3
     it_s = a.steps / elapsed
     dom_ms, dom_n = prof['k_lbs_fwd']
-    kjs = int(eng.info.get('joint_sparse') or 0)      # joints per vertex tile the LBS kernels multiply by (0: all 24)
+    kjs = int(eng.info.get('joint_sparse') or 0)      # joint slots per vertex tile and pass the LBS kernels multiply by (0: all 24)
     sparse = kjs > 0
-    flop_fwd = flop_lbs_fwd_sparse(kjs) if sparse else FLOP_LBS_FWD_PER_POSE
-    flop_bwd = flop_lbs_bwd_sparse(kjs) if sparse else FLOP_LBS_BWD_PER_POSE
+    flop_fwd = flop_lbs_fwd(dmodel.info)
+    flop_bwd = flop_lbs_bwd(dmodel.info)
     achieved = flop_fwd * B / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    traffic = None
+    traffic, pmc = None, {}
     tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
     if os.path.exists(tpath):
         try:
-            traffic = json.load(open(tpath)).get('k_lbs_fwd_hbm_bytes_per_launch') if B == 4096 else None
+            pmc = json.load(open(tpath)) if B == 4096 else {}
+            traffic = pmc.get('k_lbs_fwd_hbm_bytes_per_launch')
         except Exception:
-            traffic = None
+            traffic, pmc = None, {}
+
+    def issued(name, ms):
+        """the ISSUED matrix work of a kernel: SQ_INSTS_MFMA of one launch (static PMC pass, profiles/pmc_traffic.json:
+        `mfma_issued_b4096`) x FLOP per instruction over the LIVE duration -- beside the algorithmic figure so that a reader
+        sees the two agree; only for the benchmarked body at batch 4096"""
+        rec = (pmc.get('mfma_issued_b4096') or {}).get(name)
+        if not rec or not ms or dmodel.info['wide_tiles'] or not sparse:
+            return None
+        fl = rec['flop_per_launch']
+        return {'sq_insts_mfma': rec['sq_insts_mfma'], 'flop_per_launch': fl, 'tflops': round(fl / (ms * 1e-3) / 1e12, 2),
+                'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'source': 'profiles/pmc_traffic.json (static count, live duration)'}
     step_flop = flop_fwd + flop_bwd + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
     step_flop_dense = FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
     c1_ms = c1_el / a.steps * 1e3
@@ -521,7 +591,8 @@ def main():
                    'timed_regions': len(regions), 'value_is': 'median region',
                    'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in regions],
                    'host_calls_per_region': 'one C call (jrr_refine_run_j_steps)' if dist is None else 'refine_run + j_regressor_grad + all_reduce + j_step_apply per J step',
-                   'geometry': eng.info},
+                   'forward_reuse_after_j_step': False,
+                   'geometry': dict(eng.info, **dmodel.info)},
         'collective': collective,
         'roofline': {'bound': 'mfma', 'kernel': 'k_lbs_fwd<true,false>', 'achieved': round(achieved, 2),
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
@@ -533,8 +604,10 @@ def main():
                      'hbm_gb_s': round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms > 0 else None,
                      'hbm_frac_of_8tb_s': round(traffic / (dom_ms * 1e-3) / 8e12, 4) if traffic and dom_ms > 0 else None,
                      'algorithmic_flop_per_launch': flop_fwd * B,
-                     'formulation': (f'joint-sparse skinning: each 32-vertex tile multiplies by its own <= {kjs} of the 24 joints '
-                                     '(exact: the skipped terms are zeros); FLOP counted for THIS formulation') if sparse
+                     'issued_work': issued('k_lbs_fwd', dom_ms),
+                     'formulation': (f'joint-sparse skinning: each 32-vertex tile multiplies by its own joints only, {kjs} slots per pass '
+                                     f"({dmodel.info['wide_tiles']} wide tiles run a second pass; exact: the skipped terms are zeros); "
+                                     'FLOP counted for THIS formulation') if sparse
                                     else 'dense skinning (SURVEY.md section 8d counts)',
                      'dense_formulation': {'flop_per_launch': FLOP_LBS_FWD_PER_POSE * B,
                                            'rate_tflops': round(FLOP_LBS_FWD_PER_POSE * B / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
@@ -553,25 +626,43 @@ def main():
                      # how much of the launch the FIRST-dispatched workgroup is resident (the two workgroups of a CU
                      # do not progress evenly: the older one finishes early)
                      'sustained_clock_ghz': round(probe[0] / probe[4], 3) if probe[4] else None,
-                     'mfma_pipe_utilisation': round(achieved / (PEAK_F32_MFMA_TFLOPS * (probe[0] / probe[4] / 2.4)), 4)
-                     if probe[4] else None,
+                     # matrix-pipe busy fraction of the launch: issue clocks of every matrix instruction (32x32x2: 64 clocks, the 48
+                     # four-block regressor instructions per tile: 33) per SIMD over the launch duration at the sustained clock
+                     'mfma_pipe_utilisation': round(216 * (eng.info['BP'] / 32) * fwd_pipe_clocks_per_tile(dmodel.info) / 1024
+                                                    / (dom_ms * 1e-3 * probe[0] / probe[4] * 1e9), 4) if probe[4] and dom_ms > 0 else None,
+                     'mfma_pipe_utilisation_note': 'instruction-priced (64 / 33 issue clocks); the algorithmic-FLOP ratio achieved / (peak x clock / 2.4) reads ~1 % higher',
                      'first_workgroup_resident_frac': round(probe[4] * 1e-6 / dom_ms, 3) if probe[4] and dom_ms > 0 else None},
         'kernels_ms': {k: round(t, 4) for k, (t, n) in prof.items() if n},
         # the other matrix-core launches of the iteration against the same peak, each on the FLOP of the formulation it runs
         'kernels_roofline': {name: {'flop_per_launch': fl * B, 'achieved_tflops': round(fl * B / (prof[cls][0] * 1e-3) / 1e12, 2),
-                                    'frac': round(fl * B / (prof[cls][0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4)}
-                             for name, cls, fl in (('k_lbs_bwd', 'k_lbs_bwd', flop_bwd), ('k_blend_adjoint', 'k_gemm_tn_blend_adjoint', FLOP_BLEND_ADJ_PER_POSE),
-                                                   ('pose_disc_gemms (4 launches)', 'pose_disc_gemms', FLOP_DISC_PER_POSE))
+                                    'frac': round(fl * B / (prof[cls][0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                    'issued_work': issued(pm_name, prof[cls][0])}
+                             for name, cls, fl, pm_name in (('k_lbs_bwd', 'k_lbs_bwd', flop_bwd, 'k_lbs_bwd'),
+                                                            ('k_blend_adjoint', 'k_gemm_tn_blend_adjoint', FLOP_BLEND_ADJ_PER_POSE, 'k_blend_adjoint'),
+                                                            ('pose_disc_gemms (4 launches)', 'pose_disc_gemms', FLOP_DISC_PER_POSE, 'pose_disc_gemms'))
                              if prof.get(cls, (0, 0))[1] and prof[cls][0] > 0},
         'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
-                   'allreduce_bytes': 17 * 6890 * 4, 'in_timed_region': nj_region, 'host_calls': 2 + (1 if dist is not None else 0)},
+                   'allreduce_bytes': xch.nbytes, 'allreduce_payload': 'regressor support [17][128]' if xch.compact else 'dense (17,6890)',
+                   'in_timed_region': nj_region, 'host_calls': 2 + (1 if dist is not None else 0)},
         'cadence1': {'value': round(a.steps / c1_el * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(c1_ms, 4),
                      'j_step_every': 1, 'timed_regions': len(c1_regions), 'value_is': 'median region',
                      'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1_regions],
                      'spread_frac': round((max(c1_regions) - min(c1_regions)) / c1_el, 4),
+                     'forward_reuse_after_j_step': True,
                      'note': 'BASELINE configs[3] / north_star "all-reduce on the J_regressor gradient each step": '
-                             'the J step (+ its all-reduce) after EVERY inner iteration, timed like `value`'},
+                             'the J step (+ its all-reduce) after EVERY inner iteration, timed like `value`; the iteration after a J '
+                             'step re-regresses its joints from the J step\'s stored vertices (same poses: explicit reuse)'},
     }
+    if c1h_el is not None:
+        out['cadence1_host_driven'] = {
+            'value': round(a.steps / c1h_el, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(c1h_el / a.steps * 1e3, 4),
+            'timed_regions': len(c1h_regions), 'value_is': 'median region',
+            'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1h_regions],
+            'spread_frac': round((max(c1h_regions) - min(c1h_regions)) / c1h_el, 4),
+            'allreduce_bytes_it_would_send': xch.nbytes,
+            'note': 'cadence 1 through the call sequence N > 1 ranks execute (refine_run_after_j_step -> j_regressor_grad_support -> '
+                    '[all-reduce: a no-op at world size 1] -> j_step_apply_support per iteration, host-driven): bounds the multi-GPU '
+                    'cadence-1 cost of everything but the collective itself'}
     # outer-step work.  `value` already contains the J step (+ all-reduce) at cadence
     # `j_step_every`; the pose-D update is timed separately.  Two derived rates: everything at the measured
     # cadence, and everything after EVERY inner iteration (cadence 1).
@@ -579,9 +670,11 @@ def main():
                          'inner_only_ms_per_step': round(inner_ms, 4),
                          'it_s_incl_pose_d_update_at_cadence': round(world / ((ms_per_step + (d_ms or 0.0) / cadence) * 1e-3), 3),
                          'it_s_all_outer_work_every_iteration': round(world / ((c1_ms + (d_ms or 0.0)) * 1e-3), 3),
-                         'j_allreduce_bytes': 17 * 6890 * 4, 'pose_d_allreduce_bytes': 1840153 * 4 if use_disc else 0}
+                         'j_allreduce_bytes': xch.nbytes, 'pose_d_allreduce_bytes': 1840153 * 4 if use_disc else 0}
     if folded is not None:
         out['folded_mode'] = folded
+    if config2 is not None:
+        out['config2'] = config2
     if config5 is not None:
         out['config5'] = config5
     if skin_variants is not None:

@@ -77,6 +77,19 @@ int jrr_model_create(const float* v_template_host, const float* shapedirs_host,
                      const float* lbs_weights_host, const int32_t* parents_host,
                      jrr_model_t** out);
 void jrr_model_destroy(jrr_model_t* m);
+/* The same with the model's device memory owned by the CALLER (the caller owns every buffer):
+ * buffer_dev = jrr_model_bytes() bytes, 256-byte aligned, it must outlive the model; NULL = the library allocates its own
+ * (what jrr_model_create does).  The buffer also holds the face lists of jrr_model_set_faces.                              */
+size_t jrr_model_bytes(void);
+int jrr_model_create_in(const float* v_template_host, const float* shapedirs_host, const float* posedirs_host,
+                        const float* J_regressor_host, const float* lbs_weights_host, const int32_t* parents_host,
+                        void* buffer_dev, size_t buffer_bytes, jrr_model_t** out);
+/* What the LBS kernels will run for this body (measurement / diagnostics; the reference has no counterpart):
+ * out[0] = joint slots per 32-vertex tile and pass of the joint-sparse kernels (8 or 12; 0 = the dense kernels),
+ * out[1] = WIDE tiles (more joints than that: each runs a second pass -- it costs itself, not the model),
+ * out[2] = most joints of any tile, out[3] = 1 when the vertices are stored in the library's own joint-sorted order
+ * (invisible at the API), out[4 + k] = number of tiles with k joints, k = 0 .. 24.                                      */
+int jrr_model_info(const jrr_model_t* m, int32_t* out, int n);
 /* triangle list of the mesh (SMPL `f`, 13776 x 3 int32; the reference reads it from data/body_model/smpl_uv.obj,
  * scripts/mesh_renderer.py:40-41); needed by the silhouette renderer only.  Synchronous.                  */
 int jrr_model_set_faces(jrr_model_t* m, const int32_t* faces_host, int n_faces);
@@ -276,6 +289,27 @@ int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d_dev, const float* bet
 int jrr_j_step_apply(jrr_engine_t* e, float* J_dev, const float* dJ_dev, float* m_dev, float* v_dev, int32_t* step_dev,
                      float lr, const float* mask_dev, void* stream);
 
+/* The J step's all-reduce restricted to the regressor's SUPPORT (data parallelism; scripts/optimize.py:300-312 under sharding).
+ * dJ w.r.t. the raw regressor is exactly zero wherever J*mask <= 0 (ReLU'), so the ranks only need to exchange its values on the
+ * positive entries: [17][128] floats (8 704 bytes) instead of 17 x 6890 (468 520 bytes).  Every rank holds the same regressor,
+ * hence the same device-side support lists (ascending vertex order).
+ *   jrr_j_support_info            positive entries per row (counts_host[17], nullable) and fits_host = 1 when every row has at
+ *                                 most 128 of them.  SYNCHRONOUS (waits for `stream`); call once after jrr_engine_set_j_regressor:
+ *                                 J steps only ever shrink the support (an entry at <= 0 gets no gradient), so the answer holds
+ *                                 until the next jrr_engine_set_j_regressor from outside.
+ *   jrr_j_regressor_grad_support  = jrr_j_regressor_grad, gradient delivered as dJs_dev [17][128] (0 behind a row's count)
+ *   jrr_j_step_apply_support      = jrr_j_step_apply with the (all-reduced) dJs_dev: the dense gradient is rebuilt on the device
+ *                                 (zero outside the support, as the dense path has it) and torch's Adam runs over the whole
+ *                                 (17,6890) parameter as before -- entries that left the support keep coasting on their momentum.
+ * Both return JRR_ERR_STATE unless jrr_j_support_info has reported fits = 1 for the current regressor (fall back to the
+ * dense pair).  Same results as the dense pair bit for bit on this rank; across ranks only the all-reduce's own summation
+ * order can differ (none with two ranks).                                                                                  */
+int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t* fits_host, void* stream);
+int jrr_j_regressor_grad_support(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev, const float* gt_centred_mm_dev,
+                                 float* dJs_dev, float* sqerr_dev, float* joints_dev, void* stream);
+int jrr_j_step_apply_support(jrr_engine_t* e, float* J_dev, const float* dJs_dev, float* m_dev, float* v_dev, int32_t* step_dev,
+                             float lr, const float* mask_dev, void* stream);
+
 /* Forward reuse across the J step (needs JRR_FLAG_KEEP_VERTS).  jrr_j_regressor_grad evaluates SMPL on the current
  * poses; the inner iteration that follows evaluates it on the SAME poses (only the regressor has changed in between,
  * scripts/optimize.py:300-312 then :220-229).  jrr_refine_run_after_j_step is jrr_refine_run whose FIRST iteration
@@ -293,7 +327,9 @@ int jrr_refine_run_after_j_step(jrr_engine_t* e, float* x6d_dev, float* betas_de
  * n_iters iterations of jrr_refine_run; after every j_every-th one the J step of scripts/optimize.py:300-312
  * (jrr_j_regressor_grad into engine scratch, jrr_j_step_apply with J_dev / J_m_dev / J_v_dev / J_step_dev / j_lr /
  * mask_dev), the next iteration reusing its forward.  j_sqerr_dev (B, nullable): per-pose squared joint error of the
- * last J step.  after_j_step != 0: as jrr_refine_run_after_j_step for the first iteration.  BASELINE configs[3]'s
+ * last J step.  after_j_step bit 0: as jrr_refine_run_after_j_step for the first iteration; bit 1 (value 2): NO forward reuse
+ * inside the call either -- every iteration repeats its SMPL forward (the reference draws a new batch after each J step,
+ * scripts/optimize.py:144-148, so nothing is shared there: what bench.py's headline times).  BASELINE configs[3]'s
  * "J_regressor step each iteration" at world size 1 is j_every = 1.  Needs JRR_FLAG_KEEP_VERTS.                       */
 int jrr_refine_run_j_steps(jrr_engine_t* e, float* x6d_dev, float* betas_dev, const float* gt_centred_mm_dev,
                            float* adam_m_dev, float* adam_v_dev, int32_t* step_dev, float lr, int n_iters,
@@ -310,9 +346,10 @@ int jrr_refine_run_j_steps(jrr_engine_t* e, float* x6d_dev, float* betas_dev, co
 int jrr_engine_set_loss_history(jrr_engine_t* e, float* hist_dev, int capacity_records, int every);
 int jrr_engine_loss_history_count(const jrr_engine_t* e);
 
-/* launch geometry: {B, BP, batch_norm, nvc, nvcb, nsplit, nsplitJ, flags, joint_sparse}; joint_sparse = 8 or 12 when every
- * 32-vertex tile of the model is skinned by at most that many joints and the LBS kernels multiply by those only (exact: the
- * skipped terms are zeros), 0 = dense kernels (also forced by JRR_DENSE_SKINNING=1 in the environment of jrr_model_create) */
+/* launch geometry: {B, BP, batch_norm, nvc, nvcb, nsplit, nsplitJ, flags, joint_sparse}; joint_sparse = 8 or 12: the LBS kernels
+ * multiply each 32-vertex tile by its own joints only, that many slots per pass (exact: the skipped terms are zeros; a tile with
+ * more joints runs a second pass, jrr_model_info), 0 = dense kernels (a tile with more than 16 joints, or JRR_DENSE_SKINNING=1 in
+ * the environment of jrr_model_create) */
 int jrr_engine_info(const jrr_engine_t* e, int32_t* out, int n);
 
 /* Per-kernel timing of jrr_refine_run with HIP events recorded on the launch stream.

@@ -22,6 +22,9 @@ SIGNATURES = {
     'jrr_version': (c_int, []),
     'jrr_model_create': (c_int, [_P, _P, _P, _P, _P, _P, POINTER(_P)]),
     'jrr_model_destroy': (None, [_P]),
+    'jrr_model_bytes': (c_size_t, []),
+    'jrr_model_create_in': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, POINTER(_P)]),
+    'jrr_model_info': (c_int, [_P, POINTER(c_int32), c_int]),
     'jrr_model_set_faces': (c_int, [_P, _P, c_int]),
     'jrr_engine_workspace_bytes': (c_size_t, [c_int, c_int]),
     'jrr_engine_create': (c_int, [_P, c_int, c_int, _P, c_size_t, c_int, POINTER(_P)]),
@@ -62,6 +65,9 @@ SIGNATURES = {
     'jrr_refine_run': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),
     'jrr_j_regressor_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_j_step_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P, _P]),
+    'jrr_j_support_info': (c_int, [_P, POINTER(c_int32), POINTER(c_int32), _P]),
+    'jrr_j_regressor_grad_support': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
+    'jrr_j_step_apply_support': (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     'jrr_refine_run_after_j_step': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),
     'jrr_refine_run_j_steps': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, c_int, _P, _P, _P, _P, c_float, _P, _P, c_int, _P]),
     'jrr_engine_set_loss_history': (c_int, [_P, _P, c_int, c_int]),

@@ -40,6 +40,8 @@ def build_parser() -> argparse.ArgumentParser:
     parser.add_argument('--inner_iters', type=int, default=100, help='pose-refinement iterations per batch (optimize.py:220)')
     parser.add_argument('--j_step_every', type=int, default=100,
                         help='inner iterations per J_regressor step (100 = reference cadence: once per outer batch)')
+    parser.add_argument('--j_allreduce', type=str, default='support', choices=['support', 'dense'],
+                        help='payload of the in-loop J step all-reduce under data parallelism: the regressor\'s support (8 704 B) or the dense (17,6890) gradient')
     parser.add_argument('--no_pose_disc', action='store_true', help='drop the pose-discriminator term (BASELINE config 2)')
     parser.add_argument('--shape_disc', action='store_true', help='add the shape-discriminator term (optimize.py:244,249-250)')
     parser.add_argument('--reprojection', action='store_true',

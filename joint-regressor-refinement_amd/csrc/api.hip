@@ -34,14 +34,32 @@ extern "C" int jrr_version(void) { return 100; }
 // =============================================================================================
 // model
 // =============================================================================================
+constexpr int MAX_FACES = 14336;       // the rasteriser's capacity: 1024 threads x 14 faces (sil.hip)
+static size_t model_floats() {
+  const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nDq = nDn, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
+  const size_t nJt = 72 + 24, nJS = 720 + 16, nWc = (size_t)(VT + 1) * NJ * 32, nJl = (size_t)VT * NJ + (size_t)VT + 8, nPerm = (size_t)VP + 6912;
+  const size_t nW16 = (size_t)VT * 16 * 36, nSeg = (size_t)VT * 32;
+  return nDk + nDn + nDq + nWjv + nWvj + nJt + nJS + nWc + nJl + nPerm + nW16 + nSeg;
+}
+extern "C" size_t jrr_model_bytes(void) { return round_up(model_floats() * sizeof(float), 256) + (size_t)2 * MAX_FACES * 3 * sizeof(int32_t); }
+
 extern "C" int jrr_model_create(const float* vt, const float* sd, const float* pd, const float* Jr, const float* W,
                                 const int32_t* parents, jrr_model_t** out) {
+  return jrr_model_create_in(vt, sd, pd, Jr, W, parents, nullptr, 0, out);
+}
+
+extern "C" int jrr_model_create_in(const float* vt, const float* sd, const float* pd, const float* Jr, const float* W,
+                                   const int32_t* parents, void* buffer_dev, size_t buffer_bytes, jrr_model_t** out) {
   if (!vt || !sd || !pd || !Jr || !W || !parents || !out) { jrr_set_error("jrr_model_create: null argument"); return JRR_ERR_ARG; }
+  if (buffer_dev && (buffer_bytes < jrr_model_bytes() || ((uintptr_t)buffer_dev & 255) != 0)) {
+    jrr_set_error("jrr_model_create_in: the model buffer needs jrr_model_bytes() = %zu bytes, 256-byte aligned", jrr_model_bytes());
+    return JRR_ERR_WORKSPACE;
+  }
   for (int j = 0; j < NJ; ++j)
     if (parents[j] >= j || (j > 0 && parents[j] < 0)) { jrr_set_error("parents[%d]=%d is not a topologically ordered tree", j, parents[j]); return JRR_ERR_ARG; }
   const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nDq = nDn, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
   const size_t nJt = 72 + 24, nJS = 720 + 16;   // padded to keep 16-byte alignment of what follows
-  const size_t nWc = (size_t)(VT + 1) * KJS_MAX * 32, nJl = (size_t)VT * KJS_MAX, nPerm = (size_t)VP + 6912;   // p2v [VP], v2p [V] padded
+  const size_t nWc = (size_t)(VT + 1) * NJ * 32, nJl = (size_t)VT * NJ + (size_t)VT + 8, nPerm = (size_t)VP + 6912;   // jl [VT][24] + tnj [VT] (+ pad); p2v [VP], v2p [V] padded
   const size_t nW16 = (size_t)VT * 16 * 36, nSeg = (size_t)VT * 32;                      // segid [VT] (padded to 16 per tile), segj [VT][16]
   std::vector<float> h(nDk + nDn + nDq + nWjv + nWvj + nJt + nJS + nWc + nJl + nPerm + nW16 + nSeg, 0.f);
   float* Dk = h.data();
@@ -53,6 +71,7 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   float* JS = Jt + nJt;
   float* Wc = JS + nJS;
   int32_t* Jl = reinterpret_cast<int32_t*>(Wc + nWc);
+  int32_t* Tnj = Jl + (size_t)VT * NJ;
   int32_t* P2V = Jl + nJl;
   int32_t* V2P = P2V + VP;
   float* W16 = reinterpret_cast<float*>(P2V + nPerm);
@@ -60,8 +79,10 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   int32_t* SegJ = SegId + (size_t)VT * 16;
   // ---- internal vertex order (jrr_common.h): the file order unless it does not fit the joint-sparse kernels and the
   //      joint-sorted order does (or JRR_VERTEX_ORDER=sorted asks for it: tests) ----
-  auto tile_joints = [&](const std::vector<int>& order) {      // most joints any 32-row tile touches
-    size_t most = 0;
+  // cost of an order for the joint-sparse kernels: matrix instructions of the forward kernel with per-tile classes (a tile
+  // above the slot count pays a second pass), infinite when a tile exceeds the backward kernel's 16-joint window
+  auto order_cost = [&](const std::vector<int>& order) {
+    long cost8 = 0, cost12 = 0;
     for (int t = 0; t < VT; ++t) {
       bool used[NJ] = {false};
       for (int vv = 0; vv < 32; ++vv) {
@@ -69,11 +90,13 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
         if (p_ >= V) break;
         for (int j = 0; j < NJ; ++j) used[j] = used[j] || W[(size_t)order[p_] * NJ + j] != 0.f;
       }
-      size_t n = 0;
+      int n = 0;
       for (int j = 0; j < NJ; ++j) n += used[j];
-      most = std::max(most, n);
+      if (n > KJS_TILE_MAX) return (long)1 << 40;
+      cost8 += 423 + (n > 8 ? 78 : 0);
+      cost12 += 447 + (n > 12 ? 102 : 0);
     }
-    return most;
+    return std::min(cost8, cost12);
   };
   std::vector<int> order(V);
   for (int v = 0; v < V; ++v) order[v] = v;
@@ -81,8 +104,8 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   {
     const char* ask = getenv("JRR_VERTEX_ORDER");
     const bool force = ask && strcmp(ask, "sorted") == 0;
-    const size_t most_file = tile_joints(order);
-    if (force || most_file > 8) {
+    const long cost_file = order_cost(order);
+    if (force || cost_file > (long)VT * 423) {      // some tile of the file order is wide: would the joint-sorted order be cheaper?
       // key of a vertex: its joints by descending weight (dominant joint first), then the file index
       std::vector<std::array<int, 5>> keys(V);
       for (int v = 0; v < V; ++v) {
@@ -94,9 +117,7 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
       }
       std::vector<int> sorted(order);
       std::sort(sorted.begin(), sorted.end(), [&](int a, int b) { return keys[a] < keys[b]; });
-      const size_t most_sorted = tile_joints(sorted);
-      auto cls = [](size_t m) { return m <= 8 ? 0 : m <= (size_t)KJS_MAX ? 1 : 2; };
-      if (force || cls(most_sorted) < cls(most_file)) { order = sorted; permuted = true; }
+      if (force || order_cost(sorted) < cost_file) { order = sorted; permuted = true; }
     }
   }
   for (int p_ = 0; p_ < VP; ++p_) P2V[p_] = p_ < V ? order[p_] : -1;
@@ -120,8 +141,11 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
       Wvj[((size_t)t * 32 + vv) * 32 + j] = W[(size_t)v * NJ + j];
     }
   }
-  // joint-sparse skinning tables (jrr_common.h): per 32-vertex tile the joints with a non-zero weight
-  int kjs = 0;
+  // joint-sparse skinning tables (jrr_common.h): per 32-vertex tile the joints with a non-zero weight.  PER-TILE classes: the
+  // kernels are built for `kjs` (8 or 12) joint slots per tile and pass; a tile with more joints (up to KJS_TILE_MAX = 16:
+  // the backward kernel's joint windows) costs ITSELF a second pass over slots kjs .. 2 kjs - 1, nobody else anything.
+  int kjs = 0, wide_tiles = 0, most_joints = 0;
+  int hist[NJ + 1] = {0};
   {
     std::vector<std::vector<int>> lists(VT);
     size_t most = 0;
@@ -132,11 +156,23 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
         if (used) lists[t].push_back(j);
       }
       most = std::max(most, lists[t].size());
+      ++hist[lists[t].size()];
     }
-    kjs = most <= 8 ? 8 : most <= (size_t)KJS_MAX ? KJS_MAX : 0;
-    // JRR_DENSE_SKINNING=1 forces the dense kernels, JRR_SKIN_JOINTS=12 the 12-joint variant (verification: tests)
+    most_joints = (int)most;
+    if (most <= (size_t)KJS_TILE_MAX) {
+      // matrix instructions per tile of the forward kernel: 423 / 447 with 8 / 12 slots, + one pass (2 kjs x 3 + ~3 stage
+      // hand-overs) for a wide tile
+      long cost8 = 0, cost12 = 0;
+      for (int t = 0; t < VT; ++t) {
+        cost8 += 423 + (lists[t].size() > 8 ? 48 + 30 : 0);
+        cost12 += 447 + (lists[t].size() > 12 ? 72 + 30 : 0);
+      }
+      kjs = cost8 <= cost12 ? 8 : KJS_MAX;
+    }
+    // JRR_DENSE_SKINNING=1 forces the dense kernels, JRR_SKIN_JOINTS=12 the 12-slot variant (verification: tests)
     { const char* dense = getenv("JRR_DENSE_SKINNING"); if (dense && dense[0] == '1') kjs = 0; }
     { const char* kj = getenv("JRR_SKIN_JOINTS"); if (kj && atoi(kj) == 12 && kjs == 8) kjs = 12; }
+    for (int t = 0; t < VT && kjs; ++t) wide_tiles += (int)lists[t].size() > kjs;
     // segments for the backward kernel's 16-row dA windows: greedy runs of tiles whose joint union stays <= 16
     if (kjs) {
       int seg = 0;
@@ -163,12 +199,13 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
         }
     }
     for (int t = 0; t < VT && kjs; ++t) {
-      for (int n = 0; n < kjs; ++n) {
+      Tnj[t] = (int)lists[t].size();
+      for (int n = 0; n < NJ; ++n) {                                   // NJ slots per tile: the tile's joints, ascending, then padding
         const int j = n < (int)lists[t].size() ? lists[t][n] : 0;      // padding: joint 0 with zero weights
-        Jl[t * kjs + n] = j;
+        Jl[t * NJ + n] = j;
         for (int vv = 0; vv < 32; ++vv) {
           const int p_ = t * 32 + vv;
-          Wc[((size_t)t * kjs + n) * 32 + vv] = (n < (int)lists[t].size() && p_ < V) ? W[(size_t)order[p_] * NJ + j] : 0.f;
+          Wc[((size_t)t * NJ + n) * 32 + vv] = (n < (int)lists[t].size() && p_ < V) ? W[(size_t)order[p_] * NJ + j] : 0.f;
         }
       }
     }
@@ -188,13 +225,19 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
       for (int l = 0; l < NB; ++l) JS[(j * 3 + c) * NB + l] = (float)accs[l];
     }
   jrr_model* m = new jrr_model();
-  void* base = nullptr;
-  hipError_t e = hipMalloc(&base, h.size() * sizeof(float));
-  if (e != hipSuccess) { delete m; jrr_set_error("hipMalloc(model) failed: %s", hipGetErrorString(e)); return JRR_ERR_HIP; }
+  void* base = buffer_dev;
+  hipError_t e = hipSuccess;
+  if (h.size() != model_floats()) { delete m; jrr_set_error("internal: model size mismatch"); return JRR_ERR_ARG; }
+  if (!base) {      // no caller buffer: the library allocates (and frees) its own
+    e = hipMalloc(&base, jrr_model_bytes());
+    if (e != hipSuccess) { delete m; jrr_set_error("hipMalloc(model) failed: %s", hipGetErrorString(e)); return JRR_ERR_HIP; }
+  }
   e = hipMemcpy(base, h.data(), h.size() * sizeof(float), hipMemcpyHostToDevice);
-  if (e != hipSuccess) { (void)hipFree(base); delete m; jrr_set_error("hipMemcpy(model) failed: %s", hipGetErrorString(e)); return JRR_ERR_HIP; }
+  if (e != hipSuccess) { if (!buffer_dev) (void)hipFree(base); delete m; jrr_set_error("hipMemcpy(model) failed: %s", hipGetErrorString(e)); return JRR_ERR_HIP; }
   float* d = (float*)base;
   m->base = base;
+  m->owns_base = buffer_dev == nullptr;
+  m->faces_area = reinterpret_cast<int*>((char*)base + round_up(model_floats() * sizeof(float), 256));
   m->d.Dk = d;
   m->d.Dn = d + nDk;
   m->d.Dq = m->d.Dn + nDn;
@@ -205,6 +248,11 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   m->d.Wc = m->d.JS + nJS;
   m->d.jl = reinterpret_cast<int*>(m->d.Wc + nWc);
   m->d.kjs = kjs;
+  m->d.tnj = m->d.jl + (size_t)VT * NJ;
+  m->d.wide_tiles = wide_tiles;
+  m->d.most_joints = most_joints;
+  for (int n = 0; n <= NJ; ++n) m->d.tile_hist[n] = hist[n];
+  m->d.permuted = permuted ? 1 : 0;
   m->v2p_host = nullptr;
   if (permuted) { m->v2p_host = new int[V]; memcpy(m->v2p_host, V2P, (size_t)V * sizeof(int)); }
   m->d.p2v = permuted ? reinterpret_cast<int*>(m->d.jl + nJl) : nullptr;
@@ -213,6 +261,7 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
   m->d.segid = reinterpret_cast<int*>(m->d.W16 + nW16);
   m->d.segj = m->d.segid + (size_t)VT * 16;
   { const char* b16 = getenv("JRR_BWD16"); m->d.bwd16 = (kjs && !(b16 && b16[0] == '0')) ? 1 : 0; }
+  m->d.role_kjs = (kjs && !wide_tiles) ? kjs : 0;
   m->d.parents.maxd = 0;
   m->d.faces = nullptr;
   m->d.faces_int = nullptr;
@@ -238,16 +287,17 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
 
 extern "C" int jrr_model_set_faces(jrr_model_t* m, const int32_t* faces, int n_faces) {
   if (!m || !faces || n_faces <= 0) return JRR_ERR_ARG;
+  if (n_faces > MAX_FACES) { jrr_set_error("%d faces: the rasteriser holds at most %d", n_faces, MAX_FACES); return JRR_ERR_ARG; }
   for (int i = 0; i < n_faces * 3; ++i)
     if (faces[i] < 0 || faces[i] >= V) { jrr_set_error("face index %d out of range", faces[i]); return JRR_ERR_ARG; }
-  if (m->d.faces) (void)hipFree(m->d.faces);
-  if (m->d.faces_int) { (void)hipFree(m->d.faces_int); m->d.faces_int = nullptr; }
-  JRR_HIP(hipMalloc((void**)&m->d.faces, (size_t)n_faces * 3 * sizeof(int)));
+  // both index lists live in the tail of the model buffer (jrr_model_bytes): no allocation here
+  m->d.faces = m->faces_area;
+  m->d.faces_int = nullptr;
   JRR_HIP(hipMemcpy(m->d.faces, faces, (size_t)n_faces * 3 * sizeof(int), hipMemcpyHostToDevice));
   if (m->v2p_host) {      // the fused rasteriser reads the vertices in the internal order: faces in row indices
     std::vector<int32_t> fi((size_t)n_faces * 3);
     for (size_t i = 0; i < fi.size(); ++i) fi[i] = m->v2p_host[faces[i]];
-    JRR_HIP(hipMalloc((void**)&m->d.faces_int, fi.size() * sizeof(int)));
+    m->d.faces_int = m->faces_area + (size_t)MAX_FACES * 3;
     JRR_HIP(hipMemcpy(m->d.faces_int, fi.data(), fi.size() * sizeof(int), hipMemcpyHostToDevice));
   }
   m->d.nfaces = n_faces;
@@ -256,11 +306,17 @@ extern "C" int jrr_model_set_faces(jrr_model_t* m, const int32_t* faces, int n_f
 
 extern "C" void jrr_model_destroy(jrr_model_t* m) {
   if (!m) return;
-  if (m->d.faces) (void)hipFree(m->d.faces);
-  if (m->d.faces_int) (void)hipFree(m->d.faces_int);
-  if (m->base) (void)hipFree(m->base);
+  if (m->base && m->owns_base) (void)hipFree(m->base);
   delete[] m->v2p_host;
   delete m;
+}
+
+extern "C" int jrr_model_info(const jrr_model_t* m, int32_t* out, int n) {
+  if (!m || !out) return JRR_ERR_ARG;
+  int32_t v[4 + NJ + 1] = {m->d.kjs, m->d.wide_tiles, m->d.most_joints, m->d.permuted};
+  for (int k = 0; k <= NJ; ++k) v[4 + k] = m->d.tile_hist[k];
+  for (int i = 0; i < n && i < 4 + NJ + 1; ++i) out[i] = v[i];
+  return JRR_OK;
 }
 
 // =============================================================================================
@@ -291,6 +347,7 @@ struct jrr_engine {
   bool fwd_cached; const float *fc_x6d, *fc_betas;
   float* dJraw;                                      // (17,6890) gradient scratch of the in-call J steps (jrr_refine_run_j_steps)
   JSupport jsup; bool have_jsup;                     // support lists of the normalised regressor (KEEP_VERTS engines; lbs.hip)
+  bool jsup_fits_known;                              // jrr_j_support_info has seen flag = 1 for the current regressor lineage
   float* hist; int hist_cap, hist_every, hist_n; long long hist_iter;   // loss history (jrr_engine_set_loss_history)
   float *VTb;       // [3][VP][BP] vertices / transposed vertex adjoint (KEEP_VERTS or SILHOUETTE)
   float *dVTb, *dJnp, *dJn;   // transposed external vertex adjoint [3][VP][BP]; J-gradient partial slabs [3*nsplitJ][32][VP]
@@ -589,6 +646,7 @@ extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const
   if (!e || !J) { jrr_set_error("set_j_regressor: null"); return JRR_ERR_ARG; }
   if (!e->has_model) { jrr_set_error("engine was created without an SMPL model (discriminators only)"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
+  e->jsup_fits_known = false;      // a regressor from outside: its support is not known to fit until jrr_j_support_info says so
   JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   e->have_mask = mask != nullptr;
@@ -1171,7 +1229,7 @@ static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, floa
                         hipStream_t s);
 
 // Shared-parameter state of the in-call J steps (jrr_refine_run_j_steps)
-struct JStepArgs { int every; float* J; float* m; float* v; int32_t* step; float lr; const float* mask; float* sqerr; };
+struct JStepArgs { int every; float* J; float* m; float* v; int32_t* step; float lr; const float* mask; float* sqerr; bool reuse; };
 
 static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const float* gt_mm, float* adam_m,
                            float* adam_v, int32_t* step, float lr, int n_iters, float* sqerr, bool reuse_first,
@@ -1299,7 +1357,8 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       if (rcj) return rcj;
       rcj = j_step_apply(e, js->J, e->dJraw, js->m, js->v, js->step, js->lr, js->mask, s);
       if (rcj) return rcj;
-      reuse_next = true;
+      reuse_next = js->reuse;
+      if (!js->reuse) e->fwd_cached = false;
     }
   }
   CHECK_LAUNCH();
@@ -1322,8 +1381,8 @@ extern "C" int jrr_refine_run_j_steps(jrr_engine_t* e, float* x6d, float* betas,
                                       float* j_sqerr, int after_j_step, void* stream) {
   if (!e || j_every <= 0 || !J || !J_m || !J_v || !J_step) { jrr_set_error("refine_run_j_steps: bad argument"); return JRR_ERR_ARG; }
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("J step requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
-  JStepArgs js{j_every, J, J_m, J_v, J_step, j_lr, mask, j_sqerr};
-  return refine_run_impl(e, x6d, betas, gt_mm, adam_m, adam_v, step, lr, n_iters, sqerr, after_j_step != 0, &js, stream);
+  JStepArgs js{j_every, J, J_m, J_v, J_step, j_lr, mask, j_sqerr, (after_j_step & 2) == 0};
+  return refine_run_impl(e, x6d, betas, gt_mm, adam_m, adam_v, step, lr, n_iters, sqerr, (after_j_step & 1) != 0, &js, stream);
 }
 
 // =============================================================================================
@@ -1362,6 +1421,49 @@ extern "C" int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d, const flo
   return j_step_local(e, x6d, betas, gt_mm, dJ, sqerr, (hipStream_t)stream, joints);
 }
 
+// ---- the J step's all-reduce payload restricted to the regressor's support (include/jrr.h) ----
+extern "C" int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t* fits_host, void* stream) {
+  if (!e || !fits_host) return JRR_ERR_ARG;
+  if (!e->have_jsup || !e->have_J) { jrr_set_error("j_support_info: needs JRR_FLAG_KEEP_VERTS and a regressor"); return JRR_ERR_STATE; }
+  int32_t cnt[32] = {0}, flag = 0;
+  JRR_HIP(hipStreamSynchronize((hipStream_t)stream));
+  JRR_HIP(hipMemcpy(cnt, e->jsup.cnt, NH * sizeof(int32_t), hipMemcpyDeviceToHost));
+  JRR_HIP(hipMemcpy(&flag, e->jsup.flag, sizeof(int32_t), hipMemcpyDeviceToHost));
+  if (counts_host) for (int i = 0; i < NH; ++i) counts_host[i] = cnt[i];
+  *fits_host = flag;
+  e->jsup_fits_known = flag != 0;      // stays true under J steps (ReLU' = 0: Adam never re-activates an entry); cleared by set_j_regressor
+  return JRR_OK;
+}
+
+extern "C" int jrr_j_regressor_grad_support(jrr_engine_t* e, const float* x6d, const float* betas, const float* gt_mm,
+                                            float* dJs, float* sqerr, float* joints, void* stream) {
+  if (!e || !x6d || !betas || !gt_mm || !dJs) return JRR_ERR_ARG;
+  if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
+  if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("J step requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
+  if (!e->jsup_fits_known) { jrr_set_error("j_regressor_grad_support: call jrr_j_support_info first (it must report fits = 1)"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  int rc = j_step_local(e, x6d, betas, gt_mm, e->dJraw, sqerr, s, joints);
+  if (rc) return rc;
+  launch_jsup_gather(e->jsup, e->dJraw, e->m.p2v, dJs, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_j_step_apply_support(jrr_engine_t* e, float* J, const float* dJs, float* m, float* v, int32_t* step, float lr,
+                                        const float* mask, void* stream) {
+  if (!e || !J || !dJs || !m || !v || !step) { jrr_set_error("j_step_apply_support: null"); return JRR_ERR_ARG; }
+  if (!(e->flags & JRR_FLAG_KEEP_VERTS) || !e->jsup_fits_known) { jrr_set_error("j_step_apply_support: call jrr_j_support_info first (KEEP_VERTS engine, fits = 1)"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  // the dense gradient the optimiser sees: zero outside the support (exactly what the dense path holds there), the
+  // all-reduced values on it.  Adam itself stays dense: entries that left the support keep coasting on their momentum.
+  JRR_HIP(hipMemsetAsync(e->dJraw, 0, (size_t)NH * V * sizeof(float), s));
+  launch_jsup_scatter(e->jsup, dJs, e->m.p2v, e->dJraw, s);
+  const bool known = e->jsup_fits_known;
+  int rc = j_step_apply(e, J, e->dJraw, m, v, step, lr, mask, s);
+  e->jsup_fits_known = known;
+  return rc;
+}
+
 // torch.optim.Adam on the raw regressor with the (all-reduced) gradient, then J*mask -> ReLU -> row-normalise into the
 // engine's layouts: the second half of the J step in ONE call (step counter incremented on the device).  The forward
 // cached by jrr_j_regressor_grad stays valid: it does not depend on the regressor.
@@ -1376,9 +1478,10 @@ static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, floa
                         hipStream_t s) {
   launch_step_inc(step, s);
   launch_adam_flat(J, dJ, m, v, (size_t)NH * V, step, lr, 0.9f, 0.999f, 1e-8f, s);
-  const bool cached = e->fwd_cached;
+  const bool cached = e->fwd_cached, known = e->jsup_fits_known;
   int rc = jrr_engine_set_j_regressor(e, J, mask, (void*)s);
   e->fwd_cached = cached;
+  e->jsup_fits_known = known;      // the stepped regressor's support is a subset of the old one (ReLU' = 0 outside it)
   return rc;
 }
 

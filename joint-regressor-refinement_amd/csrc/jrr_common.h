@@ -24,7 +24,9 @@ constexpr int BG = 128;        // poses per forward workgroup (4 waves)
 constexpr int FOLD_MJ = 512;   // (H36M joint, SMPL joint) pairs 17*24 = 408, padded
 constexpr int FOLD_M = 1280;   // (i, j, c) triples 1224, padded to 10 x 128
 constexpr int NPARAM = 154;    // 144 pose6d + 10 betas per pose
-constexpr int KJS_MAX = 12;    // most joints per vertex tile the joint-sparse skinning kernels are built for (8 and 12)
+constexpr int KJS_MAX = 12;    // joint SLOTS per vertex tile and pass the joint-sparse skinning kernels are built for (8 and 12)
+constexpr int KJS_TILE_MAX = 16;   // most joints one tile may have under the joint-sparse kernels (two passes; the backward
+                                  // kernel's dA products run over 16-row joint windows); one tile above it: dense kernels
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -131,11 +133,17 @@ struct Model {
   float* Wjv;   // [VT][24][32]      skinning weights W^T tile  (lane = vertex)
   float* Wvj;   // [VT][32][32]      skinning weights tile [vertex][joint padded to 32] (lane = joint)
   // Joint-sparse skinning: every SMPL vertex has <= 4 influences, and a tile of 32 consecutive vertices usually few
-  // joints in total.  kjs = 8 or 12 when EVERY tile of this model has at most that many (0: the dense kernels run).  Per
-  // tile: the ascending list of its joints (padded to kjs with joint 0 and zero weights) and the W^T rows of exactly those.
-  float* Wc;    // [VT][kjs][32] (+ one tile of slack)
-  int* jl;      // [VT][kjs]
+  // joints in total.  kjs = 8 or 12 = the joint SLOTS a tile's skinning products run over per pass (0: the dense kernels
+  // run: some tile has more than KJS_TILE_MAX joints, or JRR_DENSE_SKINNING=1).  Per tile: the ascending list of its joints
+  // (NJ slots, padded with joint 0 and zero weights), the W^T rows of exactly those, and the joint count.  PER-TILE CLASSES:
+  // a tile with more than kjs joints ("wide") runs a second pass over slots kjs .. 2 kjs - 1 in the forward kernel and
+  // extra K steps of the T recompute in the backward kernel -- it costs itself, not the model.
+  float* Wc;    // [VT][NJ][32] (+ one tile of slack)
+  int* jl;      // [VT][NJ]
+  int* tnj;     // [VT] joints of the tile
   int kjs;
+  int wide_tiles, most_joints, permuted;      // tiles above kjs joints; most joints of any tile; internal order != file order
+  int tile_hist[NJ + 1];                      // tiles by joint count (jrr_model_info)
   // Joint WINDOWS of the backward kernel's dA products (kjs > 0).  dA_{r,c}[j][pose] = sum_v W[v][j] (...) only has
   // non-zero rows for the joints that skin the tile; it is accumulated over the tiles of a vertex chunk, so the rows must
   // mean the same joints from tile to tile: consecutive tiles are grouped (greedily, at model upload) into SEGMENTS whose
@@ -145,7 +153,8 @@ struct Model {
   int* segid;   // [VT]              segment of each tile
   int* segj;    // [VT][16]          the window of the tile's segment: joint of row n, -1 = unused row
   int bwd16;    // kjs > 0: run the symmetric 16-pose backward kernel k_lbs_bwd16 (0 with JRR_BWD16=0 in the environment
-                // of jrr_model_create: the role kernel k_lbs_bwd<., kjs>)
+                // of jrr_model_create: the role kernel k_lbs_bwd<., role_kjs>)
+  int role_kjs; // joint slots of the role kernel's T recompute: kjs when no tile is wide, else 0 (its dense form)
   // Internal vertex order.  Nothing inside the LBS path depends on WHICH vertex sits in which row (every consumer sums
   // over vertices), so jrr_model_create may store the vertices in an order that makes the tiles joint-coherent (sorted
   // by their influencing joints) when the file order does not fit kjs.  p2v / v2p are NULL for the identity; otherwise
@@ -168,7 +177,9 @@ inline size_t round_up(size_t x, size_t m) { return (x + m - 1) / m * m; }
 
 struct jrr_model {
   jrr::Model d;
-  void* base;
+  void* base;      // the model buffer (jrr_model_bytes): the caller's (jrr_model_create_in) or the library's own
+  bool owns_base;
+  int* faces_area; // tail of the buffer: faces [MAX_FACES][3], faces in internal row indices [MAX_FACES][3]
   int* v2p_host;   // host copy of Model::v2p (jrr_model_set_faces), NULL for the identity order
 };
 

@@ -98,6 +98,8 @@ int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, floa
 int launch_jgrad_sparse(const JSupport& sup, const float* dJT, const float* VTq, float* dJn, int BP, hipStream_t s);
 // joints of the stored vertices with the current regressor, one slab [3][32][BP] (rows i < 17), support entries only
 int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, int BP, hipStream_t s);
+int launch_jsup_gather(const JSupport& sup, const float* dJ, const int* p2v, float* out, hipStream_t s);
+int launch_jsup_scatter(const JSupport& sup, const float* in, const int* p2v, float* dJ, hipStream_t s);
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
                     float* dJ, const int* v2p, hipStream_t s);
 

@@ -51,7 +51,7 @@ constexpr int TB_JN = 0, TB_WJV = NHP * 32, TB_WVJ = TB_WJV + W_FLOATS, TB_FLOAT
 // [32 v][32 j]; the record then ends at 1920 floats: 8 of the 10 DMA pieces
 constexpr int TB_W16_FLOATS = 16 * 36, TB_PIECES_SPARSE = 8;
 // record of k_lbs_bwd16 (below): JN | WT | WD | JL, 7 DMA pieces
-constexpr int R16_JN = 0, R16_WT = 640, R16_WD = 1024, R16_JL = 1536, R16_FLOATS = 1792, R16_PIECES = 7;
+constexpr int R16_JN = 0, R16_WT = 640, R16_WD = 1024, R16_JL = 1536, R16_WX = 1552, R16_FLOATS = 1792, R16_PIECES = 7;   // WX: K step 3 of WT
 // v_mfma_f32_16x16x1_4b_f32: four independent 16x16 outer products per instruction (block = lane / 16), 8 passes = half the
 // issue time of v_mfma_f32_32x32x2_f32 (33 vs 64 clocks measured, tools/probe/mfma16_probe.hip):
 //   A: lane l holds A_blk[row l % 16],  B: lane l holds B_blk[col l % 16],  blk = l / 16
@@ -82,12 +82,12 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
                                                     const float* __restrict__ AT, float* __restrict__ VPb,
                                                     float* __restrict__ JP, float* __restrict__ VTb, int B, int BP,
                                                     int nvc, long long* __restrict__ probe, int paired,
-                                                    const int* __restrict__ jl) {
+                                                    const int* __restrict__ jl, const int* __restrict__ tnj) {
   constexpr bool SPARSE = KJ > 0;
   constexpr int KJS = SPARSE ? KJ : 8;                       // (8: keeps the dead sparse branch of the dense variant well-formed)
   constexpr int NST = SPARSE ? NKCH + 3 : NSTAGE;            // stages per vertex tile
-  constexpr int WT_FLOATS = SPARSE ? KJS * 32 : W_FLOATS;    // W^T rows staged per tile
-  constexpr int WT_COPIES = (WT_FLOATS + 255) / 256;
+  constexpr int WT_FLOATS = SPARSE ? KJS * 32 : W_FLOATS;    // W^T rows staged per tile (a WIDE tile: 2 KJS rows)
+  constexpr int WT_COPIES = (WT_FLOATS + 255) / 256, WT_COPIES_WIDE = (2 * WT_FLOATS + 255) / 256;
   __shared__ float lds[2 * STG_FLOATS + 2 * WJ_FLOATS];
   // shader-clock probe (profiling only), see jrr_engine_probe_read
   const long long probe_t0 = probe ? clock64() : 0, probe_w0 = probe ? wall_clock64() : 0;
@@ -129,9 +129,12 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   const float* const Fbg = FT + (size_t)bg * BG;
   const float* const Abg = AT + (size_t)bg * BG;
   unsigned lane_jl[2] = {0, 0};   // SPARSE: (row of this lane's joint of the current tile) * BP + pose offset, floats
+  unsigned lane_jx[2] = {0, 0};   // ... of the SECOND pass of a wide tile (slots KJS .. 2 KJS - 1)
+  int wide = 0, wide_next = 0;    // this tile / the next tile has more than KJS joints (wave-uniform)
+  long long n_extra = 0;          // second passes run (probe)
 
   // ---- DMA issue for stage s of tile vt into ring slot `slot` ----
-  auto issue = [&](int vt, int s, int slot) {
+  auto issue = [&](int vt, int s, int slot, int pass = 0, int wide_w = 0) {
     float* dst = ring + slot * STG_FLOATS;
     if (s < NKCH) {
       const float* dsrc = Dk + ((size_t)vt * KFP + s * KCH) * 96;
@@ -145,7 +148,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
       }
       if (s == 0) {
         float* wdst = wj + (vt & 1) * WJ_FLOATS;
-        if (wv < WT_COPIES) dma16u(Wjv + (size_t)vt * WT_FLOATS + wv * 256, lane_ln, wdst + wv * 256);   // (KJ = 12: the 2nd copy runs 128 floats into the next tile's rows; unused)
+        // (the table holds NJ slot rows per tile; a wide tile -- `wide_w`, wave-uniform -- stages 2 KJS of them)
+        if (wv < ((SPARSE && wide_w) ? WT_COPIES_WIDE : WT_COPIES)) dma16u(Wjv + (size_t)vt * W_FLOATS + wv * 256, lane_ln, wdst + wv * 256);
         dma16u(Jn_vi + (size_t)vt * JN_FLOATS + wv * 256, lane_ln, wdst + W_FLOATS + wv * 256);
       }
     } else if (SPARSE) {
@@ -153,11 +157,12 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
       // wv of each -- the rows of joints jl[2 wv], jl[2 wv + 1] (lane offset `lane_jl[0]`, set per tile) -- and, with 12
       // joints, waves 0 and 1 also row pair 4 + wv (`lane_jl[1]`)
       const int r = s - NKCH;
+      const unsigned o0 = pass ? lane_jx[0] : lane_jl[0], o1 = pass ? lane_jx[1] : lane_jl[1];
 #pragma unroll
       for (int ci = 0; ci < 4; ++ci) {
         const int c = (ci == 0) ? 3 : ci - 1;
-        dma16u(Abg + (size_t)((r * 4 + c) * NJ) * BP, lane_jl[0], dst + ci * (KJS * BG) + wv * 256);
-        if (KJS > 8 && wv < KJS / 2 - 4) dma16u(Abg + (size_t)((r * 4 + c) * NJ) * BP, lane_jl[1], dst + ci * (KJS * BG) + (4 + wv) * 256);
+        dma16u(Abg + (size_t)((r * 4 + c) * NJ) * BP, o0, dst + ci * (KJS * BG) + wv * 256);
+        if (KJS > 8 && wv < KJS / 2 - 4) dma16u(Abg + (size_t)((r * 4 + c) * NJ) * BP, o1, dst + ci * (KJS * BG) + (4 + wv) * 256);
       }
     } else {
       const int h = s - NKCH, r = h >> 1;
@@ -203,17 +208,29 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     j16[r] += p16;
   };
 
-  if (t_begin < t_end) issue(t_begin, 0, 0);
+  if (SPARSE && t_begin < t_end) wide_next = tnj[t_begin] > KJS;
+  if (t_begin < t_end) issue(t_begin, 0, 0, 0, wide_next);
   int g = 0;   // global stage counter: ring slot = g & 1
   for (int vt = t_begin; vt < t_end; ++vt) {
     const float* ldsW = wj + (vt & 1) * WJ_FLOATS;
     const float* ldsJ = ldsW + W_FLOATS;
     if (SPARSE) {      // the skinning copies of this tile are issued from its stage NKCH - 1 on
-      const int j0 = jl[vt * KJS + 2 * wv], j1 = jl[vt * KJS + 2 * wv + 1];      // wave-uniform: scalar loads
+      wide = wide_next;
+      wide_next = (vt + 1 < t_end) ? (tnj[vt + 1] > KJS) : 0;                      // wave-uniform: scalar loads
+      const int j0 = jl[vt * NJ + 2 * wv], j1 = jl[vt * NJ + 2 * wv + 1];
       lane_jl[0] = (unsigned)(half ? j1 : j0) * (unsigned)BP + (unsigned)l31 * 4u;
       if (KJS > 8 && wv < KJS / 2 - 4) {
-        const int j2 = jl[vt * KJS + 8 + 2 * wv], j3 = jl[vt * KJS + 8 + 2 * wv + 1];
+        const int j2 = jl[vt * NJ + 8 + 2 * wv], j3 = jl[vt * NJ + 8 + 2 * wv + 1];
         lane_jl[1] = (unsigned)(half ? j3 : j2) * (unsigned)BP + (unsigned)l31 * 4u;
+      }
+      if (wide) {      // second pass: slots KJS .. 2 KJS - 1
+        const int k0 = jl[vt * NJ + KJS + 2 * wv], k1 = jl[vt * NJ + KJS + 2 * wv + 1];
+        lane_jx[0] = (unsigned)(half ? k1 : k0) * (unsigned)BP + (unsigned)l31 * 4u;
+        if (KJS > 8 && wv < KJS / 2 - 4) {
+          const int k2 = jl[vt * NJ + KJS + 8 + 2 * wv], k3 = jl[vt * NJ + KJS + 8 + 2 * wv + 1];
+          lane_jx[1] = (unsigned)(half ? k3 : k2) * (unsigned)BP + (unsigned)l31 * 4u;
+        }
+        ++n_extra;
       }
     }
     static_for<0, NST>([&](auto S_) {
@@ -230,8 +247,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         if (s == 0 && vt == t_begin) barrier_keep_vm<0>();
         else barrier_keep_vm<nst>();
       }
-      if (s + 1 < NST) issue(vt, s + 1, (g + 1) & 1);
-      else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1);
+      // the stage that follows this one: a wide tile's skinning stage r is followed by its second pass over the same r
+      if (SPARSE && s >= NKCH && wide) issue(vt, s, (g + 1) & 1, 1);
+      else if (s + 1 < NST) issue(vt, s + 1, (g + 1) & 1);
+      else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1, 0, wide_next);
       __builtin_amdgcn_sched_barrier(0);   // the counted wait above relies on: copies first, this stage's stores after
       const float* buf = ring + (g & 1) * STG_FLOATS;
       if constexpr (s < NKCH) {
@@ -292,6 +311,36 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         }
         vr += T * vp[1];                         // T_{r,1} v_y
         vr += U * vp[2];                         // T_{r,2} v_z
+        if (wide) {
+          // ---- second pass of a WIDE tile (more than KJS joints): the same four products over slots KJS .. 2 KJS - 1,
+          //      added to vr.  Its own ring stage: every copy and store of this wave is drained at its barrier (rare path).
+          ++g;
+          barrier_keep_vm<0>();
+          if (s + 1 < NST) issue(vt, s + 1, (g + 1) & 1);
+          else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1, 0, wide_next);
+          __builtin_amdgcn_sched_barrier(0);
+          const float* bx = ring + (g & 1) * STG_FLOATS + half * BG + wave * BT + l31;
+          const float* wx = ldsW + (KJS + half) * 32 + l31;
+          // (two accumulators at a time, like the first pass: the register budget of the hot path is the kernel's)
+          T = zero16(); U = zero16();
+#pragma unroll
+          for (int pq = 0; pq < KJS / 2; ++pq) {
+            const float wq = wx[2 * pq * 32];
+            T = mfma(wq, bx[2 * pq * BG], T);
+            U = mfma(wq, bx[KJS * BG + 2 * pq * BG], U);
+          }
+          vr += T;
+          vr += U * vp[0];
+          T = zero16(); U = zero16();
+#pragma unroll
+          for (int pq = 0; pq < KJS / 2; ++pq) {
+            const float wq = wx[2 * pq * 32];
+            T = mfma(wq, bx[2 * KJS * BG + 2 * pq * BG], T);
+            U = mfma(wq, bx[3 * KJS * BG + 2 * pq * BG], U);
+          }
+          vr += T * vp[1];
+          vr += U * vp[2];
+        }
         if (STORE_VERTS) {
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
@@ -300,6 +349,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
           }
         }
         regress(std::integral_constant<int, r>{}, ldsJ);
+        // after a second pass the next stage's counted wait (which assumes this stage's stores are all younger than its
+        // copies) no longer holds: drain
+        if (wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         constexpr int h = s - NKCH, r = h >> 1;
         if (STORE_VP) {   // spread the v_posed stores over the six skinning stages: two 16-byte row quads each
@@ -367,7 +419,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   }
   if (probe && blockIdx.x == 0 && tid == 0) {
     probe[0] = clock64() - probe_t0;                 // shader clocks this wave was resident
-    probe[1] = (long long)(t_end - t_begin) * (SPARSE ? (KF / 2) * 3 + 3 * 2 * KJS + 3 * 16 : LBS_FWD_MFMA_PER_TILE);   // MFMA instructions it issued
+    probe[1] = (long long)(t_end - t_begin) * (SPARSE ? (KF / 2) * 3 + 3 * 2 * KJS + 3 * 16 : LBS_FWD_MFMA_PER_TILE) + n_extra * 3 * 2 * KJS;   // MFMA instructions it issued
     probe[2] = wall_clock64() - probe_w0;            // the same interval on the constant 100 MHz counter
   }
 }
@@ -469,7 +521,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
                 lo += __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 hi += __hip_atomic_load(dst + 16, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
               }
-              dst[0] = lo; dst[16] = hi;
+              // agent-scope stores: a later flush of this wave re-reads them (possibly from another lane) with agent-scope loads
+              __hip_atomic_store(dst, lo, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(dst + 16, hi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             }
           }
         }
@@ -529,7 +583,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
         float w[KJS / 2], a0[KJS / 2], a1[KJS / 2], a2[KJS / 2];
 #pragma unroll
         for (int pq = 0; pq < KJS / 2; ++pq) {
-          const int j0 = jl[vt * KJS + 2 * pq], j1 = jl[vt * KJS + 2 * pq + 1];          // wave-uniform: scalar loads
+          const int j0 = jl[vt * NJ + 2 * pq], j1 = jl[vt * NJ + 2 * pq + 1];            // wave-uniform: scalar loads
           const float* ap = ldsA + (half ? j1 : j0) * 32 + l31;
           w[pq] = wp[2 * pq * 32]; a0[pq] = ap[0]; a1[pq] = ap[12 * 64]; a2[pq] = ap[24 * 64];
         }
@@ -749,6 +803,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 //     WT [blk][s < 3][64 lanes]   W[16 blk + m][joint slot 4 s + g]       A operands of T       (slots >= KJ: 0)
 //     WD [blk][g][n][4]           W16[n][16 blk + 4 g + 0..3]             A operands of dA, one ds_read_b128 per blk
 //     JL [16]                     16 * joint of slot k (ints)              row offsets into the wave's A^T slice
+//     WX [blk][64 lanes]          K step 3 of WT (joint slots 12 .. 15)   a WIDE tile's T recompute runs ceil(joints / 4) K steps:
+//   the kernel is built for S = KJ / 4 of them; a tile with more joints (tnj[vt] > KJ, at most 16) runs the extra steps in a
+//   rare wave-uniform branch -- it costs itself, nobody else.
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -758,7 +815,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
                                                       const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                       const float* __restrict__ dVT, float* __restrict__ DVP,
                                                       float* __restrict__ dATp, int BP, int nvc, int n_bt,
-                                                      const int* __restrict__ segid, const int* __restrict__ segj, int paired) {
+                                                      const int* __restrict__ segid, const int* __restrict__ segj, int paired,
+                                                      const int* __restrict__ tnj) {
   constexpr int S = KJ / 4;                          // K steps of the T product (4 joint slots each)
   constexpr int ASL = 9 * NJ * 16;                   // floats of one wave's A^T slice [(r,c)][24 joints][16 poses]
   __shared__ __attribute__((aligned(16))) float lds[BWD_RING * R16_FLOATS + 4 * ASL];
@@ -856,7 +914,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
           float* dst = dATp + ((size_t)(vc * 12 + ent) * NJ + j) * BP + bcol;
           float val = acc[e][i];
           if (add) val += __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L1 bypassed: an earlier flush of this wave stored it, possibly from another lane
-          dst[0] = val;
+          __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // paired with the agent-scope re-read of a later flush
         }
       }
     }
@@ -910,6 +968,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) wd[blk] = *reinterpret_cast<const f32x4*>(tab + R16_WD + ((blk * 4 + g) * 16 + n) * 4);
     const int sg = segid[vt];                                      // wave-uniform
+    const int s_tile = (tnj[vt] + 3) >> 2;                         // K steps this tile's joints need (wave-uniform)
     if (sg != cur_seg) { flush_window(); cur_seg = sg; }
     seg_tile = vt;
     // ---- translation column: dA_{r,3} += W16^T dverts_r ----
@@ -933,6 +992,20 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
           T[r][0] = mfma4(wt[0][s], at, T[r][0]);
           T[r][1] = mfma4(wt[1][s], at, T[r][1]);
         }
+      if (s_tile > S) {                                             // WIDE tile: the K steps beyond the kernel's S (slots 4 S .. 15)
+#pragma unroll 1
+        for (int s = S; s < s_tile && s < 4; ++s) {
+          const int jox = reinterpret_cast<const int*>(tab + R16_JL)[4 * s + g];
+          const float w0 = s < 3 ? tab[R16_WT + (0 * 3 + s) * 64 + lane] : tab[R16_WX + lane];
+          const float w1 = s < 3 ? tab[R16_WT + (1 * 3 + s) * 64 + lane] : tab[R16_WX + 64 + lane];
+#pragma unroll
+          for (int r = 0; r < 3; ++r) {
+            const float at = ldsA[(r * 3 + c) * (NJ * 16) + jox + n];
+            T[r][0] = mfma4(w0, at, T[r][0]);
+            T[r][1] = mfma4(w1, at, T[r][1]);
+          }
+        }
+      }
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk) {
         f32x4 t;
@@ -980,20 +1053,24 @@ __global__ void k_bwd_tab_static(const float* __restrict__ Wjv, const float* __r
   if (r16) {      // record R16 of k_lbs_bwd16 (everything but its JN block, which k_jreg_tiles writes)
     if (k >= R16_FLOATS - R16_WT) return;
     const int o = R16_WT + k;
+    // joint slots: the NJ-slot tables of the model (Wc [VT][NJ][32], jl [VT][NJ]); 16 of them fit the record
     if (o < R16_WD) {               // WT [blk][s < 3][g][m] = W[16 blk + m][slot 4 s + g]
       const int q = o - R16_WT, blk = q / 192, s = (q / 64) % 3, g = (q >> 4) & 3, m = q & 15;
       const int slot = 4 * s + g;
-      dst[o] = slot < kjs ? Wc[((size_t)vt * kjs + slot) * 32 + 16 * blk + m] : 0.f;
+      dst[o] = Wc[((size_t)vt * NJ + slot) * 32 + 16 * blk + m];
     } else if (o < R16_JL) {        // WD [blk][g][n][i] = W16[n][16 blk + 4 g + i]
       const int q = o - R16_WD, blk = q >> 8, g = (q >> 6) & 3, n = (q >> 2) & 15, i = q & 3;
       dst[o] = W16[(size_t)vt * TB_W16_FLOATS + n * 36 + 16 * blk + 4 * g + i];
-    } else {                        // JL [16]: 16 * joint of slot k (row offset into a wave's A^T slice), as an int
+    } else if (o < R16_WX) {        // JL [16]: 16 * joint of slot k (row offset into a wave's A^T slice), as an int
       const int q = o - R16_JL;
-      reinterpret_cast<int*>(dst)[o] = (q < kjs) ? 16 * jl[vt * kjs + q] : 0;
-    }
+      reinterpret_cast<int*>(dst)[o] = 16 * jl[vt * NJ + q];
+    } else if (o < R16_WX + 128) {  // WX [blk][g][m] = W[16 blk + m][slot 12 + g]: K step 3
+      const int q = o - R16_WX, blk = q >> 6, g = (q >> 4) & 3, m = q & 15;
+      dst[o] = Wc[((size_t)vt * NJ + 12 + g) * 32 + 16 * blk + m];
+    } else dst[o] = 0.f;
     return;
   }
-  if (k < W_FLOATS) dst[TB_WJV + k] = Wc ? (k < kjs * 32 ? Wc[(size_t)vt * kjs * 32 + k] : 0.f) : Wjv[(size_t)vt * W_FLOATS + k];
+  if (k < W_FLOATS) dst[TB_WJV + k] = Wc ? (k < kjs * 32 ? Wc[(size_t)vt * W_FLOATS + k] : 0.f) : Wjv[(size_t)vt * W_FLOATS + k];
   else if (k < W_FLOATS + 1024) {
     const int kk = k - W_FLOATS;
     dst[TB_WVJ + kk] = Wc ? (kk < TB_W16_FLOATS ? W16[(size_t)vt * TB_W16_FLOATS + kk] : 0.f) : Wvj[(size_t)vt * 1024 + kk];
@@ -1198,12 +1275,36 @@ __global__ __launch_bounds__(256) void k_rejoints_sparse(JSupport sup, const flo
   for (int r = 0; r < 3; ++r) out[(size_t)(r * 32 + i) * BP + b] = acc[r];
 }
 
+// The J step's gradient restricted to the regressor's support, for the data-parallel all-reduce: dJ (17 x 6890, file order of
+// the columns) is exactly zero outside the support, so the ranks exchange [17][JSUP_CAP] floats instead of 468 520 bytes.
+// gather: out[i][e] = dJ[i][vertex of support entry e] (0 behind the row's count); scatter: the inverse into a zero-filled dJ.
+__global__ __launch_bounds__(JSUP_CAP) void k_jsup_gather(JSupport sup, const float* __restrict__ dJ, const int* __restrict__ p2v,
+                                                          float* __restrict__ out) {
+  const int i = blockIdx.x, e = threadIdx.x;
+  float val = 0.f;
+  if (e < sup.cnt[i]) { const int row = sup.col[i * JSUP_CAP + e]; val = dJ[(size_t)i * V + (p2v ? p2v[row] : row)]; }
+  out[i * JSUP_CAP + e] = val;
+}
+__global__ __launch_bounds__(JSUP_CAP) void k_jsup_scatter(JSupport sup, const float* __restrict__ in, const int* __restrict__ p2v,
+                                                           float* __restrict__ dJ) {
+  const int i = blockIdx.x, e = threadIdx.x;
+  if (e < sup.cnt[i]) { const int row = sup.col[i * JSUP_CAP + e]; dJ[(size_t)i * V + (p2v ? p2v[row] : row)] = in[i * JSUP_CAP + e]; }
+}
+int launch_jsup_gather(const JSupport& sup, const float* dJ, const int* p2v, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_jsup_gather, dim3(NH), dim3(JSUP_CAP), 0, s, sup, dJ, p2v, out);
+  return 0;
+}
+int launch_jsup_scatter(const JSupport& sup, const float* in, const int* p2v, float* dJ, hipStream_t s) {
+  hipLaunchKernelGGL(k_jsup_scatter, dim3(NH), dim3(JSUP_CAP), 0, s, sup, in, p2v, dJ);
+  return 0;
+}
+
 int launch_jgrad_sparse(const JSupport& sup, const float* dJT, const float* VTq, float* dJn, int BP, hipStream_t s) {
   hipLaunchKernelGGL(k_jgrad_sparse, dim3(NH, 16), dim3(256), 0, s, sup, dJT, VTq, dJn, BP);
   return 0;
 }
 int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_rejoints_sparse, dim3(BP / 256 > 0 ? BP / 256 : 1, NH), dim3(256), 0, s, sup, VTq, out, BP);
+  hipLaunchKernelGGL(k_rejoints_sparse, dim3((BP + 255) / 256, NH), dim3(256), 0, s, sup, VTq, out, BP);   // BP is a multiple of 128 only: round UP (the kernel guards b >= BP)
   return 0;
 }
 
@@ -1245,13 +1346,13 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
   do {                                                                                                                            \
     if (m.kjs == 8)                                                                                                               \
       hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, 8>), grid, block, 0, s, m.Dk, m.Wc, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,      \
-                         probe, paired, m.jl);                                                                                    \
+                         probe, paired, m.jl, m.tnj);                                                                             \
     else if (m.kjs == 12)                                                                                                         \
       hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, 12>), grid, block, 0, s, m.Dk, m.Wc, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,     \
-                         probe, paired, m.jl);                                                                                    \
+                         probe, paired, m.jl, m.tnj);                                                                             \
     else                                                                                                                          \
       hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, 0>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,     \
-                         probe, paired, m.jl);                                                                                    \
+                         probe, paired, m.jl, m.tnj);                                                                             \
   } while (0)
   if (VPb && verts) JRR_LBS_FWD(true, true);
   else if (VPb) JRR_LBS_FWD(true, false);
@@ -1273,9 +1374,9 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
 #define JRR_LBS_BWD16(DVM)                                                                                                      \
   do {                                                                                                                          \
     if (m.kjs == 8)                                                                                                             \
-      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 8>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj, paired16);  \
+      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 8>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj, paired16, m.tnj);  \
     else                                                                                                                        \
-      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 12>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj, paired16); \
+      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 12>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj, paired16, m.tnj); \
   } while (0)
     if (dVT && dJT) JRR_LBS_BWD16(2);
     else if (dVT) JRR_LBS_BWD16(1);
@@ -1285,11 +1386,12 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
   }
   const int n_bt = BP / BT;                     // one workgroup per (pose tile, vertex chunk)
   dim3 grid(n_bt * nvc), block(256);
+  const int role_kjs = m.role_kjs;              // (the role kernel has no per-tile classes: one wide tile sends it to its dense form)
 #define JRR_LBS_BWD(DVM)                                                                                                        \
   do {                                                                                                                          \
-    if (m.kjs == 8)                                                                                                             \
+    if (role_kjs == 8)                                                                                                          \
       hipLaunchKernelGGL((k_lbs_bwd<DVM, 8>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl, m.segid, m.segj);        \
-    else if (m.kjs == 12)                                                                                                       \
+    else if (role_kjs == 12)                                                                                                    \
       hipLaunchKernelGGL((k_lbs_bwd<DVM, 12>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl, m.segid, m.segj);       \
     else                                                                                                                        \
       hipLaunchKernelGGL((k_lbs_bwd<DVM, 0>), grid, block, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt, m.jl, m.segid, m.segj);        \
@@ -1315,8 +1417,9 @@ int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, floa
 }
 
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s) {
-  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb, m.kjs ? m.Wc : nullptr, m.kjs, m.W16, m.jl,
-                     (m.kjs && m.bwd16) ? 1 : 0);
+  const bool r16 = m.kjs && m.bwd16;
+  hipLaunchKernelGGL(k_bwd_tab_static, dim3(VT * 2048 / 256), dim3(256), 0, s, m.Wjv, m.Wvj, Tb, (r16 || m.role_kjs) ? m.Wc : nullptr,
+                     r16 ? m.kjs : m.role_kjs, m.W16, m.jl, r16 ? 1 : 0);
   return 0;
 }
 

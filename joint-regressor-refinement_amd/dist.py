@@ -47,24 +47,34 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
-def flat_all_reduce_sum_(tensors) -> None:
-    """One collective for several gradient tensors (flat bucket), written back in place."""
-    import torch.distributed as dist
-    if not (dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
-        return
-    flat = torch.cat([t.reshape(-1) for t in tensors])
-    dist.all_reduce(flat, op=dist.ReduceOp.SUM)
-    off = 0
-    for t in tensors:
-        n = t.numel()
-        t.copy_(flat[off:off + n].view_as(t))
-        off += n
+class JStepExchange:
+    """The J step between two segments of the inner loop under data parallelism (scripts/optimize.py:300-312 sharded):
+    local gradient -> ONE sum-all-reduce -> replicated Adam + re-normalisation, no allocation, nothing read back.
 
+    The gradient w.r.t. the raw regressor is exactly zero outside the regressor's positive support (ReLU'), and every rank
+    holds the same regressor: when the support fits the engine's device-side lists (asked ONCE, at construction: J steps
+    only shrink it) the ranks exchange the (17,128) support values -- 8 704 bytes instead of 468 520 -- through
+    jrr_j_regressor_grad_support / jrr_j_step_apply_support; otherwise the dense (17,6890) pair.  `reduce` is the
+    collective (default: the all-reduce of this module; bench.py passes a no-op to time the host-driven sequence at
+    world size 1)."""
 
-def shared_adam_step(param: torch.Tensor, local_grad: torch.Tensor, m: torch.Tensor, v: torch.Tensor, step: int,
-                     lr: float, adam_fn) -> None:
-    """Replicated shared-parameter step: all-reduce the local gradient (each rank's gradient is
-    already normalised by the GLOBAL batch, so the sum equals the single-process gradient), then
-    apply the identical Adam update on every rank.  `adam_fn(p, g, m, v, step, lr)` updates in place."""
-    all_reduce_sum_(local_grad)
-    adam_fn(param, local_grad, m, v, step, lr)
+    def __init__(self, eng, dense_buf: torch.Tensor, compact: bool = True, reduce=None):
+        self.eng = eng
+        self.dense = dense_buf
+        self.reduce = reduce if reduce is not None else all_reduce_sum_
+        self.compact = False
+        if compact:
+            _, fits = eng.j_support_info()
+            self.compact = bool(fits)
+        self.buf = torch.zeros(17, eng.J_SUPPORT_CAP, device=dense_buf.device) if self.compact else None
+        self.nbytes = (self.buf if self.compact else self.dense).numel() * 4
+
+    def step(self, J, opt_m, opt_v, opt_step, lr, x6d, betas, gt, mask=None) -> None:
+        if self.compact:
+            self.eng.j_regressor_grad_support(x6d, betas, gt, out=self.buf)
+            self.reduce(self.buf)
+            self.eng.j_step_apply_support(J, self.buf, opt_m, opt_v, opt_step, lr, mask=mask)
+        else:
+            self.eng.j_regressor_grad(x6d, betas, gt, out=self.dense)
+            self.reduce(self.dense)
+            self.eng.j_step_apply(J, self.dense, opt_m, opt_v, opt_step, lr, mask=mask)

@@ -66,10 +66,20 @@ class DeviceModel:
         assert jr.shape == (NUM_JOINTS, NUM_VERTS) and w.shape == (NUM_VERTS, NUM_JOINTS) and par.shape == (NUM_JOINTS,)
         self.faces = model.get('faces')
         h = c_void_p()
+        # the model's device memory is a torch buffer like every other buffer of the path (jrr_model_create_in)
+        nbytes = int(self.lib.jrr_model_bytes())
+        self.buffer = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
+        base = (self.buffer.data_ptr() + 255) // 256 * 256
         with torch.cuda.device(self.device):
-            check(self.lib.jrr_model_create(vt.ctypes.data, sd.ctypes.data, pd.ctypes.data, jr.ctypes.data,
-                                            w.ctypes.data, par.ctypes.data, byref(h)), 'jrr_model_create')
+            check(self.lib.jrr_model_create_in(vt.ctypes.data, sd.ctypes.data, pd.ctypes.data, jr.ctypes.data,
+                                               w.ctypes.data, par.ctypes.data, c_void_p(base), nbytes, byref(h)), 'jrr_model_create_in')
         self.handle = h
+        info = (c_int32 * 29)()
+        check(self.lib.jrr_model_info(self.handle, info, 29), 'jrr_model_info')
+        # what the LBS kernels run for this body: joint slots per tile and pass (0: dense kernels), tiles that need a second
+        # pass, the most joints of any tile, whether the library re-ordered the vertices internally, tiles by joint count
+        self.info = {'joint_slots': int(info[0]), 'wide_tiles': int(info[1]), 'most_joints_per_tile': int(info[2]),
+                     'internal_vertex_order': bool(info[3]), 'tile_joint_histogram': [int(x) for x in info[4:29]]}
         if self.faces is not None:
             f = np.ascontiguousarray(np.asarray(self.faces, dtype=np.int32))
             check(self.lib.jrr_model_set_faces(self.handle, f.ctypes.data, int(f.shape[0])), 'jrr_model_set_faces')
@@ -349,9 +359,11 @@ class RefineEngine:
                  ptr(step), float(lr), int(n_iters), ptr(sqerr), self._s()), 'refine_run')
 
     def refine_run_j_steps(self, x6d, betas, gt_centred_mm, adam_m, adam_v, step, lr: float, n_iters: int, j_every: int,
-                           J, J_m, J_v, J_step, j_lr: float, mask=None, sqerr=None, j_sqerr=None, after_j_step: bool = False):
+                           J, J_m, J_v, J_step, j_lr: float, mask=None, sqerr=None, j_sqerr=None, after_j_step: bool = False,
+                           reuse_forward: bool = True):
         """the inner loop with a J step after every j_every-th iteration, all inside ONE C call (single process only:
-        there is no collective between the two halves of a J step); J / J_m / J_v / J_step are updated in place"""
+        there is no collective between the two halves of a J step); J / J_m / J_v / J_step are updated in place.
+        reuse_forward=False: the iteration after a J step repeats its SMPL forward (include/jrr.h, after_j_step bit 1)"""
         self.generation += 1
         self._refine_args(x6d, betas, gt_centred_mm, adam_m, adam_v, step)
         for t, n in ((J, 'J'), (J_m, 'J_m'), (J_v, 'J_v')):
@@ -359,7 +371,8 @@ class RefineEngine:
         assert J_step.dtype == torch.int32 and J_step.is_cuda
         check(self.lib.jrr_refine_run_j_steps(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(adam_m), ptr(adam_v),
                                               ptr(step), float(lr), int(n_iters), ptr(sqerr), int(j_every), ptr(J), ptr(J_m),
-                                              ptr(J_v), ptr(J_step), float(j_lr), ptr(mask), ptr(j_sqerr), int(bool(after_j_step)),
+                                              ptr(J_v), ptr(J_step), float(j_lr), ptr(mask), ptr(j_sqerr),
+                                              int(bool(after_j_step)) | (0 if reuse_forward else 2),
                                               self._s()), 'refine_run_j_steps')
 
     def j_step_apply(self, J, dJ, J_m, J_v, J_step, lr: float, mask=None):
@@ -402,6 +415,34 @@ class RefineEngine:
         out = (ctypes.c_int64 * 5)()
         check(self.lib.jrr_engine_probe_read(self.handle, out), 'probe_read')
         return tuple(int(x) for x in out)
+
+    # -- J step over the regressor's support (data parallelism: 8.7 KB instead of 468 KB per all-reduce) --------------
+    J_SUPPORT_CAP = 128
+
+    def j_support_info(self):
+        """(counts per row [17], fits): positive entries of the normalised regressor per row and whether every row has at most
+        128 of them.  SYNCHRONOUS; call once after set_j_regressor (J steps only shrink the support)."""
+        counts = (c_int32 * NUM_H36M)()
+        fits = c_int32(0)
+        check(self.lib.jrr_j_support_info(self.handle, counts, byref(fits), self._s()), 'j_support_info')
+        return [int(c) for c in counts], bool(fits.value)
+
+    def j_regressor_grad_support(self, x6d, betas, gt_centred_mm, out, sqerr=None, joints=None):
+        """j_regressor_grad with the gradient delivered on the support only: out (17,128)"""
+        self.generation += 1
+        self._chk(out, (NUM_H36M, self.J_SUPPORT_CAP), 'dJs')
+        check(self.lib.jrr_j_regressor_grad_support(self.handle, ptr(x6d), ptr(betas), ptr(gt_centred_mm), ptr(out), ptr(sqerr),
+                                                    ptr(joints), self._s()), 'j_regressor_grad_support')
+        return out
+
+    def j_step_apply_support(self, J, dJs, J_m, J_v, J_step, lr: float, mask=None):
+        self.generation += 1
+        for t, n in ((J, 'J'), (J_m, 'J_m'), (J_v, 'J_v')):
+            self._chk(t, (NUM_H36M, NUM_VERTS), n)
+        self._chk(dJs, (NUM_H36M, self.J_SUPPORT_CAP), 'dJs')
+        assert J_step.dtype == torch.int32 and J_step.is_cuda
+        check(self.lib.jrr_j_step_apply_support(self.handle, ptr(J), ptr(dJs), ptr(J_m), ptr(J_v), ptr(J_step), float(lr), ptr(mask),
+                                                self._s()), 'j_step_apply_support')
 
     def j_regressor_grad(self, x6d, betas, gt_centred_mm, sqerr=None, out=None, joints=None):
         """local dJ (first half of the J step); `out` (17,6890): write into a caller-owned buffer (e.g. a slice of the flat

@@ -39,9 +39,11 @@ class Mesh_Renderer(nn.Module):
     space first (an exact sign flip and halving).  Channels 0-2 are 1 as pytorch3d's SoftSilhouetteShader returns
     them (sigmoid_alpha_blend of all-ones colours), independent of the textures."""
 
-    def __init__(self, image_size: int = 256, smpl=None):
-        # the default is the reference constructor's (scripts/mesh_renderer.py:25); like every size but 224 it is rejected below --
-        # loudly, rather than silently rendering at another size than the caller's code assumes
+    def __init__(self, image_size: int, smpl=None):
+        # `image_size` is REQUIRED here (the reference constructor defaults to 256, scripts/mesh_renderer.py:25, a size its own
+        # loop never instantiates: scripts/optimize.py:110 passes 224).  A default of 256 would make `Mesh_Renderer()` always
+        # raise, a default of 224 would silently render at another size than code written against the reference assumes; a
+        # missing argument fails at the call site instead.  Every size but 224 is rejected below.
         super().__init__()
         if image_size != 224:
             raise NotImplementedError(f'Mesh_Renderer(image_size={image_size}): the HIP rasteriser is built for the 224x224 image of '

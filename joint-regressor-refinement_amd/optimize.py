@@ -26,8 +26,9 @@ followed by the replicated Adam steps; the bucket's scalar tail is read back ONC
 needs the stepped regressor, so those two sums ride in the NEXT batch's bucket (a last 2-float
 all-reduce flushes them after the final batch): the record of batch k is logged when batch k+1's bucket
 has been read.  A J step inside the inner loop (`--j_step_every` < `--inner_iters`) is
-jrr_j_regressor_grad -> one all-reduce of dJ -> jrr_j_step_apply, with no host synchronisation; in a
-single process the whole loop including those J steps is ONE C call (jrr_refine_run_j_steps).
+jrr_j_regressor_grad[_support] -> one all-reduce (the regressor's support: 8 704 bytes; dist.JStepExchange) ->
+jrr_j_step_apply[_support], with no host synchronisation; in a single process the whole loop including those J
+steps is ONE C call (jrr_refine_run_j_steps).
 Every rank draws the same global batch (same seed) and keeps rows [lo, hi), so a sharded run
 reproduces the single-process run on the same global batch.
 """
@@ -91,7 +92,15 @@ def _dataset_batches(root: str, B_global: int, seed: int, device, drop_last: boo
     ds = jdata.data_set('validation', root=root)
     g = torch.Generator().manual_seed(seed)          # every rank shuffles identically
     loader = torch.utils.data.DataLoader(ds, batch_size=B_global, num_workers=0, shuffle=True, drop_last=drop_last, generator=g)
-    for it, batch in enumerate(loader):
+    iterator = iter(loader)
+    for it in range(len(loader)):
+        try:                                           # scripts/optimize.py:150-156: a batch that fails to load is reported and skipped
+            batch = next(iterator)
+        except StopIteration:
+            return
+        except Exception as exc:                       # noqa: BLE001  (the reference catches everything here)
+            print(f'problem loading batch {it}: {type(exc).__name__}: {exc}')
+            continue
         x6 = pose_to_rot6d(batch['orient'].to(device), batch['pose'].to(device)).cpu()
         yield {'pose6d': x6, 'betas': batch['betas'].float(), 'gt_j3d': batch['gt_j3d'].float(), 'cam': batch['cam'].float(),
                'gt_j2d': batch['gt_j2d'].float(), 'seed': seed * 1000 + it}
@@ -232,10 +241,13 @@ def optimize_pose_refiner(log=print) -> Dict:
         if n_inloop and world == 1:         # one C call for the iterations AND their J steps (no collective needed)
             eng.refine_run_j_steps(x6d, betas, gt_j3d, m, v, step, 1e-2, n_inloop, args.j_step_every, J_regressor, J_opt.m,
                                    J_opt.v, J_opt.step, J_opt.lr, mask=j_reg_mask, sqerr=sq)
-        else:
+        elif n_inloop:
+            # the J step's all-reduce carries the regressor's support only (8.7 KB) when it fits the engine's lists, the dense
+            # (17,6890) gradient otherwise or with --j_allreduce dense (asked once per batch: one small read-back)
+            xch = jdist.JStepExchange(eng, bucket.dJ, compact=args.j_allreduce == 'support')
             for done in range(0, n_inloop, args.j_step_every):
                 eng.refine_run(x6d, betas, gt_j3d, m, v, step, 1e-2, args.j_step_every, sqerr=sq, after_j_step=done > 0)
-                _j_step_in_loop(eng, J_regressor, J_opt, x6d, betas, gt_j3d, j_reg_mask, bucket.dJ)
+                xch.step(J_regressor, J_opt.m, J_opt.v, J_opt.step, J_opt.lr, x6d, betas, gt_j3d, mask=j_reg_mask)
         eng.refine_run(x6d, betas, gt_j3d, m, v, step, 1e-2, args.inner_iters - n_inloop, sqerr=sq, after_j_step=n_inloop > 0)
         bucket.flat.zero_()
         bucket.put(0, sq)                                                                   # joint_loss (:238-239)
@@ -308,14 +320,6 @@ def optimize_pose_refiner(log=print) -> Dict:
         checkpoint.save_j_regressor(J_regressor, args.save_j_regressor)
     return {'history': history, 'J_regressor': J_regressor, 'disc_flat': disc_flat, 'sdisc_flat': sdisc_flat,
             'x6d': x6d, 'betas': betas, 'shard': (lo, hi)}
-
-
-def _j_step_in_loop(eng, J_regressor, J_opt, x6d, betas, gt_j3d, mask, dJ_buf) -> None:
-    """scripts/optimize.py:300-312 between two segments of the inner loop under data parallelism: local dJ, ONE
-    all-reduce of the (17,6890) gradient, replicated Adam + re-normalisation in one call; nothing is read back."""
-    eng.j_regressor_grad(x6d, betas, gt_j3d, out=dJ_buf)
-    jdist.all_reduce_sum_(dJ_buf)
-    eng.j_step_apply(J_regressor, dJ_buf, J_opt.m, J_opt.v, J_opt.step, J_opt.lr, mask=mask)
 
 
 def _synthetic_gt_j2d(eng, x6d, betas, cam, seed, lo, hi, B_global):

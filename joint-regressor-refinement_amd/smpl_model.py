@@ -82,20 +82,84 @@ def _smooth_fields(rng, n: int) -> np.ndarray:
     return out / np.sqrt((out ** 2).mean(axis=1, keepdims=True) + 1e-12)
 
 
-def synthetic_smpl(seed: int = 1234, max_influences: int = 4) -> Dict[str, np.ndarray]:
-    """Seeded synthetic body model with SMPL's shapes and structural properties: a closed body-scale
-    triangle mesh (6890 vertices / 13776 faces, vertex order spatially coherent), shapedirs ~ N(0, 0.01^2),
-    posedirs ~ N(0, 0.002^2), sparse non-negative J_regressor rows summing to 1, <= `max_influences`
-    smooth skinning weights per vertex summing to 1, canonical SMPL parents."""
+def _capsule_surface(rng):
+    """6890 vertices on capsules around the 23 bones of the rest skeleton (265 rings of 26 vertices, shared out by bone length,
+    at least 3 per bone), one open triangle strip grid per bone (faces <= 13776), returned in a seeded RANDOM vertex order --
+    what an arbitrary mesh file looks like to the 32-vertex tiles: no locality at all in the file order."""
+    S = 26
+    n_rings_total = NUM_VERTS // S
+    assert n_rings_total * S == NUM_VERTS
+    bones = [(int(SMPL_PARENTS[j]), j) for j in range(1, NUM_JOINTS)]
+    length = np.array([np.linalg.norm(_REST_JOINTS[c] - _REST_JOINTS[p]) for p, c in bones])
+    rings = np.maximum(3, np.floor(length / length.sum() * n_rings_total).astype(int))
+    while rings.sum() > n_rings_total:
+        rings[np.argmax(rings)] -= 1
+    while rings.sum() < n_rings_total:
+        rings[np.argmax(length / rings)] += 1
+    verts, faces, base = [], [], 0
+    for (p, c), nr in zip(bones, rings):
+        a, b = _REST_JOINTS[p], _REST_JOINTS[c]
+        ax = (b - a) / (np.linalg.norm(b - a) + 1e-12)
+        ref = np.array([0.0, 0.0, 1.0]) if abs(ax[2]) < 0.9 else np.array([1.0, 0.0, 0.0])
+        u = np.cross(ax, ref); u /= np.linalg.norm(u)
+        w = np.cross(ax, u)
+        rad = 0.035 + 0.06 * np.exp(-np.linalg.norm(0.5 * (a + b) - np.array([0.0, 0.0, 0.0])) / 0.35)   # thicker near the trunk
+        for k in range(nr):
+            t = (k + 0.5) / nr
+            taper = np.sqrt(max(1e-3, 1.0 - (2 * t - 1) ** 4))                    # rounded ends
+            for q in range(S):
+                ph = 2 * np.pi * q / S
+                verts.append(a + t * (b - a) + rad * taper * (np.cos(ph) * u + np.sin(ph) * w))
+        for k in range(nr - 1):
+            for q in range(S):
+                v00, v01 = base + k * S + q, base + k * S + (q + 1) % S
+                v10, v11 = v00 + S, v01 + S
+                faces.append((v00, v10, v11)); faces.append((v00, v11, v01))
+        base += nr * S
+    verts = np.stack(verts)
+    faces = np.asarray(faces, dtype=np.int64)
+    perm = rng.permutation(NUM_VERTS)              # file position k holds grid vertex perm[k]
+    inv = np.empty_like(perm); inv[perm] = np.arange(NUM_VERTS)
+    return verts[perm], inv[faces].astype(np.int32)
+
+
+def synthetic_smpl(seed: int = 1234, max_influences: int = 4, kind: str = 'surface') -> Dict[str, np.ndarray]:
+    """Seeded synthetic body model with SMPL's shapes and structural properties.
+    kind='surface' (default; the benchmarked body): a closed body-scale triangle mesh (6890 vertices / 13776 faces, vertex order
+    spatially coherent: ring-major), shapedirs ~ N(0, 0.01^2), posedirs ~ N(0, 0.002^2), sparse non-negative J_regressor rows
+    summing to 1, <= `max_influences` smooth skinning weights per vertex summing to 1, canonical SMPL parents.
+    kind='capsules': vertices on capsules around the 23 bones in a seeded RANDOM file order, the 4 nearest joints skin each
+    vertex -- the stand-in for a real model file whose vertex order means nothing to the 32-vertex tiles of the LBS kernels
+    (the library's internal joint-sorted order then decides the tile classes)."""
+    if kind == 'capsules':
+        return _synthetic_from_surface(seed, max_influences, *_capsule_surface(np.random.RandomState(seed + 99)), smooth=False,
+                                       provenance=f'synthetic-capsules(seed={seed})')
+    if kind != 'surface':
+        raise ValueError(f'unknown synthetic body kind {kind!r}')
+    v_template, faces = _body_surface()
+    assert v_template.shape == (NUM_VERTS, 3) and faces.shape == (13776, 3)
+    return _synthetic_from_surface(seed, max_influences, v_template, faces, smooth=True, provenance=None)
+
+
+def _synthetic_from_surface(seed, max_influences, v_template, faces, smooth, provenance):
     rng = np.random.RandomState(seed)
     V = NUM_VERTS
-    v_template, faces = _body_surface()
-    assert v_template.shape == (V, 3) and faces.shape == (13776, 3)
     v_template = v_template + rng.normal(0.0, 0.002, size=(V, 3))       # break the exact symmetry
-    # blend shapes: spatially SMOOTH displacement fields (low-order harmonics over the surface
-    # parametrisation), like real SMPL's -- independent per-vertex noise would crumple the mesh
-    shapedirs = _smooth_fields(rng, 3 * NUM_BETAS).T.reshape(V, 3, NUM_BETAS) * 0.01
-    posedirs = _smooth_fields(rng, 207 * 3).reshape(207, 3, V).transpose(0, 2, 1).reshape(207, V * 3) * 0.002
+    if smooth:
+        # blend shapes: spatially SMOOTH displacement fields (low-order harmonics over the surface
+        # parametrisation), like real SMPL's -- independent per-vertex noise would crumple the mesh
+        shapedirs = _smooth_fields(rng, 3 * NUM_BETAS).T.reshape(V, 3, NUM_BETAS) * 0.01
+        posedirs = _smooth_fields(rng, 207 * 3).reshape(207, 3, V).transpose(0, 2, 1).reshape(207, V * 3) * 0.002
+    else:
+        # no surface parametrisation in a random file order: smooth functions of the rest POSITION instead
+        def fields(n):
+            out = np.zeros((n, V))
+            for _ in range(3):
+                k = rng.normal(0.0, 4.0, size=(n, 3))
+                out += rng.normal(0.0, 1.0, size=(n, 1)) * np.cos(k @ v_template.T + rng.uniform(0, 2 * np.pi, size=(n, 1)))
+            return out / np.sqrt((out ** 2).mean(axis=1, keepdims=True) + 1e-12)
+        shapedirs = fields(3 * NUM_BETAS).T.reshape(V, 3, NUM_BETAS) * 0.01
+        posedirs = fields(207 * 3).reshape(207, 3, V).transpose(0, 2, 1).reshape(207, V * 3) * 0.002
     # skinning weights: the nearest rest joints, Gaussian fall-off
     d2 = ((v_template[:, None, :] - _REST_JOINTS[None]) ** 2).sum(-1)           # (V, 24)
     W = np.zeros((V, NUM_JOINTS))
@@ -109,9 +173,41 @@ def synthetic_smpl(seed: int = 1234, max_influences: int = 4) -> Dict[str, np.nd
         pick = np.argsort(d2[:, j])[:12]
         w = rng.uniform(0.2, 1.0, size=len(pick))
         J_regressor[j, pick] = w / w.sum()
-    return dict(v_template=v_template.astype(np.float32), shapedirs=shapedirs.astype(np.float32),
-                posedirs=posedirs.astype(np.float32), J_regressor=J_regressor.astype(np.float32),
-                lbs_weights=W.astype(np.float32), parents=SMPL_PARENTS.copy(), faces=faces)
+    out = dict(v_template=v_template.astype(np.float32), shapedirs=shapedirs.astype(np.float32),
+               posedirs=posedirs.astype(np.float32), J_regressor=J_regressor.astype(np.float32),
+               lbs_weights=W.astype(np.float32), parents=SMPL_PARENTS.copy(), faces=faces)
+    if provenance:
+        out['provenance'] = provenance
+    return out
+
+
+def with_wide_tile(model: Dict[str, np.ndarray], tile: int = 100, joints: int = 13, seed: int = 3) -> Dict[str, np.ndarray]:
+    """The same body with ONE 32-vertex tile of the file order skinned by `joints` joints in total (<= 4 influences per vertex
+    kept, rows still sum to 1): the test / bench case of the per-tile skinning classes -- one wide tile must cost itself a
+    second pass, not move the whole model to slower kernels."""
+    rng = np.random.RandomState(seed)
+    W = model['lbs_weights'].copy()
+    rows = np.arange(tile * 32, min(tile * 32 + 32, NUM_VERTS))
+    used = set(np.nonzero((W[rows] != 0).any(0))[0].tolist())
+    spare = [j for j in range(NUM_JOINTS) if j not in used]
+    rng.shuffle(spare)
+    need = joints - len(used)
+    assert 0 <= need <= len(spare), (len(used), joints)
+    k = 0
+    for v in rows:
+        if need <= 0:
+            break
+        take = spare[k:k + min(3, need)]
+        k += len(take); need -= len(take)
+        keep = int(np.argmax(W[v]))
+        w = np.zeros(NUM_JOINTS, dtype=W.dtype)
+        w[keep] = 0.55
+        w[take] = 0.45 / len(take)
+        W[v] = w
+    out = dict(model)
+    out['lbs_weights'] = W
+    out['provenance'] = f"{model.get('provenance', 'synthetic')}+wide_tile({tile},{joints})"
+    return out
 
 
 def shuffled_vertex_order(model: Dict[str, np.ndarray], seed: int = 5, scope: str = 'parts'):
@@ -161,6 +257,138 @@ def shuffled_vertex_order(model: Dict[str, np.ndarray], seed: int = 5, scope: st
     return out, perm
 
 
+# ---- the licensed model file --------------------------------------------------------------------------------------
+# SMPL_NEUTRAL.pkl as distributed (and as SPIN's data/smpl holds it; smplx reads it at scripts/smpl.py:7-9 through
+# pickle.load(..., encoding='latin1')) is a Python-2 pickle whose arrays are `chumpy.ch.Ch` objects (v_template, shapedirs,
+# posedirs, weights, J), whose J_regressor is a scipy.sparse matrix and whose kintree_table is uint32.  Unpickling it the plain
+# way imports chumpy -- which is absent here and on the GPU boxes (and does not import under numpy >= 1.24 anyway).  The
+# loader below never imports it: a restricted Unpickler maps every `chumpy.*` class to a stand-in that just keeps the pickled
+# state, and the numeric content is taken from that state (`x` of a leaf Ch; the few re-ordering nodes SMPL files have been
+# seen with are resolved recursively).  Everything that is not numpy / scipy.sparse / a plain container is refused.
+class _ChumpyStandIn:
+    """Holds the pickled state of a chumpy object; np.asarray(obj) gives its value (no chumpy import)."""
+    _jrr_chumpy_class = 'chumpy.ch.Ch'
+
+    def __new__(cls, *args, **kwargs):
+        return object.__new__(cls)
+
+    def __init__(self, *args, **kwargs):
+        pass
+
+    def __setstate__(self, state):
+        self.__dict__['_state'] = state if isinstance(state, dict) else {'x': state}
+
+    def _value(self):
+        st = self.__dict__.get('_state', {})
+        name = self._jrr_chumpy_class.rsplit('.', 1)[-1].lower()
+        if 'x' in st and not isinstance(st['x'], _ChumpyStandIn):
+            return np.asarray(st['x'])
+        inner = st.get('a', st.get('x'))
+        if inner is None:
+            raise ValueError(f'cannot take the value of a pickled {self._jrr_chumpy_class} (state keys: {sorted(st)})')
+        a = np.asarray(inner)
+        if name == 'transpose':
+            return np.transpose(a, st.get('axes'))
+        if name == 'reshape':
+            return np.reshape(a, st.get('newshape'))
+        if name == 'select':
+            return a.ravel()[np.asarray(st['idxs'])]
+        if name == 'ch':
+            return a
+        raise ValueError(f'unsupported chumpy node {self._jrr_chumpy_class} in the model file (state keys: {sorted(st)})')
+
+    def __array__(self, dtype=None, copy=None):
+        v = self._value()
+        return v.astype(dtype) if dtype is not None else v
+
+
+_SAFE_GLOBALS = {
+    ('numpy.core.multiarray', '_reconstruct'), ('numpy._core.multiarray', '_reconstruct'), ('numpy', 'ndarray'), ('numpy', 'dtype'),
+    ('numpy.core.multiarray', 'scalar'), ('numpy._core.multiarray', 'scalar'), ('numpy.core.numeric', '_frombuffer'),
+    ('numpy._core.numeric', '_frombuffer'), ('copy_reg', '_reconstructor'), ('copyreg', '_reconstructor'),
+    ('__builtin__', 'object'), ('builtins', 'object'), ('__builtin__', 'set'), ('builtins', 'set'), ('__builtin__', 'frozenset'),
+    ('builtins', 'frozenset'), ('__builtin__', 'slice'), ('builtins', 'slice'), ('__builtin__', 'complex'), ('builtins', 'complex'),
+    ('collections', 'OrderedDict'), ('_codecs', 'encode'),
+}
+
+
+class _SMPLUnpickler(pickle.Unpickler):
+    _standins: Dict[str, type] = {}
+
+    def find_class(self, module, name):
+        if module == 'chumpy' or module.startswith('chumpy.'):
+            full = f'{module}.{name}'
+            if full not in self._standins:
+                self._standins[full] = type('Chumpy_' + name, (_ChumpyStandIn,), {'_jrr_chumpy_class': full})
+            return self._standins[full]
+        if module == 'scipy.sparse' or module.startswith('scipy.sparse.'):
+            import scipy.sparse as sp
+            if hasattr(sp, name) and name.endswith(('_matrix', '_array')):
+                return getattr(sp, name)        # (py2-era files name the defining sub-module, e.g. scipy.sparse.csc)
+        if (module, name) in _SAFE_GLOBALS:
+            if module in ('copy_reg', '__builtin__'):
+                module = {'copy_reg': 'copyreg', '__builtin__': 'builtins'}[module]
+            if module.startswith('numpy.core') and not _has_module(module):
+                module = module.replace('numpy.core', 'numpy._core')
+            return super().find_class(module, name)
+        raise pickle.UnpicklingError(f'SMPL model file refers to {module}.{name}: not a numpy / scipy.sparse / chumpy object')
+
+
+def _has_module(name: str) -> bool:
+    import importlib.util
+    try:
+        return importlib.util.find_spec(name) is not None
+    except (ImportError, ValueError):
+        return False
+
+
+def load_smpl_pickle(path: str) -> Dict:
+    """SMPL_NEUTRAL.pkl -> dict of plain arrays, without importing chumpy (see above)."""
+    with open(path, 'rb') as f:
+        d = _SMPLUnpickler(f, encoding='latin1').load()
+    if not isinstance(d, dict):
+        raise ValueError(f'{path}: expected a pickled dict of SMPL arrays, got {type(d).__name__}')
+    return {(k.decode('latin1') if isinstance(k, bytes) else k): v for k, v in d.items()}
+
+
+def _model_from_file_dict(d: Dict, path: str) -> Dict[str, np.ndarray]:
+    """The arrays smplx.SMPL takes from the model file (smplx 0.1.26 body_models.py: v_template, shapedirs[:, :, :10],
+    posedirs reshaped to (207, 20670), J_regressor, weights, kintree_table[0], f) in this package's layout."""
+    V = NUM_VERTS
+
+    def arr(key, dtype=np.float32):
+        if key not in d:
+            raise KeyError(f'{path}: no {key!r} in the model file (keys: {sorted(map(str, d))})')
+        x = d[key]
+        x = x.toarray() if hasattr(x, 'toarray') else np.asarray(x)
+        return np.ascontiguousarray(x.astype(dtype))
+
+    v_template = arr('v_template')
+    shapedirs = arr('shapedirs')
+    if shapedirs.ndim != 3 or shapedirs.shape[:2] != (V, 3) or shapedirs.shape[2] < NUM_BETAS:
+        raise ValueError(f'{path}: shapedirs has shape {shapedirs.shape}, expected (6890, 3, >= {NUM_BETAS})')
+    shapedirs = np.ascontiguousarray(shapedirs[:, :, :NUM_BETAS])          # the 300-component files: first 10, as smplx does
+    posedirs = arr('posedirs')
+    if posedirs.ndim == 3:                                                  # file layout (6890, 3, 207)
+        posedirs = np.ascontiguousarray(posedirs.reshape(V * 3, -1).T)      # smplx: (207, 20670)
+    Jr = arr('J_regressor')
+    W = arr('weights')
+    if 'kintree_table' in d:
+        parents = np.asarray(d['kintree_table'])[0].astype(np.int64).astype(np.int32)    # uint32 with 2^32 - 1 at the root
+    else:
+        parents = SMPL_PARENTS.copy()
+    parents[0] = -1
+    faces = arr('f', np.int64).astype(np.int32)
+    for name, a, shape in (('v_template', v_template, (V, 3)), ('posedirs', posedirs, (207, V * 3)), ('J_regressor', Jr, (NUM_JOINTS, V)),
+                           ('weights', W, (V, NUM_JOINTS)), ('kintree_table[0]', parents, (NUM_JOINTS,))):
+        if a.shape != shape:
+            raise ValueError(f'{path}: {name} has shape {a.shape}, expected {shape}')
+    if faces.ndim != 2 or faces.shape[1] != 3:
+        raise ValueError(f'{path}: f has shape {faces.shape}, expected (F, 3)')
+    return dict(v_template=v_template, shapedirs=shapedirs, posedirs=posedirs, J_regressor=Jr, lbs_weights=W, parents=parents,
+                faces=faces, provenance=f'file:{path}')
+
+
 def load_smpl_model(model_dir: Optional[str], allow_synthetic: bool = True) -> Dict[str, np.ndarray]:
     """Load a real SMPL model if the user supplies one (`<dir>/SMPL_NEUTRAL.pkl` or `.npz`, the
     layout smplx expects at scripts/optimize.py:96-99).  If no model file is found: the seeded synthetic
@@ -173,24 +401,12 @@ def load_smpl_model(model_dir: Optional[str], allow_synthetic: bool = True) -> D
             if not os.path.exists(path):
                 continue
             if path.endswith('.npz'):
-                d = dict(np.load(path, allow_pickle=True))
+                # (smplx reads .npz model files with allow_pickle=True too: a scipy-sparse J_regressor arrives as a 0-d object array)
+                d = {k: (v.item() if isinstance(v, np.ndarray) and v.dtype == object and v.ndim == 0 else v)
+                     for k, v in np.load(path, allow_pickle=True).items()}
             else:
-                with open(path, 'rb') as f:
-                    d = pickle.load(f, encoding='latin1')
-            V = NUM_VERTS
-            shapedirs = np.asarray(d['shapedirs'], dtype=np.float32)[:, :, :NUM_BETAS]
-            posedirs = np.asarray(d['posedirs'], dtype=np.float32)            # (6890,3,207)
-            if posedirs.ndim == 3:
-                posedirs = posedirs.reshape(V * 3, -1).T                       # smplx: (207, 20670)
-            Jr = d['J_regressor']
-            Jr = np.asarray(Jr.todense() if hasattr(Jr, 'todense') else Jr, dtype=np.float32)
-            parents = np.asarray(d['kintree_table'])[0].astype(np.int32) if 'kintree_table' in d \
-                else SMPL_PARENTS.copy()
-            parents[0] = -1
-            return dict(v_template=np.asarray(d['v_template'], dtype=np.float32), shapedirs=shapedirs,
-                        posedirs=np.ascontiguousarray(posedirs), J_regressor=Jr,
-                        lbs_weights=np.asarray(d['weights'], dtype=np.float32), parents=parents,
-                        faces=np.asarray(d['f'], dtype=np.int32), provenance=f'file:{path}')
+                d = load_smpl_pickle(path)
+            return _model_from_file_dict(d, path)
         if not allow_synthetic:
             raise FileNotFoundError(f'no SMPL_NEUTRAL.{{npz,pkl}} under {model_dir!r}; pass --synthetic to run on the '
                                     f'seeded synthetic body model instead')

@@ -1,6 +1,8 @@
 import importlib
 import os
+import pickle
 import sys
+import types
 
 import numpy as np
 import pytest
@@ -24,6 +26,9 @@ def pytest_configure(config):
 DP_RUNS = {}
 DP_FLAGS = ['--batch_size', '256', '--synthetic_batches', '1', '--inner_iters', '3', '--j_step_every', '2', '--shape_disc',
             '--reprojection', '--camera_iters', '20', '--synthetic', '--device', 'cuda:0']
+
+
+BIG_FLAGS = ['--batch_size', '32768', '--synthetic_batches', '1', '--inner_iters', '3', '--j_step_every', '1', '--synthetic', '--device', 'cuda:0']
 
 
 def _torchrun(nproc, port, script_and_args):
@@ -59,6 +64,13 @@ def pytest_collection_finish(session):
         'bench2t': _torchrun(2, 29542, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--batch', '256',
                                         '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded',
                                         '--no_skin_variants', '--no_config5', '--min_timed_ms', '50']),
+        # the in-loop J step with the DENSE (17,6890) all-reduce payload instead of the regressor's support (default): same J
+        'w2d': _torchrun(2, 29546, [worker, os.path.join(tmp, 'w2d')] + DP_FLAGS + ['--dist_backend', 'gloo', '--single_device', '--j_allreduce', 'dense']),
+        'w8d': _torchrun(8, 29547, [worker, os.path.join(tmp, 'w8d')] + DP_FLAGS + ['--dist_backend', 'gloo', '--single_device', '--j_allreduce', 'dense']),
+        # BASELINE configs[3] at its own shard size: 8 ranks x 4096 poses (one GPU stands in for eight), a J step + all-reduce
+        # after every inner iteration, against the 1-rank run on the same 32 768 poses
+        'w1big': [sys.executable, worker, os.path.join(tmp, 'w1big')] + BIG_FLAGS,
+        'w8big': _torchrun(8, 29548, [worker, os.path.join(tmp, 'w8big')] + BIG_FLAGS + ['--dist_backend', 'gloo', '--single_device']),
         # a launcher world that contradicts --gpus must fail loudly
         'bench_mismatch': _torchrun(2, 29543, [os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
                                                '--batch', '128', '--backend', 'gloo', '--single_device', '--no_cpu_baseline']),
@@ -71,10 +83,56 @@ def pytest_collection_finish(session):
     DP_RUNS['dir'] = tmp
     for name, cmd in runs.items():
         try:
-            r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=900)
+            r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
             DP_RUNS[name] = dict(rc=r.returncode, out=r.stdout, err=r.stderr[-4000:])
         except subprocess.TimeoutExpired as e:
             DP_RUNS[name] = dict(rc=-999, out=str(e.stdout)[-2000:], err='timeout: ' + str(e.stderr)[-2000:])
+
+
+def write_chumpy_style_pickle(model, path):
+    """SMPL_NEUTRAL.pkl as distributed: chumpy.ch.Ch arrays, scipy.sparse J_regressor, (6890,3,207) posedirs, 300 shape
+    components, uint32 kintree_table -- written with a stand-in `chumpy` package that is removed again afterwards"""
+    import scipy.sparse as sp
+    mods = {n: types.ModuleType(n) for n in ('chumpy', 'chumpy.ch', 'chumpy.reordering')}
+
+    class Ch(object):
+        def __init__(self, x):
+            self.x = np.asarray(x)
+            self._dirty_vars = set()
+            self._itr = None
+
+        def __getstate__(self):
+            return self.__dict__.copy()
+
+        def __setstate__(self, d):
+            self.__dict__.update(d)
+    Ch.__module__, Ch.__qualname__ = 'chumpy.ch', 'Ch'
+
+    class transpose(Ch):
+        def __init__(self, a, axes=None):
+            self.a, self.axes = a, axes
+    transpose.__module__, transpose.__qualname__ = 'chumpy.reordering', 'transpose'
+    mods['chumpy.ch'].Ch = Ch
+    mods['chumpy.reordering'].transpose = transpose
+    mods['chumpy'].ch, mods['chumpy'].reordering = mods['chumpy.ch'], mods['chumpy.reordering']
+    V = 6890
+    rng = np.random.RandomState(0)
+    sd300 = np.concatenate([model['shapedirs'], rng.normal(size=(V, 3, 290)).astype(np.float32)], 2).astype(np.float64)
+    kt = np.stack([np.array([2 ** 32 - 1] + list(model['parents'][1:]), dtype=np.uint32), np.arange(24, dtype=np.uint32)])
+    d = {'v_template': Ch(model['v_template'].astype(np.float64)), 'shapedirs': Ch(sd300),
+         'posedirs': Ch(model['posedirs'].T.reshape(V, 3, 207).astype(np.float64)),
+         'J_regressor': sp.csc_matrix(model['J_regressor'].astype(np.float64)),
+         'weights': transpose(Ch(model['lbs_weights'].T.astype(np.float64))),        # a re-ordering node over a leaf
+         'kintree_table': kt, 'f': model['faces'].astype(np.uint32), 'bs_type': 'lrotmin', 'bs_style': 'lbs',
+         'J': Ch(np.zeros((24, 3)))}
+    sys.modules.update(mods)
+    try:
+        with open(path, 'wb') as f:
+            pickle.dump(d, f, protocol=2)
+    finally:
+        for n in mods:
+            sys.modules.pop(n, None)
+
 
 
 def load_golden(name):

@@ -1,0 +1,285 @@
+"""Round-4 parity rows, HIP path (through the C ABI) vs the CPU oracle (pytest -m gpu):
+  * EVERY skinning / backward kernel family the library can select -- the 8-slot default, the 12-slot variant
+    (JRR_SKIN_JOINTS=12), the dense kernels (JRR_DENSE_SKINNING=1), the role backward kernel (JRR_BWD16=0), the internally
+    re-ordered body (JRR_VERTEX_ORDER=sorted), and the PER-TILE classes on two bodies (a capsule body in a random file order:
+    the library sorts it and a few tiles stay wide; the benchmarked body with ONE 13-joint tile) -- each against the ORACLE,
+    not against each other: find_joints forward + backward incl. dJ (B = 37, 130), the J step's gradient, a 3-iteration
+    refinement with the pose discriminator (B = 200) and the benchmarked batch of 4096 on a strided subset.
+    Reference: /root/reference/scripts/utils.py:85-103, scripts/optimize.py:220-265,300-312.
+  * forward reuse after a J step at batches whose padded size is an odd multiple of 128 (B = 300, 600: the last 128 pose
+    columns of the re-regression slab), against the sequence that repeats the forward
+  * the J step over the regressor's support with the all-reduce payload restricted to it (jrr_j_regressor_grad_support /
+    jrr_j_step_apply_support): bit-identical to the dense pair
+  * a model FILE in the licensed distribution's format (chumpy objects, sparse J_regressor) -> SMPL(model_dir) -> kernels
+"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import PKG_NAME, write_chumpy_style_pickle
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+DEV = 'cuda:0'
+KNOBS = ('JRR_DENSE_SKINNING', 'JRR_SKIN_JOINTS', 'JRR_VERTEX_ORDER', 'JRR_BWD16')
+
+
+def _mod(name):
+    return importlib.import_module(f'{PKG_NAME}.{name}')
+
+
+def _fresh_state(B):
+    return (torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV), torch.zeros(1, dtype=torch.int32, device=DEV))
+
+
+# variant id -> (environment of jrr_model_create, body, expected joint slots, wide tiles expected?)
+VARIANTS = {
+    'default': ({}, 'surface', 8, False),
+    'skin12': ({'JRR_SKIN_JOINTS': '12'}, 'surface', 12, False),
+    'dense': ({'JRR_DENSE_SKINNING': '1'}, 'surface', 0, False),
+    'role_bwd': ({'JRR_BWD16': '0'}, 'surface', 8, False),
+    'role_bwd12': ({'JRR_BWD16': '0', 'JRR_SKIN_JOINTS': '12'}, 'surface', 12, False),
+    'sorted': ({'JRR_VERTEX_ORDER': 'sorted'}, 'surface', 8, True),            # the surface body sorted: 5 tiles above 8 joints
+    'capsules': ({}, 'capsules', 8, True),                                     # random file order -> sorted internally, per-tile classes
+    'capsules_role_bwd': ({'JRR_BWD16': '0'}, 'capsules', 8, True),            # wide tiles + role kernel: its dense form
+    'wide13': ({}, 'wide13', 8, True),                                         # ONE 13-joint tile in the file order
+    'wide13_skin12': ({'JRR_SKIN_JOINTS': '12'}, 'wide13', 12, True),          # ... under the 12-slot kernels: second pass over slots 12..
+}
+
+
+@pytest.fixture(scope='module', params=list(VARIANTS))
+def variant(request, smpl_model_np, j_h36m_np):
+    if any(k in os.environ for k in KNOBS):
+        pytest.skip('the suite itself runs under a forced skinning variant')
+    env, body, slots, wide = VARIANTS[request.param]
+    sm, eng_mod = _mod('smpl_model'), _mod('engine')
+    if body == 'capsules':
+        model = sm.synthetic_smpl(1234, kind='capsules')
+    elif body == 'wide13':
+        model = sm.with_wide_tile(smpl_model_np, 100, 13)
+    else:
+        model = smpl_model_np
+    os.environ.update(env)          # the knobs are read by jrr_model_create
+    try:
+        dm = eng_mod.DeviceModel(model, DEV)
+    finally:
+        for k in env:
+            os.environ.pop(k, None)
+    assert dm.info['joint_slots'] == slots, dm.info
+    assert (dm.info['wide_tiles'] > 0) == wide, dm.info
+    if body == 'capsules':
+        assert dm.info['internal_vertex_order'] and dm.info['most_joints_per_tile'] <= 16
+    if body == 'wide13':
+        assert dm.info['most_joints_per_tile'] == 13 and dm.info['wide_tiles'] == 1 and not dm.info['internal_vertex_order']
+    # a regressor with the shipped checkpoint's structure on THIS body's vertices (the capsule body has its own vertex order)
+    J = j_h36m_np if body != 'capsules' else sm.synthetic_h36m_regressor(model, seed=7, support=8)
+    return dict(name=request.param, model=model, dm=dm, J=np.ascontiguousarray(J), eng_mod=eng_mod, sm=sm)
+
+
+def _relerr(a, b):
+    return ((a.cpu().double() - b.double()).abs().max() / b.double().abs().max()).item()
+
+
+@pytest.mark.parametrize('B', [37, 130])
+def test_find_joints_forward_backward_vs_oracle(variant, B):
+    v = variant
+    batch = v['sm'].synthetic_batch(v['model'], v['J'], B, seed=40 + B)
+    x6d, betas = T(batch['pose6d']).double(), T(batch['betas']).double()
+    dj = torch.randn(B, 17, 3, generator=torch.Generator().manual_seed(3), dtype=torch.float64)
+    J = T(v['J']).double().requires_grad_(True)
+    smpl = oracle.OracleSMPL(v['model'], dtype=torch.float64)
+    xr, br = x6d.clone().requires_grad_(True), betas.clone().requires_grad_(True)
+    R = oracle.rot6d_to_rotmat(xr.reshape(-1, 6)).view(B, 24, 3, 3)
+    ref_j, ref_v = oracle.find_joints(smpl, br, R[:, :1], R[:, 1:], J, mask=oracle.find_j_reg_mask(J.detach()), return_verts=True)
+    (ref_j * dj).sum().backward()
+    eng = v['eng_mod'].RefineEngine(v['dm'], B, flags=v['eng_mod'].FLAG_KEEP_VERTS)
+    eng.set_j_regressor(T(v['J']))
+    xd, bd = x6d.float().contiguous().to(DEV), betas.float().contiguous().to(DEV)
+    joints, verts = eng.find_joints_forward(bd, x6d=xd, return_verts=True)
+    assert (verts.cpu().double() - ref_v.detach()).abs().max().item() < 2e-5          # results in FILE order of the vertices
+    assert (joints.cpu().double() - ref_j.detach()).abs().max().item() < 2e-5         # north_star bar: 1e-4 m
+    dx, db, dJ = eng.find_joints_backward(bd, dj.float().to(DEV), x6d=xd, want_dJ=True)
+    assert _relerr(dx, xr.grad) < 2e-4 and _relerr(db, br.grad) < 2e-4 and _relerr(dJ, J.grad) < 2e-4
+    assert (dJ.cpu()[T(v['J']) <= 0] == 0).all()
+
+
+def test_j_step_gradient_vs_oracle(variant):
+    v = variant
+    B = 130
+    batch = v['sm'].synthetic_batch(v['model'], v['J'], B, seed=61)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    smpl = oracle.OracleSMPL(v['model'])
+    _, dJ_ref, _ = oracle.j_regressor_loss_and_grad(smpl, T(v['J']), x6[:, :1], x6[:, 1:], betas, gt_c)
+    eng = v['eng_mod'].RefineEngine(v['dm'], B, flags=v['eng_mod'].FLAG_KEEP_VERTS)
+    eng.set_j_regressor(T(v['J']))
+    dJ = eng.j_regressor_grad(x6.to(DEV).contiguous(), betas.to(DEV).contiguous(), gt_c.to(DEV).contiguous())
+    assert _relerr(dJ, dJ_ref) < 5e-4
+    assert torch.equal(dJ.cpu() != 0, dJ_ref != 0)
+
+
+def test_three_iterations_with_pose_discriminator_vs_oracle(variant):
+    v = variant
+    B = 200
+    batch = v['sm'].synthetic_batch(v['model'], v['J'], B, seed=62)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+    smpl = oracle.OracleSMPL(v['model'])
+    o, p, b_, _ = oracle.refine_poses(smpl, T(v['J']), x6[:, :1], x6[:, 1:], betas, gt_c, 3, disc_sd=dsd)
+    em = v['eng_mod']
+    eng = em.RefineEngine(v['dm'], B, flags=em.FLAG_POSE_DISC)
+    eng.set_j_regressor(T(v['J']))
+    eng.set_pose_disc(em.flatten_state_dict(dsd, em.DISC_KEYS))
+    xd, bd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous()
+    m, vv, step = _fresh_state(B)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, vv, step, 1e-2, 3)
+    d = (xd.cpu() - torch.cat([o, p], 1)).abs()
+    # Adam's first steps are lr * g / (|g| + eps): last-bit differences of the summation order are amplified wherever a gradient
+    # entry is ~ 0; the bound on the mean is what pins the trajectory
+    assert d.max().item() < 6e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+    assert (bd.cpu() - b_).abs().max().item() < 3e-4
+
+
+def test_benchmarked_batch_4096_strided_subset_vs_oracle(variant):
+    """BASELINE configs[2]'s own size: joints of all 4096 poses are finite and pelvis-consistent, and on a strided subset the
+    joints, the gradients of a random joint adjoint and 2 refinement iterations equal the oracle's"""
+    v = variant
+    B, sub = 4096, slice(5, 4096, 128)
+    batch = v['sm'].synthetic_batch(v['model'], v['J'], B, seed=63)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    em = v['eng_mod']
+    eng = em.RefineEngine(v['dm'], B, flags=0)
+    eng.set_j_regressor(T(v['J']))
+    xd, bd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous()
+    joints = eng.find_joints_forward(bd, x6d=xd)
+    dj = torch.randn(B, 17, 3, generator=torch.Generator().manual_seed(9))
+    dx, db, _ = eng.find_joints_backward(bd, dj.to(DEV).contiguous(), x6d=xd)
+    assert torch.isfinite(joints).all() and torch.isfinite(dx).all()
+    xs, bs = x6[sub].clone().requires_grad_(True), betas[sub].clone().requires_grad_(True)
+    smpl = oracle.OracleSMPL(v['model'])
+    R = oracle.rot6d_to_rotmat(xs.reshape(-1, 6)).view(-1, 24, 3, 3)
+    j = oracle.find_joints(smpl, bs, R[:, :1], R[:, 1:], T(v['J']))
+    (j * dj[sub]).sum().backward()
+    assert (joints.cpu()[sub] - j.detach()).abs().max().item() < 2e-5
+    assert _relerr(dx[sub], xs.grad) < 5e-4 and _relerr(db[sub], bs.grad) < 5e-4
+    # two iterations of the loop (joint loss; batch_norm = 4096 in both)
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    o, p, b_, _ = oracle.refine_poses(smpl, T(v['J']), x6[sub, :1], x6[sub, 1:], betas[sub], gt_c[sub], 2, batch_norm=B)
+    m, vv, step = _fresh_state(B)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, vv, step, 1e-2, 2)
+    d = (xd.cpu()[sub] - torch.cat([o, p], 1)).abs()
+    assert d.max().item() < 6e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+
+
+# ---- forward reuse after a J step where BP is an odd multiple of 128 ---------------------------------------------------------
+@pytest.mark.parametrize('B', [300, 600])
+def test_forward_reuse_after_j_step_at_odd_multiples_of_128(smpl_model_np, j_h36m_np, B):
+    """The iteration after a J step re-regresses its joints from the J step's stored vertices into ONE slab of BP pose columns
+    (support path).  BP = 384 / 640 is not a multiple of the kernel's 256-pose blocks: every pose column -- including the last
+    128 -- must be written.  Against the sequence that repeats the SMPL forward (mode A), and the in-call J steps against both."""
+    sm, em = _mod('smpl_model'), _mod('engine')
+    dm = em.DeviceModel(smpl_model_np, DEV)
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=500 + B)
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d'])).to(DEV).contiguous()
+
+    def run(mode):
+        eng = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS)
+        assert eng.info['BP'] % 256 == 128 and eng.info['BP'] > 128
+        J = T(j_h36m_np).to(DEV).clone()
+        Jm, Jv, Js = torch.zeros_like(J), torch.zeros_like(J), torch.zeros(1, dtype=torch.int32, device=DEV)
+        eng.set_j_regressor(J)
+        xd, bd = T(batch['pose6d']).to(DEV).contiguous(), T(batch['betas']).to(DEV).contiguous()
+        m, v, step = _fresh_state(B)
+        sq = torch.zeros(B, device=DEV)
+        if mode == 'in_call':
+            eng.refine_run_j_steps(xd, bd, gt_c, m, v, step, 1e-2, 4, 1, J, Jm, Jv, Js, 1e-2, sqerr=sq)
+        else:
+            for _ in range(4):
+                eng.refine_run(xd, bd, gt_c, m, v, step, 1e-2, 1, sqerr=sq, after_j_step=(mode == 'reuse' and int(Js.item()) > 0))
+                dJ = eng.j_regressor_grad(xd, bd, gt_c)
+                eng.j_step_apply(J, dJ, Jm, Jv, Js, 1e-2)
+        return xd.cpu(), bd.cpu(), J.cpu(), sq.cpu()
+
+    a, r, c = run('repeat'), run('reuse'), run('in_call')
+    for x, y in zip(r, c):
+        assert torch.equal(x, y)                                  # in-call J steps == the host-driven reuse sequence, bit for bit
+    # reuse vs repeated forward: the regressor product is summed in another order (Adam-amplified rounding);
+    # a stale slab for the last 128 poses would be off by the joints themselves
+    d = (a[0] - r[0]).abs()
+    assert d.max().item() < 6e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+    tail = slice(B - (B % 128 or 128), B)                          # poses in the last 128 columns
+    np.testing.assert_allclose(r[3][tail].numpy(), a[3][tail].numpy(), rtol=2e-3, atol=1e-9)
+    assert (a[2] - r[2]).abs().max().item() < 5e-5
+
+
+# ---- the J step with its all-reduce payload restricted to the support -------------------------------------------------------
+def test_support_sized_j_step_is_bit_identical_to_the_dense_pair(smpl_model_np, j_h36m_np):
+    sm, em = _mod('smpl_model'), _mod('engine')
+    dm = em.DeviceModel(smpl_model_np, DEV)
+    B = 130
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=71)
+    xd, bd = T(batch['pose6d']).to(DEV).contiguous(), T(batch['betas']).to(DEV).contiguous()
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d'])).to(DEV).contiguous()
+    outs = []
+    for compact in (False, True):
+        eng = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS)
+        J = T(j_h36m_np).to(DEV).clone()
+        Jm, Jv, Js = torch.zeros_like(J), torch.zeros_like(J), torch.zeros(1, dtype=torch.int32, device=DEV)
+        eng.set_j_regressor(J)
+        if compact:
+            with pytest.raises(Exception):                         # not before the support has been asked for
+                eng.j_regressor_grad_support(xd, bd, gt_c, out=torch.zeros(17, 128, device=DEV))
+            counts, fits = eng.j_support_info()
+            assert fits and sum(counts) == int((j_h36m_np > 0).sum()) == 62
+        for _ in range(3):                                         # three J steps: the support may only shrink
+            if compact:
+                buf = torch.full((17, 128), 7.0, device=DEV)
+                eng.j_regressor_grad_support(xd, bd, gt_c, out=buf)
+                assert int((buf != 0).sum()) <= 62
+                eng.j_step_apply_support(J, buf, Jm, Jv, Js, 1e-2)
+            else:
+                dJ = eng.j_regressor_grad(xd, bd, gt_c)
+                eng.j_step_apply(J, dJ, Jm, Jv, Js, 1e-2)
+        joints = eng.find_joints_forward(bd, x6d=xd)
+        outs.append((J.cpu(), Jm.cpu(), Jv.cpu(), joints.cpu()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    # a regressor whose rows do not fit the lists: fits = 0, the support entry points refuse, the dense pair works
+    Jwide = j_h36m_np.copy()
+    Jwide[3, :200] = 0.01
+    eng = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS)
+    eng.set_j_regressor(T(Jwide).to(DEV))
+    counts, fits = eng.j_support_info()
+    assert not fits
+    with pytest.raises(Exception):
+        eng.j_regressor_grad_support(xd, bd, gt_c, out=torch.zeros(17, 128, device=DEV))
+
+
+# ---- a model file in the licensed distribution's format, end to end ----------------------------------------------------------
+def test_model_file_with_chumpy_objects_end_to_end(tmp_path):
+    """SMPL('<dir>', batch_size=1) on a file in the distribution's format (scripts/optimize.py:96-99, scripts/smpl.py:7-9):
+    loaded without chumpy, uploaded (random file order: the library sorts it, per-tile classes), joints vs the oracle"""
+    sm, em = _mod('smpl_model'), _mod('engine')
+    body = sm.synthetic_smpl(1234, kind='capsules')
+    write_chumpy_style_pickle(body, str(tmp_path / 'SMPL_NEUTRAL.pkl'))
+    smpl = _mod('smpl').SMPL(str(tmp_path), batch_size=1, allow_synthetic=False).to(DEV)
+    assert not any(k == 'chumpy' or k.startswith('chumpy.') for k in sys.modules)
+    assert smpl.provenance.startswith('file:')
+    for k in ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'lbs_weights', 'parents', 'faces'):
+        assert np.array_equal(smpl.model_np[k], body[k]), k
+    B = 21
+    J = sm.synthetic_h36m_regressor(body, seed=7, support=8)
+    batch = sm.synthetic_batch(body, J, B, seed=3)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    R = _mod('utils').rot6d_to_rotmat(x6.reshape(-1, 6).to(DEV)).view(B, 24, 3, 3)
+    joints = _mod('utils').find_joints(smpl, betas.to(DEV), R[:, :1], R[:, 1:], T(J).to(DEV))
+    so = oracle.OracleSMPL(body, dtype=torch.float64)
+    Ro = oracle.rot6d_to_rotmat(x6.double().reshape(-1, 6)).view(B, 24, 3, 3)
+    ref = oracle.find_joints(so, betas.double(), Ro[:, :1], Ro[:, 1:], T(J).double())
+    assert (joints.cpu().double() - ref).abs().max().item() < 2e-5

@@ -113,11 +113,13 @@ gt_c = oracle.move_pelvis(T(full["gt_j3d"]))
 o, p, b, _ = oracle.refine_poses(smpl, J0, x6[lo:hi, :1], x6[lo:hi, 1:], betas[lo:hi], gt_c[lo:hi], 2, batch_norm=B)
 _, gJ, _ = oracle.j_regressor_loss_and_grad(smpl, J0, o, p, b, gt_c[lo:hi], batch_norm=B)
 J = J0.clone(); m = torch.zeros_like(J); v = torch.zeros_like(J)
-d.shared_adam_step(J, gJ, m, v, 1, 1e-2, lambda P, G, M, V, s, lr: oracle.adam_step(P, G, M, V, s, lr))
-# flat bucket all-reduce helper
-a, c = torch.full((3,), float(rank + 1)), torch.full((2, 2), float(rank + 1))
-d.flat_all_reduce_sum_([a, c])
-assert a.tolist() == [sum(range(1, world + 1))] * 3 and c.flatten().tolist() == [sum(range(1, world + 1))] * 4
+# the replicated shared-parameter step: every rank's gradient is normalised by the GLOBAL batch, so the all-reduced sum is
+# the single-process gradient; then the identical Adam update on every rank (what optimize.py does with its flat bucket)
+d.all_reduce_sum_(gJ)
+oracle.adam_step(J, gJ, m, v, 1, 1e-2)
+a = torch.full((3,), float(rank + 1))
+d.all_reduce_sum_(a)
+assert a.tolist() == [sum(range(1, world + 1))] * 3
 if rank == 0:
     np.savez(sys.argv[2], J=J.numpy(), o=o.numpy(), lo=lo, hi=hi)
 dist.barrier()
@@ -227,3 +229,62 @@ def test_bench_gpus_n_starts_n_ranks_before_touching_the_gpu():
     assert r.returncode != 0
     assert r.stderr.count('bench.py needs an MI355X') == 2, r.stderr[-1500:]      # two ranks got as far as the check
     assert not [l for l in r.stdout.splitlines() if l.startswith('{')]
+
+
+def test_smpl_model_file_with_chumpy_objects_loads_without_chumpy(tmp_path):
+    """SMPL('SPIN/data/smpl', batch_size=1) reads SMPL_NEUTRAL.pkl (/root/reference/scripts/optimize.py:96-99,
+    scripts/smpl.py:7-9): a Python-2 pickle of chumpy.ch.Ch arrays, a scipy.sparse J_regressor, (6890,3,207) posedirs, 300
+    shape components, a uint32 kintree_table.  chumpy is absent here and on the GPU boxes: the loader maps chumpy classes to a
+    stand-in that keeps the pickled state, refuses anything that is not numpy / scipy.sparse / a plain container."""
+    import pickle
+    from conftest import write_chumpy_style_pickle
+    sm = _mod('smpl_model')
+    body = sm.synthetic_smpl(1234, kind='capsules')
+    write_chumpy_style_pickle(body, str(tmp_path / 'SMPL_NEUTRAL.pkl'))
+    assert not any(k == 'chumpy' or k.startswith('chumpy.') for k in sys.modules)
+    got = sm.load_smpl_model(str(tmp_path), allow_synthetic=False)
+    assert not any(k == 'chumpy' or k.startswith('chumpy.') for k in sys.modules)          # still not imported
+    assert got['provenance'] == f"file:{tmp_path / 'SMPL_NEUTRAL.pkl'}"
+    for k in ('v_template', 'shapedirs', 'posedirs', 'J_regressor', 'lbs_weights', 'parents', 'faces'):
+        assert got[k].dtype == body[k].dtype and np.array_equal(got[k], body[k]), k
+    assert got['parents'][0] == -1 and got['shapedirs'].shape == (6890, 3, 10)
+    # the same arrays as a plain .npz (with a sparse regressor stored as an object, as np.savez does)
+    import scipy.sparse as sp
+    (tmp_path / 'SMPL_NEUTRAL.pkl').unlink()
+    np.savez(tmp_path / 'SMPL_NEUTRAL.npz', v_template=body['v_template'], shapedirs=body['shapedirs'],
+             posedirs=body['posedirs'].T.reshape(6890, 3, 207), J_regressor=np.array(sp.csr_matrix(body['J_regressor']), dtype=object),
+             weights=body['lbs_weights'], kintree_table=np.stack([body['parents'].astype(np.int64), np.arange(24)]), f=body['faces'])
+    got2 = sm.load_smpl_model(str(tmp_path), allow_synthetic=False)
+    for k in ('v_template', 'posedirs', 'J_regressor', 'lbs_weights', 'parents', 'faces'):
+        assert np.array_equal(got2[k], body[k]), k
+    # a pickle that names anything else is refused before it can run
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ('true',))
+    (tmp_path / 'SMPL_NEUTRAL.npz').unlink()
+    with open(tmp_path / 'SMPL_NEUTRAL.pkl', 'wb') as f:
+        pickle.dump({'v_template': Evil()}, f, protocol=2)
+    with pytest.raises(pickle.UnpicklingError):
+        sm.load_smpl_model(str(tmp_path), allow_synthetic=False)
+    # a wrong shape is an error with the file's name in it, not a crash further down
+    bad = dict(body); bad['v_template'] = body['v_template'][:100]
+    write_chumpy_style_pickle(bad, str(tmp_path / 'SMPL_NEUTRAL.pkl'))
+    with pytest.raises(ValueError, match='v_template'):
+        sm.load_smpl_model(str(tmp_path), allow_synthetic=False)
+
+
+def test_synthetic_bodies_and_tile_classes():
+    """the two synthetic bodies and the wide-tile variant: SMPL's shapes, <= 4 influences, rows summing to 1; the capsule body's
+    file order has no locality (every tile sees nearly every joint) while its joint-sorted order fits 16-joint windows"""
+    sm = _mod('smpl_model')
+    for kind in ('surface', 'capsules'):
+        m = sm.synthetic_smpl(1234, kind=kind)
+        W = m['lbs_weights']
+        assert m['v_template'].shape == (6890, 3) and m['posedirs'].shape == (207, 20670) and m['faces'].max() == 6889
+        assert (W != 0).sum(1).max() <= 4 and np.abs(W.sum(1) - 1).max() < 1e-6 and m['faces'].shape[0] <= 14336
+        per_tile = [int((W[32 * t:32 * t + 32] != 0).any(0).sum()) for t in range(216)]
+        assert (max(per_tile) <= 8) == (kind == 'surface')
+    w = sm.with_wide_tile(sm.synthetic_smpl(1234), 100, 13)
+    W = w['lbs_weights']
+    per_tile = [int((W[32 * t:32 * t + 32] != 0).any(0).sum()) for t in range(216)]
+    assert per_tile[100] == 13 and sum(n > 8 for n in per_tile) == 1 and (W != 0).sum(1).max() <= 4
