@@ -303,36 +303,51 @@ def main():
         xch.step(J, Jm, Jv, Jstep, 1e-2, x6d, betas, gt_c)
         after_j[0] = not use_sil
 
+    it_count = [0]     # inner iterations run so far in the current measurement: the J step follows every cadence-th one, counted
+                       # ACROSS timed regions (a region of --steps 20 at the reference cadence of 100 holds a J step every 5th time)
+
     def run_host_driven(n, cadence, reuse=True):
         """what N > 1 ranks execute: the host issues refine_run / j_regressor_grad / all_reduce / j_step_apply per J step"""
         left, nj = n, 0
         while left > 0:
-            seg = min(left, cadence)
+            seg = min(left, cadence - it_count[0] % cadence)
             eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, seg, sqerr=sq, after_j_step=after_j[0] and reuse)
             after_j[0] = False
             left -= seg
-            if seg == cadence:
+            it_count[0] += seg
+            if it_count[0] % cadence == 0:
                 j_step()
                 nj += 1
         return nj
 
     def run(n, cadence, reuse=False):
-        """n inner iterations with a J step after every `cadence`-th one (counted from the start of the call).
-        One process: ONE C call for everything (jrr_refine_run_j_steps).  N > 1: the all-reduce sits between the two
+        """n inner iterations with a J step after every `cadence`-th one (counted across calls: it_count).
+        One process: ONE C call per aligned stretch (jrr_refine_run_j_steps).  N > 1: the all-reduce sits between the two
         halves of each J step, so the host drives the segments (run_host_driven).
         reuse: the iteration after a J step re-regresses its joints from the J step's stored vertices instead of repeating the
         SMPL forward.  The reference draws a NEW batch after every J step (scripts/optimize.py:144-148, 300-312), so the headline
         runs with reuse=False; only `cadence1` (a J step after every iteration on the same poses) uses it."""
         if dist is not None:
             return run_host_driven(n, cadence, reuse)
-        nj = n // cadence
-        if nj:
-            eng.refine_run_j_steps(x6d, betas, gt_c, m, v, step, 1e-2, nj * cadence, cadence, J, Jm, Jv, Jstep, 1e-2, sqerr=sq,
+        left, nj = n, 0
+
+        def with_j(k, every):
+            eng.refine_run_j_steps(x6d, betas, gt_c, m, v, step, 1e-2, k, every, J, Jm, Jv, Jstep, 1e-2, sqerr=sq,
                                    after_j_step=after_j[0] and reuse, reuse_forward=reuse)
             after_j[0] = (not use_sil) and reuse
-        if n - nj * cadence:
-            eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, n - nj * cadence, sqerr=sq, after_j_step=after_j[0] and reuse)
+            it_count[0] += k
+        off = it_count[0] % cadence
+        if off and left >= cadence - off:          # finish the cadence a previous region left open: its J step closes this stretch
+            with_j(cadence - off, cadence - off)
+            left -= cadence - off; nj += 1
+        if it_count[0] % cadence == 0 and left >= cadence:
+            k = left // cadence
+            with_j(k * cadence, cadence)
+            left -= k * cadence; nj += k
+        if left:
+            eng.refine_run(x6d, betas, gt_c, m, v, step, 1e-2, left, sqerr=sq, after_j_step=after_j[0] and reuse)
             after_j[0] = False
+            it_count[0] += left
         return nj
 
     def barrier():
@@ -360,21 +375,31 @@ def main():
             reps = int(t.item())
         return reps
 
-    cadence = max(1, min(a.j_step_every, a.steps))   # >= 1 J step (SMPL fwd, dJ, RCCL all-reduce, Adam) per timed region
+    cadence = max(1, a.j_step_every)   # the reference's: one J step (SMPL fwd, dJ, RCCL all-reduce, Adam) per 100 inner iterations
     run(a.warmup, cadence)
     j_step()                       # untimed: the first J step zero-fills the padded vertex buffer
-    timed_region(a.steps, cadence)  # untimed: the first region loads the code objects of the J step / re-regression path
-    regions = []
-    el, nj_region = timed_region(a.steps, cadence)
-    regions.append(el)
-    for _ in range(repeats_for(el) - 1):
-        regions.append(timed_region(a.steps, cadence)[0])
-    elapsed = statistics.median(regions)
+    it_count[0] = 0
+    timed_region(max(a.steps, cadence), cadence)  # untimed: loads the code objects of the J step path (holds >= 1 J step)
+    it_count[0] = 0
+    regions, region_nj = [], []
+    el, nj0 = timed_region(a.steps, cadence)
+    regions.append(el); region_nj.append(nj0)
+    # whole cadences: the timed regions together hold the reference's share of J steps exactly (1 per `cadence` iterations)
+    reps = repeats_for(el)
+    per_cad = max(1, cadence // np.gcd(cadence, a.steps))          # regions per whole number of cadences
+    reps = min(a.max_repeats, (reps + per_cad - 1) // per_cad * per_cad)
+    for _ in range(reps - 1):
+        el, njr = timed_region(a.steps, cadence)
+        regions.append(el); region_nj.append(njr)
+    # `value`: every timed step over every timed second (the J steps amortised at the reference cadence)
+    elapsed = sum(regions) / len(regions)
+    nj_region = sum(region_nj)
     loss_joint = float(sq.sum().item()) / (B * 51)
 
     # ---- BASELINE configs[3] "all-reduce on the J_regressor gradient EACH step": J step after every iteration,
     #      timed like `value` (median of >= 5 regions) ----
     run_c1 = lambda n, c: run(n, c, reuse=True)      # noqa: E731
+    it_count[0] = 0
     timed_region(a.steps, 1, run_c1)       # untimed warm-up region
     c1_regions = [timed_region(a.steps, 1, run_c1)[0]]
     for _ in range(max(4, min(repeats_for(c1_regions[0]), 10) - 1)):
@@ -385,6 +410,7 @@ def main():
     c1h_el, c1h_regions = None, []
     if dist is None:
         run_c1h = lambda n, c: run_host_driven(n, c, reuse=True)      # noqa: E731
+        it_count[0] = 0
         timed_region(a.steps, 1, run_c1h)
         c1h_regions = [timed_region(a.steps, 1, run_c1h)[0] for _ in range(5)]
         c1h_el = statistics.median(c1h_regions)
@@ -523,7 +549,9 @@ def main():
         variants = [('skin12', {'JRR_SKIN_JOINTS': '12'}, model_np), ('dense', {'JRR_DENSE_SKINNING': '1'}, model_np),
                     # a body whose FILE order means nothing to the tiles (seeded random): the library's joint-sorted order + per-tile
                     # classes decide; a few tiles are wide and pay a second pass themselves
-                    ('capsules_random_file_order', {}, sm.synthetic_smpl(1234, kind='capsules'))]
+                    ('capsules_random_file_order', {}, sm.synthetic_smpl(1234, kind='capsules')),
+                    # the benchmarked body with ONE tile skinned by 13 joints: it pays a second pass itself, the model stays in its class
+                    ('one_13_joint_tile', {}, sm.with_wide_tile(model_np, 100, 13))]
         for name, env, mnp in variants:
             old = {k: os.environ.get(k) for k in env}
             os.environ.update(env)                       # read by jrr_model_create
@@ -587,8 +615,12 @@ def main():
                                + (' + pose-discriminator adversarial term' if use_disc else '')
                                + (' + soft-silhouette loss (224x224 rasteriser)' if use_sil else ''),
                    'global_batch': B * world, 'poses_per_sec': round(it_s * world * B, 1),
-                   'j_step_every': cadence, 'j_steps_in_timed_region': nj_region, 'parallelism': f'dp{world}', 'joint_loss_last': loss_joint,
-                   'timed_regions': len(regions), 'value_is': 'median region',
+                   'j_step_every': cadence, 'j_steps_in_timed_regions': nj_region, 'parallelism': f'dp{world}', 'joint_loss_last': loss_joint,
+                   'timed_regions': len(regions), 'timed_steps': len(regions) * a.steps,
+                   'value_is': 'all timed regions: timed steps / timed seconds (the J step follows every j_step_every-th iteration, counted '
+                               'across regions: the reference cadence, not one J step per region)',
+                   'median_region_ms_per_step': round(statistics.median(regions) / a.steps * 1e3, 4),
+                   'j_steps_per_region': region_nj if len(set(region_nj)) > 1 else region_nj[0],
                    'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in regions],
                    'host_calls_per_region': 'one C call (jrr_refine_run_j_steps)' if dist is None else 'refine_run + j_regressor_grad + all_reduce + j_step_apply per J step',
                    'forward_reuse_after_j_step': False,
@@ -643,7 +675,7 @@ def main():
                              if prof.get(cls, (0, 0))[1] and prof[cls][0] > 0},
         'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
                    'allreduce_bytes': xch.nbytes, 'allreduce_payload': 'regressor support [17][128]' if xch.compact else 'dense (17,6890)',
-                   'in_timed_region': nj_region, 'host_calls': 2 + (1 if dist is not None else 0)},
+                   'in_timed_regions': nj_region, 'host_calls': 2 + (1 if dist is not None else 0)},
         'cadence1': {'value': round(a.steps / c1_el * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(c1_ms, 4),
                      'j_step_every': 1, 'timed_regions': len(c1_regions), 'value_is': 'median region',
                      'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1_regions],

@@ -76,7 +76,10 @@ __device__ __forceinline__ void dma16u(const float* base_uniform, unsigned lane_
 // regressor 16 MFMA) instead of six half-stages of 24 (+16) MFMA: with KJ = 8, 423 instead of 519 MFMA per tile and 48
 // instead of 144 KB of A^T streamed per tile (KJ = 12: 447 MFMA, 72 KB).  Skipped terms are exact zeros: the result is the dense product's up to the
 // grouping of the K pairs.
-template <bool STORE_VP, bool STORE_VERTS, int KJ>
+// WIDE: the model has tiles with more than KJ joints (per-tile classes: such a tile runs a second pass over slots KJ .. 2 KJ - 1).
+// A separate instantiation: the branches of the second pass cost the stage loop ~2 % even when never taken (measured: 0.361 vs
+// 0.369 ms at B = 4096), so a model without wide tiles runs the kernel without them.
+template <bool STORE_VP, bool STORE_VERTS, int KJ, bool WIDE>
 __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk, const float* __restrict__ Wjv,
                                                     const float* __restrict__ Jn_vi, const float* __restrict__ FT,
                                                     const float* __restrict__ AT, float* __restrict__ VPb,
@@ -208,22 +211,24 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     j16[r] += p16;
   };
 
-  if (SPARSE && t_begin < t_end) wide_next = tnj[t_begin] > KJS;
+  if (SPARSE && WIDE && t_begin < t_end) wide_next = tnj[t_begin] > KJS;
   if (t_begin < t_end) issue(t_begin, 0, 0, 0, wide_next);
   int g = 0;   // global stage counter: ring slot = g & 1
   for (int vt = t_begin; vt < t_end; ++vt) {
     const float* ldsW = wj + (vt & 1) * WJ_FLOATS;
     const float* ldsJ = ldsW + W_FLOATS;
     if (SPARSE) {      // the skinning copies of this tile are issued from its stage NKCH - 1 on
-      wide = wide_next;
-      wide_next = (vt + 1 < t_end) ? (tnj[vt + 1] > KJS) : 0;                      // wave-uniform: scalar loads
+      if (WIDE) {
+        wide = wide_next;
+        wide_next = (vt + 1 < t_end) ? (tnj[vt + 1] > KJS) : 0;                    // wave-uniform: scalar loads
+      }
       const int j0 = jl[vt * NJ + 2 * wv], j1 = jl[vt * NJ + 2 * wv + 1];
       lane_jl[0] = (unsigned)(half ? j1 : j0) * (unsigned)BP + (unsigned)l31 * 4u;
       if (KJS > 8 && wv < KJS / 2 - 4) {
         const int j2 = jl[vt * NJ + 8 + 2 * wv], j3 = jl[vt * NJ + 8 + 2 * wv + 1];
         lane_jl[1] = (unsigned)(half ? j3 : j2) * (unsigned)BP + (unsigned)l31 * 4u;
       }
-      if (wide) {      // second pass: slots KJS .. 2 KJS - 1
+      if (WIDE && wide) {      // second pass: slots KJS .. 2 KJS - 1
         const int k0 = jl[vt * NJ + KJS + 2 * wv], k1 = jl[vt * NJ + KJS + 2 * wv + 1];
         lane_jx[0] = (unsigned)(half ? k1 : k0) * (unsigned)BP + (unsigned)l31 * 4u;
         if (KJS > 8 && wv < KJS / 2 - 4) {
@@ -248,7 +253,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         else barrier_keep_vm<nst>();
       }
       // the stage that follows this one: a wide tile's skinning stage r is followed by its second pass over the same r
-      if (SPARSE && s >= NKCH && wide) issue(vt, s, (g + 1) & 1, 1);
+      if (SPARSE && WIDE && s >= NKCH && wide) issue(vt, s, (g + 1) & 1, 1);
       else if (s + 1 < NST) issue(vt, s + 1, (g + 1) & 1);
       else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1, 0, wide_next);
       __builtin_amdgcn_sched_barrier(0);   // the counted wait above relies on: copies first, this stage's stores after
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         }
         vr += T * vp[1];                         // T_{r,1} v_y
         vr += U * vp[2];                         // T_{r,2} v_z
-        if (wide) {
+        if (WIDE && wide) {
           // ---- second pass of a WIDE tile (more than KJS joints): the same four products over slots KJS .. 2 KJS - 1,
           //      added to vr.  Its own ring stage: every copy and store of this wave is drained at its barrier (rare path).
           ++g;
@@ -351,7 +356,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         regress(std::integral_constant<int, r>{}, ldsJ);
         // after a second pass the next stage's counted wait (which assumes this stage's stores are all younger than its
         // copies) no longer holds: drain
-        if (wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (WIDE && wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       } else {
         constexpr int h = s - NKCH, r = h >> 1;
         if (STORE_VP) {   // spread the v_posed stores over the six skinning stages: two 16-byte row quads each
@@ -810,7 +815,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-template <int DV, int KJ>
+template <int DV, int KJ, bool WIDE>      // WIDE: as in k_lbs_fwd (0.184 vs 0.187 ms)
 __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ Tb, const float* __restrict__ AT,
                                                       const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                       const float* __restrict__ dVT, float* __restrict__ DVP,
@@ -968,7 +973,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
 #pragma unroll
     for (int blk = 0; blk < 2; ++blk) wd[blk] = *reinterpret_cast<const f32x4*>(tab + R16_WD + ((blk * 4 + g) * 16 + n) * 4);
     const int sg = segid[vt];                                      // wave-uniform
-    const int s_tile = (tnj[vt] + 3) >> 2;                         // K steps this tile's joints need (wave-uniform)
+    const int s_tile = WIDE ? (tnj[vt] + 3) >> 2 : 0;              // K steps this tile's joints need (wave-uniform)
     if (sg != cur_seg) { flush_window(); cur_seg = sg; }
     seg_tile = vt;
     // ---- translation column: dA_{r,3} += W16^T dverts_r ----
@@ -992,7 +997,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
           T[r][0] = mfma4(wt[0][s], at, T[r][0]);
           T[r][1] = mfma4(wt[1][s], at, T[r][1]);
         }
-      if (s_tile > S) {                                             // WIDE tile: the K steps beyond the kernel's S (slots 4 S .. 15)
+      if (WIDE && s_tile > S) {                                     // WIDE tile: the K steps beyond the kernel's S (slots 4 S .. 15)
 #pragma unroll 1
         for (int s = S; s < s_tile && s < 4; ++s) {
           const int jox = reinterpret_cast<const int*>(tab + R16_JL)[4 * s + g];
@@ -1342,23 +1347,23 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
   // exactly one round of two workgroups per CU, an even number of chunks and whole pose groups per XCD
   static const int fwd_split = [] { const char* e = getenv("JRR_FWD_SPLIT"); return e ? atoi(e) : 556; }();   // 5/9 (15 : 12 tiles at B = 4096)
   const int paired = (grid.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? fwd_split : 0;
+#define JRR_LBS_FWD_K(SVP, SVT, KJV, WD, WT)                                                                                      \
+  hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, KJV, WD>), grid, block, 0, s, m.Dk, WT, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe,  \
+                     paired, m.jl, m.tnj)
 #define JRR_LBS_FWD(SVP, SVT)                                                                                                     \
   do {                                                                                                                            \
-    if (m.kjs == 8)                                                                                                               \
-      hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, 8>), grid, block, 0, s, m.Dk, m.Wc, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,      \
-                         probe, paired, m.jl, m.tnj);                                                                             \
-    else if (m.kjs == 12)                                                                                                         \
-      hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, 12>), grid, block, 0, s, m.Dk, m.Wc, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,     \
-                         probe, paired, m.jl, m.tnj);                                                                             \
-    else                                                                                                                          \
-      hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, 0>), grid, block, 0, s, m.Dk, m.Wjv, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,     \
-                         probe, paired, m.jl, m.tnj);                                                                             \
+    if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_FWD_K(SVP, SVT, 8, false, m.Wc);                                                     \
+    else if (m.kjs == 8) JRR_LBS_FWD_K(SVP, SVT, 8, true, m.Wc);                                                                  \
+    else if (m.kjs == 12 && !m.wide_tiles) JRR_LBS_FWD_K(SVP, SVT, 12, false, m.Wc);                                              \
+    else if (m.kjs == 12) JRR_LBS_FWD_K(SVP, SVT, 12, true, m.Wc);                                                                \
+    else JRR_LBS_FWD_K(SVP, SVT, 0, false, m.Wjv);                                                                                \
   } while (0)
   if (VPb && verts) JRR_LBS_FWD(true, true);
   else if (VPb) JRR_LBS_FWD(true, false);
   else if (verts) JRR_LBS_FWD(false, true);
   else JRR_LBS_FWD(false, false);
 #undef JRR_LBS_FWD
+#undef JRR_LBS_FWD_K
   return 0;
 }
 
@@ -1371,17 +1376,21 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
     // pairing, -2 = chunk-major mapping without pairing
     static const int pair_env = [] { const char* e = getenv("JRR_BWD16_PAIRED"); return e ? atoi(e) : 480; }();
     const int paired16 = (pair_env > 0) ? ((grid16.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? pair_env : 0) : pair_env;
+#define JRR_LBS_BWD16_K(DVM, KJV, WD)                                                                                           \
+  hipLaunchKernelGGL((k_lbs_bwd16<DVM, KJV, WD>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, \
+                     m.segj, paired16, m.tnj)
 #define JRR_LBS_BWD16(DVM)                                                                                                      \
   do {                                                                                                                          \
-    if (m.kjs == 8)                                                                                                             \
-      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 8>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj, paired16, m.tnj);  \
-    else                                                                                                                        \
-      hipLaunchKernelGGL((k_lbs_bwd16<DVM, 12>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, m.segj, paired16, m.tnj); \
+    if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_BWD16_K(DVM, 8, false);                                                            \
+    else if (m.kjs == 8) JRR_LBS_BWD16_K(DVM, 8, true);                                                                         \
+    else if (!m.wide_tiles) JRR_LBS_BWD16_K(DVM, 12, false);                                                                    \
+    else JRR_LBS_BWD16_K(DVM, 12, true);                                                                                        \
   } while (0)
     if (dVT && dJT) JRR_LBS_BWD16(2);
     else if (dVT) JRR_LBS_BWD16(1);
     else JRR_LBS_BWD16(0);
 #undef JRR_LBS_BWD16
+#undef JRR_LBS_BWD16_K
     return 0;
   }
   const int n_bt = BP / BT;                     // one workgroup per (pose tile, vertex chunk)

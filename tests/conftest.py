@@ -53,15 +53,15 @@ def pytest_collection_finish(session):
         # the node's world size (BASELINE configs[3]: 8 ranks), 32 poses per rank, still on one GPU over gloo
         'w8': _torchrun(8, 29544, [worker, os.path.join(tmp, 'w8')] + DP_FLAGS + ['--dist_backend', 'gloo', '--single_device']),
         # bench.py --gpus 2 WITHOUT torchrun: bench.py starts its own 2-rank child (what the driver's command line does)
-        'bench2': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--batch', '256',
+        'bench2': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--j_step_every', '2', '--batch', '256',
                    '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5',
                    '--min_timed_ms', '50'],
         # ... and at the node's world size
-        'bench8': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '1', '--batch', '128',
+        'bench8': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '1', '--j_step_every', '2', '--batch', '128',
                    '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5',
                    '--min_timed_ms', '50'],
         # the same under an explicit torchrun (the README's / the contract's N > 1 command line)
-        'bench2t': _torchrun(2, 29542, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--batch', '256',
+        'bench2t': _torchrun(2, 29542, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--j_step_every', '2', '--batch', '256',
                                         '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded',
                                         '--no_skin_variants', '--no_config5', '--min_timed_ms', '50']),
         # the in-loop J step with the DENSE (17,6890) all-reduce payload instead of the regressor's support (default): same J
@@ -78,7 +78,7 @@ def pytest_collection_finish(session):
     if torch.cuda.device_count() >= 2:
         # a box with two or more GPUs: the SAME runs with one rank per GPU over RCCL (backend nccl), no --single_device
         runs['w2n'] = _torchrun(2, 29545, [worker, os.path.join(tmp, 'w2n')] + DP_FLAGS[:-2] + ['--dist_backend', 'nccl'])
-        runs['bench2n'] = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--batch', '256',
+        runs['bench2n'] = [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--j_step_every', '2', '--batch', '256',
                            '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5', '--min_timed_ms', '50']
     DP_RUNS['dir'] = tmp
     for name, cmd in runs.items():
