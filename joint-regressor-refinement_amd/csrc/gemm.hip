@@ -423,7 +423,9 @@ __global__ __launch_bounds__(256, 2) void k_blend_adjoint(const float* __restric
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
       const int p = wave + 4 * i;
-      __builtin_amdgcn_global_load_lds(JRR_GLB(b + ((size_t)(p >> 1) * BP + (p & 1) * 64 + lane) * 4), JRR_LDS(dB + p * 256), 16, 0, 0);
+      // dvp is read exactly once (340 MB): non-temporal (aux bit 1), so that it does not push the basis D and this kernel's own
+      // output slabs out of L2 / the Infinity Cache (measured: the slab sum that follows 52 -> 46 us, this kernel -1 us)
+      __builtin_amdgcn_global_load_lds(JRR_GLB(b + ((size_t)(p >> 1) * BP + (p & 1) * 64 + lane) * 4), JRR_LDS(dB + p * 256), 16, 0, 2);
     }
   };
   f32x16 acc[7];
