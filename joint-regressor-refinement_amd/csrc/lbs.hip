@@ -840,7 +840,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
     // slots j and j + per_xcd / 2 of an XCD -- take the two halves of a PAIR of vertex chunks of the SAME pose group.
     // Measured (B = 4096): 0.204 -> 0.184 ms; what matters is that the two share the pose group (the chunk-major mapping
     // without pairing gains nothing), the split itself is flat around even: `paired` = the first-dispatched workgroup's
-    // share of the pair's tiles in thousandths, 480 (26 : 28 tiles) measured best by 1 %.  Static: bitwise reproducible.
+    // share of the pair's tiles in thousandths (launcher default).  Static: bitwise reproducible.
     const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int p = j % (per_xcd / 2), slot_ = j / (per_xcd / 2);
     const int npair = nvc / 2, bt_per_xcd = (per_xcd / 2) / npair;
@@ -1372,9 +1372,11 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
   if (m.kjs && m.bwd16) {                       // four symmetric waves of 16 poses: one workgroup per (64 poses, vertex chunk)
     const int n_bt16 = BP / 64;
     dim3 grid16(n_bt16 * nvc), block16(256);
-    // JRR_BWD16_PAIRED (experiments): share of the first-dispatched workgroup of a CU in thousandths (default 480), 0 = no
+    // JRR_BWD16_PAIRED (experiments): share of the first-dispatched workgroup of a CU in thousandths (default 520: round 4, with
+    // the non-temporal streams -- 0.1797 ms against 0.1815 at 480, 0.186 at 560; shader-clock stamps: the first-dispatched workgroup's
+    // tiles take ~12 300 clocks, its partner's ~14 000 while both run and 7 400 once it is alone), 0 = no
     // pairing, -2 = chunk-major mapping without pairing
-    static const int pair_env = [] { const char* e = getenv("JRR_BWD16_PAIRED"); return e ? atoi(e) : 480; }();
+    static const int pair_env = [] { const char* e = getenv("JRR_BWD16_PAIRED"); return e ? atoi(e) : 520; }();
     const int paired16 = (pair_env > 0) ? ((grid16.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? pair_env : 0) : pair_env;
 #define JRR_LBS_BWD16_K(DVM, KJV, WD)                                                                                           \
   hipLaunchKernelGGL((k_lbs_bwd16<DVM, KJV, WD>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, \
