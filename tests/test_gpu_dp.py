@@ -109,7 +109,11 @@ def test_eight_ranks_of_4096_poses_equal_one_rank_of_32768():
     x8 = np.concatenate([r['x6d'] for r in eight])
     b8 = np.concatenate([r['betas'] for r in eight])
     assert x8.shape == one['x6d'].shape == (32768, 24, 6)
-    assert np.abs(x8 - one['x6d']).max() < 2e-4 and np.abs(b8 - one['betas']).max() < 2e-4
+    # two launch geometries (4096 vs 32 768 poses per engine): fp32 summation orders differ in the last bit and Adam's first steps
+    # lr * g / (|g| + eps) amplify that wherever a gradient entry is ~ 0 -- the bound of every geometry comparison of the suite
+    # (DESIGN.md section 6): max 6e-4 over the 4.7 M entries, and the MEAN pins the trajectory
+    dx, db = np.abs(x8 - one['x6d']), np.abs(b8 - one['betas'])
+    assert dx.max() < 6e-4 and dx.mean() < 1e-6 and db.max() < 6e-4 and db.mean() < 1e-6, (dx.max(), dx.mean(), db.max(), db.mean())
     for k in ('J', 'disc'):
         for r in eight[1:]:
             assert np.array_equal(eight[0][k], r[k]), k

@@ -6,7 +6,7 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # kernel trace: the default bench command itself (100 timed steps); PMC passes: a short run (counters serialise kernels)
-FULL="python3 $PWD/bench.py --no_cpu_baseline --min_timed_ms 600"
+FULL="python3 $PWD/bench.py --no_cpu_baseline --min_timed_ms 600 --no_config2"
 CMD="python3 $PWD/bench.py --steps 5 --warmup 2 --no_cpu_baseline --min_timed_ms 1 --no_skin_variants --no_folded --no_config2"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $FULL > $OUT/trace.log 2>&1
