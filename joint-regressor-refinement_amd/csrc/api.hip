@@ -642,7 +642,12 @@ extern "C" int jrr_engine_set_folded(jrr_engine_t* e, int enabled, void* stream)
   return JRR_OK;
 }
 
+static int set_j_regressor_impl(jrr_engine_t* e, const float* J, const float* mask, void* stream, int32_t* step_inc);
 extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const float* mask, void* stream) {
+  return set_j_regressor_impl(e, J, mask, stream, nullptr);
+}
+// step_inc (J step only): the Adam step counter, incremented by the first launch of the normalisation
+static int set_j_regressor_impl(jrr_engine_t* e, const float* J, const float* mask, void* stream, int32_t* step_inc) {
   if (!e || !J) { jrr_set_error("set_j_regressor: null"); return JRR_ERR_ARG; }
   if (!e->has_model) { jrr_set_error("engine was created without an SMPL model (discriminators only)"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
@@ -656,7 +661,7 @@ extern "C" int jrr_engine_set_j_regressor(jrr_engine_t* e, const float* J, const
     if (e->have_jsup) JRR_HIP(hipMemsetAsync(e->dJn, 0, (size_t)NH * VP * sizeof(float), s));
   }
   launch_jreg_normalize(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->rowsum, e->Jn, e->Jn_vi, e->Jn_iv, e->Jn_q, e->m.p2v, s,
-                        (e->m.kjs && e->m.bwd16) ? 1 : 0, e->m.v2p, e->have_jsup ? &e->jsup : nullptr);
+                        (e->m.kjs && e->m.bwd16) ? 1 : 0, e->m.v2p, e->have_jsup ? &e->jsup : nullptr, step_inc);
   e->fold_valid = false;
   if (e->folded) {
     int rc = fold_rebuild(e, s);
@@ -1174,11 +1179,11 @@ extern "C" int jrr_silhouette_loss_grad(jrr_engine_t* e, const float* x6d, const
 
 // joints^T partials from the STORED vertices: JPv[split][r][32][BP] = sum_{v in split} Jn[i,v] verts_r[v,b]
 // (both operands in vertex quads: Jn_q [VP/4][32][4], VTb [3][VP/4][BP][4]; rows i >= 17 of Jn_q are zero)
-static int joints_from_stored_verts(jrr_engine* e, hipStream_t s) {
+static int joints_from_stored_verts(jrr_engine* e, hipStream_t s, int32_t* step_inc = nullptr) {
   // slab layout [split][plane][32][BP], what k_joints_loss reads with jp_rows = 32.  The support-restricted kernel writes ONE
   // complete slab (slab 0) when the regressor's support lists fit (device flag jsup.flag, which k_joints_loss also reads to
   // sum one slab only); otherwise it returns at once and the dense product below does the work -- and vice versa.
-  if (e->have_jsup) launch_rejoints_sparse(e->jsup, e->VTb, e->dFTp, e->BP, s);
+  if (e->have_jsup) launch_rejoints_sparse(e->jsup, e->VTb, e->dFTp, e->BP, s, step_inc);
   return launch_gemm_q32(e->Jn_q, 32, 0, e->VTb, e->BP, (size_t)VP * e->BP, e->dFTp, e->BP, (size_t)3 * 32 * e->BP,
                          (size_t)32 * e->BP, e->BP, VP, 3, e->nsplit, s, e->have_jsup ? e->jsup.flag : nullptr);
 }
@@ -1264,13 +1269,13 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     // with the pose discriminator its per-joint MLP rides in the chain-forward launch, and its adjoint in the launch of
     // the dF^T slab sum (two independent latency-bound kernels side by side: prep.hip)
     const bool fuse_conv = pd && !reuse;
-    if (reuse) launch_step_inc(step, s);
+    if (reuse) { if (!e->have_jsup) launch_step_inc(step, s); }      // (with support lists the count rides in k_rejoints_sparse)
     else if (fuse_conv) launch_prep_fwd_dconv(e->m, x6d, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, e->convL, e->H2T, nullptr, s);
     else launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, s);
     prof_mark(e, 0, s);
     prof_mark(e, 1, s);
     if (reuse) {
-      int rcr = joints_from_stored_verts(e, s);
+      int rcr = joints_from_stored_verts(e, s, step);
       if (rcr) return rcr;
     } else if (folded) {
       GemmArgs g;   // M^T[(i,j,c)][b] = sum_k H[(i,j,c)][k] F^T[k][b]
@@ -1476,10 +1481,10 @@ extern "C" int jrr_j_step_apply(jrr_engine_t* e, float* J, const float* dJ, floa
 
 static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, float* v, int32_t* step, float lr, const float* mask,
                         hipStream_t s) {
-  launch_step_inc(step, s);
-  launch_adam_flat(J, dJ, m, v, (size_t)NH * V, step, lr, 0.9f, 0.999f, 1e-8f, s);
+  // Adam with step + 1; the counter itself is incremented by the normalisation's first launch (one launch less per J step)
+  launch_adam_flat(J, dJ, m, v, (size_t)NH * V, step, lr, 0.9f, 0.999f, 1e-8f, s, 1);
   const bool cached = e->fwd_cached, known = e->jsup_fits_known;
-  int rc = jrr_engine_set_j_regressor(e, J, mask, (void*)s);
+  int rc = set_j_regressor_impl(e, J, mask, (void*)s, step);
   e->fwd_cached = cached;
   e->jsup_fits_known = known;      // the stepped regressor's support is a subset of the old one (ReLU' = 0 outside it)
   return rc;

@@ -75,7 +75,7 @@ int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s);
 int launch_reduce_slabs(const float* P, int nslab, size_t stride, float* out, size_t n, hipStream_t s, int accumulate = 0);
 int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr, float b1,
-                     float b2, float eps, hipStream_t s);
+                     float b2, float eps, hipStream_t s, int step_plus = 0);
 
 // lbs.hip
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
@@ -92,12 +92,14 @@ int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int
 constexpr int JSUP_CAP = 128;
 struct JSupport { int* flag; int* cnt; int* col; float* val; };     // flag[1], cnt[32], col[17][JSUP_CAP], val[17][JSUP_CAP]
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv, float* Jn_q,
-                          const int* p2v, hipStream_t s, int r16 = 0, const int* v2p = nullptr, const JSupport* sup = nullptr);
+                          const int* p2v, hipStream_t s, int r16 = 0, const int* v2p = nullptr, const JSupport* sup = nullptr,
+                          int32_t* step_inc = nullptr);
 // dJn[i][row] = sum_{b, r} dj_r[i][b] verts_r[row][b] for the support entries only (sup.flag != 0; the other entries of dJn keep
 // whatever finite value they hold: they meet Jn = 0 and relu' = 0 in k_jreg_bwd)
 int launch_jgrad_sparse(const JSupport& sup, const float* dJT, const float* VTq, float* dJn, int BP, hipStream_t s);
 // joints of the stored vertices with the current regressor, one slab [3][32][BP] (rows i < 17), support entries only
-int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, int BP, hipStream_t s);
+// step_inc (nullable): incremented by one thread of the launch (the reuse iteration's Adam step count: one launch less)
+int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, int BP, hipStream_t s, int32_t* step_inc = nullptr);
 int launch_jsup_gather(const JSupport& sup, const float* dJ, const int* p2v, float* out, hipStream_t s);
 int launch_jsup_scatter(const JSupport& sup, const float* in, const int* p2v, float* dJ, hipStream_t s);
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,

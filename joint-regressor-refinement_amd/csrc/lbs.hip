@@ -1162,10 +1162,12 @@ __global__ void k_dverts_transpose(const float* __restrict__ dverts, int ldv, fl
 // ------------------------------------------------------------------------------------------
 constexpr int JREG_THREADS = 1024;     // one block per regressor row: 6890 columns, 7 per thread
 __global__ __launch_bounds__(JREG_THREADS) void k_jreg_rowsum(const float* __restrict__ J, const float* __restrict__ mask,
-                                                               float* __restrict__ rowsum, int* __restrict__ sup_flag) {
+                                                               float* __restrict__ rowsum, int* __restrict__ sup_flag,
+                                                               int32_t* __restrict__ step_inc) {
   __shared__ float red[JREG_THREADS];
   const int i = blockIdx.x;
   if (sup_flag && i == 0 && threadIdx.x == 0) *sup_flag = 1;      // k_jreg_support (two launches later) may clear it
+  if (step_inc && i == 0 && threadIdx.x == 0) step_inc[0] += 1;   // the J step's Adam count (k_adam_flat, the launch before, used + 1)
   float acc = 0.f;
   for (int v = threadIdx.x; v < V; v += blockDim.x) {
     float x = J[(size_t)i * V + v];
@@ -1238,23 +1240,25 @@ __global__ __launch_bounds__(JREG_THREADS) void k_jreg_support(const float* __re
   }
 }
 
-// one workgroup per (row i, entry slot): dJn[i][row] = sum_b sum_r dj_r[i][b] verts_r[row][b]; fixed-order sums
-__global__ __launch_bounds__(256) void k_jgrad_sparse(JSupport sup, const float* __restrict__ dJT, const float* __restrict__ VTq,
-                                                      float* __restrict__ dJn, int BP) {
+// one workgroup per (row i, entry slot): dJn[i][row] = sum_b sum_r dj_r[i][b] verts_r[row][b]; fixed-order sums.
+// (1024 threads: the sum over the poses is a chain of dependent load rounds -- 4 per thread at 4096 poses instead of 16: 17 -> ~6 us)
+constexpr int JGS_THREADS = 1024;
+__global__ __launch_bounds__(JGS_THREADS) void k_jgrad_sparse(JSupport sup, const float* __restrict__ dJT, const float* __restrict__ VTq,
+                                                              float* __restrict__ dJn, int BP) {
   if (*sup.flag == 0) return;
-  __shared__ float red[256];
+  __shared__ float red[JGS_THREADS];
   const int i = blockIdx.x;
   for (int e = blockIdx.y; e < sup.cnt[i]; e += gridDim.y) {
     const int row = sup.col[i * JSUP_CAP + e];
     float acc = 0.f;
-    for (int b = threadIdx.x; b < BP; b += 256) {          // padded poses carry dj = 0
+    for (int b = threadIdx.x; b < BP; b += JGS_THREADS) {          // padded poses carry dj = 0
 #pragma unroll
       for (int r = 0; r < 3; ++r)
         acc = fmaf(dJT[(size_t)(r * NHP + i) * BP + b], VTq[(((size_t)r * (VP / 4) + (row >> 2)) * BP + b) * 4 + (row & 3)], acc);
     }
     red[threadIdx.x] = acc;
     __syncthreads();
-    for (int w = 128; w > 0; w >>= 1) {
+    for (int w = JGS_THREADS / 2; w > 0; w >>= 1) {
       if ((int)threadIdx.x < w) red[threadIdx.x] += red[threadIdx.x + w];
       __syncthreads();
     }
@@ -1264,7 +1268,9 @@ __global__ __launch_bounds__(256) void k_jgrad_sparse(JSupport sup, const float*
 }
 
 // joints^T slab [3][32][BP] (rows i < 17) of the stored vertices with the current regressor: one thread per (pose, row i)
-__global__ __launch_bounds__(256) void k_rejoints_sparse(JSupport sup, const float* __restrict__ VTq, float* __restrict__ out, int BP) {
+__global__ __launch_bounds__(256) void k_rejoints_sparse(JSupport sup, const float* __restrict__ VTq, float* __restrict__ out, int BP,
+                                                         int32_t* __restrict__ step_inc) {
+  if (step_inc && blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) step_inc[0] += 1;      // before the early return
   if (*sup.flag == 0) return;
   const int b = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
   if (b >= BP) return;
@@ -1305,11 +1311,11 @@ int launch_jsup_scatter(const JSupport& sup, const float* in, const int* p2v, fl
 }
 
 int launch_jgrad_sparse(const JSupport& sup, const float* dJT, const float* VTq, float* dJn, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_jgrad_sparse, dim3(NH, 16), dim3(256), 0, s, sup, dJT, VTq, dJn, BP);
+  hipLaunchKernelGGL(k_jgrad_sparse, dim3(NH, 16), dim3(JGS_THREADS), 0, s, sup, dJT, VTq, dJn, BP);
   return 0;
 }
-int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, int BP, hipStream_t s) {
-  hipLaunchKernelGGL(k_rejoints_sparse, dim3((BP + 255) / 256, NH), dim3(256), 0, s, sup, VTq, out, BP);   // BP is a multiple of 128 only: round UP (the kernel guards b >= BP)
+int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, int BP, hipStream_t s, int32_t* step_inc) {
+  hipLaunchKernelGGL(k_rejoints_sparse, dim3((BP + 255) / 256, NH), dim3(256), 0, s, sup, VTq, out, BP, step_inc);   // BP is a multiple of 128 only: round UP (the kernel guards b >= BP)
   return 0;
 }
 
@@ -1420,8 +1426,8 @@ int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int
 }
 
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv,
-                          float* Jn_q, const int* p2v, hipStream_t s, int r16, const int* v2p, const JSupport* sup) {
-  hipLaunchKernelGGL(k_jreg_rowsum, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, rowsum, sup ? sup->flag : nullptr);
+                          float* Jn_q, const int* p2v, hipStream_t s, int r16, const int* v2p, const JSupport* sup, int32_t* step_inc) {
+  hipLaunchKernelGGL(k_jreg_rowsum, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, rowsum, sup ? sup->flag : nullptr, step_inc);
   hipLaunchKernelGGL(k_jreg_tiles, dim3(VT * 1024 / 256), dim3(256), 0, s, J, mask, rowsum, Jn, Jn_vi, Jn_iv, Jn_q, p2v, r16);
   if (sup) hipLaunchKernelGGL(k_jreg_support, dim3(NH), dim3(JREG_THREADS), 0, s, Jn, v2p, *sup);
   return 0;

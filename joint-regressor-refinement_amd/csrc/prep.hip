@@ -586,9 +586,11 @@ __global__ void k_joint_loss_plain(const float* __restrict__ joints, const float
 
 __global__ void k_adam_flat(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                             float* __restrict__ v, size_t n, const int32_t* __restrict__ step, float lr, float beta1,
-                            float beta2, float eps) {
+                            float beta2, float eps, int step_plus) {
   __shared__ AdamScalars sc;
-  if (threadIdx.x == 0) sc = adam_scalars(step[0], lr, beta1, beta2, eps);
+  // step_plus = 1: the counter still holds the number of COMPLETED steps; a later launch of the same stream increments it (the J
+  // step: k_jreg_rowsum -- one launch less than a separate increment kernel before this one)
+  if (threadIdx.x == 0) sc = adam_scalars(step[0] + step_plus, lr, beta1, beta2, eps);
   __syncthreads();
   AdamScalars s = sc;
   for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -996,10 +998,10 @@ int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
 }
 
 int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr, float b1,
-                     float b2, float eps, hipStream_t s) {
+                     float b2, float eps, hipStream_t s, int step_plus) {
   int blocks = (int)((n + 255) / 256);
   if (blocks > 2048) blocks = 2048;
-  hipLaunchKernelGGL(k_adam_flat, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, step, lr, b1, b2, eps);
+  hipLaunchKernelGGL(k_adam_flat, dim3(blocks), dim3(256), 0, s, p, g, m, v, n, step, lr, b1, b2, eps, step_plus);
   return 0;
 }
 
