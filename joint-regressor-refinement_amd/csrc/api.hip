@@ -1184,6 +1184,9 @@ static int joints_from_stored_verts(jrr_engine* e, hipStream_t s, int32_t* step_
   // complete slab (slab 0) when the regressor's support lists fit (device flag jsup.flag, which k_joints_loss also reads to
   // sum one slab only); otherwise it returns at once and the dense product below does the work -- and vice versa.
   if (e->have_jsup) launch_rejoints_sparse(e->jsup, e->VTb, e->dFTp, e->BP, s, step_inc);
+  // the host KNOWS that the lists fit (jrr_j_support_info; J steps only shrink the support): the dense product need not even be
+  // enqueued (an idle launch still costs ~4.7 us of stream time)
+  if (e->have_jsup && e->jsup_fits_known) return 0;
   return launch_gemm_q32(e->Jn_q, 32, 0, e->VTb, e->BP, (size_t)VP * e->BP, e->dFTp, e->BP, (size_t)3 * 32 * e->BP,
                          (size_t)32 * e->BP, e->BP, VP, 3, e->nsplit, s, e->have_jsup ? e->jsup.flag : nullptr);
 }
@@ -1410,9 +1413,11 @@ static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s) {
   // over the regressor's support when its lists fit (lbs.hip, "J step over the regressor's SUPPORT"), else the dense product
   const int* sflag = e->have_jsup ? e->jsup.flag : nullptr;
   if (e->have_jsup) launch_jgrad_sparse(e->jsup, e->dJT, e->VTb, e->dJn, e->BP, s);
-  int rc = launch_jgrad_q(e->dJT, e->VTb, e->dJnp, e->BP, e->nsplitJ, s, sflag);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_djn_reduce, dim3((NH * VP + 255) / 256), dim3(256), 0, s, e->dJnp, 3 * e->nsplitJ, e->dJn, sflag);
+  if (!(e->have_jsup && e->jsup_fits_known)) {      // (known to fit: the dense product and its slab sum are not even enqueued)
+    int rc = launch_jgrad_q(e->dJT, e->VTb, e->dJnp, e->BP, e->nsplitJ, s, sflag);
+    if (rc) return rc;
+    hipLaunchKernelGGL(k_djn_reduce, dim3((NH * VP + 255) / 256), dim3(256), 0, s, e->dJnp, 3 * e->nsplitJ, e->dJn, sflag);
+  }
   launch_jreg_bwd(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->Jn, e->rowsum, e->dJn, VP, dJ, e->m.v2p, s);
   CHECK_LAUNCH();
   return JRR_OK;

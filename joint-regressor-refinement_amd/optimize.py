@@ -170,6 +170,8 @@ def optimize_pose_refiner(log=print) -> Dict:
         eng = engines[B_local]
         eng.set_batch_norm(B_global)
         eng.set_j_regressor(J_regressor, j_reg_mask)
+        eng.j_support_info()      # one small read-back per outer batch: an engine that knows its regressor's support fits the device
+        #                           lists enqueues the support-restricted J-step products only (include/jrr.h, jrr_j_support_info)
         if use_pd:
             eng.set_pose_disc(disc_flat)
         if use_sd:
