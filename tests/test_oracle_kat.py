@@ -102,3 +102,21 @@ def test_k6_gradcheck_fp64(smpl_model_np, j_h36m_np):
         d[0, l] = eps
         fd = (f(x6, b + d) - f(x6, b - d)) / (2 * eps)
         assert abs(float(fd) - float(gb[0, l])) < 1e-6 * max(1.0, abs(float(fd)))
+
+
+def test_k8_two_independent_restatements_agree(smpl_model_np):
+    """The torch restatement (homogeneous 4x4 chain, smplx's op order) against the float64 numpy LBS of the data generator
+    (smpl_model._lbs_np: rotation / translation parts kept apart, einsum contractions) -- written separately from the same published
+    algorithm.  Agreement pins neither to smplx, but a slip in one of the two would show here; also on the
+    capsule body (another skeleton-relative vertex layout, random file order)."""
+    import importlib
+    from conftest import PKG_NAME
+    sm = importlib.import_module(PKG_NAME + '.smpl_model')
+    for body in (smpl_model_np, sm.synthetic_smpl(1234, kind='capsules')):
+        m = _model64(body)
+        B = 5
+        R = _rand_rot(B * 24, seed=21, scale=0.6).view(B, 24, 3, 3)
+        betas = torch.randn(B, 10, generator=torch.Generator().manual_seed(22), dtype=torch.float64)
+        verts, _ = oracle.smpl_lbs(m, R, betas)
+        ref = sm._lbs_np(body, R.numpy(), betas.numpy())
+        assert np.abs(verts.numpy() - ref).max() < 1e-9
