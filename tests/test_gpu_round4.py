@@ -283,3 +283,34 @@ def test_model_file_with_chumpy_objects_end_to_end(tmp_path):
     Ro = oracle.rot6d_to_rotmat(x6.double().reshape(-1, 6)).view(B, 24, 3, 3)
     ref = oracle.find_joints(so, betas.double(), Ro[:, :1], Ro[:, 1:], T(J).double())
     assert (joints.cpu().double() - ref).abs().max().item() < 2e-5
+
+
+def test_driver_on_a_model_file_and_a_regressor_file(tmp_path):
+    """the reference's two file inputs end to end (/root/reference/scripts/optimize.py:96-99,105-107): `--smpl_dir` with a
+    SMPL_NEUTRAL.pkl in the distribution's format (chumpy objects; random vertex order -> internal sort, per-tile classes) and
+    `--j_regressor_init` with a (17,6890) .npy; two inner iterations + the outer step (discriminator update, J step) against the
+    oracle on the same body; the log record names the file as the body model"""
+    sm, argsmod, opt = _mod('smpl_model'), _mod('args'), _mod('optimize')
+    body = sm.synthetic_smpl(1234, kind='capsules')
+    write_chumpy_style_pickle(body, str(tmp_path / 'SMPL_NEUTRAL.pkl'))
+    J0 = sm.synthetic_h36m_regressor(body, seed=7, support=8)
+    np.save(tmp_path / 'J_regressor_h36m.npy', J0)
+    B = 48
+    argsmod._LazyArgs._ns = argsmod.get_args(['--batch_size', str(B), '--inner_iters', '2', '--device', DEV, '--synthetic_batches', '1',
+                                               '--smpl_dir', str(tmp_path), '--j_regressor_init', str(tmp_path / 'J_regressor_h36m.npy')])
+    res = opt.optimize_pose_refiner(log=lambda r: None)
+    rec = res['history'][0]
+    assert rec['body_model'] == f"file:{tmp_path / 'SMPL_NEUTRAL.pkl'}" and rec['data'] == 'synthetic'
+    # the same batch (the driver's seed 0 -> synthetic_batch seed 0) through the oracle
+    full = sm.synthetic_batch(body, J0, B, seed=0)
+    torch.manual_seed(0)
+    dsd = {k: v.detach() for k, v in _mod('discriminator').Discriminator().state_dict().items()}
+    x6 = T(full['pose6d'])
+    gt_c = oracle.move_pelvis(T(full['gt_j3d']))
+    smpl = oracle.OracleSMPL(body)
+    o, p, b_, hist = oracle.refine_poses(smpl, T(J0), x6[:, :1], x6[:, 1:], T(full['betas']), gt_c, 2, disc_sd=dsd)
+    assert (res['x6d'].cpu() - torch.cat([o, p], 1)).abs().max().item() < 3e-4
+    np.testing.assert_allclose(rec['joint_loss'], hist[-1]['joint_loss'], rtol=2e-3)
+    # the J step moved exactly the positive support of the file's regressor
+    moved = res['J_regressor'].cpu().numpy() != J0
+    assert moved.sum() == (J0 > 0).sum() and not moved[J0 <= 0].any()
