@@ -190,10 +190,18 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   // (the [v][32 i] tile of the record, read with i = lane % 16), B operand register q of the vertex tile; one four-block
   // instruction adds the two rows acc_row(q, 0), acc_row(q, 1) for all 32 pose columns (blocks 0 + 2: columns 0..15,
   // 1 + 3: 16..31).  Operands four steps ahead (an instruction is 32 clocks).
-  auto regress = [&](auto R_, const float* ldsJ) __attribute__((always_inline)) {
+  // (the first four A operands are requested by the caller -- `ra`, before anything that would fence the schedule: in the WIDE
+  // instantiation the second-pass branch sits between the skinning products and this product, and operands requested behind it
+  // exposed ~200 clocks of LDS latency per stage)
+  auto regress_operands = [&](const float* ldsJ, float (&ra)[4]) __attribute__((always_inline)) {
+    const float* jp = ldsJ + half * 128 + (lane & 15);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ra[q] = jp[acc_row_u(q) * 32];
+  };
+  auto regress = [&](auto R_, const float* ldsJ, const float (&ra)[4]) __attribute__((always_inline)) {
     constexpr int r = decltype(R_)::value;
     const float* jp = ldsJ + half * 128 + (lane & 15);              // row acc_row(q, half) = acc_row_u(q) + 4 half
-    float a0 = jp[acc_row_u(0) * 32], a1 = jp[acc_row_u(1) * 32], a2 = jp[acc_row_u(2) * 32], a3 = jp[acc_row_u(3) * 32];
+    float a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3];
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const float ac = a0;
@@ -316,6 +324,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         }
         vr += T * vp[1];                         // T_{r,1} v_y
         vr += U * vp[2];                         // T_{r,2} v_z
+        float ra[4];
+        regress_operands(ldsJ, ra);
         if (WIDE && wide) {
           // ---- second pass of a WIDE tile (more than KJS joints): the same four products over slots KJS .. 2 KJS - 1,
           //      added to vr.  Its own ring stage: every copy and store of this wave is drained at its barrier (rare path).
@@ -353,7 +363,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
             *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g4, BP, qoff) = t;
           }
         }
-        regress(std::integral_constant<int, r>{}, ldsJ);
+        regress(std::integral_constant<int, r>{}, ldsJ, ra);
         // after a second pass the next stage's counted wait (which assumes this stage's stores are all younger than its
         // copies) no longer holds: drain
         if (WIDE && wide) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -402,7 +412,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
               *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g, BP, qoff) = t;
             }
           }
-          regress(std::integral_constant<int, r>{}, ldsJ);
+          float ra[4];
+          regress_operands(ldsJ, ra);
+          regress(std::integral_constant<int, r>{}, ldsJ, ra);
         }
       }
       ++g;

@@ -1,0 +1,19 @@
+#!/bin/bash
+# usage (GPU box, repo root): bash tools/exp/ab_variants.sh <tag> name ...   -- like ab_libs.sh, printing the skin_variants block
+TAG=$1; shift
+LIB=joint-regressor-refinement_amd/libjrr_hip.so
+mkdir -p gpurun_out/$TAG
+cp $LIB /tmp/lib_base.so
+FLAGS="--no_cpu_baseline --no_folded --no_config5 --no_config2 --min_timed_ms 800"
+for round in 1 2; do
+  for which in base "$@"; do
+    if [ $which = base ]; then cp /tmp/lib_base.so $LIB; else cp tools/probe/libjrr_$which.so $LIB; fi
+    python bench.py $FLAGS > gpurun_out/$TAG/${which}_${round}.json 2>/dev/null
+    python - <<PY
+import json
+j = json.load(open('gpurun_out/$TAG/${which}_${round}.json'))
+print('%-8s %d  head %.4f  fwd %.4f |' % ('$which', $round, j['ms_per_step'], j['kernels_ms']['k_lbs_fwd']), {k: v['ms_per_step'] for k, v in j['skin_variants'].items()})
+PY
+  done
+done
+cp /tmp/lib_base.so $LIB
