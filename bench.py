@@ -547,8 +547,8 @@ def main():
     if not a.no_skin_variants and not use_sil:
         skin_variants = {}
         variants = [('skin12', {'JRR_SKIN_JOINTS': '12'}, model_np), ('dense', {'JRR_DENSE_SKINNING': '1'}, model_np),
-                    # a body whose FILE order means nothing to the tiles (seeded random): the library's joint-sorted order + per-tile
-                    # classes decide; a few tiles are wide and pay a second pass themselves
+                    # a body whose FILE order means nothing to the tiles (seeded random): the library stores it in its own order along the
+                    # kinematic chains (invisible at the API); tiles that are still wide would pay a second pass themselves
                     ('capsules_random_file_order', {}, sm.synthetic_smpl(1234, kind='capsules')),
                     # the benchmarked body with ONE tile skinned by 13 joints: it pays a second pass itself, the model stays in its class
                     ('one_13_joint_tile', {}, sm.with_wide_tile(model_np, 100, 13))]

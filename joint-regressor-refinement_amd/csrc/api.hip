@@ -5,6 +5,7 @@
 #include <cstdio>
 #include <cstring>
 #include <cstdlib>
+#include <tuple>
 #include <vector>
 
 #include "jrr_common.h"
@@ -105,19 +106,52 @@ extern "C" int jrr_model_create_in(const float* vt, const float* sd, const float
     const char* ask = getenv("JRR_VERTEX_ORDER");
     const bool force = ask && strcmp(ask, "sorted") == 0;
     const long cost_file = order_cost(order);
-    if (force || cost_file > (long)VT * 423) {      // some tile of the file order is wide: would the joint-sorted order be cheaper?
-      // key of a vertex: its joints by descending weight (dominant joint first), then the file index
-      std::vector<std::array<int, 5>> keys(V);
+    if (force || cost_file > (long)VT * 423) {      // some tile of the file order is wide: would a joint-sorted order be cheaper?
+      // joints of each vertex by descending weight (dominant joint first)
+      std::vector<std::array<int, 4>> inf4(V);
       for (int v = 0; v < V; ++v) {
         std::vector<std::pair<float, int>> inf;
         for (int j = 0; j < NJ; ++j) if (W[(size_t)v * NJ + j] != 0.f) inf.push_back({-W[(size_t)v * NJ + j], j});
         std::sort(inf.begin(), inf.end());
-        for (int k = 0; k < 4; ++k) keys[v][k] = k < (int)inf.size() ? inf[k].second : NJ;
-        keys[v][4] = v;
+        for (int k = 0; k < 4; ++k) inf4[v][k] = k < (int)inf.size() ? inf[k].second : NJ;
       }
-      std::vector<int> sorted(order);
-      std::sort(sorted.begin(), sorted.end(), [&](int a, int b) { return keys[a] < keys[b]; });
-      if (force || order_cost(sorted) < cost_file) { order = sorted; permuted = true; }
+      // (a) lexicographic: (dominant joint, second, third, fourth, file index)
+      std::vector<int> lex(order);
+      std::sort(lex.begin(), lex.end(), [&](int a, int b) { return std::tie(inf4[a], a) < std::tie(inf4[b], b); });
+      // (b) along the KINEMATIC CHAINS: body parts (dominant joint) in depth-first order of the skeleton, so that neighbouring
+      //     parts share joints; inside a part the vertices also tied to the previous part first, those tied to the next part last,
+      //     the rest by their other joints.  A tile that straddles two parts then sees few joints beyond either part's own
+      //     (capsule body in a random file order: 0 of 216 tiles above 8 joints, mean 4.4 -- the lexicographic order: 4, mean 4.8)
+      std::vector<int> dfs, pos(NJ + 1, NJ);
+      {
+        std::vector<int> stack{0};
+        while (!stack.empty()) {
+          const int j = stack.back(); stack.pop_back();
+          dfs.push_back(j);
+          for (int q = NJ - 1; q > j; --q) if (parents[q] == j) stack.push_back(q);      // children in ascending order
+        }
+        for (int i = 0; i < (int)dfs.size(); ++i) pos[dfs[i]] = i;
+      }
+      std::vector<std::array<int, 6>> ckey(V);
+      for (int v = 0; v < V; ++v) {
+        const int p0 = pos[inf4[v][0]];
+        const int prev_j = p0 > 0 ? dfs[p0 - 1] : -1, next_j = p0 + 1 < (int)dfs.size() ? dfs[p0 + 1] : -1;
+        bool has_prev = false, has_next = false;
+        std::array<int, 3> sec{NJ, NJ, NJ};
+        for (int k = 1; k < 4; ++k) {
+          const int j = inf4[v][k];
+          if (j == NJ) continue;
+          has_prev = has_prev || j == prev_j; has_next = has_next || j == next_j;
+          sec[k - 1] = pos[j];
+        }
+        std::sort(sec.begin(), sec.end());
+        ckey[v] = {p0, (has_prev && !has_next) ? 0 : (has_next && !has_prev) ? 2 : 1, sec[0], sec[1], sec[2], v};
+      }
+      std::vector<int> chain(order);
+      std::sort(chain.begin(), chain.end(), [&](int a, int b) { return ckey[a] < ckey[b]; });
+      const long cost_lex = order_cost(lex), cost_chain = order_cost(chain);
+      const std::vector<int>& best = cost_chain <= cost_lex ? chain : lex;
+      if (force || std::min(cost_chain, cost_lex) < cost_file) { order = best; permuted = true; }
     }
   }
   for (int p_ = 0; p_ < VP; ++p_) P2V[p_] = p_ < V ? order[p_] : -1;

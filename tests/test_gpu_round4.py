@@ -1,8 +1,8 @@
 """Round-4 parity rows, HIP path (through the C ABI) vs the CPU oracle (pytest -m gpu):
   * EVERY skinning / backward kernel family the library can select -- the 8-slot default, the 12-slot variant
     (JRR_SKIN_JOINTS=12), the dense kernels (JRR_DENSE_SKINNING=1), the role backward kernel (JRR_BWD16=0), the internally
-    re-ordered body (JRR_VERTEX_ORDER=sorted), and the PER-TILE classes on two bodies (a capsule body in a random file order:
-    the library sorts it and a few tiles stay wide; the benchmarked body with ONE 13-joint tile) -- each against the ORACLE,
+    re-ordered body (JRR_VERTEX_ORDER=sorted: one tile stays wide), a capsule body in a random file order (the library's
+    kinematic-chain order leaves no tile above 8 joints) and the PER-TILE classes (the benchmarked body with ONE 13-joint tile) -- each against the ORACLE,
     not against each other: find_joints forward + backward incl. dJ (B = 37, 130), the J step's gradient, a 3-iteration
     refinement with the pose discriminator (B = 200) and the benchmarked batch of 4096 on a strided subset.
     Reference: /root/reference/scripts/utils.py:85-103, scripts/optimize.py:220-265,300-312.
@@ -44,10 +44,11 @@ VARIANTS = {
     'dense': ({'JRR_DENSE_SKINNING': '1'}, 'surface', 0, False),
     'role_bwd': ({'JRR_BWD16': '0'}, 'surface', 8, False),
     'role_bwd12': ({'JRR_BWD16': '0', 'JRR_SKIN_JOINTS': '12'}, 'surface', 12, False),
-    'sorted': ({'JRR_VERTEX_ORDER': 'sorted'}, 'surface', 8, True),            # the surface body sorted: 5 tiles above 8 joints
-    'capsules': ({}, 'capsules', 8, True),                                     # random file order -> sorted internally, per-tile classes
-    'capsules_role_bwd': ({'JRR_BWD16': '0'}, 'capsules', 8, True),            # wide tiles + role kernel: its dense form
+    'sorted': ({'JRR_VERTEX_ORDER': 'sorted'}, 'surface', 8, True),            # the surface body in the library's chain order: 1 tile of 9 joints
+    'capsules': ({}, 'capsules', 8, False),                                    # random file order -> kinematic-chain order: no tile above 8
+    'capsules_role_bwd': ({'JRR_BWD16': '0'}, 'capsules', 8, False),           # ... with the role backward kernel
     'wide13': ({}, 'wide13', 8, True),                                         # ONE 13-joint tile in the file order
+    'wide13_role_bwd': ({'JRR_BWD16': '0'}, 'wide13', 8, True),                # a wide tile + role kernel: its dense form
     'wide13_skin12': ({'JRR_SKIN_JOINTS': '12'}, 'wide13', 12, True),          # ... under the 12-slot kernels: second pass over slots 12..
 }
 
@@ -73,7 +74,7 @@ def variant(request, smpl_model_np, j_h36m_np):
     assert dm.info['joint_slots'] == slots, dm.info
     assert (dm.info['wide_tiles'] > 0) == wide, dm.info
     if body == 'capsules':
-        assert dm.info['internal_vertex_order'] and dm.info['most_joints_per_tile'] <= 16
+        assert dm.info['internal_vertex_order'] and dm.info['most_joints_per_tile'] <= 8
     if body == 'wide13':
         assert dm.info['most_joints_per_tile'] == 13 and dm.info['wide_tiles'] == 1 and not dm.info['internal_vertex_order']
     # a regressor with the shipped checkpoint's structure on THIS body's vertices (the capsule body has its own vertex order)
