@@ -296,7 +296,9 @@ int jrr_j_step_apply(jrr_engine_t* e, float* J_dev, const float* dJ_dev, float* 
  *   jrr_j_support_info            positive entries per row (counts_host[17], nullable) and fits_host = 1 when every row has at
  *                                 most 128 of them.  SYNCHRONOUS (waits for `stream`); call once after jrr_engine_set_j_regressor:
  *                                 J steps only ever shrink the support (an entry at <= 0 gets no gradient), so the answer holds
- *                                 until the next jrr_engine_set_j_regressor from outside.  Once the engine has been told that the
+ *                                 until the next jrr_engine_set_j_regressor from outside or a J step with ANOTHER mask pointer (a
+ *                                 mask whose contents change in place must be re-announced through jrr_engine_set_j_regressor).
+ *                                 Once the engine has been told that the
  *                                 support fits, EVERY J step on it (jrr_j_regressor_grad, jrr_refine_run_j_steps, the forward reuse)
  *                                 enqueues the support-restricted products only; before, the dense products are enqueued beside them
  *                                 and a device flag picks (no host knowledge needed, ~14 us of idle launches per J step).

@@ -382,6 +382,7 @@ struct jrr_engine {
   float* dJraw;                                      // (17,6890) gradient scratch of the in-call J steps (jrr_refine_run_j_steps)
   JSupport jsup; bool have_jsup;                     // support lists of the normalised regressor (KEEP_VERTS engines; lbs.hip)
   bool jsup_fits_known;                              // jrr_j_support_info has seen flag = 1 for the current regressor lineage
+  const float* jsup_mask;                            // ... under this mask (another mask may un-mask entries: knowledge dropped)
   float* hist; int hist_cap, hist_every, hist_n; long long hist_iter;   // loss history (jrr_engine_set_loss_history)
   float *VTb;       // [3][VP][BP] vertices / transposed vertex adjoint (KEEP_VERTS or SILHOUETTE)
   float *dVTb, *dJnp, *dJn;   // transposed external vertex adjoint [3][VP][BP]; J-gradient partial slabs [3*nsplitJ][32][VP]
@@ -689,6 +690,8 @@ static int set_j_regressor_impl(jrr_engine_t* e, const float* J, const float* ma
   JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   e->have_mask = mask != nullptr;
+  if (mask != e->jsup_mask) e->jsup_fits_known = false;      // a different mask may un-mask entries: the support may have grown
+  e->jsup_mask = mask;
   if (!e->tab_static) {                                                                     // model-only: once per engine
     launch_bwd_tab_static(e->m, e->Jn_iv, s); e->tab_static = true;
     // the support-restricted J step writes dJn on the support only: everything else must be finite (it meets Jn = 0)
@@ -1502,10 +1505,7 @@ extern "C" int jrr_j_step_apply_support(jrr_engine_t* e, float* J, const float* 
   // all-reduced values on it.  Adam itself stays dense: entries that left the support keep coasting on their momentum.
   JRR_HIP(hipMemsetAsync(e->dJraw, 0, (size_t)NH * V * sizeof(float), s));
   launch_jsup_scatter(e->jsup, dJs, e->m.p2v, e->dJraw, s);
-  const bool known = e->jsup_fits_known;
-  int rc = j_step_apply(e, J, e->dJraw, m, v, step, lr, mask, s);
-  e->jsup_fits_known = known;
-  return rc;
+  return j_step_apply(e, J, e->dJraw, m, v, step, lr, mask, s);
 }
 
 // torch.optim.Adam on the raw regressor with the (all-reduced) gradient, then J*mask -> ReLU -> row-normalise into the
@@ -1522,10 +1522,10 @@ static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, floa
                         hipStream_t s) {
   // Adam with step + 1; the counter itself is incremented by the normalisation's first launch (one launch less per J step)
   launch_adam_flat(J, dJ, m, v, (size_t)NH * V, step, lr, 0.9f, 0.999f, 1e-8f, s, 1);
-  const bool cached = e->fwd_cached, known = e->jsup_fits_known;
+  const bool cached = e->fwd_cached, known = e->jsup_fits_known && mask == e->jsup_mask;
   int rc = set_j_regressor_impl(e, J, mask, (void*)s, step);
   e->fwd_cached = cached;
-  e->jsup_fits_known = known;      // the stepped regressor's support is a subset of the old one (ReLU' = 0 outside it)
+  e->jsup_fits_known = known;      // the stepped regressor's support is a subset of the old one (ReLU' = 0 outside it; same mask)
   return rc;
 }
 
