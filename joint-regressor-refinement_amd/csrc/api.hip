@@ -781,7 +781,11 @@ static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s, const float* c
   if (conv_x6d)
     launch_dconv_bwd_reduce(e->convL, conv_x6d, e->dH2T, nullptr, dscale, 1.f, e->gx, e->dsq, e->B, e->BP, e->dFTp, e->nsplit,
                             (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
-  else launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
+  else if (e->nvcb > MAX_SLABS_IN_CONSUMER) {      // both slab sums in one launch
+    launch_reduce_slabs2(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, e->dATp, e->nvcb, (size_t)12 * NJ * e->BP, e->dA,
+                         (size_t)12 * NJ * e->BP, s);
+    return;
+  } else launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
   if (e->nvcb > MAX_SLABS_IN_CONSUMER)
     launch_reduce_slabs(e->dATp, e->nvcb, (size_t)12 * NJ * e->BP, e->dA, (size_t)12 * NJ * e->BP, s);
 }

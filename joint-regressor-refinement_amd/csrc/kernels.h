@@ -74,6 +74,8 @@ int launch_joint_loss_plain(const float* joints, const float* gt_mm, float scale
                             hipStream_t s);
 int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s);
 int launch_reduce_slabs(const float* P, int nslab, size_t stride, float* out, size_t n, hipStream_t s, int accumulate = 0);
+int launch_reduce_slabs2(const float* P1, int nslab1, size_t stride1, float* out1, size_t n1, const float* P2, int nslab2,
+                         size_t stride2, float* out2, size_t n2, hipStream_t s);
 int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, const int32_t* step, float lr, float b1,
                      float b2, float eps, hipStream_t s, int step_plus = 0);
 
