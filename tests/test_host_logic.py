@@ -288,3 +288,18 @@ def test_synthetic_bodies_and_tile_classes():
     W = w['lbs_weights']
     per_tile = [int((W[32 * t:32 * t + 32] != 0).any(0).sum()) for t in range(216)]
     assert per_tile[100] == 13 and sum(n > 8 for n in per_tile) == 1 and (W != 0).sum(1).max() <= 4
+
+
+def test_integration_table_names_every_entry_point():
+    """INTEGRATION.md's call-site table has a row for every exported symbol of include/jrr.h (rows abbreviate families as
+    `jrr_model_create / _create_in / _destroy`)"""
+    hdr = open(os.path.join(ROOT, 'include', 'jrr.h')).read()
+    doc = open(os.path.join(ROOT, 'INTEGRATION.md')).read()
+    declared = set(re.findall(r'\b(jrr_[a-z0-9_]+)\s*\(', hdr)) - {'jrr_status'}
+    named = set(re.findall(r'\bjrr_[a-z0-9_]+', doc))
+    for cell in re.findall(r'`([^`]*)`', doc):
+        parts = [p.strip() for p in cell.split('/')]
+        if len(parts) > 1 and parts[0].startswith('jrr_'):
+            stem = parts[0].rsplit('_', 1)[0]
+            named |= {stem + p for p in parts[1:] if p.startswith('_')}
+    assert not (declared - named), sorted(declared - named)
