@@ -69,6 +69,12 @@ def test_c_abi_exports_every_declared_symbol():
     import ctypes
     rc = lib.jrr_engine_create(None, 4, 4, None, 0, 0, ctypes.byref(ctypes.c_void_p()))
     assert rc == -1 and b'bad argument' in lib.jrr_last_error()
+    # a caller-owned model buffer that is too small is refused before anything touches the device (JRR_ERR_WORKSPACE)
+    assert lib.jrr_model_bytes() > 3 * 3 * 6912 * 224 * 4
+    z = np.zeros(8, dtype=np.float32)
+    rc = lib.jrr_model_create_in(z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data, z.ctypes.data,
+                                 ctypes.c_void_p(256), 1024, ctypes.byref(ctypes.c_void_p()))
+    assert rc == -3 and b'jrr_model_bytes' in lib.jrr_last_error()
 
 
 def test_product_path_has_no_oracle_import():
