@@ -165,7 +165,7 @@ extern "C" int jrr_model_create_in(const float* vt, const float* sd, const float
         if (k < 207) val = pd[(size_t)k * (V * 3) + v * 3 + c];
         else if (k < 217) val = sd[((size_t)v * 3 + c) * NB + (k - 207)];
         else val = vt[v * 3 + c];
-        Dk[(((size_t)t * KFP + k) * 3 + c) * 32 + vv] = val;
+        Dk[((((size_t)t * (KFP / 4) + (k >> 2)) * 3 + c) * 32 + vv) * 4 + (k & 3)] = val;      // K-quads [tile][k / 4][plane][32 v][4]
         Dn[((size_t)c * VP + p_) * KFP + k] = val;
         Dq[(((size_t)c * (VP / 4) + (p_ >> 2)) * KFP + k) * 4 + (p_ & 3)] = val;
       }
@@ -364,7 +364,7 @@ struct jrr_engine {
   // workspace sections
   float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv, *Jn_q;
   bool tab_static;                                   // the W parts of the backward operand records are in place
-  float *FT, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
+  float *FT, *FTq, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
   float *convL;                                      // LDS image of the per-joint MLP parameters (k_conv_image)
   float *W2s, *zpart;                                // fc2.w rows scaled by fc4.w; partial fc4 dots [16][BP]
   float *W0Tq, *W2Tq, *W2sq, *W0q;                   // the four GEMM weight operands in quads [k/4][m][4]
@@ -455,6 +455,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->Jn_iv = c.take((size_t)VT * 2560);   // backward per-tile operand records [Jn | W^T | W | pad]
     t->Jn_q = c.take((size_t)VP * 32);      // normalised regressor in vertex quads [VP/4][32][4]
     t->FT = c.take((size_t)KFP * BP);
+    t->FTq = c.take((size_t)KFP * BP);      // the features in K-quads: B operand of k_lbs_fwd's blend product
     t->AT = c.take((size_t)12 * NJ * BP);
     t->VPb = c.take((size_t)3 * VP * BP);
     t->JP = c.take((size_t)nvc * 3 * NH * BP);
@@ -796,8 +797,8 @@ static void set_adjoint_slabs(jrr_engine* e, PrepBwdLaunch& L) {
 
 static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,
                         bool keep_verts, int32_t* step_inc, hipStream_t s) {
-  launch_prep_fwd(e->m, x6d, R, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step_inc, s);
-  launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, keep_vp ? e->VPb : nullptr, e->JP, keep_verts ? e->VTb : nullptr, e->B, e->BP,
+  launch_prep_fwd(e->m, x6d, R, betas, e->FT, e->FTq, e->AT, e->R0T, e->B, e->BP, step_inc, s);
+  launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, keep_vp ? e->VPb : nullptr, e->JP, keep_verts ? e->VTb : nullptr, e->B, e->BP,
                  e->nvc, s);
   return 0;
 }
@@ -1314,8 +1315,8 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     // the dF^T slab sum (two independent latency-bound kernels side by side: prep.hip)
     const bool fuse_conv = pd && !reuse;
     if (reuse) { if (!e->have_jsup) launch_step_inc(step, s); }      // (with support lists the count rides in k_rejoints_sparse)
-    else if (fuse_conv) launch_prep_fwd_dconv(e->m, x6d, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, e->convL, e->H2T, nullptr, s);
-    else launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->AT, e->R0T, e->B, e->BP, step, s);
+    else if (fuse_conv) launch_prep_fwd_dconv(e->m, x6d, betas, e->FT, e->FTq, e->AT, e->R0T, e->B, e->BP, step, e->convL, e->H2T, nullptr, s);
+    else launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->FTq, e->AT, e->R0T, e->B, e->BP, step, s);
     prof_mark(e, 0, s);
     prof_mark(e, 1, s);
     if (reuse) {
@@ -1330,7 +1331,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       launch_fold_fwd(e->MT, e->AT, e->G0, e->Jsum, e->BP, s);
     } else {
       const bool silf = e->sil_mask != nullptr;      // the silhouette term needs the vertices
-      launch_lbs_fwd(e->m, e->Jn_vi, e->FT, e->AT, e->VPb, e->JP, silf ? e->VTb : nullptr, e->B, e->BP, e->nvc, s,
+      launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, e->VPb, e->JP, silf ? e->VTb : nullptr, e->B, e->BP, e->nvc, s,
                      e->profiling ? e->probe : nullptr);
     }
     prof_mark(e, 1, s);

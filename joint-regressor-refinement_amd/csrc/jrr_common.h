@@ -127,7 +127,7 @@ struct Parents {
 
 // ---- device-resident SMPL model ------------------------------------------------------------
 struct Model {
-  float* Dk;    // [VT][KFP][3][32]  blend basis, feature-major inside a vertex tile
+  float* Dk;    // [VT][KFP/4][3][32][4]  blend basis in K-quads inside a vertex tile (a K chunk of a tile = one contiguous 12 KB DMA)
   float* Dn;    // [3][VP][KFP]      blend basis, feature-contiguous (folded-regressor tables)
   float* Dq;    // [3][VP/4][KFP][4] blend basis in vertex quads (A operand of the blend adjoint, k_blend_adjoint)
   float* Wjv;   // [VT][24][32]      skinning weights W^T tile  (lane = vertex)

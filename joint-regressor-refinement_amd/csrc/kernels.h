@@ -54,12 +54,13 @@ int launch_rot6d_fwd(const float* x, float* R, int n, hipStream_t s);
 int launch_rot6d_bwd(const float* x, const float* dR, float* dx, int n, hipStream_t s);
 int launch_rodrigues_fwd(const float* aa, float* R, int n, hipStream_t s);
 int launch_rodrigues_bwd(const float* aa, const float* dR, float* daa, int n, hipStream_t s);
-int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT,
+// FT: blend features row-major [KFP][BP] (chain adjoint, folded product); FTq: the same in K-quads [KFP/4][BP][4] (k_lbs_fwd)
+int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* FTq, float* AT,
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s);
 // horizontally fused launches of the inner loop (prep.hip): chain forward || per-joint MLP forward, and
 // per-joint MLP adjoint || dF^T slab sum
-int launch_prep_fwd_dconv(const Model& m, const float* x6d, const float* betas, float* FT, float* AT, float* R0T, int B, int BP,
-                          int32_t* step_inc, const float* img, float* H2T, float* out, hipStream_t s);
+int launch_prep_fwd_dconv(const Model& m, const float* x6d, const float* betas, float* FT, float* FTq, float* AT, float* R0T, int B,
+                          int BP, int32_t* step_inc, const float* img, float* H2T, float* out, hipStream_t s);
 int launch_dconv_bwd_reduce(const float* img, const float* x6d, const float* dH2T, const float* gout, float scale, float target,
                             float* gx, float* sqj, int B, int BP, const float* P, int nslab, size_t stride, float* out, size_t n,
                             hipStream_t s);

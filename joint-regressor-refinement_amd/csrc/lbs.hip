@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   const int wv = __builtin_amdgcn_readfirstlane(wave);
   const unsigned lane_rp = (unsigned)half * (unsigned)BP + (unsigned)l31 * 4u;   // floats
   const unsigned lane_ln = (unsigned)lane * 4u;                                  // floats
-  const float* const Fbg = FT + (size_t)bg * BG;
+  const float* const Fbg = FT + (size_t)bg * BG * 4;            // FT in K-quads [KFP / 4][BP][4] (k_prep_fwd writes it beside the row-major copy)
   const float* const Abg = AT + (size_t)bg * BG;
   unsigned lane_jl[2] = {0, 0};   // SPARSE: (row of this lane's joint of the current tile) * BP + pose offset, floats
   unsigned lane_jx[2] = {0, 0};   // ... of the SECOND pass of a wide tile (slots KJS .. 2 KJS - 1)
@@ -140,14 +140,16 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   auto issue = [&](int vt, int s, int slot, int pass = 0, int wide_w = 0) {
     float* dst = ring + slot * STG_FLOATS;
     if (s < NKCH) {
+      // K chunk s of the basis, K-QUADS [8 quads][3][32 v][4]: one contiguous 12 KB block of Dk
       const float* dsrc = Dk + ((size_t)vt * KFP + s * KCH) * 96;
 #pragma unroll
       for (int i = 0; i < 3; ++i) { const int o = wv + 4 * i; dma16u(dsrc + o * 256, lane_ln, dst + o * 256); }
+      // ... and of the features, K-quads [8 quads][128 poses][4]: piece o = (quad o / 2, poses (o % 2) * 64 + lane)
       float* fdst = dst + KCH * 96;
 #pragma unroll
       for (int i = 0; i < 4; ++i) {
         const int o = wv + 4 * i;
-        dma16u(Fbg + (size_t)(s * KCH + 2 * o) * BP, lane_rp, fdst + o * 256);
+        dma16u(Fbg + ((size_t)(s * (KCH / 4) + (o >> 1)) * BP + (o & 1) * 64) * 4, lane_ln, fdst + o * 256);
       }
       if (s == 0) {
         float* wdst = wj + (vt & 1) * WJ_FLOATS;
@@ -202,6 +204,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     constexpr int r = decltype(R_)::value;
     const float* jp = ldsJ + half * 128 + (lane & 15);              // row acc_row(q, half) = acc_row_u(q) + 4 half
     float a0 = ra[0], a1 = ra[1], a2 = ra[2], a3 = ra[3];
+    // (a second accumulator chain -- even / odd rows, added at the end -- fits since the quad-operand blend stage and was measured
+    // SLOWER: 0.3641 vs 0.3614 ms; the single chain's dependent issue is covered by the SIMD's other wave)
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
       const float ac = a0;
@@ -268,30 +272,39 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
       const float* buf = ring + (g & 1) * STG_FLOATS;
       if constexpr (s < NKCH) {
         if (s == 0) { vp[0] = zero16(); vp[1] = zero16(); vp[2] = zero16(); }
-        constexpr int npairs = (s == NKCH - 1) ? (KF - (NKCH - 1) * KCH) / 2 : KCH / 2;   // 13 : 16
-        const float* dp = buf + half * 96 + l31;
-        const float* fp = buf + KCH * 96 + half * BG + wave * BT + l31;
-        // The operands of K-pair kk+2 are requested right after the FIRST MFMA of pair kk has issued: the reads
-        // complete under two pairs' worth of MFMAs (384 clocks), so the wait before a pair costs nothing even when the
-        // LDS is busy with the other workgroup's DMA.  (The compiler's own schedule reads right before use and exposes
-        // the LDS latency after every third MFMA.)
-        float f0 = fp[0], d00 = dp[0], d01 = dp[32], d02 = dp[64];
-        float f1 = fp[2 * BG], d10 = dp[2 * 96], d11 = dp[2 * 96 + 32], d12 = dp[2 * 96 + 64];
+        // Both operands arrive in K-QUADS: a lane's ds_read_b128 is FOUR K steps (a K pair may take any two k as long as both
+        // operands agree: step t of group g takes k = 8 g + t and 8 g + 4 + t, the lane half picks the quad 2 g + half) --
+        // 4 LDS reads per 12 matrix instructions instead of 16.  The last chunk holds k = 192 .. 217: its group 3 has only the
+        // steps t = 0, 1 (k = 216, 217 against zero rows).  Operands of group g + 1 are requested right after the first
+        // instruction of group g.
+        constexpr int ngroups = 4;
+        const f32x4* dq = reinterpret_cast<const f32x4*>(buf) + half * 96 + l31;                          // quad q, plane c: + (q * 3 + c) * 32
+        const f32x4* fq = reinterpret_cast<const f32x4*>(buf + KCH * 96) + half * BG + wave * BT + l31;   // quad q: + q * 128
+        f32x4 a0 = dq[0], a1 = dq[32], a2 = dq[64], bq = fq[0];
+        f32x4 n0 = a0, n1 = a1, n2 = a2, nb = bq;
 #pragma unroll
-        for (int kk = 0; kk < KCH / 2; ++kk) {
-          if (kk >= npairs) break;
-          const float fc = f0, c0 = d00, c1 = d01, c2 = d02;
-          f0 = f1; d00 = d10; d01 = d11; d02 = d12;
+        for (int gq = 0; gq < ngroups; ++gq) {
+          constexpr int last_steps = KF - (NKCH - 1) * KCH - 24;      // valid steps of group 3 of the last chunk: 218 - 192 - 24 = 2
+          const int nsteps = (s == NKCH - 1 && gq == ngroups - 1) ? last_steps : 4;
+          const f32x4 c0 = a0, c1 = a1, c2 = a2, cb = bq;
           __builtin_amdgcn_sched_barrier(0);
-          vp[0] = mfma(c0, fc, vp[0]);
+          vp[0] = mfma(c0[0], cb[0], vp[0]);
           __builtin_amdgcn_sched_barrier(0);
-          if (kk + 2 < npairs) {
-            f1 = fp[(2 * kk + 4) * BG];
-            d10 = dp[(2 * kk + 4) * 96]; d11 = dp[(2 * kk + 4) * 96 + 32]; d12 = dp[(2 * kk + 4) * 96 + 64];
+          if (gq + 1 < ngroups) {
+            n0 = dq[(2 * gq + 2) * 96]; n1 = dq[(2 * gq + 2) * 96 + 32]; n2 = dq[(2 * gq + 2) * 96 + 64];
+            nb = fq[(2 * gq + 2) * BG];
           }
           __builtin_amdgcn_sched_barrier(0);
-          vp[1] = mfma(c1, fc, vp[1]);
-          vp[2] = mfma(c2, fc, vp[2]);
+          vp[1] = mfma(c1[0], cb[0], vp[1]);
+          vp[2] = mfma(c2[0], cb[0], vp[2]);
+#pragma unroll
+          for (int t = 1; t < 4; ++t) {
+            if (t >= nsteps) break;
+            vp[0] = mfma(c0[t], cb[t], vp[0]);
+            vp[1] = mfma(c1[t], cb[t], vp[1]);
+            vp[2] = mfma(c2[t], cb[t], vp[2]);
+          }
+          a0 = n0; a1 = n1; a2 = n2; bq = nb;
         }
       } else if constexpr (SPARSE) {
         constexpr int r = s - NKCH;

@@ -237,11 +237,14 @@ __device__ __forceinline__ void prep_fwd_body(int blk, const float* __restrict__
                                               const float* __restrict__ betas, const float* __restrict__ Jt,
                                               const float* __restrict__ JS, const Parents& par, float* __restrict__ FT,
                                               float* __restrict__ AT, float* __restrict__ R0T, int B, int BP,
-                                              int32_t* step_inc) {
+                                              int32_t* step_inc, float* __restrict__ FTq) {
+  // FTq: the same features in K-quads [KFP / 4][BP][4] -- the B operand of k_lbs_fwd's blend product (one 16-byte LDS read = four
+  // K steps); the row-major FT stays for the chain adjoint and the folded-regressor product
   __shared__ float Gs[NJ][12][PP];
   __shared__ float Js[NJ][3][PP];
   const int bl = threadIdx.x & (PP - 1), j = threadIdx.x / PP;
   const int b = blk * PP + bl;
+  auto fq = [&](int k) -> float& { return FTq[((size_t)(k >> 2) * BP + b) * 4 + (k & 3)]; };
   if (step_inc && blk == 0 && threadIdx.x == 0) step_inc[0] += 1;   // Adam step count of this iteration
   const bool ok = b < B;
   float R[9], J[3] = {0.f, 0.f, 0.f}, beta[NB];
@@ -260,15 +263,19 @@ __device__ __forceinline__ void prep_fwd_body(int blk, const float* __restrict__
   // blend features: F[(j-1)*9 + k] = R_j[k] - I  (j >= 1), shape rows, template row, zero padding
   if (j > 0) {
 #pragma unroll
-    for (int k = 0; k < 9; ++k)
-      FT[(size_t)((j - 1) * 9 + k) * BP + b] = ok ? R[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f) : 0.f;
+    for (int k = 0; k < 9; ++k) {
+      const float f = ok ? R[k] - ((k == 0 || k == 4 || k == 8) ? 1.f : 0.f) : 0.f;
+      FT[(size_t)((j - 1) * 9 + k) * BP + b] = f;
+      fq((j - 1) * 9 + k) = f;
+    }
   } else {
 #pragma unroll
     for (int k = 0; k < 9; ++k) R0T[(size_t)k * BP + b] = R[k];
 #pragma unroll
-    for (int l = 0; l < NB; ++l) FT[(size_t)(207 + l) * BP + b] = beta[l];
+    for (int l = 0; l < NB; ++l) { FT[(size_t)(207 + l) * BP + b] = beta[l]; fq(207 + l) = beta[l]; }
     FT[(size_t)217 * BP + b] = ok ? 1.f : 0.f;
-    for (int k = KF; k < KFP; ++k) FT[(size_t)k * BP + b] = 0.f;
+    fq(217) = ok ? 1.f : 0.f;
+    for (int k = KF; k < KFP; ++k) { FT[(size_t)k * BP + b] = 0.f; fq(k) = 0.f; }
   }
 #pragma unroll
   for (int cc = 0; cc < 3; ++cc) Js[j][cc][bl] = J[cc];
@@ -318,8 +325,8 @@ __global__ __launch_bounds__(PP * NJ) void k_prep_fwd(const float* __restrict__ 
                                                       const float* __restrict__ betas, const float* __restrict__ Jt,
                                                       const float* __restrict__ JS, Parents par, float* __restrict__ FT,
                                                       float* __restrict__ AT, float* __restrict__ R0T, int B, int BP,
-                                                      int32_t* step_inc) {
-  prep_fwd_body(blockIdx.x, x6d, Rin, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc);
+                                                      int32_t* step_inc, float* __restrict__ FTq) {
+  prep_fwd_body(blockIdx.x, x6d, Rin, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc, FTq);
 }
 
 // Horizontal fusion (fused inner loop with the pose discriminator): the chain forward and the discriminator's per-joint MLP
@@ -331,9 +338,9 @@ __global__ __launch_bounds__(PP * NJ) void k_prep_fwd_dconv(const float* __restr
                                                             const float* __restrict__ Jt, const float* __restrict__ JS,
                                                             Parents par, float* __restrict__ FT, float* __restrict__ AT,
                                                             float* __restrict__ R0T, int B, int BP, int32_t* step_inc,
-                                                            DconvFwdArgs d, int nprep) {
+                                                            DconvFwdArgs d, int nprep, float* __restrict__ FTq) {
   __shared__ __attribute__((aligned(16))) float L[CL_FLOATS];
-  if ((int)blockIdx.x < nprep) prep_fwd_body(blockIdx.x, x6d, nullptr, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc);
+  if ((int)blockIdx.x < nprep) prep_fwd_body(blockIdx.x, x6d, nullptr, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc, FTq);
   else dconv_fwd_body<true>(L, blockIdx.x - nprep, d.img, x6d, d.H2T, d.out, B, BP);
 }
 
@@ -967,19 +974,19 @@ int launch_rodrigues_bwd(const float* aa, const float* dR, float* daa, int n, hi
   return 0;
 }
 
-int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* AT,
+int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* FTq, float* AT,
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s) {
   hipLaunchKernelGGL(k_prep_fwd, dim3(BP / PP), dim3(PP * NJ), 0, s, x6d, Rin, betas, m.Jt, m.JS, m.parents, FT, AT, R0T,
-                     B, BP, step_inc);
+                     B, BP, step_inc, FTq);
   return 0;
 }
 
-int launch_prep_fwd_dconv(const Model& m, const float* x6d, const float* betas, float* FT, float* AT, float* R0T, int B, int BP,
-                          int32_t* step_inc, const float* img, float* H2T, float* out, hipStream_t s) {
+int launch_prep_fwd_dconv(const Model& m, const float* x6d, const float* betas, float* FT, float* FTq, float* AT, float* R0T, int B,
+                          int BP, int32_t* step_inc, const float* img, float* H2T, float* out, hipStream_t s) {
   const int nprep = BP / PP;
   DconvFwdArgs d{img, H2T, out};
   hipLaunchKernelGGL(k_prep_fwd_dconv, dim3(nprep + (BP / 32) * 2), dim3(PP * NJ), 0, s, x6d, betas, m.Jt, m.JS, m.parents, FT, AT,
-                     R0T, B, BP, step_inc, d, nprep);
+                     R0T, B, BP, step_inc, d, nprep, FTq);
   return 0;
 }
 
