@@ -70,11 +70,12 @@ def flop_lbs_bwd(model_info):
     if not model_info['joint_slots']:
         return FLOP_LBS_BWD_PER_POSE
     return 2 * 17 * 6890 * 3 + 2 * 6890 * skin_slots(model_info)[1] * 9 + 2 * 6890 * 9 + 2 * 6890 * 16 * 12   # dverts, T, dvp, dA (16-row windows)
-# matrix instructions per (32-vertex tile x 32 poses) of the forward kernel, for the pipe-busy figure: 327 blend K-pairs x 3
-# planes + 2 x slots x 3 rows on v_mfma_f32_32x32x2_f32 (64 clocks) and 48 four-block regressor instructions (33 clocks measured)
+# matrix instructions per (32-vertex tile x 32 poses) of the forward kernel, for the pipe-busy figure: 110 blend K steps x 3 planes
+# (109 pairs of the 218 features + one step of the K-quad layout against zero rows) + 2 x slots x 3 rows on v_mfma_f32_32x32x2_f32
+# (64 clocks) and 48 four-block regressor instructions (33 clocks measured)
 def fwd_pipe_clocks_per_tile(model_info):
     slots = skin_slots(model_info)[0]
-    return (327 + 6 * slots) * 64 + 48 * 33 if model_info['joint_slots'] else 519 * 64
+    return (330 + 6 * slots) * 64 + 48 * 33 if model_info['joint_slots'] else 522 * 64
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
 
 

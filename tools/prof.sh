@@ -48,13 +48,14 @@ if f is not None and w is not None:
             out['traffic'][name + '_FETCH_SIZE_KB'] = ff
             out['traffic'][name + '_WRITE_SIZE_KB'] = ww
     # ISSUED matrix work per launch: SQ_INSTS_MFMA x FLOP per instruction (32x32x2: 4096; 16x16x4 and the four-block 16x16x1:
-    # 2048; k_lbs_fwd mixes 375 + 48 per tile and wave), printed by bench.py beside every algorithmic figure
+    # 2048; k_lbs_fwd mixes 378 + 48 per tile and wave: 330 blend steps incl. 3 against the zero rows 218, 219, 222, 223 of the
+    # K-quad layout, 48 skinning, 48 four-block regressor), printed by bench.py beside every algorithmic figure
     sq = out.get('pmc_sq', {})
     def mf(key):
         return pick(sq, key).get('SQ_INSTS_MFMA')
     issued = {}
     n = mf('k_lbs_fwd<true, false, 8, false')
-    if n: issued['k_lbs_fwd'] = {'sq_insts_mfma': int(n), 'flop_per_launch': int(n * (375 * 4096 + 48 * 2048) / 423)}
+    if n: issued['k_lbs_fwd'] = {'sq_insts_mfma': int(n), 'flop_per_launch': int(n * (378 * 4096 + 48 * 2048) / 426)}
     n = mf('k_lbs_bwd16<0, 8, false')
     if n: issued['k_lbs_bwd'] = {'sq_insts_mfma': int(n), 'flop_per_launch': int(n * 2048)}
     n = mf('k_blend_adjoint')
