@@ -533,7 +533,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
     // the slab rows belong to this wave alone) and start the next one
     auto flush_window = [&]() {
       if constexpr (SPARSE) {
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // earlier slab stores of this wave have landed
+        if (seen != 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // earlier slab stores of this wave have landed (first flush: nothing to re-read)
         const int* sj = segj + seg_tile * 16;
         const int col = b0 + (lane & 15);
 #pragma unroll
@@ -931,7 +931,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
   // close a segment: add the accumulators into this workgroup's dA slab (first touch of a joint stores, later ones add;
   // the 16 pose columns belong to this wave alone)
   auto flush_window = [&]() __attribute__((always_inline)) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // a later flush re-reads slab rows an earlier one stored: those stores must have landed.  The FIRST flush of a workgroup (seen == 0,
+    // wave-uniform: most workgroups lie inside one segment and flush once, at the end) reads nothing and need not wait for the tile's
+    // last dvp stores
+    if (seen != 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int* sj = segj + seg_tile * 16;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
