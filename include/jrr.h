@@ -45,7 +45,7 @@ enum {
   JRR_POSE6D = 144,        /* 24 joints x 6 */
   JRR_DISC_PARAMS = 1840153,
   JRR_SHAPE_DISC_PARAMS = 171,
-  JRR_SIL_SIZE = 224       /* silhouette image size (square); see jrr_silhouette_forward */
+  JRR_SIL_SIZE = 224       /* silhouette image size (square) of an engine without JRR_FLAG_SIL_256; see jrr_silhouette_forward */
 };
 
 /* engine flags */
@@ -55,8 +55,11 @@ enum {
   JRR_FLAG_KEEP_VERTS = 4,  /* reserve a (B,6890,3) vertex buffer for return_verts / J step */
   JRR_FLAG_FOLDED = 8,      /* reserve the folded-regressor tables (jrr_engine_set_folded) */
   JRR_FLAG_SILHOUETTE = 16, /* reserve the soft-silhouette buffers (needs JRR_FLAG_KEEP_VERTS and model faces) */
-  JRR_FLAG_NO_MODEL = 32    /* discriminator-only engine (model == NULL): the SMPL sections (~230 KB per pose) are not
+  JRR_FLAG_NO_MODEL = 32,   /* discriminator-only engine (model == NULL): the SMPL sections (~230 KB per pose) are not
                                part of the workspace; only JRR_FLAG_POSE_DISC / JRR_FLAG_SHAPE_DISC may accompany it */
+  JRR_FLAG_SIL_256 = 64     /* with JRR_FLAG_SILHOUETTE: 256 x 256 silhouettes (the reference constructor's default,
+                               scripts/mesh_renderer.py:25; focal length 5000 / 256) instead of 224 x 224 (scripts/optimize.py:110):
+                               every (B,224,224) below then reads (B,256,256) */
 };
 
 typedef struct jrr_model jrr_model_t;   /* device-resident, re-laid-out SMPL constants */
@@ -227,10 +230,10 @@ int jrr_camera_prefit(jrr_engine_t* e, const float* x6d_dev, const float* betas_
  * render_mesh(...) = Mesh_Renderer(224)(batch, verts*[-2,-2,2])[:, 3], scripts/optimize.py:77-85 +
  * scripts/mesh_renderer.py:23-79 (pytorch3d 0.3.0 rasteriser, blur_radius 0, 1 face per pixel,
  * SoftSilhouetteShader sigma 1e-4).  verts (B,6890,3), cam (B,3) -> alpha (B,224,224).
- * The image size is FIXED at 224 (JRR_SIL_SIZE): the only size the reference's loop instantiates (scripts/optimize.py:110
- * `Mesh_Renderer(image_size=224)`; the constructor's own default of 256, scripts/mesh_renderer.py:25, is never used by the
- * reference).  The z-buffer strips, the pixel-index packing of the covered-pixel lists and the LDS budget of the rasteriser
- * are built for it; the host mirror's Mesh_Renderer(image_size != 224) raises NotImplementedError naming this line.   */
+ * Image size: 224 (JRR_SIL_SIZE: what the reference's loop instantiates, scripts/optimize.py:110 `Mesh_Renderer(image_size=224)`)
+ * or -- engines created with JRR_FLAG_SIL_256 -- 256, the constructor's own default (scripts/mesh_renderer.py:25); the camera's focal
+ * length is 5000 / size (mesh_renderer.py:52-53).  The kernels are instantiated for these two sizes (the pixel-index packing of the
+ * covered-pixel lists holds 16 bits: at most 256 x 256); the host mirror's Mesh_Renderer raises NotImplementedError for others. */
 int jrr_silhouette_forward(jrr_engine_t* e, const float* verts_dev, const float* cam_dev, float* alpha_dev,
                            void* stream);
 /* adjoint for the SAME inputs (must follow the forward): galpha (B,224,224) -> dverts (B,6890,3), dcam (B,3);

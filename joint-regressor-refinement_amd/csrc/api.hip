@@ -359,6 +359,7 @@ extern "C" int jrr_model_info(const jrr_model_t* m, int32_t* out, int n) {
 struct jrr_engine {
   Model m;
   int B, BP, bnorm, flags;
+  int sil;                                           // silhouette image size: 224, or 256 with JRR_FLAG_SIL_256
   int nvc, nvcb, nsplit, nsplitJ;
   bool have_J, have_mask, have_pd, have_sd, has_model;
   // workspace sections
@@ -511,7 +512,8 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   if (flags & (JRR_FLAG_SILHOUETTE | JRR_FLAG_KEEP_VERTS)) t->VTb = c.take((size_t)3 * VP * BP);
   if (flags & JRR_FLAG_SILHOUETTE) {
     t->ndc = c.take((size_t)BP * V * 4);
-    t->cover = (unsigned*)c.take((size_t)BP * 224 * 224);
+    const size_t S = (flags & JRR_FLAG_SIL_256) ? 256 : 224;
+    t->cover = (unsigned*)c.take((size_t)BP * S * S);
     t->ncover = (int*)c.take((size_t)BP);
     t->sqsil = c.take((size_t)BP);
     t->smask = c.take((size_t)BP);
@@ -548,6 +550,7 @@ extern "C" size_t jrr_engine_workspace_bytes(int batch, int flags) {
 extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_norm, void* ws, size_t ws_bytes,
                                  int flags, jrr_engine_t** out) {
   if (!ws || !out || batch <= 0) { jrr_set_error("jrr_engine_create: bad argument"); return JRR_ERR_ARG; }
+  if ((flags & JRR_FLAG_SIL_256) && !(flags & JRR_FLAG_SILHOUETTE)) { jrr_set_error("jrr_engine_create: JRR_FLAG_SIL_256 without JRR_FLAG_SILHOUETTE"); return JRR_ERR_ARG; }
   if (!model && (flags & ~(JRR_FLAG_POSE_DISC | JRR_FLAG_SHAPE_DISC | JRR_FLAG_NO_MODEL))) {
     jrr_set_error("jrr_engine_create: a model-less engine serves the discriminators only");
     return JRR_ERR_ARG;
@@ -563,6 +566,7 @@ extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_
   e->B = batch;
   e->bnorm = batch_norm > 0 ? batch_norm : batch;
   e->flags = flags;
+  e->sil = (flags & JRR_FLAG_SIL_256) ? 256 : 224;
   carve(e, ws, batch, flags);
   e->have_jsup = (flags & JRR_FLAG_KEEP_VERTS) != 0;
   *out = e;
@@ -1154,8 +1158,8 @@ extern "C" int jrr_silhouette_forward(jrr_engine_t* e, const float* verts, const
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   e->fwd_cached = false;
-  launch_sil_project(verts, V * 3, cam, e->ndc, e->B, s);
-  launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, e->cover, e->ncover, alpha, e->B, s);
+  launch_sil_project(verts, V * 3, cam, e->ndc, e->B, s, e->sil);
+  launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, e->cover, e->ncover, alpha, e->B, s, e->sil);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -1166,7 +1170,7 @@ extern "C" int jrr_silhouette_backward(jrr_engine_t* e, const float* galpha, flo
   if (rc) return rc;
   hipStream_t s = (hipStream_t)stream;
   e->fwd_cached = false;
-  launch_sil_bwd(e->ndc, e->m.faces, e->cover, e->ncover, nullptr, galpha, 0.f, dverts, V * 3, dcam, 0, e->B, s);
+  launch_sil_bwd(e->ndc, e->m.faces, e->cover, e->ncover, nullptr, galpha, 0.f, dverts, V * 3, dcam, 0, e->B, s, e->sil);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -1175,7 +1179,7 @@ extern "C" int jrr_silhouette_pix_to_face(jrr_engine_t* e, int32_t* p2f, void* s
   if (!e || !p2f) return JRR_ERR_ARG;
   int rc = sil_check(e);
   if (rc) return rc;
-  launch_sil_pix_to_face(e->cover, e->ncover, p2f, e->B, (hipStream_t)stream);
+  launch_sil_pix_to_face(e->cover, e->ncover, p2f, e->B, (hipStream_t)stream, e->sil);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -1207,11 +1211,11 @@ extern "C" int jrr_silhouette_loss_grad(jrr_engine_t* e, const float* x6d, const
   hipStream_t s = (hipStream_t)stream;
   e->fwd_cached = false;
   smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s);
-  launch_mask_sq(mask, e->smask, e->B, s);
+  launch_mask_sq(mask, e->smask, e->B, s, e->sil);
   e->smask_valid = false;
-  const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * 224.0 * 224.0));      // optimize.py:252 weight 100
+  const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * (double)e->sil * (double)e->sil));      // optimize.py:252 weight 100
   launch_sil_raster_adj(e->VTb, e->BP, cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, mask, e->smask, e->cover,
-                        e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s);
+                        e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s, e->sil);
   if (sqsil) JRR_HIP(hipMemcpyAsync(sqsil, e->sqsil, (size_t)e->B * 4, hipMemcpyDeviceToDevice, s));
   if (dverts) launch_verts_untranspose(e->VTb, dverts, V * 3, V, nullptr, nullptr, e->B, e->BP, s, e->m.p2v);
   if (dcam) JRR_HIP(hipMemcpyAsync(dcam, e->gcam, (size_t)e->B * 3 * 4, hipMemcpyDeviceToDevice, s));
@@ -1241,7 +1245,7 @@ static int joints_from_stored_verts(jrr_engine* e, hipStream_t s, int32_t* step_
 __global__ void __launch_bounds__(1024) k_loss_record(const float* __restrict__ sqj, const float* __restrict__ sq2d,
                                                       const float* __restrict__ sqsil, const float* __restrict__ dsq,
                                                       const float* __restrict__ ssq, int B, int BP, float bnorm,
-                                                      float* __restrict__ rec) {
+                                                      float* __restrict__ rec, float npix) {
   __shared__ float red[5][1024];
   float acc[5] = {0.f, 0.f, 0.f, 0.f, 0.f};
   for (int b = threadIdx.x; b < B; b += 1024) {
@@ -1259,7 +1263,7 @@ __global__ void __launch_bounds__(1024) k_loss_record(const float* __restrict__ 
   }
   if (threadIdx.x == 0) {
     rec[0] = red[0][0] / (bnorm * 34.f) * 0.01f;            // loss_j2d / 100
-    rec[1] = red[1][0] / (bnorm * 224.f * 224.f) * 100.f;   // silhouette_loss * 100
+    rec[1] = red[1][0] / (bnorm * npix) * 100.f;            // silhouette_loss * 100
     rec[2] = red[2][0] / (bnorm * 51.f) * 10000.f;          // joint_loss * 10000
     rec[3] = red[3][0] / (bnorm * 25.f) * 10.f;             // pose_discriminated_loss * 10
     rec[4] = red[4][0] / bnorm * 10.f;                      // shape_discriminated_loss * 10
@@ -1345,11 +1349,11 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     const bool sil = e->sil_mask != nullptr && !folded;
     if (sil) {   // 100 * mean((silhouette - mask)^2), optimize.py:234-237,252
       prof_mark(e, 8, s);
-      const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * 224.0 * 224.0));
-      if (!e->smask_valid) { launch_mask_sq(e->sil_mask, e->smask, e->B, s); e->smask_valid = true; }
+      const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * (double)e->sil * (double)e->sil));
+      if (!e->smask_valid) { launch_mask_sq(e->sil_mask, e->smask, e->B, s, e->sil); e->smask_valid = true; }
       // projection, rasterisation, loss and adjoint in one kernel, straight from / into the row-quad vertex buffer
       launch_sil_raster_adj(e->VTb, e->BP, e->cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil,
-                            silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s);
+                            silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s, e->sil);
       prof_mark(e, 8, s);
     }
     prof_mark(e, 3, s);
@@ -1397,7 +1401,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       if (e->hist_iter % e->hist_every == 0 && e->hist_n < e->hist_cap) {
         hipLaunchKernelGGL(k_loss_record, dim3(1), dim3(1024), 0, s, sqerr ? sqerr : e->sqerr, e->gt_j2d ? e->sq2d : nullptr,
                            sil ? e->sqsil : nullptr, pd ? e->dsq : nullptr, sd ? e->ssq : nullptr, e->B, e->BP, (float)e->bnorm,
-                           e->hist + (size_t)e->hist_n * 5);
+                           e->hist + (size_t)e->hist_n * 5, (float)(e->sil * e->sil));
         ++e->hist_n;
       }
       ++e->hist_iter;

@@ -124,20 +124,21 @@ int launch_gemm_q32(const float* A, int ldA, size_t planeA, const float* Bm, int
 int launch_jgrad_q(const float* dJT, const float* VTq, float* Out, int BP, int ksplit, hipStream_t s, const int* skip_flag = nullptr);
 
 // sil.hip
-int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s);
-// cover [B][224*224] / ncover [B]: the covered pixels of each pose (pixel << 14 | winning face), written by the
+// S = image size (224 or 256; focal length 5000 / S)
+int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s, int S = 224);
+// cover [B][S*S] / ncover [B]: the covered pixels of each pose (pixel << 14 | winning face), written by the
 // rasteriser and consumed by the adjoint
 int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* cover, int* ncover, float* alpha, int B,
-                      hipStream_t s);
+                      hipStream_t s, int S = 224);
 // smask [B] = per-pose sum(mask^2) over the image (launch_mask_sq): the rasteriser only visits the mesh's pixel box
-int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s);
+int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s, int S = 224);
 int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
                           unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
-                          hipStream_t s);
-int launch_sil_pix_to_face(const unsigned* cover, const int* ncover, int* p2f, int B, hipStream_t s);
+                          hipStream_t s, int S = 224);
+int launch_sil_pix_to_face(const unsigned* cover, const int* ncover, int* p2f, int B, hipStream_t s, int S = 224);
 int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, const int* ncover, const float* mask,
                    const float* galpha, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
-                   hipStream_t s);
+                   hipStream_t s, int S = 224);
 
 // fold.hip
 int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, const int* p2v, hipStream_t s);

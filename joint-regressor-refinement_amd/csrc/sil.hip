@@ -24,16 +24,17 @@
 
 namespace jrr {
 
-constexpr int SIL = 224;                 // image size (scripts/optimize.py:110 Mesh_Renderer(image_size=224))
-constexpr int SIL_STRIP = 40;            // z-buffer capacity in full-width rows (40*224*8 B = 70 KB); strips cover the mesh's pixel box
+// Image size S: 224 (scripts/optimize.py:110 Mesh_Renderer(image_size=224)) or 256 (the reference constructor's default,
+// scripts/mesh_renderer.py:25) -- a template parameter of the kernels; the focal length follows it (5000 / S, mesh_renderer.py:52-53).
+constexpr int SIL_MAX = 256;
+constexpr int SIL_ZPIX = 40 * 224;       // z-buffer capacity in pixels (8960 * 8 B = 70 KB); strips cover the mesh's pixel box
 constexpr int SIL_RT = 1024;             // threads of the raster workgroup (one workgroup per pose and per CU: LDS-bound)
 constexpr int SIL_FPT = 14;              // faces per thread, kept in registers (14 * 1024 >= 13776)
 constexpr int SIL_FBITS = 14;             // covered-pixel list entry = pixel << 14 | face (faces < 16384, pixels < 65536)
 constexpr int SIL_EB = 6;                 // list entries fetched together per thread in the resolve
 static_assert((3 * V + 2) % 2 == 0, "z-buffer alignment");
-static_assert(V * 8 <= 40 * 224 * 8, "adjoint accumulators must fit the z-buffer");
+static_assert(V * 8 <= SIL_ZPIX * 8, "adjoint accumulators must fit the z-buffer");
 constexpr int SIL_VPAD = 3 * V + 2;      // floats of the LDS vertex arrays, padded so the u64 z-buffer is 8-byte aligned
-constexpr float SIL_F = 5000.f / 224.f;  // NDC focal length
 // BlendParams sigma = 1e-4 (mesh_renderer.py:28); only its reciprocal is used
 constexpr float SIL_ISIGMA = 1e4f;
 constexpr float SIL_EPS = 1e-8f;
@@ -41,7 +42,7 @@ constexpr float SIL_EPS = 1e-8f;
 struct alignas(16) NdcV { float x, y, z, pad; };
 
 __global__ void k_sil_project(const float* __restrict__ verts, int ldv, const float* __restrict__ cam,
-                              NdcV* __restrict__ ndc, int B) {
+                              NdcV* __restrict__ ndc, int B, float SIL_F) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;   // over B*V
   if (idx >= B * V) return;
   const int b = idx / V, v = idx % V;
@@ -59,7 +60,9 @@ __device__ __forceinline__ float edge_fn(float px, float py, float ax, float ay,
 // pixel centre 1 - fl32((2 xi + 1)/224).  The fp32 quotient is formed as a rounded f64 product: (2 xi + 1)/224 is
 // never within 2^-53 (relative) of an fp32 rounding boundary, so this equals the IEEE fp32 division bit for bit
 // (checked for all 224 indices in tests/test_host_logic.py) at 3 instructions instead of 12.
-__device__ __forceinline__ float pix_x(int xi) { return 1.f - (float)((double)(2 * xi + 1) * (1.0 / SIL)); }
+// (S = 256: 1 / S and the product are exact, the statement holds trivially)
+template <int S>
+__device__ __forceinline__ float pix_x(int xi) { return 1.f - (float)((double)(2 * xi + 1) * (1.0 / S)); }
 
 // squared distance from p to segment a-b, and the clamped parameter t
 __device__ __forceinline__ float seg_dist2(float px, float py, float ax, float ay, float bx, float by, float& t) {
@@ -99,7 +102,7 @@ __device__ __forceinline__ float sil_alpha(float dist) { return 1.f / (1.f + exp
 // same pieces with the vertex adjoint -- the layout k_lbs_bwd<2> consumes.  No pose-major copies of the vertices or of
 // their adjoint exist (two transposes of 0.35 ms and 0.8 GB of buffers gone).  A 128-byte line of VQ holds 8 consecutive
 // poses, so consecutive poses are given to the SAME XCD (blockIdx % 8 selects the XCD) and meet in its L2.
-template <bool ADJ>
+template <bool ADJ, int SIL>
 __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ ndc, const int* __restrict__ faces,
                                                        int nfaces, const float* __restrict__ mask,
                                                        unsigned* __restrict__ cover, int* __restrict__ ncover,
@@ -108,13 +111,14 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
                                                        const float* __restrict__ cam, int B,
                                                        float* __restrict__ gcam, int accumulate_cam,
                                                        const float* __restrict__ smask) {
+  constexpr float SIL_F = 5000.f / (float)SIL;        // NDC focal length (mesh_renderer.py:52-53)
   extern __shared__ unsigned long long smem64[];      // 8-byte aligned whatever static LDS precedes it
   float* vx = reinterpret_cast<float*>(smem64);       // [V]; the vertex arrays first: ds offsets stay < 64 KB
-  unsigned long long* zb = smem64 + SIL_VPAD / 2;     // [SIL_STRIP][SIL]
+  unsigned long long* zb = smem64 + SIL_VPAD / 2;     // [SIL_ZPIX]
   float* vy = vx + V;
   float* vz = vx + 2 * V;
   __shared__ float red[SIL_RT];
-  __shared__ float pxt[SIL];          // pixel centres
+  __shared__ float pxt[SIL_MAX];      // pixel centres
   __shared__ int ncov;
   int b = blockIdx.x;
   if (ADJ) {                                 // poses [x per, (x + 1) per) on XCD x; BP is a multiple of 128
@@ -130,7 +134,7 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   unsigned* lst = cover + (size_t)b * SIL * SIL;
   __shared__ float bbp[4][SIL_RT / 64];   // per-wave partial bounding box of the projected vertices
   if (threadIdx.x == 0) ncov = 0;
-  if (threadIdx.x < SIL) pxt[threadIdx.x] = pix_x(threadIdx.x);
+  if (threadIdx.x < SIL) pxt[threadIdx.x] = pix_x<SIL>(threadIdx.x);
   float bxn = 3e38f, bxx = -3e38f, byn = 3e38f, byx = -3e38f;
   // this thread's faces: vertex indices now (requested BEFORE the vertex loads below: both batches of loads fly together),
   // pixel-row range after the vertices have landed
@@ -212,7 +216,7 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
     by1 = (fy1 < (float)(SIL - 1)) ? (int)floorf(fmaxf(fy1, -1.f)) : SIL - 1;
   }
   const int bw = bx1 - bx0 + 1;
-  const int rows_per = (bw > 0) ? (SIL_STRIP * SIL) / bw : SIL;
+  const int rows_per = (bw > 0) ? SIL_ZPIX / bw : SIL;
   for (int y0 = by0; y0 <= by1 && bw > 0; y0 += rows_per) {
     const int y1 = min(y0 + rows_per, by1 + 1);                        // rows [y0, y1) of the box columns [bx0, bx1]
     const int npx = (y1 - y0) * bw;
@@ -415,12 +419,14 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
 // bits, varies between runs.
 constexpr int SIL_BT = 1024;
 constexpr int SIL_PB = 3;                // list entries fetched together per thread
+template <int SIL>
 __global__ __launch_bounds__(SIL_BT) void k_sil_bwd(const NdcV* __restrict__ ndc, const int* __restrict__ faces,
                                                     const unsigned* __restrict__ cover, const int* __restrict__ ncover,
                                                     const float* __restrict__ mask,
                                                     const float* __restrict__ galpha, float scale,
                                                     float* __restrict__ dverts, int ldv, float* __restrict__ gcam,
                                                     int accumulate_cam) {
+  constexpr float SIL_F = 5000.f / (float)SIL;
   extern __shared__ float acc[];                 // [V*2]
   __shared__ float gcs[3];
   const int b = blockIdx.x;
@@ -455,7 +461,7 @@ __global__ __launch_bounds__(SIL_BT) void k_sil_bwd(const NdcV* __restrict__ ndc
     for (int u = 0; u < SIL_PB; ++u) {
       if (e0 + u * SIL_BT >= n) continue;
       const int pix = (int)(ent[u] >> SIL_FBITS);
-      const float px = pix_x(pix % SIL), py = pix_x(pix / SIL);
+      const float px = pix_x<SIL>(pix % SIL), py = pix_x<SIL>(pix / SIL);
       const float x[3] = {vv[u][0].x, vv[u][1].x, vv[u][2].x}, y[3] = {vv[u][0].y, vv[u][1].y, vv[u][2].y};
       int ka;
       float tt;
@@ -505,7 +511,7 @@ __global__ __launch_bounds__(SIL_BT) void k_sil_bwd(const NdcV* __restrict__ ndc
 }
 
 // per-pose sum(mask^2) over the image (the squared error of an all-background rendering), once per mask
-__global__ __launch_bounds__(256) void k_mask_sq(const float* __restrict__ mask, float* __restrict__ smask) {
+__global__ __launch_bounds__(256) void k_mask_sq(const float* __restrict__ mask, float* __restrict__ smask, int SIL) {
   __shared__ float red[256];
   const int b = blockIdx.x;
   float acc = 0.f;
@@ -518,14 +524,14 @@ __global__ __launch_bounds__(256) void k_mask_sq(const float* __restrict__ mask,
   }
   if (threadIdx.x == 0) smask[b] = red[0];
 }
-int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s) {
-  hipLaunchKernelGGL(k_mask_sq, dim3(B), dim3(256), 0, s, mask, smask);
+int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s, int S) {
+  hipLaunchKernelGGL(k_mask_sq, dim3(B), dim3(256), 0, s, mask, smask, S);
   return 0;
 }
 
 // pix_to_face of the last rasterisation (pytorch3d Fragments.pix_to_face, faces_per_pixel = 1): -1 = background, else the
 // winning face, from the per-pose covered-pixel lists
-__global__ void k_sil_pix_to_face(const unsigned* __restrict__ cover, const int* __restrict__ ncover, int* __restrict__ p2f) {
+__global__ void k_sil_pix_to_face(const unsigned* __restrict__ cover, const int* __restrict__ ncover, int* __restrict__ p2f, int SIL) {
   const int b = blockIdx.x;
   int* out = p2f + (size_t)b * SIL * SIL;
   for (int i = threadIdx.x; i < SIL * SIL; i += blockDim.x) out[i] = -1;
@@ -537,29 +543,43 @@ __global__ void k_sil_pix_to_face(const unsigned* __restrict__ cover, const int*
     out[e >> SIL_FBITS] = (int)(e & ((1u << SIL_FBITS) - 1));
   }
 }
-int launch_sil_pix_to_face(const unsigned* cover, const int* ncover, int* p2f, int B, hipStream_t s) {
-  hipLaunchKernelGGL(k_sil_pix_to_face, dim3(B), dim3(1024), 0, s, cover, ncover, p2f);
+int launch_sil_pix_to_face(const unsigned* cover, const int* ncover, int* p2f, int B, hipStream_t s, int S) {
+  hipLaunchKernelGGL(k_sil_pix_to_face, dim3(B), dim3(1024), 0, s, cover, ncover, p2f, S);
   return 0;
 }
 
 static bool g_sil_attr = false;
+constexpr int SIL_LDS_BYTES = SIL_VPAD * 4 + SIL_ZPIX * 8;
 static void sil_attrs() {
   if (g_sil_attr) return;
-  (void)hipFuncSetAttribute((const void*)k_sil_raster<false>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_VPAD * 4 + SIL_STRIP * SIL * 8);
-  (void)hipFuncSetAttribute((const void*)k_sil_raster<true>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_VPAD * 4 + SIL_STRIP * SIL * 8);
-  (void)hipFuncSetAttribute((const void*)k_sil_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, V * 2 * 4);
+  (void)hipFuncSetAttribute((const void*)k_sil_raster<false, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)k_sil_raster<true, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)k_sil_raster<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)k_sil_raster<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
+  (void)hipFuncSetAttribute((const void*)k_sil_bwd<224>, hipFuncAttributeMaxDynamicSharedMemorySize, V * 2 * 4);
+  (void)hipFuncSetAttribute((const void*)k_sil_bwd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, V * 2 * 4);
   g_sil_attr = true;
 }
-int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s) {
-  hipLaunchKernelGGL(k_sil_project, dim3((B * V + 255) / 256), dim3(256), 0, s, verts, ldv, cam, (NdcV*)ndc, B);
+static int sil_size_ok(int S) {
+  if (S == 224 || S == 256) return 0;
+  jrr_set_error("silhouette: image size %d (the kernels are built for 224 and 256)", S);
+  return JRR_ERR_ARG;
+}
+int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s, int S) {
+  hipLaunchKernelGGL(k_sil_project, dim3((B * V + 255) / 256), dim3(256), 0, s, verts, ldv, cam, (NdcV*)ndc, B, 5000.f / (float)S);
   return 0;
 }
 int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* cover, int* ncover, float* alpha, int B,
-                      hipStream_t s) {
+                      hipStream_t s, int S) {
   sil_attrs();
+  if (sil_size_ok(S)) return JRR_ERR_ARG;
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
-  hipLaunchKernelGGL(k_sil_raster<false>, dim3(B), dim3(SIL_RT), SIL_VPAD * 4 + SIL_STRIP * SIL * 8, s, (const NdcV*)ndc, faces,
-                     nfaces, nullptr, cover, ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr);
+  if (S == 224)
+    hipLaunchKernelGGL((k_sil_raster<false, 224>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc, faces, nfaces, nullptr, cover,
+                       ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr);
+  else
+    hipLaunchKernelGGL((k_sil_raster<false, 256>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc, faces, nfaces, nullptr, cover,
+                       ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr);
   return 0;
 }
 // fused loop: project the pose's vertices from the row-quad buffer VQ [3][VP/4][BP][4], rasterise, squared error against
@@ -567,21 +587,31 @@ int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* 
 // accumulate
 int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
                           unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
-                          hipStream_t s) {
+                          hipStream_t s, int S) {
   sil_attrs();
+  if (sil_size_ok(S)) return JRR_ERR_ARG;
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
   const int grid = BP;                     // pose = (block % 8) * (BP / 8) + block / 8; blocks of padded poses zero their pieces
-  hipLaunchKernelGGL(k_sil_raster<true>, dim3(grid), dim3(SIL_RT), SIL_VPAD * 4 + SIL_STRIP * SIL * 8, s, (const NdcV*)nullptr, faces,
-                     nfaces, mask, cover, ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask);
+  if (S == 224)
+    hipLaunchKernelGGL((k_sil_raster<true, 224>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, faces, nfaces, mask, cover,
+                       ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask);
+  else
+    hipLaunchKernelGGL((k_sil_raster<true, 256>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, faces, nfaces, mask, cover,
+                       ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask);
   return 0;
 }
 // writes ALL of dverts[b][0 .. 6890*3) (no zero-fill needed); gcam: overwrite or accumulate
 int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, const int* ncover, const float* mask,
                    const float* galpha, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
-                   hipStream_t s) {
+                   hipStream_t s, int S) {
   sil_attrs();
-  hipLaunchKernelGGL(k_sil_bwd, dim3(B), dim3(SIL_BT), V * 2 * 4, s, (const NdcV*)ndc, faces, cover, ncover, mask, galpha,
-                     scale, dverts, ldv, gcam, accumulate_cam);
+  if (sil_size_ok(S)) return JRR_ERR_ARG;
+  if (S == 224)
+    hipLaunchKernelGGL(k_sil_bwd<224>, dim3(B), dim3(SIL_BT), V * 2 * 4, s, (const NdcV*)ndc, faces, cover, ncover, mask, galpha, scale, dverts,
+                       ldv, gcam, accumulate_cam);
+  else
+    hipLaunchKernelGGL(k_sil_bwd<256>, dim3(B), dim3(SIL_BT), V * 2 * 4, s, (const NdcV*)ndc, faces, cover, ncover, mask, galpha, scale, dverts,
+                       ldv, gcam, accumulate_cam);
   return 0;
 }
 

@@ -21,6 +21,7 @@ FLAG_KEEP_VERTS = 4
 FLAG_FOLDED = 8
 FLAG_SILHOUETTE = 16
 FLAG_NO_MODEL = 32
+FLAG_SIL_256 = 64      # with FLAG_SILHOUETTE: 256 x 256 silhouettes (the reference constructor's default) instead of 224 x 224
 SIL = 224
 
 NUM_VERTS, NUM_JOINTS, NUM_H36M, NUM_BETAS = 6890, 24, 17, 10
@@ -105,6 +106,7 @@ class RefineEngine:
         self.batch = int(batch)
         self.batch_norm = int(batch_norm or batch)
         self.flags = int(flags) | (FLAG_NO_MODEL if model is None else 0)   # no SMPL workspace for a discriminator-only engine
+        self.sil = 256 if (self.flags & FLAG_SIL_256) else SIL              # silhouette image size of this engine
         # Forward-generation counter: the adjoint entry points read the engine's internal state of the MOST RECENT
         # forward (include/jrr.h: "must follow it"), while autograd defers backward.  Every call that overwrites that
         # state bumps the counter; the autograd wrappers compare it with the value saved at forward time and re-run
@@ -294,16 +296,16 @@ class RefineEngine:
         return sq
 
     def silhouette_forward(self, verts, cam):
-        """render_mesh alpha channel: verts (B,6890,3) in SMPL space, cam (B,3) -> (B,224,224)"""
+        """render_mesh alpha channel: verts (B,6890,3) in SMPL space, cam (B,3) -> (B,S,S), S = 224 (256 with FLAG_SIL_256)"""
         self.generation += 1
         self._chk(verts, (self.batch, NUM_VERTS, 3), 'verts')
         self._chk(cam, (self.batch, 3), 'cam')
-        alpha = torch.empty(self.batch, SIL, SIL, device=self.device)
+        alpha = torch.empty(self.batch, self.sil, self.sil, device=self.device)
         check(self.lib.jrr_silhouette_forward(self.handle, ptr(verts), ptr(cam), ptr(alpha), self._s()), 'silhouette_forward')
         return alpha
 
     def silhouette_backward(self, galpha):
-        self._chk(galpha, (self.batch, SIL, SIL), 'galpha')
+        self._chk(galpha, (self.batch, self.sil, self.sil), 'galpha')
         dverts = torch.empty(self.batch, NUM_VERTS, 3, device=self.device)
         dcam = torch.empty(self.batch, 3, device=self.device)
         check(self.lib.jrr_silhouette_backward(self.handle, ptr(galpha), ptr(dverts), ptr(dcam), self._s()), 'silhouette_backward')
@@ -311,7 +313,7 @@ class RefineEngine:
 
     def silhouette_pix_to_face(self) -> torch.Tensor:
         """(B,224,224) int32 nearest-face index per pixel (-1 = background) of the most recent rasterisation"""
-        p2f = torch.empty(self.batch, SIL, SIL, dtype=torch.int32, device=self.device)
+        p2f = torch.empty(self.batch, self.sil, self.sil, dtype=torch.int32, device=self.device)
         check(self.lib.jrr_silhouette_pix_to_face(self.handle, ptr(p2f), self._s()), 'silhouette_pix_to_face')
         return p2f
 
@@ -321,7 +323,7 @@ class RefineEngine:
         self.generation += 1
         B = self.batch
         self._chk(x6d, (B, NUM_JOINTS, 6), 'x6d'); self._chk(betas, (B, NUM_BETAS), 'betas')
-        self._chk(cam, (B, 3), 'cam'); self._chk(mask, (B, SIL, SIL), 'mask')
+        self._chk(cam, (B, 3), 'cam'); self._chk(mask, (B, self.sil, self.sil), 'mask')
         sq = torch.empty(B, device=self.device)
         dv = torch.empty(B, NUM_VERTS, 3, device=self.device) if want_dverts else None
         dc = torch.empty(B, 3, device=self.device)
@@ -332,7 +334,7 @@ class RefineEngine:
     def set_silhouette(self, mask=None, cam=None, cam_m=None, cam_v=None):
         """enable (tensors) / disable (None) the silhouette term of refine_run"""
         if mask is not None:
-            self._chk(mask, (self.batch, SIL, SIL), 'mask')
+            self._chk(mask, (self.batch, self.sil, self.sil), 'mask')
             for t, n in ((cam, 'cam'), (cam_m, 'cam_m'), (cam_v, 'cam_v')):
                 self._chk(t, (self.batch, 3), n)
         self._sil_refs = (mask, cam, cam_m, cam_v)

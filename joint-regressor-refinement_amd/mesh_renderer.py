@@ -39,23 +39,22 @@ class Mesh_Renderer(nn.Module):
     space first (an exact sign flip and halving).  Channels 0-2 are 1 as pytorch3d's SoftSilhouetteShader returns
     them (sigmoid_alpha_blend of all-ones colours), independent of the textures."""
 
-    def __init__(self, image_size: int, smpl=None):
-        # `image_size` is REQUIRED here (the reference constructor defaults to 256, scripts/mesh_renderer.py:25, a size its own
-        # loop never instantiates: scripts/optimize.py:110 passes 224).  A default of 256 would make `Mesh_Renderer()` always
-        # raise, a default of 224 would silently render at another size than code written against the reference assumes; a
-        # missing argument fails at the call site instead.  Every size but 224 is rejected below.
+    def __init__(self, image_size: int = 256, smpl=None):
+        # the reference constructor's signature and default (scripts/mesh_renderer.py:25); its loop instantiates 224
+        # (scripts/optimize.py:110).  The HIP rasteriser is built for exactly these two sizes (include/jrr.h, JRR_FLAG_SIL_256);
+        # the camera's focal length is 5000 / image_size as in the reference (mesh_renderer.py:52-53).
         super().__init__()
-        if image_size != 224:
-            raise NotImplementedError(f'Mesh_Renderer(image_size={image_size}): the HIP rasteriser is built for the 224x224 image of '
-                                      'scripts/optimize.py:110 only (include/jrr.h, JRR_SIL_SIZE / jrr_silhouette_forward); the '
-                                      'reference constructor\'s default of 256 is never instantiated by the reference')
+        if image_size not in (224, 256):
+            raise NotImplementedError(f'Mesh_Renderer(image_size={image_size}): the HIP rasteriser is built for 224 (scripts/optimize.py:110) '
+                                      'and 256 (the reference constructor\'s default) -- include/jrr.h, jrr_silhouette_forward')
         self.image_size = image_size
         self.smpl = smpl
         self._engines = {}
 
     def _engine(self, batch):
         if batch not in self._engines:
-            self._engines[batch] = _engine.RefineEngine(self.smpl.device_model, batch, flags=_engine.FLAG_SILHOUETTE)
+            flags = _engine.FLAG_SILHOUETTE | (_engine.FLAG_SIL_256 if self.image_size == 256 else 0)
+            self._engines[batch] = _engine.RefineEngine(self.smpl.device_model, batch, flags=flags)
         return self._engines[batch]
 
     def forward(self, batch, smpl_verts):

@@ -315,3 +315,45 @@ def test_driver_on_a_model_file_and_a_regressor_file(tmp_path):
     # the J step moved exactly the positive support of the file's regressor
     moved = res['J_regressor'].cpu().numpy() != J0
     assert moved.sum() == (J0 > 0).sum() and not moved[J0 <= 0].any()
+
+
+def test_silhouette_at_the_reference_constructors_default_size(smpl_model_np, j_h36m_np):
+    """Mesh_Renderer() -- image_size = 256, scripts/mesh_renderer.py:25, focal length 5000 / 256 (:52-53) -- beside the 224 of the loop
+    (scripts/optimize.py:110): alpha and the winning faces against the restated rasteriser (oracle/silhouette_port.py) at 256 x 256,
+    the fused loss / gradient kernel against the stand-alone rasteriser + adjoint, and the module's output shape."""
+    from oracle import silhouette_port as sp
+    sm, em = _mod('smpl_model'), _mod('engine')
+    B = 9
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=91)
+    x6, betas, cam = T(batch['pose6d']), T(batch['betas']), T(batch['cam'])
+    smpl_hip = _mod('smpl').SMPL(model=smpl_model_np).to(DEV)
+    eng = em.RefineEngine(smpl_hip.device_model, B, flags=em.FLAG_SILHOUETTE | em.FLAG_KEEP_VERTS | em.FLAG_SIL_256)
+    assert eng.sil == 256
+    eng.set_j_regressor(T(j_h36m_np))
+    xd, bd, cd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous(), cam.to(DEV).contiguous()
+    _, verts = eng.find_joints_forward(bd, x6d=xd, return_verts=True)
+    alpha = eng.silhouette_forward(verts, cd)
+    assert alpha.shape == (B, 256, 256)
+    p2f = eng.silhouette_pix_to_face().cpu()
+    ref, p2f_o = sp.soft_silhouette(verts.cpu(), smpl_model_np['faces'], cam, image_size=256, return_pix_to_face=True)
+    ref, p2f_o = ref[:, 0], torch.from_numpy(p2f_o)
+    agree = (p2f == p2f_o) & ((alpha.cpu() - ref).abs() < 2e-3)
+    covered = (p2f_o >= 0).sum().item()
+    assert covered > 4000 * B * (256 / 224) ** 2 * 0.8                      # the same body covers (256 / 224)^2 as many pixels
+    assert (~agree).sum().item() < 5e-3 * covered, ((~agree).sum().item(), covered)
+    assert torch.equal(p2f >= 0, alpha.cpu() > 0)
+    # the fused kernel (in-kernel projection with focal 5000 / 256, fixed-point adjoint) == stand-alone rasteriser + adjoint
+    mask = (eng.silhouette_forward(verts, (cd + torch.tensor([0.15, -0.1, 1.0], device=DEV)).contiguous()) > 0).float().contiguous()
+    sq_f, dv_f, dc_f = eng.silhouette_loss_grad(xd, bd, cd, mask)
+    al = eng.silhouette_forward(verts, cd)
+    sq_s = ((al - mask) ** 2).sum((1, 2))
+    np.testing.assert_allclose(sq_f.cpu().numpy(), sq_s.cpu().numpy(), rtol=2e-3)
+    dv_s, dc_s = eng.silhouette_backward(((al - mask) * (2.0 * 100.0 / (B * 256 * 256))).contiguous())
+    rel = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm()).item()      # noqa: E731
+    assert rel(dv_f, dv_s) < 2e-5 and rel(dc_f, dc_s) < 2e-5
+    # the module with the reference constructor's default
+    mr = _mod('mesh_renderer')
+    out = mr.Mesh_Renderer(smpl=smpl_hip)({'cam': cd}, verts * verts.new_tensor([-2.0, -2.0, 2.0]))
+    assert out.shape == (B, 4, 256, 256) and torch.equal(out[:, 3], al)
+    with pytest.raises(NotImplementedError):
+        mr.Mesh_Renderer(300, smpl_hip)
