@@ -826,7 +826,7 @@ static int blend_adjoint_gemm(jrr_engine* e, hipStream_t s) {
   return launch_blend_adjoint(e->m.Dq, e->DVP, e->dFTp, (size_t)KFP * e->BP, e->BP, e->nsplit, s);
 }
 
-static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s);
+static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s, float* dJs = nullptr);
 
 extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const float* R, const float* betas,
                                         const float* djoints, float* dx6d, float* dR, float* dbetas, float* dJ,
@@ -1278,9 +1278,9 @@ extern "C" int jrr_engine_set_loss_history(jrr_engine_t* e, float* hist_dev, int
 extern "C" int jrr_engine_loss_history_count(const jrr_engine_t* e) { return e ? e->hist_n : JRR_ERR_ARG; }
 
 static int j_step_local(jrr_engine* e, const float* x6d, const float* betas, const float* gt_mm, float* dJ, float* sqerr, hipStream_t s,
-                        float* joints = nullptr);
+                        float* joints = nullptr, float* dJs = nullptr);
 static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, float* v, int32_t* step, float lr, const float* mask,
-                        hipStream_t s);
+                        hipStream_t s, const float* dJs = nullptr);
 
 // Shared-parameter state of the in-call J steps (jrr_refine_run_j_steps)
 struct JStepArgs { int every; float* J; float* m; float* v; int32_t* step; float lr; const float* mask; float* sqerr; bool reuse; };
@@ -1454,7 +1454,7 @@ __global__ void k_djn_reduce(const float* __restrict__ P, int nslab, float* __re
 }
 
 // dJ from the joint adjoint dJT [3][18][BP] (already in the engine) and the stored vertices VTb [3][VP][BP]
-static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s) {
+static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s, float* dJs) {
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("dJ requires an engine created with JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
   // over the regressor's support when its lists fit (lbs.hip, "J step over the regressor's SUPPORT"), else the dense product
   const int* sflag = e->have_jsup ? e->jsup.flag : nullptr;
@@ -1464,7 +1464,8 @@ static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s) {
     if (rc) return rc;
     hipLaunchKernelGGL(k_djn_reduce, dim3((NH * VP + 255) / 256), dim3(256), 0, s, e->dJnp, 3 * e->nsplitJ, e->dJn, sflag);
   }
-  launch_jreg_bwd(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->Jn, e->rowsum, e->dJn, VP, dJ, e->m.v2p, s);
+  launch_jreg_bwd(e->Jraw, e->have_mask ? e->Jmask : nullptr, e->Jn, e->rowsum, e->dJn, VP, dJ, e->m.v2p, s,
+                  dJs ? &e->jsup : nullptr, e->m.p2v, dJs);      // dJs: the same gradient on the support lists, same launch
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -1498,11 +1499,7 @@ extern "C" int jrr_j_regressor_grad_support(jrr_engine_t* e, const float* x6d, c
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("J step requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
   if (!e->jsup_fits_known) { jrr_set_error("j_regressor_grad_support: call jrr_j_support_info first (it must report fits = 1)"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
-  int rc = j_step_local(e, x6d, betas, gt_mm, e->dJraw, sqerr, s, joints);
-  if (rc) return rc;
-  launch_jsup_gather(e->jsup, e->dJraw, e->m.p2v, dJs, s);
-  CHECK_LAUNCH();
-  return JRR_OK;
+  return j_step_local(e, x6d, betas, gt_mm, e->dJraw, sqerr, s, joints, dJs);
 }
 
 extern "C" int jrr_j_step_apply_support(jrr_engine_t* e, float* J, const float* dJs, float* m, float* v, int32_t* step, float lr,
@@ -1511,10 +1508,9 @@ extern "C" int jrr_j_step_apply_support(jrr_engine_t* e, float* J, const float* 
   if (!(e->flags & JRR_FLAG_KEEP_VERTS) || !e->jsup_fits_known) { jrr_set_error("j_step_apply_support: call jrr_j_support_info first (KEEP_VERTS engine, fits = 1)"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   // the dense gradient the optimiser sees: zero outside the support (exactly what the dense path holds there), the
-  // all-reduced values on it.  Adam itself stays dense: entries that left the support keep coasting on their momentum.
-  JRR_HIP(hipMemsetAsync(e->dJraw, 0, (size_t)NH * V * sizeof(float), s));
-  launch_jsup_scatter(e->jsup, dJs, e->m.p2v, e->dJraw, s);
-  return j_step_apply(e, J, e->dJraw, m, v, step, lr, mask, s);
+  // all-reduced values on it (scattered inside the update kernel).  Adam itself stays dense: entries that left the support
+  // keep coasting on their momentum.
+  return j_step_apply(e, J, nullptr, m, v, step, lr, mask, s, dJs);
 }
 
 // torch.optim.Adam on the raw regressor with the (all-reduced) gradient, then J*mask -> ReLU -> row-normalise into the
@@ -1528,10 +1524,31 @@ extern "C" int jrr_j_step_apply(jrr_engine_t* e, float* J, const float* dJ, floa
 }
 
 static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, float* v, int32_t* step, float lr, const float* mask,
-                        hipStream_t s) {
+                        hipStream_t s, const float* dJs) {
+  const bool cached = e->fwd_cached, known = e->jsup_fits_known && mask == e->jsup_mask;
+  if (e->have_jsup && e->have_J && e->tab_static) {
+    // Adam, the engine's copy, the row sums, the normalised layouts and the support lists in ONE launch (lbs.hip k_jstep_update)
+    JStepUpdate a;
+    a.J = J; a.dJ = dJ; a.dJs = dJs; a.m = m; a.v = v; a.step = step; a.lr = lr;
+    a.mask = mask; a.Jraw = e->Jraw; a.Jmask = e->Jmask; a.rowsum = e->rowsum; a.Jn = e->Jn; a.Jn_vi = e->Jn_vi; a.Jn_iv = e->Jn_iv;
+    a.Jn_q = e->Jn_q; a.p2v = e->m.p2v; a.v2p = e->m.v2p; a.r16 = (e->m.kjs && e->m.bwd16) ? 1 : 0;
+    a.sup = e->jsup; a.sync = e->jsup.flag + 1;
+    launch_jstep_update(a, s);
+    e->have_mask = mask != nullptr;
+    e->jsup_mask = mask;
+    e->jsup_fits_known = known;      // the stepped regressor's support is a subset of the old one (ReLU' = 0 outside it; same mask)
+    e->fold_valid = false;
+    if (e->folded) { int rcf = fold_rebuild(e, s); if (rcf) return rcf; }
+    CHECK_LAUNCH();
+    return JRR_OK;
+  }
+  if (!dJ) {      // (no support lists: jrr_j_step_apply_support has refused already; kept for completeness)
+    JRR_HIP(hipMemsetAsync(e->dJraw, 0, (size_t)NH * V * sizeof(float), s));
+    launch_jsup_scatter(e->jsup, dJs, e->m.p2v, e->dJraw, s);
+    dJ = e->dJraw;
+  }
   // Adam with step + 1; the counter itself is incremented by the normalisation's first launch (one launch less per J step)
   launch_adam_flat(J, dJ, m, v, (size_t)NH * V, step, lr, 0.9f, 0.999f, 1e-8f, s, 1);
-  const bool cached = e->fwd_cached, known = e->jsup_fits_known && mask == e->jsup_mask;
   int rc = set_j_regressor_impl(e, J, mask, (void*)s, step);
   e->fwd_cached = cached;
   e->jsup_fits_known = known;      // the stepped regressor's support is a subset of the old one (ReLU' = 0 outside it; same mask)
@@ -1539,10 +1556,10 @@ static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, floa
 }
 
 static int j_step_local(jrr_engine* e, const float* x6d, const float* betas, const float* gt_mm, float* dJ, float* sqerr, hipStream_t s,
-                        float* joints) {
+                        float* joints, float* dJs) {
   smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s);      // v_posed kept: the next inner iteration may reuse this forward
   e->fwd_cached = true; e->fc_x6d = x6d; e->fc_betas = betas;
   const float scale = (float)(2.0 * 1.0 / ((double)e->bnorm * 51.0));   // optimize.py:307 unweighted MSE
   launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, scale, joints ? joints : e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);
-  return j_grad_from_verts(e, dJ, s);
+  return j_grad_from_verts(e, dJ, s, dJs);
 }

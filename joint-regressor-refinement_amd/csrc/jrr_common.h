@@ -116,6 +116,25 @@ __device__ __forceinline__ void barrier_keep_vm() {
   asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
+// torch.optim.Adam, single-tensor formula: m = b1 m + (1-b1) g ; v = b2 v + (1-b2) g^2 ; p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps),
+// bias corrections evaluated in double like torch's Python scalars
+struct AdamScalars { float step_size, bc2_sqrt, beta1, beta2, eps; };
+__device__ __forceinline__ AdamScalars adam_scalars(int step, float lr, float beta1, float beta2, float eps) {
+  AdamScalars s;
+  double bc1 = 1.0 - pow((double)beta1, (double)step);
+  double bc2 = 1.0 - pow((double)beta2, (double)step);
+  s.step_size = (float)((double)lr / bc1);
+  s.bc2_sqrt = (float)sqrt(bc2);
+  s.beta1 = beta1; s.beta2 = beta2; s.eps = eps;
+  return s;
+}
+__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamScalars& s) {
+  m = m * s.beta1 + (1.f - s.beta1) * g;
+  v = v * s.beta2 + (1.f - s.beta2) * g * g;
+  float denom = sqrtf(v) / s.bc2_sqrt + s.eps;
+  return p - s.step_size * (m / denom);
+}
+
 struct Parents {
   int p[NJ];       // parent joint (p[0] = -1), parents precede children
   int depth[NJ];   // tree depth of each joint (root = 0)

@@ -103,10 +103,18 @@ int launch_jgrad_sparse(const JSupport& sup, const float* dJT, const float* VTq,
 // joints of the stored vertices with the current regressor, one slab [3][32][BP] (rows i < 17), support entries only
 // step_inc (nullable): incremented by one thread of the launch (the reuse iteration's Adam step count: one launch less)
 int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, int BP, hipStream_t s, int32_t* step_inc = nullptr);
-int launch_jsup_gather(const JSupport& sup, const float* dJ, const int* p2v, float* out, hipStream_t s);
 int launch_jsup_scatter(const JSupport& sup, const float* in, const int* p2v, float* dJ, hipStream_t s);
+// sup / p2v / dJs (nullable): also deliver the gradient on the support lists, dJs [17][JSUP_CAP]
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
-                    float* dJ, const int* v2p, hipStream_t s);
+                    float* dJ, const int* v2p, hipStream_t s, const JSupport* sup = nullptr, const int* p2v = nullptr, float* dJs = nullptr);
+// the J step's second half in one launch (lbs.hip k_jstep_update)
+struct JStepUpdate {
+  float* J; const float* dJ; const float* dJs; float* m; float* v; int32_t* step; float lr;
+  const float* mask; float* Jraw; float* Jmask; float* rowsum; float* Jn; float* Jn_vi; float* Jn_iv; float* Jn_q;
+  const int* p2v; const int* v2p; int r16;
+  JSupport sup; int* sync;          // sync[0] workgroups done, sync[1] rows above the list capacity (both zero between launches)
+};
+int launch_jstep_update(const JStepUpdate& a, hipStream_t s);
 
 // gemm.hip
 int launch_disc_gemm_q(const GemmArgs& g, int epi, int btr, hipStream_t s, int* ndot = nullptr);

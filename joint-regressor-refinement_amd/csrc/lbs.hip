@@ -1316,22 +1316,11 @@ __global__ __launch_bounds__(256) void k_rejoints_sparse(JSupport sup, const flo
 
 // The J step's gradient restricted to the regressor's support, for the data-parallel all-reduce: dJ (17 x 6890, file order of
 // the columns) is exactly zero outside the support, so the ranks exchange [17][JSUP_CAP] floats instead of 468 520 bytes.
-// gather: out[i][e] = dJ[i][vertex of support entry e] (0 behind the row's count); scatter: the inverse into a zero-filled dJ.
-__global__ __launch_bounds__(JSUP_CAP) void k_jsup_gather(JSupport sup, const float* __restrict__ dJ, const int* __restrict__ p2v,
-                                                          float* __restrict__ out) {
-  const int i = blockIdx.x, e = threadIdx.x;
-  float val = 0.f;
-  if (e < sup.cnt[i]) { const int row = sup.col[i * JSUP_CAP + e]; val = dJ[(size_t)i * V + (p2v ? p2v[row] : row)]; }
-  out[i * JSUP_CAP + e] = val;
-}
+// The compact values come out of k_jreg_bwd (zeros behind the row's count); scatter: their way back into a zero-filled dJ.
 __global__ __launch_bounds__(JSUP_CAP) void k_jsup_scatter(JSupport sup, const float* __restrict__ in, const int* __restrict__ p2v,
                                                            float* __restrict__ dJ) {
   const int i = blockIdx.x, e = threadIdx.x;
   if (e < sup.cnt[i]) { const int row = sup.col[i * JSUP_CAP + e]; dJ[(size_t)i * V + (p2v ? p2v[row] : row)] = in[i * JSUP_CAP + e]; }
-}
-int launch_jsup_gather(const JSupport& sup, const float* dJ, const int* p2v, float* out, hipStream_t s) {
-  hipLaunchKernelGGL(k_jsup_gather, dim3(NH), dim3(JSUP_CAP), 0, s, sup, dJ, p2v, out);
-  return 0;
 }
 int launch_jsup_scatter(const JSupport& sup, const float* in, const int* p2v, float* dJ, hipStream_t s) {
   hipLaunchKernelGGL(k_jsup_scatter, dim3(NH), dim3(JSUP_CAP), 0, s, sup, in, p2v, dJ);
@@ -1351,7 +1340,8 @@ int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, in
 __global__ __launch_bounds__(JREG_THREADS) void k_jreg_bwd(const float* __restrict__ J, const float* __restrict__ mask,
                                                             const float* __restrict__ Jn, const float* __restrict__ rowsum,
                                                             const float* __restrict__ dJn, int ldn, float* __restrict__ dJ,
-                                                            const int* __restrict__ v2p) {
+                                                            const int* __restrict__ v2p, JSupport sup, const int* __restrict__ p2v,
+                                                            float* __restrict__ dJs) {
   __shared__ float red[JREG_THREADS];
   const int i = blockIdx.x;
   float acc = 0.f;
@@ -1370,6 +1360,119 @@ __global__ __launch_bounds__(JREG_THREADS) void k_jreg_bwd(const float* __restri
     float g = (x > 0.f) ? (dJn[(size_t)i * ldn + (v2p ? v2p[v] : v)] - dot) / rs * mk : 0.f;
     dJ[(size_t)i * V + v] = g;
   }
+  // dJs (nullable): the same gradient on the regressor's support, [17][JSUP_CAP] with zeros behind the row's count -- the payload of
+  // the data-parallel all-reduce (jrr_j_regressor_grad_support).  Entry e of the list is internal row col[e]; its vertex is p2v[col[e]].
+  if (dJs) {
+    const int n = sup.cnt[i];
+    for (int e = threadIdx.x; e < JSUP_CAP; e += blockDim.x) {
+      float g = 0.f;
+      if (e < n) {
+        const int row = sup.col[i * JSUP_CAP + e];
+        const int vo = p2v ? p2v[row] : row;
+        const float mk = mask ? mask[(size_t)i * V + vo] : 1.f;
+        const float x = J[(size_t)i * V + vo] * mk;
+        g = (x > 0.f) ? (dJn[(size_t)i * ldn + row] - dot) / rs * mk : 0.f;
+      }
+      dJs[i * JSUP_CAP + e] = g;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// The second half of the J step in ONE launch (scripts/optimize.py:312 `J_Regressor_optimizer.step()` + the re-normalisation of the
+// next find_joints, scripts/utils.py:87-92): one workgroup per regressor row does what used to be five launches -- torch's Adam on
+// the row (k_adam_flat), the engine's copy of the raw parameter, the row sum, the normalised row in all layouts (k_jreg_tiles) and the
+// row's support list (k_jreg_support) -- with the arithmetic and the summation orders of those kernels (bit-identical results).  The
+// gradient arrives dense (dJ) or on the OLD support lists (dJs, the all-reduced payload of jrr_j_step_apply_support: scattered through
+// LDS, zero elsewhere -- what the dense gradient holds there).  The workgroup that finishes LAST increments the step counter (every
+// workgroup read it at its start) and publishes the fits-the-lists flag.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(JREG_THREADS) void k_jstep_update(JStepUpdate a) {
+  __shared__ float red[JREG_THREADS];
+  __shared__ float gl[V];
+  __shared__ AdamScalars sc;
+  __shared__ int wcount[JREG_THREADS / 64];
+  __shared__ int base, islast;
+  const int i = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) { sc = adam_scalars(a.step[0] + 1, a.lr, 0.9f, 0.999f, 1e-8f); base = 0; }
+  if (a.dJs) {
+    for (int v = tid; v < V; v += JREG_THREADS) gl[v] = 0.f;
+    __syncthreads();
+    if (tid < a.sup.cnt[i]) { const int row = a.sup.col[i * JSUP_CAP + tid]; gl[a.p2v ? a.p2v[row] : row] = a.dJs[i * JSUP_CAP + tid]; }
+  }
+  __syncthreads();
+  const AdamScalars s = sc;
+  constexpr int NK = (V + JREG_THREADS - 1) / JREG_THREADS;      // 7 columns per thread
+  float x[NK];
+  float acc = 0.f;
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int v = tid + k * JREG_THREADS;
+    x[k] = 0.f;
+    if (v < V) {
+      const size_t o = (size_t)i * V + v;
+      const float g = a.dJs ? gl[v] : a.dJ[o];
+      float mm = a.m[o], vv = a.v[o];
+      const float pn = adam_update(a.J[o], g, mm, vv, s);
+      a.J[o] = pn; a.m[o] = mm; a.v[o] = vv;
+      a.Jraw[o] = pn;
+      float mk = 1.f;
+      if (a.mask) { mk = a.mask[o]; a.Jmask[o] = mk; }
+      x[k] = fmaxf(pn * mk, 0.f);
+      acc += x[k];
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int w = JREG_THREADS / 2; w > 0; w >>= 1) {
+    if (tid < w) red[tid] += red[tid + w];
+    __syncthreads();
+  }
+  const float rs = red[0];
+  if (tid == 0) a.rowsum[i] = rs;
+  // the normalised row in every layout (k_jreg_tiles), then its support list in ascending FILE order of the vertices (k_jreg_support)
+#pragma unroll
+  for (int k = 0; k < NK; ++k) {
+    const int v = tid + k * JREG_THREADS;
+    const float val = (v < V) ? x[k] / rs : 0.f;
+    int r = 0;
+    if (v < V) {
+      r = a.v2p ? a.v2p[v] : v;                      // internal row of the vertex
+      const int vt = r >> 5, vv = r & 31;
+      a.Jn[(size_t)i * V + v] = val;
+      a.Jn_vi[(size_t)vt * 1024 + vv * 32 + i] = val;
+      a.Jn_q[((size_t)(r >> 2) * 32 + i) * 4 + (r & 3)] = val;
+      if (a.r16) a.Jn_iv[(size_t)vt * TB_FLOATS + R16_JN + ((vv >> 4) * 5 + (i >> 2)) * 64 + (i & 3) * 16 + (vv & 15)] = val;
+      else a.Jn_iv[(size_t)vt * TB_FLOATS + TB_JN + i * 32 + vv] = val;
+    }
+    const bool on = val > 0.f;
+    const unsigned long long bal = __ballot(on);
+    if (lane == 0) wcount[wave] = __popcll(bal);
+    __syncthreads();
+    int off = base;
+    for (int q = 0; q < wave; ++q) off += wcount[q];
+    off += __popcll(bal & ((1ull << lane) - 1ull));
+    if (on && off < JSUP_CAP) { a.sup.col[i * JSUP_CAP + off] = r; a.sup.val[i * JSUP_CAP + off] = val; }
+    __syncthreads();
+    if (tid == 0) { int t = 0; for (int q = 0; q < JREG_THREADS / 64; ++q) t += wcount[q]; base += t; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    a.sup.cnt[i] = base < JSUP_CAP ? base : JSUP_CAP;
+    if (base > JSUP_CAP) atomicAdd(&a.sync[1], 1);
+    __threadfence();
+    islast = atomicAdd(&a.sync[0], 1) == (int)gridDim.x - 1;
+    if (islast) {
+      __threadfence();
+      *a.sup.flag = atomicAdd(&a.sync[1], 0) == 0 ? 1 : 0;
+      a.step[0] += 1;
+      a.sync[0] = 0; a.sync[1] = 0;
+    }
+  }
+}
+int launch_jstep_update(const JStepUpdate& a, hipStream_t s) {
+  hipLaunchKernelGGL(k_jstep_update, dim3(NH), dim3(JREG_THREADS), 0, s, a);
+  return 0;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1469,8 +1572,10 @@ int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s) {
 }
 
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
-                    float* dJ, const int* v2p, hipStream_t s) {
-  hipLaunchKernelGGL(k_jreg_bwd, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, Jn, rowsum, dJn, ldn, dJ, v2p);
+                    float* dJ, const int* v2p, hipStream_t s, const JSupport* sup, const int* p2v, float* dJs) {
+  const JSupport none{nullptr, nullptr, nullptr, nullptr};
+  hipLaunchKernelGGL(k_jreg_bwd, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, Jn, rowsum, dJn, ldn, dJ, v2p, sup ? *sup : none, p2v,
+                     sup ? dJs : nullptr);
   return 0;
 }
 

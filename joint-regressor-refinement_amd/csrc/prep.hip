@@ -349,24 +349,7 @@ __global__ __launch_bounds__(PP * NJ) void k_prep_fwd_dconv(const float* __restr
 // p -= (lr/bc1) * m / (sqrt(v)/sqrt(bc2) + eps), bias corrections evaluated in double like
 // torch's Python scalars.
 // ------------------------------------------------------------------------------------------
-struct AdamScalars { float step_size, bc2_sqrt, beta1, beta2, eps; };
-
-__device__ __forceinline__ AdamScalars adam_scalars(int step, float lr, float beta1, float beta2, float eps) {
-  AdamScalars s;
-  double bc1 = 1.0 - pow((double)beta1, (double)step);
-  double bc2 = 1.0 - pow((double)beta2, (double)step);
-  s.step_size = (float)((double)lr / bc1);
-  s.bc2_sqrt = (float)sqrt(bc2);
-  s.beta1 = beta1; s.beta2 = beta2; s.eps = eps;
-  return s;
-}
-
-__device__ __forceinline__ float adam_update(float p, float g, float& m, float& v, const AdamScalars& s) {
-  m = m * s.beta1 + (1.f - s.beta1) * g;
-  v = v * s.beta2 + (1.f - s.beta2) * g * g;
-  float denom = sqrtf(v) / s.bc2_sqrt + s.eps;
-  return p - s.step_size * (m / denom);
-}
+// (AdamScalars / adam_scalars / adam_update: jrr_common.h -- shared with the fused J-step update of lbs.hip)
 
 // ------------------------------------------------------------------------------------------
 // Perspective projection of the regressed joints (scripts/renderer.py:35-49 with pytorch3d 0.3.0
