@@ -890,10 +890,11 @@ extern "C" int jrr_joint_loss(const float* joints, const float* gt_mm, float wei
 
 // ---- pose discriminator --------------------------------------------------------------------
 // Six launches per forward + input gradient (scripts/discriminator.py:32-54 and its adjoint):
-//   k_dconv_fwd (per-joint MLP, MFMA)  ->  fc0 GEMM (+bias, ReLU)  ->  fc2 GEMM (+bias, ReLU, and the fc4 dot product
-//   w4 . a2 as per-column partials in the epilogue)  ->  fc2 adjoint GEMM whose B operand is a2 itself, turned into
-//   relu'(a2) dz on the way to the MFMA (dz from the partial dots in the prologue; fc2.w pre-scaled by w4: the
-//   rank-one output-layer adjoint is never materialised)  ->  fc0 adjoint GEMM  ->  k_dconv_bwd.
+//   k_dconv_fwd (per-joint MLP, MFMA)  ->  fc0 GEMM (+bias, ReLU)  ->  fc2 GEMM (+bias, ReLU, the fc4 dot product
+//   w4 . a2 as per-column partials in the epilogue; what it stores is relu'(a2) as 0 / 1: nothing else of a2 is read again)
+//   ->  fc2 adjoint GEMM on that indicator (dz from the partial dots in the prologue multiplies the finished column sums
+//   in the epilogue; fc2.w pre-scaled by w4: the rank-one output-layer adjoint is never materialised)  ->  fc0 adjoint
+//   GEMM  ->  k_dconv_bwd.
 // All four GEMMs: exact 128x64 tiles (512 workgroups at 4096 poses), 3-deep LDS-DMA ring.
 // The loop path keeps every activation in quads [row/4][pose][4] (k_disc_gemm); the weight-gradient path of the outer
 // step (disc_backward_params) needs row-major activations for its transposes / row sums and runs the row-major kernels.

@@ -534,7 +534,10 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_disc_gemm(GemmArgs g
   };
   issue(0, 0);
   if (nch > 1) issue(1, 1);
-  float cscale = 0.f;                                        // BTR = 2: dz of this lane's column (computed while the copies fly)
+  // BTR = 2 (the adjoint of fc2, scripts/discriminator.py:47-52 backwards): B holds relu'(a2) as 0 / 1 -- written by the
+  // EPI_BIAS_RELU_DOT epilogue of the forward product -- and the column factor dz, which does not depend on the summation index,
+  // multiplies the finished sums in the epilogue: no per-element transform between the LDS read and the matrix instruction.
+  float cscale = 0.f;                                        // dz of this lane's column (computed while the copies fly)
   if (BTR == 2) {
     const int n = n0 + wn * 32 + l31;
     float z = g.zbias[0];
@@ -570,7 +573,7 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_disc_gemm(GemmArgs g
 #pragma unroll
       for (int i = 0; i < WM; ++i) ca[i] = a4[i];
 #pragma unroll
-      for (int t = 0; t < 4; ++t) cb[t] = BTR ? ((b4[t] > 0.f) ? cscale : 0.f) : b4[t];
+      for (int t = 0; t < 4; ++t) cb[t] = b4[t];
       __builtin_amdgcn_sched_barrier(0);
       acc[0] = mfma(ca[0][0], cb[0], acc[0]);
       __builtin_amdgcn_sched_barrier(0);
@@ -611,7 +614,11 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_disc_gemm(GemmArgs g
       if (EPI == EPI_MASK) {
         const f32x4 mk = reinterpret_cast<const f32x4*>(g.mask)[qi];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) v[u] = (mk[u] > 0.f) ? v[u] : 0.f;
+        for (int u = 0; u < 4; ++u) v[u] = (mk[u] > 0.f) ? (BTR == 2 ? v[u] * cscale : v[u]) : 0.f;
+      }
+      if (EPI == EPI_BIAS_RELU_DOT) {      // the only reader of this output is the BTR = 2 product: it needs relu'(a2), not a2
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = (v[u] > 0.f) ? 1.f : 0.f;
       }
       reinterpret_cast<f32x4*>(g.Out)[qi] = v;
     }
