@@ -309,6 +309,11 @@ int jrr_j_step_apply(jrr_engine_t* e, float* J_dev, const float* dJ_dev, float* 
  *   jrr_j_step_apply_support      = jrr_j_step_apply with the (all-reduced) dJs_dev: the dense gradient is rebuilt on the device
  *                                 (zero outside the support, as the dense path has it) and torch's Adam runs over the whole
  *                                 (17,6890) parameter as before -- entries that left the support keep coasting on their momentum.
+ *                                 Its forward (and that of the in-call steps of jrr_refine_run_j_steps) keeps the vertices of
+ *                                 the 32-vertex tiles that hold a support entry only -- what the gradient product and the reusing
+ *                                 iteration read -- not all 6890 x 3 x B of them: a jrr_find_joints_backward(dJ) afterwards
+ *                                 needs its own jrr_find_joints_forward, and a jrr_engine_set_j_regressor from outside between
+ *                                 this call and jrr_refine_run_after_j_step drops the cached forward (JRR_ERR_STATE there).
  * Both return JRR_ERR_STATE unless jrr_j_support_info has reported fits = 1 for the current regressor (fall back to the
  * dense pair).  Same results as the dense pair bit for bit on this rank; across ranks only the all-reduce's own summation
  * order can differ (none with two ranks).                                                                                  */

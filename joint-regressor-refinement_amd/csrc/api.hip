@@ -389,6 +389,7 @@ struct jrr_engine {
   float *dVTb, *dJnp, *dJn;   // transposed external vertex adjoint [3][VP][BP]; J-gradient partial slabs [3*nsplitJ][32][VP]
   int32_t* step_scratch;
   bool profiling;
+  bool verts_partial;                                // VTb holds the support tiles of the last J step only
   std::vector<hipEvent_t>* ev[JRR_PROF_CLASSES];
   const float* gt_j2d; float* cam; float* cam_m; float* cam_v;   // 2-D reprojection term (nullable)
   float *gcam, *sq2d;
@@ -535,6 +536,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->jsup.cnt = (int*)c.take(64);
     t->jsup.col = (int*)c.take((size_t)NH * JSUP_CAP);
     t->jsup.val = c.take((size_t)NH * JSUP_CAP);
+    t->jsup.tmask = (int*)c.take(256);
   }
   if (e) {
     e->BP = BP; e->nvc = nvc; e->nvcb = (e->has_model && e->m.kjs && e->m.bwd16) ? nvcb16 : nvcb; e->nsplit = nsplit; e->nsplitJ = nsplitJ;
@@ -692,6 +694,7 @@ static int set_j_regressor_impl(jrr_engine_t* e, const float* J, const float* ma
   if (!e->has_model) { jrr_set_error("engine was created without an SMPL model (discriminators only)"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   e->jsup_fits_known = false;      // a regressor from outside: its support is not known to fit until jrr_j_support_info says so
+  if (e->verts_partial) e->fwd_cached = false;      // the stored vertices cover the OLD regressor's support tiles only
   JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   e->have_mask = mask != nullptr;
@@ -800,10 +803,11 @@ static void set_adjoint_slabs(jrr_engine* e, PrepBwdLaunch& L) {
 }
 
 static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,
-                        bool keep_verts, int32_t* step_inc, hipStream_t s) {
+                        bool keep_verts, int32_t* step_inc, hipStream_t s, const int* vmask = nullptr) {
   launch_prep_fwd(e->m, x6d, R, betas, e->FT, e->FTq, e->AT, e->R0T, e->B, e->BP, step_inc, s);
   launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, keep_vp ? e->VPb : nullptr, e->JP, keep_verts ? e->VTb : nullptr, e->B, e->BP,
-                 e->nvc, s);
+                 e->nvc, s, nullptr, vmask);
+  if (keep_verts) e->verts_partial = vmask != nullptr;
   return 0;
 }
 
@@ -1279,7 +1283,7 @@ extern "C" int jrr_engine_set_loss_history(jrr_engine_t* e, float* hist_dev, int
 extern "C" int jrr_engine_loss_history_count(const jrr_engine_t* e) { return e ? e->hist_n : JRR_ERR_ARG; }
 
 static int j_step_local(jrr_engine* e, const float* x6d, const float* betas, const float* gt_mm, float* dJ, float* sqerr, hipStream_t s,
-                        float* joints = nullptr, float* dJs = nullptr);
+                        float* joints = nullptr, float* dJs = nullptr, bool support_verts = false);
 static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, float* v, int32_t* step, float lr, const float* mask,
                         hipStream_t s, const float* dJs = nullptr);
 
@@ -1312,7 +1316,8 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     // The J step that preceded this call ran the SMPL forward on exactly these poses (jrr_j_regressor_grad keeps
     // v_posed, the skinning transforms and the vertices): the first iteration re-regresses the joints with the NEW
     // regressor from the stored vertices instead of repeating the 0.47 ms forward (jrr_refine_run_after_j_step).
-    const bool reuse = reuse_next && e->fwd_cached && !folded && e->sil_mask == nullptr;
+    const bool reuse = reuse_next && e->fwd_cached && !folded && e->sil_mask == nullptr &&
+                       !(e->verts_partial && !(e->have_jsup && e->jsup_fits_known));
     reuse_next = false;
     e->fwd_cached = false;
     prof_mark(e, 0, s);
@@ -1338,6 +1343,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       const bool silf = e->sil_mask != nullptr;      // the silhouette term needs the vertices
       launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, e->VPb, e->JP, silf ? e->VTb : nullptr, e->B, e->BP, e->nvc, s,
                      e->profiling ? e->probe : nullptr);
+      if (silf) e->verts_partial = false;
     }
     prof_mark(e, 1, s);
     prof_mark(e, 2, s);
@@ -1408,7 +1414,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       ++e->hist_iter;
     }
     if (js && (it + 1) % js->every == 0) {      // scripts/optimize.py:300-312 inside the call (single process: no collective)
-      int rcj = j_step_local(e, x6d, betas, gt_mm, e->dJraw, js->sqerr, s);
+      int rcj = j_step_local(e, x6d, betas, gt_mm, e->dJraw, js->sqerr, s, nullptr, nullptr, true);
       if (rcj) return rcj;
       rcj = j_step_apply(e, js->J, e->dJraw, js->m, js->v, js->step, js->lr, js->mask, s);
       if (rcj) return rcj;
@@ -1457,6 +1463,10 @@ __global__ void k_djn_reduce(const float* __restrict__ P, int nslab, float* __re
 // dJ from the joint adjoint dJT [3][18][BP] (already in the engine) and the stored vertices VTb [3][VP][BP]
 static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s, float* dJs) {
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("dJ requires an engine created with JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
+  if (e->verts_partial && !(e->have_jsup && e->jsup_fits_known)) {
+    jrr_set_error("dJ: the stored vertices are those of a J step over the regressor's support; run jrr_find_joints_forward first");
+    return JRR_ERR_STATE;
+  }
   // over the regressor's support when its lists fit (lbs.hip, "J step over the regressor's SUPPORT"), else the dense product
   const int* sflag = e->have_jsup ? e->jsup.flag : nullptr;
   if (e->have_jsup) launch_jgrad_sparse(e->jsup, e->dJT, e->VTb, e->dJn, e->BP, s);
@@ -1500,7 +1510,7 @@ extern "C" int jrr_j_regressor_grad_support(jrr_engine_t* e, const float* x6d, c
   if (!(e->flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("J step requires JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
   if (!e->jsup_fits_known) { jrr_set_error("j_regressor_grad_support: call jrr_j_support_info first (it must report fits = 1)"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
-  return j_step_local(e, x6d, betas, gt_mm, e->dJraw, sqerr, s, joints, dJs);
+  return j_step_local(e, x6d, betas, gt_mm, e->dJraw, sqerr, s, joints, dJs, true);
 }
 
 extern "C" int jrr_j_step_apply_support(jrr_engine_t* e, float* J, const float* dJs, float* m, float* v, int32_t* step, float lr,
@@ -1557,8 +1567,13 @@ static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, floa
 }
 
 static int j_step_local(jrr_engine* e, const float* x6d, const float* betas, const float* gt_mm, float* dJ, float* sqerr, hipStream_t s,
-                        float* joints, float* dJs) {
-  smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s);      // v_posed kept: the next inner iteration may reuse this forward
+                        float* joints, float* dJs, bool support_verts) {
+  // v_posed kept: the next inner iteration may reuse this forward.  The vertices (support_verts: the callers whose second half of
+  // the step is the engine's own -- the in-call J steps and the support-sized pair): when the regressor's support is known to fit
+  // the lists, both consumers (k_jgrad_sparse here, k_rejoints_sparse in the reusing iteration) read support rows only -- the forward
+  // stores the tiles that hold one (a few dozen of 216) instead of 340 MB at 4096 poses
+  const bool few = support_verts && e->have_jsup && e->jsup_fits_known;
+  smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s, few ? e->jsup.tmask : nullptr);
   e->fwd_cached = true; e->fc_x6d = x6d; e->fc_betas = betas;
   const float scale = (float)(2.0 * 1.0 / ((double)e->bnorm * 51.0));   // optimize.py:307 unweighted MSE
   launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, scale, joints ? joints : e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);

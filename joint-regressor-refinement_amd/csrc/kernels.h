@@ -82,7 +82,8 @@ int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, con
 
 // lbs.hip
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
-                   float* VTb, int B, int BP, int nvc, hipStream_t s, long long* probe = nullptr);
+                   float* VTb, int B, int BP, int nvc, hipStream_t s, long long* probe = nullptr, const int* vmask = nullptr);
+// vmask (nullable, with VTb): store the vertices of the tiles with vmask[tile] != 0 only (JSupport::tmask)
 int launch_verts_untranspose(const float* VTb, float* verts, int ldv, int vlimit, const float* cam, float* ndc, int B, int BP,
                              hipStream_t s, const int* p2v = nullptr);
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s);
@@ -93,7 +94,8 @@ int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int
 // JSupport lives in the engine workspace: cnt[i] positive entries of row i, their internal vertex rows / weights in ascending
 // vertex order, flag[0] = 1 when every row has at most JSUP_CAP of them (else the dense products run).
 constexpr int JSUP_CAP = 128;
-struct JSupport { int* flag; int* cnt; int* col; float* val; };     // flag[1], cnt[32], col[17][JSUP_CAP], val[17][JSUP_CAP]
+struct JSupport { int* flag; int* cnt; int* col; float* val; int* tmask; };     // flag[1], cnt[32], col[17][JSUP_CAP], val[17][JSUP_CAP], tmask[VT]
+// tmask[tile] = 1 when a support entry lives in that 32-vertex tile (rebuilt with the lists)
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv, float* Jn_q,
                           const int* p2v, hipStream_t s, int r16 = 0, const int* v2p = nullptr, const JSupport* sup = nullptr,
                           int32_t* step_inc = nullptr);
@@ -103,6 +105,7 @@ int launch_jgrad_sparse(const JSupport& sup, const float* dJT, const float* VTq,
 // joints of the stored vertices with the current regressor, one slab [3][32][BP] (rows i < 17), support entries only
 // step_inc (nullable): incremented by one thread of the launch (the reuse iteration's Adam step count: one launch less)
 int launch_rejoints_sparse(const JSupport& sup, const float* VTq, float* out, int BP, hipStream_t s, int32_t* step_inc = nullptr);
+int launch_jsup_tilemask(const JSupport& sup, hipStream_t s);
 int launch_jsup_scatter(const JSupport& sup, const float* in, const int* p2v, float* dJ, hipStream_t s);
 // sup / p2v / dJs (nullable): also deliver the gradient on the support lists, dJs [17][JSUP_CAP]
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,

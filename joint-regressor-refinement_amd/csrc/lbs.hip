@@ -85,7 +85,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
                                                     const float* __restrict__ AT, float* __restrict__ VPb,
                                                     float* __restrict__ JP, float* __restrict__ VTb, int B, int BP,
                                                     int nvc, long long* __restrict__ probe, int paired,
-                                                    const int* __restrict__ jl, const int* __restrict__ tnj) {
+                                                    const int* __restrict__ jl, const int* __restrict__ tnj,
+                                                    const int* __restrict__ vmask) {
+  // vmask (STORE_VERTS only, nullable): vertices leave the chip only for the tiles with vmask[tile] != 0 -- the J step over the
+  // regressor's support reads a few dozen vertex rows, not 340 MB
   constexpr bool SPARSE = KJ > 0;
   constexpr int KJS = SPARSE ? KJ : 8;                       // (8: keeps the dead sparse branch of the dense variant well-formed)
   constexpr int NST = SPARSE ? NKCH + 3 : NSTAGE;            // stages per vertex tile
@@ -229,6 +232,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   for (int vt = t_begin; vt < t_end; ++vt) {
     const float* ldsW = wj + (vt & 1) * WJ_FLOATS;
     const float* ldsJ = ldsW + W_FLOATS;
+    const bool stv = STORE_VERTS && (!vmask || vmask[vt] != 0);      // wave-uniform
     if (SPARSE) {      // the skinning copies of this tile are issued from its stage NKCH - 1 on
       if (WIDE) {
         wide = wide_next;
@@ -261,7 +265,11 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         constexpr int nst = (hp < 0) ? 0
                             : SPARSE ? (STORE_VP ? 4 : 0) + (STORE_VERTS ? 4 : 0)
                                      : (STORE_VP ? 2 : 0) + ((STORE_VERTS && (hp & 1)) ? 4 : 0);
+        // (with a tile mask the vertex stores of the previous stage may not exist: count the v_posed stores only -- waiting for
+        // more than necessary is always safe)
+        constexpr int nst_vp = (hp < 0) ? 0 : SPARSE ? (STORE_VP ? 4 : 0) : (STORE_VP ? 2 : 0);
         if (s == 0 && vt == t_begin) barrier_keep_vm<0>();
+        else if (STORE_VERTS && nst != nst_vp && vmask) barrier_keep_vm<nst_vp>();
         else barrier_keep_vm<nst>();
       }
       // the stage that follows this one: a wide tile's skinning stage r is followed by its second pass over the same r
@@ -369,7 +377,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
           vr += T * vp[1];
           vr += U * vp[2];
         }
-        if (STORE_VERTS) {
+        if (STORE_VERTS && stv) {
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 t = {vr[4 * g4], vr[4 * g4 + 1], vr[4 * g4 + 2], vr[4 * g4 + 3]};
@@ -418,7 +426,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         } else {
           vr += T * vp[1];                       // T_{r,1} v_y
           vr += U * vp[2];                       // T_{r,2} v_z
-          if (STORE_VERTS) {      // vertices, in the row-quad layout of v_posed: four 16-byte stores per lane
+          if (STORE_VERTS && stv) {      // vertices, in the row-quad layout of v_posed: four 16-byte stores per lane
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const f32x4 t = {vr[4 * g], vr[4 * g + 1], vr[4 * g + 2], vr[4 * g + 3]};
@@ -1268,6 +1276,23 @@ __global__ __launch_bounds__(JREG_THREADS) void k_jreg_support(const float* __re
   }
 }
 
+// tmask[tile] = 1 for the 32-vertex tiles that hold a support entry: the J step's forward stores the vertices of those tiles only
+__global__ __launch_bounds__(256) void k_jsup_tilemask(JSupport sup) {
+  __shared__ int m[VT];
+  for (int t = threadIdx.x; t < VT; t += 256) m[t] = 0;
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < NH * JSUP_CAP; idx += 256) {
+    const int i = idx / JSUP_CAP, e = idx % JSUP_CAP;
+    if (e < sup.cnt[i]) m[sup.col[idx] >> 5] = 1;
+  }
+  __syncthreads();
+  for (int t = threadIdx.x; t < VT; t += 256) sup.tmask[t] = m[t];
+}
+int launch_jsup_tilemask(const JSupport& sup, hipStream_t s) {
+  hipLaunchKernelGGL(k_jsup_tilemask, dim3(1), dim3(256), 0, s, sup);
+  return 0;
+}
+
 // one workgroup per (row i, entry slot): dJn[i][row] = sum_b sum_r dj_r[i][b] verts_r[row][b]; fixed-order sums.
 // (1024 threads: the sum over the poses is a chain of dependent load rounds -- 4 per thread at 4096 poses instead of 16: 17 -> ~6 us)
 constexpr int JGS_THREADS = 1024;
@@ -1472,6 +1497,7 @@ __global__ __launch_bounds__(JREG_THREADS) void k_jstep_update(JStepUpdate a) {
 }
 int launch_jstep_update(const JStepUpdate& a, hipStream_t s) {
   hipLaunchKernelGGL(k_jstep_update, dim3(NH), dim3(JREG_THREADS), 0, s, a);
+  launch_jsup_tilemask(a.sup, s);
   return 0;
 }
 
@@ -1479,14 +1505,14 @@ int launch_jstep_update(const JStepUpdate& a, hipStream_t s) {
 // launchers
 // ------------------------------------------------------------------------------------------
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
-                   float* verts, int B, int BP, int nvc, hipStream_t s, long long* probe) {
+                   float* verts, int B, int BP, int nvc, hipStream_t s, long long* probe, const int* vmask) {
   dim3 grid((BP / BG) * nvc), block(256);
   // exactly one round of two workgroups per CU, an even number of chunks and whole pose groups per XCD
   static const int fwd_split = [] { const char* e = getenv("JRR_FWD_SPLIT"); return e ? atoi(e) : 556; }();   // 5/9 (15 : 12 tiles at B = 4096)
   const int paired = (grid.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? fwd_split : 0;
 #define JRR_LBS_FWD_K(SVP, SVT, KJV, WD, WT)                                                                                      \
   hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, KJV, WD>), grid, block, 0, s, m.Dk, WT, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe,  \
-                     paired, m.jl, m.tnj)
+                     paired, m.jl, m.tnj, verts ? vmask : nullptr)
 #define JRR_LBS_FWD(SVP, SVT)                                                                                                     \
   do {                                                                                                                            \
     if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_FWD_K(SVP, SVT, 8, false, m.Wc);                                                     \
@@ -1560,7 +1586,10 @@ int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, floa
                           float* Jn_q, const int* p2v, hipStream_t s, int r16, const int* v2p, const JSupport* sup, int32_t* step_inc) {
   hipLaunchKernelGGL(k_jreg_rowsum, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, rowsum, sup ? sup->flag : nullptr, step_inc);
   hipLaunchKernelGGL(k_jreg_tiles, dim3(VT * 1024 / 256), dim3(256), 0, s, J, mask, rowsum, Jn, Jn_vi, Jn_iv, Jn_q, p2v, r16);
-  if (sup) hipLaunchKernelGGL(k_jreg_support, dim3(NH), dim3(JREG_THREADS), 0, s, Jn, v2p, *sup);
+  if (sup) {
+    hipLaunchKernelGGL(k_jreg_support, dim3(NH), dim3(JREG_THREADS), 0, s, Jn, v2p, *sup);
+    launch_jsup_tilemask(*sup, s);
+  }
   return 0;
 }
 
@@ -1573,7 +1602,7 @@ int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s) {
 
 int launch_jreg_bwd(const float* J, const float* mask, const float* Jn, const float* rowsum, const float* dJn, int ldn,
                     float* dJ, const int* v2p, hipStream_t s, const JSupport* sup, const int* p2v, float* dJs) {
-  const JSupport none{nullptr, nullptr, nullptr, nullptr};
+  const JSupport none{nullptr, nullptr, nullptr, nullptr, nullptr};
   hipLaunchKernelGGL(k_jreg_bwd, dim3(NH), dim3(JREG_THREADS), 0, s, J, mask, Jn, rowsum, dJn, ldn, dJ, v2p, sup ? *sup : none, p2v,
                      sup ? dJs : nullptr);
   return 0;
