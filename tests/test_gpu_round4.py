@@ -251,6 +251,28 @@ def test_support_sized_j_step_is_bit_identical_to_the_dense_pair(smpl_model_np, 
         outs.append((J.cpu(), Jm.cpu(), Jv.cpu(), joints.cpu()))
     for a, b in zip(*outs):
         assert torch.equal(a, b)
+    # the support-sized step's forward keeps the vertex tiles of the support only: a regressor from outside between it and the
+    # reusing iteration drops the cached forward (the engine refuses instead of regressing joints from vertices it did not store);
+    # without such an intervention the reuse works
+    eng = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS)
+    J = T(j_h36m_np).to(DEV).clone()
+    Jm, Jv, Js = torch.zeros_like(J), torch.zeros_like(J), torch.zeros(1, dtype=torch.int32, device=DEV)
+    eng.set_j_regressor(J)
+    assert eng.j_support_info()[1]
+    x2, b2 = xd.clone(), bd.clone()
+    am, av = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
+    st = torch.zeros(1, dtype=torch.int32, device=DEV)
+    buf = torch.zeros(17, 128, device=DEV)
+    eng.j_regressor_grad_support(x2, b2, gt_c, out=buf)
+    eng.j_step_apply_support(J, buf, Jm, Jv, Js, 1e-2)
+    eng.refine_run(x2, b2, gt_c, am, av, st, 1e-3, 1, after_j_step=True)
+    eng.j_regressor_grad_support(x2, b2, gt_c, out=buf)
+    J2 = T(j_h36m_np).to(DEV).clone()
+    J2[5, 4000:4010] = 0.02                                       # support outside the stored tiles
+    eng.set_j_regressor(J2)
+    with pytest.raises(Exception):
+        eng.refine_run(x2, b2, gt_c, am, av, st, 1e-3, 1, after_j_step=True)
+    eng.refine_run(x2, b2, gt_c, am, av, st, 1e-3, 1)              # a plain run is fine
     # a regressor whose rows do not fit the lists: fits = 0, the support entry points refuse, the dense pair works
     Jwide = j_h36m_np.copy()
     Jwide[3, :200] = 0.01
