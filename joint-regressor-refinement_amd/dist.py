@@ -19,10 +19,11 @@ def env_rank_world() -> Tuple[int, int, int]:
 
 
 def init(backend: Optional[str] = None):
-    """Initialise torch.distributed from the torchrun environment (no-op for world size 1)."""
+    """Initialise torch.distributed from the torchrun environment (no-op for world size 1, unless JRR_DIST_SINGLE_RANK=1
+    asks for the collectives' call sites to run with a one-rank group: the way a 1-GPU box executes them over RCCL)."""
     import torch.distributed as dist
     rank, local_rank, world = env_rank_world()
-    if world == 1:
+    if world == 1 and os.environ.get('JRR_DIST_SINGLE_RANK', '0') != '1':
         return None
     if not dist.is_initialized():
         if backend is None:
@@ -42,7 +43,7 @@ def shard_bounds(n: int, rank: int, world: int) -> Tuple[int, int]:
 
 def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     import torch.distributed as dist
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+    if dist.is_available() and dist.is_initialized():      # (a one-rank group too: JRR_DIST_SINGLE_RANK)
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return t
 

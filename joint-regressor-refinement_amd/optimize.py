@@ -240,7 +240,7 @@ def optimize_pose_refiner(log=print) -> Dict:
         eng.set_loss_history(n_hist, 10)                                                   # :255-261 (read back with the bucket)
         # ---- the 100 inner iterations (:220-265); J steps inside the loop only when --j_step_every < --inner_iters ----
         n_inloop = (args.inner_iters - 1) // args.j_step_every * args.j_step_every if args.inner_iters > 0 else 0
-        if n_inloop and world == 1:         # one C call for the iterations AND their J steps (no collective needed)
+        if n_inloop and dist is None:       # one C call for the iterations AND their J steps (no collective needed)
             eng.refine_run_j_steps(x6d, betas, gt_j3d, m, v, step, 1e-2, n_inloop, args.j_step_every, J_regressor, J_opt.m,
                                    J_opt.v, J_opt.step, J_opt.lr, mask=j_reg_mask, sqerr=sq)
         elif n_inloop:

@@ -71,6 +71,10 @@ def pytest_collection_finish(session):
         # after every inner iteration, against the 1-rank run on the same 32 768 poses
         'w1big': [sys.executable, worker, os.path.join(tmp, 'w1big')] + BIG_FLAGS,
         'w8big': _torchrun(8, 29548, [worker, os.path.join(tmp, 'w8big')] + BIG_FLAGS + ['--dist_backend', 'gloo', '--single_device']),
+        # ONE rank over RCCL (backend nccl, JRR_DIST_SINGLE_RANK=1): the N > 1 branch of the driver -- host-driven J steps with the
+        # support-sized all-reduce, the flat bucket of the outer step -- with every collective executed by RCCL on device buffers
+        # (what a 1-GPU box can execute of the RCCL path)
+        'w1n_1rank': _torchrun(1, 29549, [worker, os.path.join(tmp, 'w1n')] + DP_FLAGS + ['--dist_backend', 'nccl']),
         # a launcher world that contradicts --gpus must fail loudly
         'bench_mismatch': _torchrun(2, 29543, [os.path.join(ROOT, 'bench.py'), '--gpus', '1', '--steps', '2', '--warmup', '1',
                                                '--batch', '128', '--backend', 'gloo', '--single_device', '--no_cpu_baseline']),
@@ -83,7 +87,8 @@ def pytest_collection_finish(session):
     DP_RUNS['dir'] = tmp
     for name, cmd in runs.items():
         try:
-            r = subprocess.run(cmd, env=env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+            run_env = dict(env, JRR_DIST_SINGLE_RANK='1') if name.endswith('_1rank') else env
+            r = subprocess.run(cmd, env=run_env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
             DP_RUNS[name] = dict(rc=r.returncode, out=r.stdout, err=r.stderr[-4000:])
         except subprocess.TimeoutExpired as e:
             DP_RUNS[name] = dict(rc=-999, out=str(e.stdout)[-2000:], err='timeout: ' + str(e.stderr)[-2000:])

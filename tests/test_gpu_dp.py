@@ -75,6 +75,21 @@ def test_eight_rank_driver_equals_single_process():
     np.testing.assert_allclose(np.array(h8['loss_history']), np.array(h1['loss_history']), rtol=2e-3, atol=1e-6)
 
 
+def test_one_rank_over_rccl_runs_the_collective_call_sites():
+    """backend nccl (= RCCL) with a one-rank group on this box's GPU: the driver takes its N > 1 branch (refine_run ->
+    jrr_j_regressor_grad_support -> all-reduce -> jrr_j_step_apply_support per J step; ONE flat all-reduce per outer step) and
+    RCCL executes every collective on the device buffers.  A sum over one rank is the identity: results equal the plain run's
+    (the in-call J steps of the plain run and the host-driven ones are the same kernels on the same numbers)."""
+    _run('w1'); r = _run('w1n_1rank')
+    (one,) = _load('w1', 1)
+    (n,) = _load('w1n', 1)
+    for k in ('J', 'disc', 'sdisc', 'x6d', 'betas'):
+        if k == 'sdisc':      # float atomics in the shape discriminator's gradient: order differs run to run
+            assert np.abs(n[k] - one[k]).max() < 5e-5, k
+        else:
+            assert np.array_equal(n[k], one[k]), k
+
+
 def test_support_sized_all_reduce_equals_the_dense_one():
     """the in-loop J step exchanges the regressor's support (8 704 B, default) or the dense (17,6890) gradient
     (--j_allreduce dense): per rank the exchanged values are the same numbers, so with two ranks (a + b: one order) J and
