@@ -100,6 +100,7 @@ def parse():
     ap.add_argument('--no_config2', action='store_true', help='skip the separately reported BASELINE configs[1] block (batch 1024, joint loss only)')
     ap.add_argument('--no_skin_variants', action='store_true',
                     help='skip the separately reported 12-joint / dense skinning runs (what a body model with a less coherent vertex order runs)')
+    ap.add_argument('--no_rccl_one_rank', action='store_true', help='skip the cadence-1 host-driven run whose all-reduce is executed by a one-rank RCCL group')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL); gloo for debugging')
     ap.add_argument('--single_device', action='store_true',
                     help='debug: every rank uses cuda:0 (exercises the N > 1 code path on a 1-GPU box; use with --backend gloo)')
@@ -408,7 +409,7 @@ def main():
     c1_el = statistics.median(c1_regions)
     # ---- the same cadence through the call sequence N > 1 ranks execute (host-driven segments, the support-sized payload, a
     #      no-op in place of the collective at world size 1): bounds the multi-GPU cadence-1 cost before any 8-GPU box sees it ----
-    c1h_el, c1h_regions = None, []
+    c1h_el, c1h_regions, c1r = None, [], None
     if dist is None:
         run_c1h = lambda n, c: run_host_driven(n, c, reuse=True)      # noqa: E731
         it_count[0] = 0
@@ -416,6 +417,42 @@ def main():
         c1h_regions = [timed_region(a.steps, 1, run_c1h)[0] for _ in range(5)]
         c1h_el = statistics.median(c1h_regions)
         after_j[0] = False
+        # ... and with the collective EXECUTED: a one-rank RCCL group on this GPU (a sum over one rank is the identity; what is timed
+        # is RCCL's own enqueue + kernel on the 8 704-byte device buffer between the two halves of every J step)
+        if not a.no_rccl_one_rank and a.backend == 'nccl':
+            # (RCCL prints a version banner through C stdio on stdout: this program's stdout is ONE JSON line, so fd 1 points at
+            # stderr while the group lives, and C stdio is flushed before it is restored)
+            import ctypes
+            sys.stdout.flush()
+            fd1 = os.dup(1)
+            os.dup2(2, 1)
+            try:
+                import socket
+                import torch.distributed as tdist
+                with socket.socket() as so:
+                    so.bind(('127.0.0.1', 0))
+                    port = so.getsockname()[1]
+                tdist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
+                keep = xch.reduce
+                xch.reduce = lambda t: tdist.all_reduce(t)
+                it_count[0] = 0
+                timed_region(a.steps, 1, run_c1h)
+                c1r_regions = [timed_region(a.steps, 1, run_c1h)[0] for _ in range(5)]
+                xch.reduce = keep
+                torch.cuda.synchronize()
+                tdist.destroy_process_group()
+                c1r = {'ms_per_step': round(statistics.median(c1r_regions) / a.steps * 1e3, 4),
+                       'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1r_regions], 'backend': 'nccl (RCCL), one rank'}
+            except Exception as ex:      # the bench line survives a box whose RCCL cannot start
+                c1r = {'ms_per_step': None, 'error': repr(ex)[:200]}
+            finally:
+                try:
+                    ctypes.CDLL(None).fflush(None)
+                except Exception:
+                    pass
+                os.dup2(fd1, 1)
+                os.close(fd1)
+            after_j[0] = False
 
     # ---- the inner iteration ALONE (no J step in the region, no forward reuse): the denominator of roofline.whole_step ----
     def run_inner(n, _cadence):
@@ -693,6 +730,7 @@ def main():
             'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1h_regions],
             'spread_frac': round((max(c1h_regions) - min(c1h_regions)) / c1h_el, 4),
             'allreduce_bytes_it_would_send': xch.nbytes,
+            'with_rccl_one_rank_allreduce': c1r,
             'note': 'cadence 1 through the call sequence N > 1 ranks execute (refine_run_after_j_step -> j_regressor_grad_support -> '
                     '[all-reduce: a no-op at world size 1] -> j_step_apply_support per iteration, host-driven): bounds the multi-GPU '
                     'cadence-1 cost of everything but the collective itself'}

@@ -6,8 +6,8 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # kernel trace: the default bench command itself (100 timed steps); PMC passes: a short run (counters serialise kernels)
-FULL="python3 $PWD/bench.py --no_cpu_baseline --min_timed_ms 600 --no_config2"
-CMD="python3 $PWD/bench.py --steps 5 --warmup 2 --no_cpu_baseline --min_timed_ms 1 --no_skin_variants --no_folded --no_config2"
+FULL="python3 $PWD/bench.py --no_cpu_baseline --min_timed_ms 600 --no_config2 --no_rccl_one_rank"
+CMD="python3 $PWD/bench.py --steps 5 --warmup 2 --no_cpu_baseline --min_timed_ms 1 --no_skin_variants --no_folded --no_config2 --no_rccl_one_rank"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $FULL > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
