@@ -57,9 +57,17 @@ enum {
   JRR_FLAG_SILHOUETTE = 16, /* reserve the soft-silhouette buffers (needs JRR_FLAG_KEEP_VERTS and model faces) */
   JRR_FLAG_NO_MODEL = 32,   /* discriminator-only engine (model == NULL): the SMPL sections (~230 KB per pose) are not
                                part of the workspace; only JRR_FLAG_POSE_DISC / JRR_FLAG_SHAPE_DISC may accompany it */
-  JRR_FLAG_SIL_256 = 64     /* with JRR_FLAG_SILHOUETTE: 256 x 256 silhouettes (the reference constructor's default,
+  JRR_FLAG_SIL_256 = 64,    /* with JRR_FLAG_SILHOUETTE: 256 x 256 silhouettes (the reference constructor's default,
                                scripts/mesh_renderer.py:25; focal length 5000 / 256) instead of 224 x 224 (scripts/optimize.py:110):
                                every (B,224,224) below then reads (B,256,256) */
+  JRR_FLAG_SUPPORT_TILES = 128 /* with JRR_FLAG_KEEP_VERTS: once jrr_j_support_info has reported that the regressor's support fits,
+                               the iterations of jrr_refine_run* whose loss reads the JOINTS only (no silhouette term) run their three
+                               skinning kernels on the 32-vertex tiles that hold a support entry -- every other tile multiplies
+                               its vertices by a zero block of the regressor and receives a zero vertex adjoint: exact zeros in
+                               the joints and in every gradient.  Same numbers as without the flag up to the order of the sums
+                               over the tiles; until jrr_j_support_info is called (and after a jrr_engine_set_j_regressor from
+                               outside) the iterations run all 216 tiles.  v_posed / vertices of the other tiles are NOT
+                               produced by those iterations (jrr_find_joints_forward and jrr_smpl_vertices* always are dense). */
 };
 
 typedef struct jrr_model jrr_model_t;   /* device-resident, re-laid-out SMPL constants */
@@ -318,6 +326,11 @@ int jrr_j_step_apply(jrr_engine_t* e, float* J_dev, const float* dJ_dev, float* 
  * dense pair).  Same results as the dense pair bit for bit on this rank; across ranks only the all-reduce's own summation
  * order can differ (none with two ranks).                                                                                  */
 int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t* fits_host, void* stream);
+/* JRR_FLAG_SUPPORT_TILES: returns 1 when the next joint-loss iteration of jrr_refine_run* will run on the support's tiles only
+ * (*n_tiles_host = their number, nullable), 0 when it will run all 216 (flag absent, jrr_j_support_info not asked or fits = 0,
+ * a silhouette term set, folded mode on, a model without the joint-sparse kernels).  No reference counterpart: the reference
+ * multiplies all 6890 vertices by the (17,6890) regressor, zeros included (scripts/utils.py:87-92).                          */
+int jrr_engine_support_tiles(const jrr_engine_t* e, int32_t* n_tiles_host);
 int jrr_j_regressor_grad_support(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev, const float* gt_centred_mm_dev,
                                  float* dJs_dev, float* sqerr_dev, float* joints_dev, void* stream);
 int jrr_j_step_apply_support(jrr_engine_t* e, float* J_dev, const float* dJs_dev, float* m_dev, float* v_dev, int32_t* step_dev,

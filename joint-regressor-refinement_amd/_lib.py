@@ -66,6 +66,7 @@ SIGNATURES = {
     'jrr_j_regressor_grad': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_j_step_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     'jrr_j_support_info': (c_int, [_P, POINTER(c_int32), POINTER(c_int32), _P]),
+    'jrr_engine_support_tiles': (c_int, [_P, POINTER(c_int32)]),
     'jrr_j_regressor_grad_support': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_j_step_apply_support': (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     'jrr_refine_run_after_j_step': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),

@@ -390,6 +390,9 @@ struct jrr_engine {
   int32_t* step_scratch;
   bool profiling;
   bool verts_partial;                                // VTb holds the support tiles of the last J step only
+  // JRR_FLAG_SUPPORT_TILES: the 32-vertex tiles that hold an entry of the regressor's support (ascending), taken when
+  // jrr_j_support_info reports that the support fits; J steps only shrink the support, so the list stays a superset
+  int* act_list; int nact; bool act_valid;
   std::vector<hipEvent_t>* ev[JRR_PROF_CLASSES];
   const float* gt_j2d; float* cam; float* cam_m; float* cam_v;   // 2-D reprojection term (nullable)
   float *gcam, *sq2d;
@@ -537,6 +540,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->jsup.col = (int*)c.take((size_t)NH * JSUP_CAP);
     t->jsup.val = c.take((size_t)NH * JSUP_CAP);
     t->jsup.tmask = (int*)c.take(256);
+    t->act_list = (int*)c.take(256);
   }
   if (e) {
     e->BP = BP; e->nvc = nvc; e->nvcb = (e->has_model && e->m.kjs && e->m.bwd16) ? nvcb16 : nvcb; e->nsplit = nsplit; e->nsplitJ = nsplitJ;
@@ -558,6 +562,7 @@ extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_
     return JRR_ERR_ARG;
   }
   if (model && (flags & JRR_FLAG_NO_MODEL)) { jrr_set_error("jrr_engine_create: JRR_FLAG_NO_MODEL with a model"); return JRR_ERR_ARG; }
+  if ((flags & JRR_FLAG_SUPPORT_TILES) && !(flags & JRR_FLAG_KEEP_VERTS)) { jrr_set_error("jrr_engine_create: JRR_FLAG_SUPPORT_TILES needs JRR_FLAG_KEEP_VERTS (the support lists live there)"); return JRR_ERR_ARG; }
   if (((uintptr_t)ws & 255) != 0) { jrr_set_error("workspace must be 256-byte aligned"); return JRR_ERR_ARG; }
   const size_t need = jrr_engine_workspace_bytes(batch, flags);
   if (ws_bytes < need) { jrr_set_error("workspace too small: %zu < %zu", ws_bytes, need); return JRR_ERR_WORKSPACE; }
@@ -695,6 +700,7 @@ static int set_j_regressor_impl(jrr_engine_t* e, const float* J, const float* ma
   hipStream_t s = (hipStream_t)stream;
   e->jsup_fits_known = false;      // a regressor from outside: its support is not known to fit until jrr_j_support_info says so
   if (e->verts_partial) e->fwd_cached = false;      // the stored vertices cover the OLD regressor's support tiles only
+  e->act_valid = false;
   JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   e->have_mask = mask != nullptr;
@@ -803,11 +809,11 @@ static void set_adjoint_slabs(jrr_engine* e, PrepBwdLaunch& L) {
 }
 
 static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,
-                        bool keep_verts, int32_t* step_inc, hipStream_t s, const int* vmask = nullptr) {
+                        bool keep_verts, int32_t* step_inc, hipStream_t s, const int* vmask = nullptr, const int* tl = nullptr, int ntl = 0) {
   launch_prep_fwd(e->m, x6d, R, betas, e->FT, e->FTq, e->AT, e->R0T, e->B, e->BP, step_inc, s);
   launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, keep_vp ? e->VPb : nullptr, e->JP, keep_verts ? e->VTb : nullptr, e->B, e->BP,
-                 e->nvc, s, nullptr, vmask);
-  if (keep_verts) e->verts_partial = vmask != nullptr;
+                 e->nvc, s, nullptr, tl ? nullptr : vmask, tl, ntl);
+  if (keep_verts) e->verts_partial = vmask != nullptr || tl != nullptr;
   return 0;
 }
 
@@ -826,8 +832,13 @@ extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const 
   return JRR_OK;
 }
 
-static int blend_adjoint_gemm(jrr_engine* e, hipStream_t s) {
-  return launch_blend_adjoint(e->m.Dq, e->DVP, e->dFTp, (size_t)KFP * e->BP, e->BP, e->nsplit, s);
+static int blend_adjoint_gemm(jrr_engine* e, hipStream_t s, const int* tl = nullptr, int ntl = 0) {
+  return launch_blend_adjoint(e->m.Dq, e->DVP, e->dFTp, (size_t)KFP * e->BP, e->BP, e->nsplit, s, tl, ntl);
+}
+// the joint-loss iteration on the regressor's support tiles only (JRR_FLAG_SUPPORT_TILES)
+static bool use_tile_list(const jrr_engine* e) {
+  return (e->flags & JRR_FLAG_SUPPORT_TILES) && e->act_valid && e->have_jsup && e->jsup_fits_known && e->sil_mask == nullptr &&
+         e->m.kjs && e->m.bwd16 && !(e->folded && e->fold_valid);
 }
 
 static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s, float* dJs = nullptr);
@@ -1313,6 +1324,9 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
   bool reuse_next = reuse_first;
   for (int it = 0; it < n_iters; ++it) {
     const bool folded = e->folded && e->fold_valid;
+    const bool listed = use_tile_list(e);
+    const int* tl = listed ? e->act_list : nullptr;
+    const int ntl = listed ? e->nact : 0;
     // The J step that preceded this call ran the SMPL forward on exactly these poses (jrr_j_regressor_grad keeps
     // v_posed, the skinning transforms and the vertices): the first iteration re-regresses the joints with the NEW
     // regressor from the stored vertices instead of repeating the 0.47 ms forward (jrr_refine_run_after_j_step).
@@ -1341,8 +1355,9 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       launch_fold_fwd(e->MT, e->AT, e->G0, e->Jsum, e->BP, s);
     } else {
       const bool silf = e->sil_mask != nullptr;      // the silhouette term needs the vertices
-      launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, e->VPb, e->JP, silf ? e->VTb : nullptr, e->B, e->BP, e->nvc, s,
-                     e->profiling ? e->probe : nullptr);
+      int rcl = launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, e->VPb, e->JP, silf ? e->VTb : nullptr, e->B, e->BP, e->nvc, s,
+                               e->profiling ? e->probe : nullptr, nullptr, tl, ntl);
+      if (rcl) return rcl;
       if (silf) e->verts_partial = false;
     }
     prof_mark(e, 1, s);
@@ -1365,7 +1380,10 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     }
     prof_mark(e, 3, s);
     if (folded) launch_fold_bwd(e->dJT, e->AT, e->MT, e->G0, e->dMT, e->dA, e->BP, s);
-    else launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, sil ? e->VTb : nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
+    else {
+      int rcb = launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, sil ? e->VTb : nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s, tl, ntl);
+      if (rcb) return rcb;
+    }
     prof_mark(e, 3, s);
     prof_mark(e, 4, s);
     if (folded) {
@@ -1374,7 +1392,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       g.bias = nullptr; g.mask = nullptr; g.split_stride = (size_t)KFP * e->BP; g.M = KFP; g.N = e->BP; g.K = FOLD_M;
       rc = launch_gemm_224(g, EPI_STORE, e->nsplit, s);
     } else {
-      rc = blend_adjoint_gemm(e, s);
+      rc = blend_adjoint_gemm(e, s, tl, ntl);
     }
     prof_mark(e, 4, s);
     if (rc) return rc;
@@ -1500,7 +1518,25 @@ extern "C" int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t
   if (counts_host) for (int i = 0; i < NH; ++i) counts_host[i] = cnt[i];
   *fits_host = flag;
   e->jsup_fits_known = flag != 0;      // stays true under J steps (ReLU' = 0: Adam never re-activates an entry); cleared by set_j_regressor
+  e->act_valid = false;
+  if (flag && (e->flags & JRR_FLAG_SUPPORT_TILES)) {      // the support's tiles, for the kernels of the joint-loss iteration
+    int32_t tm[VT], list[VT];
+    JRR_HIP(hipMemcpy(tm, e->jsup.tmask, VT * sizeof(int32_t), hipMemcpyDeviceToHost));
+    int n = 0;
+    for (int t = 0; t < VT; ++t) if (tm[t]) list[n++] = t;
+    if (n > 0) {
+      JRR_HIP(hipMemcpy(e->act_list, list, n * sizeof(int32_t), hipMemcpyHostToDevice));
+      e->nact = n; e->act_valid = true;
+    }
+  }
   return JRR_OK;
+}
+
+extern "C" int jrr_engine_support_tiles(const jrr_engine_t* e, int32_t* n_tiles_host) {
+  if (!e) return JRR_ERR_ARG;
+  const bool on = use_tile_list(e);
+  if (n_tiles_host) *n_tiles_host = on ? e->nact : VT;
+  return on ? 1 : 0;
 }
 
 extern "C" int jrr_j_regressor_grad_support(jrr_engine_t* e, const float* x6d, const float* betas, const float* gt_mm,
@@ -1573,7 +1609,8 @@ static int j_step_local(jrr_engine* e, const float* x6d, const float* betas, con
   // the lists, both consumers (k_jgrad_sparse here, k_rejoints_sparse in the reusing iteration) read support rows only -- the forward
   // stores the tiles that hold one (a few dozen of 216) instead of 340 MB at 4096 poses
   const bool few = support_verts && e->have_jsup && e->jsup_fits_known;
-  smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s, few ? e->jsup.tmask : nullptr);
+  const bool listed = few && use_tile_list(e);      // ... and with JRR_FLAG_SUPPORT_TILES nothing but those tiles is computed
+  smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s, few ? e->jsup.tmask : nullptr, listed ? e->act_list : nullptr, listed ? e->nact : 0);
   e->fwd_cached = true; e->fc_x6d = x6d; e->fc_betas = betas;
   const float scale = (float)(2.0 * 1.0 / ((double)e->bnorm * 51.0));   // optimize.py:307 unweighted MSE
   launch_joints_loss(e->JP, e->nvc, gt_mm, nullptr, scale, joints ? joints : e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s);

@@ -397,18 +397,24 @@ int launch_jgrad_q(const float* dJT, const float* VTq, float* Out, int BP, int k
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int BA_QUADS = 4;                                   // quads per chunk
 constexpr int BA_SA = BA_QUADS * KFP * 4, BA_SB = BA_QUADS * 128 * 4, BA_SLOT = BA_SA + BA_SB;   // floats
+template <bool LIST>      // LIST: the K range is the rows of the ntl tiles tl[] (the others hold a zero dvp nobody wrote: k_lbs_bwd16<LIST>)
 __global__ __launch_bounds__(256, 2) void k_blend_adjoint(const float* __restrict__ Dq, const float* __restrict__ DVPq,
-                                                          float* __restrict__ dFTp, size_t split_stride, int BP) {
+                                                          float* __restrict__ dFTp, size_t split_stride, int BP,
+                                                          const int* __restrict__ tl, int ntl) {
   __shared__ __attribute__((aligned(16))) float lds[3 * BA_SLOT];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int nt = xcd_remap(blockIdx.x, gridDim.x);
   const int n0 = nt * 128;
   const int split = blockIdx.y, nsplit = gridDim.y;
-  constexpr int NCH = 3 * (VP / 4) / BA_QUADS;                // 1296 chunks over the three coordinate planes
+  constexpr int NCH_ALL = 3 * (VP / 4) / BA_QUADS;            // 1296 chunks over the three coordinate planes (two per tile and plane)
+  const int NCH = LIST ? 6 * ntl : NCH_ALL;
   const int c_begin = (int)((long)NCH * split / nsplit), c_end = (int)((long)NCH * (split + 1) / nsplit);
+  // listed chunk k = (plane k / (2 ntl), tile tl[(k % (2 ntl)) / 2], half k % 2)
+  auto chunk_of = [&](int k) { return LIST ? (k / (2 * ntl)) * (NCH_ALL / 3) + 2 * tl[(k % (2 * ntl)) >> 1] + (k & 1) : k; };
   // copies per chunk: A = 14 linear 1 KB pieces (pieces wave, wave + 4, ...), B = 8 pieces (quad p / 2, poses (p % 2) * 64 + lane)
-  auto issue = [&](int ch, int slot) {
+  auto issue = [&](int kch, int slot) {
+    const int ch = chunk_of(kch);
     const float* a = Dq + (size_t)ch * BA_SA;                 // chunk ch = quads [4 ch, 4 ch + 4) of the flattened (plane, quad) axis
     const float* b = DVPq + ((size_t)ch * BA_QUADS * BP + n0) * 4;
     asm volatile("" : "+s"(a));
@@ -481,8 +487,10 @@ __global__ __launch_bounds__(256, 2) void k_blend_adjoint(const float* __restric
     for (int q = 0; q < 16; ++q) urow(out, (size_t)(32 * i + acc_row_u(q)), BP)[lane_off] = acc[i][q];
 }
 
-int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s) {
-  hipLaunchKernelGGL(k_blend_adjoint, dim3(BP / 128, nsplit), dim3(256), 0, s, Dq, DVPq, dFTp, split_stride, BP);
+int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s,
+                         const int* tl, int ntl) {
+  if (tl) hipLaunchKernelGGL(k_blend_adjoint<true>, dim3(BP / 128, nsplit), dim3(256), 0, s, Dq, DVPq, dFTp, split_stride, BP, tl, ntl);
+  else hipLaunchKernelGGL(k_blend_adjoint<false>, dim3(BP / 128, nsplit), dim3(256), 0, s, Dq, DVPq, dFTp, split_stride, BP, nullptr, 0);
   return 0;
 }
 

@@ -82,13 +82,16 @@ int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, con
 
 // lbs.hip
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
-                   float* VTb, int B, int BP, int nvc, hipStream_t s, long long* probe = nullptr, const int* vmask = nullptr);
+                   float* VTb, int B, int BP, int nvc, hipStream_t s, long long* probe = nullptr, const int* vmask = nullptr,
+                   const int* tl = nullptr, int ntl = 0);
+// tl / ntl (nullable; joint-sparse classes, VPb kept): run the ntl listed tiles only (the regressor's support tiles: every other
+// tile adds exact zeros to the joints); also launch_lbs_bwd and launch_blend_adjoint
 // vmask (nullable, with VTb): store the vertices of the tiles with vmask[tile] != 0 only (JSupport::tmask)
 int launch_verts_untranspose(const float* VTb, float* verts, int ldv, int vlimit, const float* cam, float* ndc, int B, int BP,
                              hipStream_t s, const int* p2v = nullptr);
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s);
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
-                   const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s);
+                   const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s, const int* tl = nullptr, int ntl = 0);
 int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s, const int* p2v = nullptr);
 // Support of the normalised regressor (the J step's products only need it: ReLU' makes dJ exactly zero elsewhere).
 // JSupport lives in the engine workspace: cnt[i] positive entries of row i, their internal vertex rows / weights in ascending
@@ -127,7 +130,8 @@ int launch_gemm_128x64(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_128x32(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 // blend-basis adjoint dF^T[split][224][BP] = sum_{c, v in split} D_c[v][.] dvp_c[v][.], both operands in vertex quads
-int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s);
+int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s,
+                         const int* tl = nullptr, int ntl = 0);
 // skip_flag (device, nullable): the launch returns at once when *skip_flag != 0 (the support-restricted kernels did the work)
 int launch_gemm_q32(const float* A, int ldA, size_t planeA, const float* Bm, int ldB, size_t planeB, float* Out, int ldo,
                     size_t ks_stride, size_t plane_stride, int N, int K, int nplanes, int ksplit, hipStream_t s,

@@ -79,14 +79,18 @@ __device__ __forceinline__ void dma16u(const float* base_uniform, unsigned lane_
 // WIDE: the model has tiles with more than KJ joints (per-tile classes: such a tile runs a second pass over slots KJ .. 2 KJ - 1).
 // A separate instantiation: the branches of the second pass cost the stage loop ~2 % even when never taken (measured: 0.361 vs
 // 0.369 ms at B = 4096), so a model without wide tiles runs the kernel without them.
-template <bool STORE_VP, bool STORE_VERTS, int KJ, bool WIDE>
+template <bool STORE_VP, bool STORE_VERTS, int KJ, bool WIDE, bool LIST = false>
 __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk, const float* __restrict__ Wjv,
                                                     const float* __restrict__ Jn_vi, const float* __restrict__ FT,
                                                     const float* __restrict__ AT, float* __restrict__ VPb,
                                                     float* __restrict__ JP, float* __restrict__ VTb, int B, int BP,
                                                     int nvc, long long* __restrict__ probe, int paired,
                                                     const int* __restrict__ jl, const int* __restrict__ tnj,
-                                                    const int* __restrict__ vmask) {
+                                                    const int* __restrict__ vmask, const int* __restrict__ tl, int ntl) {
+  // LIST: the launch covers the ntl tiles tl[0 .. ntl) only (ascending) -- the tiles that hold an entry of the regressor's support.
+  // Every other tile multiplies its vertices by a zero block of the regressor: it adds exact zeros to the joints, and nothing else
+  // of it is read by the joint-loss iteration (the backward kernels skip the same tiles).
+  const int NT = LIST ? ntl : VT;
   // vmask (STORE_VERTS only, nullable): vertices leave the chip only for the tiles with vmask[tile] != 0 -- the J step over the
   // regressor's support reads a few dozen vertex rows, not 340 MB
   constexpr bool SPARSE = KJ > 0;
@@ -104,7 +108,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   const int wave = tid >> 6, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   int bg = L / nvc, vc = L % nvc;
-  int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
+  int t_begin = (int)((long)NT * vc / nvc), t_end = (int)((long)NT * (vc + 1) / nvc);
   if (paired) {
     // One full round of 512 workgroups = two per CU, and the two do NOT progress evenly: the first-dispatched one
     // wins the issue arbitration and would finish ~20 % earlier, leaving its partner alone (one wave per SIMD) for
@@ -118,7 +122,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     bg = xcd * bg_per_xcd + p / npair;
     const int vcp = p % npair;
     vc = 2 * vcp + slot;
-    const int P0 = (int)((long)VT * vcp / npair), P1 = (int)((long)VT * (vcp + 1) / npair);
+    const int P0 = (int)((long)NT * vcp / npair), P1 = (int)((long)NT * (vcp + 1) / npair);
     const int mid = P0 + ((P1 - P0) * paired + 500) / 1000;      // `paired` = the first workgroup's share in thousandths
     t_begin = slot ? mid : P0;
     t_end = slot ? P1 : mid;
@@ -140,7 +144,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   long long n_extra = 0;          // second passes run (probe)
 
   // ---- DMA issue for stage s of tile vt into ring slot `slot` ----
-  auto issue = [&](int vt, int s, int slot, int pass = 0, int wide_w = 0) {
+  auto issue = [&](int vt, int s, int slot, int pass = 0, int wide_w = 0, int par = 0) {      // par: W / Jn buffer of the tile (s == 0)
     float* dst = ring + slot * STG_FLOATS;
     if (s < NKCH) {
       // K chunk s of the basis, K-QUADS [8 quads][3][32 v][4]: one contiguous 12 KB block of Dk
@@ -155,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         dma16u(Fbg + ((size_t)(s * (KCH / 4) + (o >> 1)) * BP + (o & 1) * 64) * 4, lane_ln, fdst + o * 256);
       }
       if (s == 0) {
-        float* wdst = wj + (vt & 1) * WJ_FLOATS;
+        float* wdst = wj + par * WJ_FLOATS;
         // (the table holds NJ slot rows per tile; a wide tile -- `wide_w`, wave-uniform -- stages 2 KJS of them)
         if (wv < ((SPARSE && wide_w) ? WT_COPIES_WIDE : WT_COPIES)) dma16u(Wjv + (size_t)vt * W_FLOATS + wv * 256, lane_ln, wdst + wv * 256);
         dma16u(Jn_vi + (size_t)vt * JN_FLOATS + wv * 256, lane_ln, wdst + W_FLOATS + wv * 256);
@@ -226,17 +230,20 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     j16[r] += p16;
   };
 
-  if (SPARSE && WIDE && t_begin < t_end) wide_next = tnj[t_begin] > KJS;
-  if (t_begin < t_end) issue(t_begin, 0, 0, 0, wide_next);
+  const int t_first = (t_begin < t_end) ? (LIST ? tl[t_begin] : t_begin) : 0;
+  if (SPARSE && WIDE && t_begin < t_end) wide_next = tnj[t_first] > KJS;
+  if (t_begin < t_end) issue(t_first, 0, 0, 0, wide_next, t_begin & 1);
   int g = 0;   // global stage counter: ring slot = g & 1
-  for (int vt = t_begin; vt < t_end; ++vt) {
-    const float* ldsW = wj + (vt & 1) * WJ_FLOATS;
+  for (int ix = t_begin; ix < t_end; ++ix) {
+    const int vt = LIST ? tl[ix] : ix;                                       // the tile (wave-uniform)
+    const int vtn = (ix + 1 < t_end) ? (LIST ? tl[ix + 1] : ix + 1) : 0;     // the next one
+    const float* ldsW = wj + (ix & 1) * WJ_FLOATS;
     const float* ldsJ = ldsW + W_FLOATS;
     const bool stv = STORE_VERTS && (!vmask || vmask[vt] != 0);      // wave-uniform
     if (SPARSE) {      // the skinning copies of this tile are issued from its stage NKCH - 1 on
       if (WIDE) {
         wide = wide_next;
-        wide_next = (vt + 1 < t_end) ? (tnj[vt + 1] > KJS) : 0;                    // wave-uniform: scalar loads
+        wide_next = (ix + 1 < t_end) ? (tnj[vtn] > KJS) : 0;                    // wave-uniform: scalar loads
       }
       const int j0 = jl[vt * NJ + 2 * wv], j1 = jl[vt * NJ + 2 * wv + 1];
       lane_jl[0] = (unsigned)(half ? j1 : j0) * (unsigned)BP + (unsigned)l31 * 4u;
@@ -268,14 +275,14 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         // (with a tile mask the vertex stores of the previous stage may not exist: count the v_posed stores only -- waiting for
         // more than necessary is always safe)
         constexpr int nst_vp = (hp < 0) ? 0 : SPARSE ? (STORE_VP ? 4 : 0) : (STORE_VP ? 2 : 0);
-        if (s == 0 && vt == t_begin) barrier_keep_vm<0>();
+        if (s == 0 && ix == t_begin) barrier_keep_vm<0>();
         else if (STORE_VERTS && nst != nst_vp && vmask) barrier_keep_vm<nst_vp>();
         else barrier_keep_vm<nst>();
       }
       // the stage that follows this one: a wide tile's skinning stage r is followed by its second pass over the same r
       if (SPARSE && WIDE && s >= NKCH && wide) issue(vt, s, (g + 1) & 1, 1);
       else if (s + 1 < NST) issue(vt, s + 1, (g + 1) & 1);
-      else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1, 0, wide_next);
+      else if (ix + 1 < t_end) issue(vtn, 0, (g + 1) & 1, 0, wide_next, (ix + 1) & 1);
       __builtin_amdgcn_sched_barrier(0);   // the counted wait above relies on: copies first, this stage's stores after
       const float* buf = ring + (g & 1) * STG_FLOATS;
       if constexpr (s < NKCH) {
@@ -353,7 +360,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
           ++g;
           barrier_keep_vm<0>();
           if (s + 1 < NST) issue(vt, s + 1, (g + 1) & 1);
-          else if (vt + 1 < t_end) issue(vt + 1, 0, (g + 1) & 1, 0, wide_next);
+          else if (ix + 1 < t_end) issue(vtn, 0, (g + 1) & 1, 0, wide_next, (ix + 1) & 1);
           __builtin_amdgcn_sched_barrier(0);
           const float* bx = ring + (g & 1) * STG_FLOATS + half * BG + wave * BT + l31;
           const float* wx = ldsW + (KJS + half) * 32 + l31;
@@ -848,13 +855,16 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-template <int DV, int KJ, bool WIDE>      // WIDE: as in k_lbs_fwd (0.184 vs 0.187 ms)
+template <int DV, int KJ, bool WIDE, bool LIST = false>      // WIDE, LIST: as in k_lbs_fwd (WIDE: 0.184 vs 0.187 ms)
 __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ Tb, const float* __restrict__ AT,
                                                       const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                       const float* __restrict__ dVT, float* __restrict__ DVP,
                                                       float* __restrict__ dATp, int BP, int nvc, int n_bt,
                                                       const int* __restrict__ segid, const int* __restrict__ segj, int paired,
-                                                      const int* __restrict__ tnj) {
+                                                      const int* __restrict__ tnj, const int* __restrict__ tl, int ntl) {
+  // LIST: the ntl tiles tl[] only.  A tile without a support entry of the regressor has a zero vertex adjoint (DV == 0: no adjoint
+  // from outside): its dvp and its dA contributions are exact zeros, and the blend adjoint skips its rows of DVP as well.
+  const int NT = LIST ? ntl : VT;
   constexpr int S = KJ / 4;                          // K steps of the T product (4 joint slots each)
   constexpr int ASL = 9 * NJ * 16;                   // floats of one wave's A^T slice [(r,c)][24 joints][16 poses]
   __shared__ __attribute__((aligned(16))) float lds[BWD_RING * R16_FLOATS + 4 * ASL];
@@ -867,7 +877,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
   // default mapping: an XCD's contiguous range of L = one vertex chunk x all pose groups (paired == -2: chunk-major inside a
   // pose group instead; measured equal or slower: 0.200 vs 0.203 ms at B = 4096, 0.069 vs 0.066 ms at B = 1024)
   int vc = (paired == -2) ? L % nvc : L / n_bt, bt = (paired == -2) ? L / nvc : L % n_bt;
-  int t_begin = (int)((long)VT * vc / nvc), t_end = (int)((long)VT * (vc + 1) / nvc);
+  int t_begin = (int)((long)NT * vc / nvc), t_end = (int)((long)NT * (vc + 1) / nvc);
   if (paired > 0) {
     // Exactly one round of two workgroups per CU (k_lbs_fwd's geometry, see there): the two workgroups of a CU -- dispatch
     // slots j and j + per_xcd / 2 of an XCD -- take the two halves of a PAIR of vertex chunks of the SAME pose group.
@@ -880,7 +890,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
     bt = xcd * bt_per_xcd + p / npair;
     const int vcp = p % npair;
     vc = 2 * vcp + slot_;
-    const int P0 = (int)((long)VT * vcp / npair), P1 = (int)((long)VT * (vcp + 1) / npair);
+    const int P0 = (int)((long)NT * vcp / npair), P1 = (int)((long)NT * (vcp + 1) / npair);
     const int mid = P0 + ((P1 - P0) * paired + 500) / 1000;       // `paired` = the first workgroup's share in thousandths
     t_begin = slot_ ? mid : P0;
     t_end = slot_ ? P1 : mid;
@@ -897,8 +907,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
       if (o < R16_PIECES) dma16u(src + o * 256, lane_ln, dst + o * 256);
     }
   };
-  issue(t_begin, 0);
-  if (t_begin + 1 < t_end) issue(t_begin + 1, 1);
+  auto tile_of = [&](int ix) { return LIST ? tl[ix] : ix; };      // wave-uniform (scalar load)
+  if (t_begin < t_end) issue(tile_of(t_begin), 0);
+  if (t_begin + 1 < t_end) issue(tile_of(t_begin + 1), 1);
 
   // this wave's A^T slice (the 3x3 rotation part; the translation column is not needed for T) -> LDS, once
 #pragma unroll
@@ -933,8 +944,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
   f32x4 acc[12];                                   // dA_{r,c} at 3 r + c (c < 3), dA_{r,3} at 9 + r: 16 window rows x 16 poses
 #pragma unroll
   for (int e = 0; e < 12; ++e) acc[e] = zero4();
-  int cur_seg = segid[t_begin];
-  int seg_tile = t_begin;
+  int cur_seg = (t_begin < t_end) ? segid[tile_of(t_begin)] : 0;
+  int seg_tile = (t_begin < t_end) ? tile_of(t_begin) : 0;
   unsigned seen = 0u;
   // close a segment: add the accumulators into this workgroup's dA slab (first touch of a joint stores, later ones add;
   // the 16 pose columns belong to this wave alone)
@@ -969,17 +980,18 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
   };
 
   f32x4 vpA[3][2], vpB[3][2];
-  load_vp(t_begin, vpA);
+  if (t_begin < t_end) load_vp(tile_of(t_begin), vpA);
   int slot = 0;
-  auto tile = [&](int vt, const f32x4 (&vpc)[3][2], f32x4 (&vpn)[3][2]) __attribute__((always_inline)) {
+  auto tile = [&](int ix, const f32x4 (&vpc)[3][2], f32x4 (&vpn)[3][2]) __attribute__((always_inline)) {
+    const int vt = tile_of(ix);
     // record vt has landed (it was issued two tiles ago: older than the 6 prefetch loads and the 6 dvp stores of the previous
     // tile, which stay in flight) and every wave is done with the slot the next copy overwrites
     barrier_keep_vm<12>();
     const int slot1 = (slot + 1 == BWD_RING) ? 0 : slot + 1, slot2 = (slot1 + 1 == BWD_RING) ? 0 : slot1 + 1;
-    if (vt + 2 < t_end) issue(vt + 2, slot2);
+    if (ix + 2 < t_end) issue(tile_of(ix + 2), slot2);
     __builtin_amdgcn_sched_barrier(0);
     const float* tab = ring + slot * R16_FLOATS;
-    if (vt + 1 < t_end) load_vp(vt + 1, vpn);
+    if (ix + 1 < t_end) load_vp(tile_of(ix + 1), vpn);
     // ---- vertex adjoint of the tile: dverts_r = Jn^T dj_r and / or the caller's ----
     f32x4 dv[3][2];
 #pragma unroll
@@ -1066,9 +1078,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
     }
     slot = slot1;
   };
-  for (int vt = t_begin; vt < t_end; vt += 2) {
-    tile(vt, vpA, vpB);
-    if (vt + 1 < t_end) tile(vt + 1, vpB, vpA);
+  for (int ix = t_begin; ix < t_end; ix += 2) {
+    tile(ix, vpA, vpB);
+    if (ix + 1 < t_end) tile(ix + 1, vpB, vpA);
   }
   flush_window();
   // joints no tile of this chunk touches: zero rows
@@ -1505,14 +1517,18 @@ int launch_jstep_update(const JStepUpdate& a, hipStream_t s) {
 // launchers
 // ------------------------------------------------------------------------------------------
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
-                   float* verts, int B, int BP, int nvc, hipStream_t s, long long* probe, const int* vmask) {
+                   float* verts, int B, int BP, int nvc, hipStream_t s, long long* probe, const int* vmask, const int* tl, int ntl) {
   dim3 grid((BP / BG) * nvc), block(256);
+  if (tl && !(m.kjs && VPb)) { jrr_set_error("lbs_fwd: the tile list serves the joint-sparse kernels with v_posed kept"); return JRR_ERR_ARG; }
   // exactly one round of two workgroups per CU, an even number of chunks and whole pose groups per XCD
   static const int fwd_split = [] { const char* e = getenv("JRR_FWD_SPLIT"); return e ? atoi(e) : 556; }();   // 5/9 (15 : 12 tiles at B = 4096)
   const int paired = (grid.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? fwd_split : 0;
 #define JRR_LBS_FWD_K(SVP, SVT, KJV, WD, WT)                                                                                      \
   hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, KJV, WD>), grid, block, 0, s, m.Dk, WT, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe,  \
-                     paired, m.jl, m.tnj, verts ? vmask : nullptr)
+                     paired, m.jl, m.tnj, verts ? vmask : nullptr, nullptr, 0)
+#define JRR_LBS_FWD_L(SVT, KJV, WD)                                                                                               \
+  hipLaunchKernelGGL((k_lbs_fwd<true, SVT, KJV, WD, true>), grid, block, 0, s, m.Dk, m.Wc, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,  \
+                     probe, paired, m.jl, m.tnj, nullptr, tl, ntl)
 #define JRR_LBS_FWD(SVP, SVT)                                                                                                     \
   do {                                                                                                                            \
     if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_FWD_K(SVP, SVT, 8, false, m.Wc);                                                     \
@@ -1521,17 +1537,33 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
     else if (m.kjs == 12) JRR_LBS_FWD_K(SVP, SVT, 12, true, m.Wc);                                                                \
     else JRR_LBS_FWD_K(SVP, SVT, 0, false, m.Wjv);                                                                                \
   } while (0)
+  if (tl) {      // the listed tiles only (all of them keep v_posed; with `verts`, their vertices)
+    if (verts) {
+      if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_FWD_L(true, 8, false);
+      else if (m.kjs == 8) JRR_LBS_FWD_L(true, 8, true);
+      else if (!m.wide_tiles) JRR_LBS_FWD_L(true, 12, false);
+      else JRR_LBS_FWD_L(true, 12, true);
+    } else {
+      if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_FWD_L(false, 8, false);
+      else if (m.kjs == 8) JRR_LBS_FWD_L(false, 8, true);
+      else if (!m.wide_tiles) JRR_LBS_FWD_L(false, 12, false);
+      else JRR_LBS_FWD_L(false, 12, true);
+    }
+    return 0;
+  }
   if (VPb && verts) JRR_LBS_FWD(true, true);
   else if (VPb) JRR_LBS_FWD(true, false);
   else if (verts) JRR_LBS_FWD(false, true);
   else JRR_LBS_FWD(false, false);
 #undef JRR_LBS_FWD
 #undef JRR_LBS_FWD_K
+#undef JRR_LBS_FWD_L
   return 0;
 }
 
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
-                   const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s) {
+                   const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s, const int* tl, int ntl) {
+  if (tl && !(m.kjs && m.bwd16 && !dVT)) { jrr_set_error("lbs_bwd: the tile list serves k_lbs_bwd16 without an outside vertex adjoint"); return JRR_ERR_ARG; }
   if (m.kjs && m.bwd16) {                       // four symmetric waves of 16 poses: one workgroup per (64 poses, vertex chunk)
     const int n_bt16 = BP / 64;
     dim3 grid16(n_bt16 * nvc), block16(256);
@@ -1543,7 +1575,10 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
     const int paired16 = (pair_env > 0) ? ((grid16.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? pair_env : 0) : pair_env;
 #define JRR_LBS_BWD16_K(DVM, KJV, WD)                                                                                           \
   hipLaunchKernelGGL((k_lbs_bwd16<DVM, KJV, WD>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, \
-                     m.segj, paired16, m.tnj)
+                     m.segj, paired16, m.tnj, nullptr, 0)
+#define JRR_LBS_BWD16_L(KJV, WD)                                                                                                \
+  hipLaunchKernelGGL((k_lbs_bwd16<0, KJV, WD, true>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, \
+                     m.segj, paired16, m.tnj, tl, ntl)
 #define JRR_LBS_BWD16(DVM)                                                                                                      \
   do {                                                                                                                          \
     if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_BWD16_K(DVM, 8, false);                                                            \
@@ -1551,11 +1586,19 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
     else if (!m.wide_tiles) JRR_LBS_BWD16_K(DVM, 12, false);                                                                    \
     else JRR_LBS_BWD16_K(DVM, 12, true);                                                                                        \
   } while (0)
+    if (tl) {
+      if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_BWD16_L(8, false);
+      else if (m.kjs == 8) JRR_LBS_BWD16_L(8, true);
+      else if (!m.wide_tiles) JRR_LBS_BWD16_L(12, false);
+      else JRR_LBS_BWD16_L(12, true);
+      return 0;
+    }
     if (dVT && dJT) JRR_LBS_BWD16(2);
     else if (dVT) JRR_LBS_BWD16(1);
     else JRR_LBS_BWD16(0);
 #undef JRR_LBS_BWD16
 #undef JRR_LBS_BWD16_K
+#undef JRR_LBS_BWD16_L
     return 0;
   }
   const int n_bt = BP / BT;                     // one workgroup per (pose tile, vertex chunk)

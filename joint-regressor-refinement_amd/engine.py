@@ -22,6 +22,7 @@ FLAG_FOLDED = 8
 FLAG_SILHOUETTE = 16
 FLAG_NO_MODEL = 32
 FLAG_SIL_256 = 64      # with FLAG_SILHOUETTE: 256 x 256 silhouettes (the reference constructor's default) instead of 224 x 224
+FLAG_SUPPORT_TILES = 128      # joint-loss iterations on the tiles of the regressor's support only (see include/jrr.h)
 SIL = 224
 
 NUM_VERTS, NUM_JOINTS, NUM_H36M, NUM_BETAS = 6890, 24, 17, 10
@@ -428,6 +429,15 @@ class RefineEngine:
         fits = c_int32(0)
         check(self.lib.jrr_j_support_info(self.handle, counts, byref(fits), self._s()), 'j_support_info')
         return [int(c) for c in counts], bool(fits.value)
+
+    def support_tiles(self):
+        """(active, n_tiles): whether the next joint-loss iteration runs on the regressor's support tiles only (FLAG_SUPPORT_TILES
+        after j_support_info reported fits) and on how many of the 216 tiles"""
+        n = c_int32(0)
+        rc = self.lib.jrr_engine_support_tiles(self.handle, byref(n))
+        if rc < 0:
+            check(rc, 'support_tiles')
+        return bool(rc), int(n.value)
 
     def j_regressor_grad_support(self, x6d, betas, gt_centred_mm, out, sqerr=None, joints=None):
         """j_regressor_grad with the gradient delivered on the support only: out (17,128)"""

@@ -178,6 +178,101 @@ def test_benchmarked_batch_4096_strided_subset_vs_oracle(variant):
     assert d.max().item() < 6e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
 
 
+# ---- JRR_FLAG_SUPPORT_TILES: the joint-loss iteration on the tiles of the regressor's support only ----------------------------
+def _tiles_engine(v, B, extra=0):
+    em = v['eng_mod']
+    eng = em.RefineEngine(v['dm'], B, flags=em.FLAG_KEEP_VERTS | em.FLAG_SUPPORT_TILES | extra)
+    eng.set_j_regressor(T(v['J']))
+    assert eng.support_tiles() == (False, 216)                    # not before the support has been asked for
+    counts, fits = eng.j_support_info()
+    assert fits
+    on, n = eng.support_tiles()
+    listable = v['dm'].info['joint_slots'] in (8, 12) and 'role_bwd' not in v['name']
+    assert on == listable, (v['name'], on, n)
+    if on:
+        assert 0 < n <= min(216, sum(counts)), (n, counts)        # at most one tile per support entry
+    return eng, on
+
+
+def test_support_tiles_three_iterations_with_pose_discriminator_vs_oracle(variant):
+    """every other tile multiplies its vertices by a zero block of the regressor (scripts/utils.py:87-92) and gets a zero vertex
+    adjoint: the iteration restricted to the support's tiles against the ORACLE (which computes all 6890 vertices), same bounds as
+    the all-tiles test above; variants without the joint-sparse 16-pose backward kernel run all tiles under the same flag"""
+    v = variant
+    B = 200
+    batch = v['sm'].synthetic_batch(v['model'], v['J'], B, seed=62)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+    smpl = oracle.OracleSMPL(v['model'])
+    o, p, b_, _ = oracle.refine_poses(smpl, T(v['J']), x6[:, :1], x6[:, 1:], betas, gt_c, 3, disc_sd=dsd)
+    em = v['eng_mod']
+    eng, _ = _tiles_engine(v, B, em.FLAG_POSE_DISC)
+    eng.set_pose_disc(em.flatten_state_dict(dsd, em.DISC_KEYS))
+    xd, bd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous()
+    m, vv, step = _fresh_state(B)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, vv, step, 1e-2, 3)
+    d = (xd.cpu() - torch.cat([o, p], 1)).abs()
+    assert d.max().item() < 6e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+    assert (bd.cpu() - b_).abs().max().item() < 3e-4
+
+
+@pytest.mark.parametrize('every', [1, 2])
+def test_support_tiles_with_j_steps_equal_the_all_tiles_run(variant, every):
+    """in-call J steps (forward reuse after each) on the support's tiles against the same call on all tiles: poses within the
+    suite's geometry bound (another order of the sums over the tiles), the regressor to 1e-6, the same entries moved"""
+    v = variant
+    em = v['eng_mod']
+    B = 130
+    batch = v['sm'].synthetic_batch(v['model'], v['J'], B, seed=64)
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d'])).to(DEV).contiguous()
+    outs = []
+    for tiles in (False, True):
+        if tiles:
+            eng, on = _tiles_engine(v, B)
+        else:
+            eng = em.RefineEngine(v['dm'], B, flags=em.FLAG_KEEP_VERTS)
+            eng.set_j_regressor(T(v['J']))
+            eng.j_support_info()
+        J = T(v['J']).to(DEV).clone()
+        eng.set_j_regressor(J)
+        eng.j_support_info()
+        Jm, Jv, Js = torch.zeros_like(J), torch.zeros_like(J), torch.zeros(1, dtype=torch.int32, device=DEV)
+        xd, bd = T(batch['pose6d']).to(DEV).contiguous(), T(batch['betas']).to(DEV).contiguous()
+        m, vv, step = _fresh_state(B)
+        eng.refine_run_j_steps(xd, bd, gt_c, m, vv, step, 1e-2, 4, every, J, Jm, Jv, Js, 1e-2)
+        eng.refine_run(xd, bd, gt_c, m, vv, step, 1e-2, 1, after_j_step=True)
+        outs.append((xd.cpu(), bd.cpu(), J.cpu(), int(Js.item())))
+    (xa, ba, Ja, na), (xt, bt, Jt, nt) = outs
+    assert na == nt == 4 // every
+    d = (xa - xt).abs()
+    assert d.max().item() < 6e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+    assert (ba - bt).abs().max().item() < 3e-4
+    assert (Ja - Jt).abs().max().item() < 1e-6
+    assert torch.equal(Ja != T(v['J']), Jt != T(v['J']))
+
+
+def test_support_tiles_batch_4096_strided_subset_vs_oracle(variant):
+    v = variant
+    if v['name'] not in ('default', 'capsules', 'wide13', 'skin12'):
+        pytest.skip('the benchmarked size on the variants that differ in the listed kernels')
+    B, sub = 4096, slice(5, 4096, 128)
+    batch = v['sm'].synthetic_batch(v['model'], v['J'], B, seed=63)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    eng, on = _tiles_engine(v, B)
+    assert on
+    xd, bd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous()
+    smpl = oracle.OracleSMPL(v['model'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    o, p, b_, _ = oracle.refine_poses(smpl, T(v['J']), x6[sub, :1], x6[sub, 1:], betas[sub], gt_c[sub], 2, batch_norm=B)
+    m, vv, step = _fresh_state(B)
+    sq = torch.zeros(B, device=DEV)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, vv, step, 1e-2, 2, sqerr=sq)
+    assert torch.isfinite(xd).all() and torch.isfinite(sq).all()
+    d = (xd.cpu()[sub] - torch.cat([o, p], 1)).abs()
+    assert d.max().item() < 6e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+
+
 # ---- forward reuse after a J step where BP is an odd multiple of 128 ---------------------------------------------------------
 @pytest.mark.parametrize('B', [300, 600])
 def test_forward_reuse_after_j_step_at_odd_multiples_of_128(smpl_model_np, j_h36m_np, B):
