@@ -98,6 +98,7 @@ def parse():
     ap.add_argument('--no_folded', action='store_true', help='skip the separately reported folded-regressor mode')
     ap.add_argument('--no_config5', action='store_true', help='skip the separately reported BASELINE configs[4] block')
     ap.add_argument('--no_config2', action='store_true', help='skip the separately reported BASELINE configs[1] block (batch 1024, joint loss only)')
+    ap.add_argument('--no_support_tiles', action='store_true', help='skip the side run restricted to the vertex tiles of the regressor\'s support')
     ap.add_argument('--no_skin_variants', action='store_true',
                     help='skip the separately reported 12-joint / dense skinning runs (what a body model with a less coherent vertex order runs)')
     ap.add_argument('--no_rccl_one_rank', action='store_true', help='skip the cadence-1 host-driven run whose all-reduce is executed by a one-rank RCCL group')
@@ -510,15 +511,17 @@ def main():
         d_ms = (time.perf_counter() - td) / nj * 1e3
         eng.set_pose_disc(disc_flat.to(dev))
 
-    def side_run(flags_, setup=None, model=None, Bs=None, disc=None):
+    def side_run(flags_, setup=None, model=None, Bs=None, disc=None, tiles=False):
         """a separately reported mode on a fresh copy of the same batch (its first Bs poses): warm-up, then --steps timed
         iterations (median of 3)"""
         Bs = Bs or B
         disc = use_disc if disc is None else disc
-        e2 = eng_mod.RefineEngine(model or dmodel, Bs, batch_norm=Bs * world, flags=flags_)
+        e2 = eng_mod.RefineEngine(model or dmodel, Bs, batch_norm=Bs * world, flags=flags_ | (eng_mod.FLAG_SUPPORT_TILES if tiles else 0))
         if flags_ & eng_mod.FLAG_FOLDED:
             e2.set_folded(True)
         e2.set_j_regressor(J)
+        if tiles:
+            e2.j_support_info()      # engages FLAG_SUPPORT_TILES when the support fits the device lists
         if disc:
             e2.set_pose_disc(disc_flat.to(dev))
         fx = torch.from_numpy(batch_np['pose6d'][:Bs]).to(dev).contiguous()
@@ -535,7 +538,10 @@ def main():
         fel = statistics.median([timed_region(a.steps, 0, go)[0] for _ in range(3)])
         out_ = {'value': round(a.steps / fel * world, 3), 'unit': f'it/s (x{Bs} poses)', 'ms_per_step': round(fel / a.steps * 1e3, 4),
                 'joint_sparse': int(e2.info.get('joint_sparse') or 0)}
-        if setup is silhouette_setup or Bs != B:
+        if tiles:
+            on, nt = e2.support_tiles()
+            out_['vertex_tiles'] = {'run': nt, 'of': 216, 'restricted_to_regressor_support': on}
+        if setup is silhouette_setup or Bs != B or tiles:
             e2.set_profiling(True)
             e2.refine_run(fx, fb, fgt, fm, fv, fstep, 1e-2, max(2, min(a.steps, 10)))
             pr = e2.profile_read()
@@ -550,6 +556,24 @@ def main():
         folded.update({'algorithmic_flop_per_pose_iter': 2 * (2 * 1224 * 218) + 4 * (17 * 3 * 24 * 4 * 2),
                        'note': 'joints = A.(H F) with H = sum_v Jn W D contracted once per J update (exact re-association, '
                                'same losses/updates; no vertices).  Separate mode, separate denominator: not the headline.'})
+    # ---- the same iteration on the vertex tiles of the regressor's SUPPORT only (JRR_FLAG_SUPPORT_TILES; what optimize.py runs by
+    #      default).  Exact: the other tiles meet a zero block of the regressor and a zero vertex adjoint.  Reported beside the
+    #      headline, which keeps running all 6890 vertices (north_star: "linear blend skinning over 6890 vertices") ----
+    support_tiles = None
+    if not a.no_support_tiles and not use_sil:
+        support_tiles = side_run(eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0), tiles=True)
+        nt = support_tiles['vertex_tiles']['run']
+        fl = (flop_lbs_fwd(dmodel.info) + flop_lbs_bwd(dmodel.info) + FLOP_BLEND_ADJ_PER_POSE) * nt / 216 + (FLOP_DISC_PER_POSE if use_disc else 0)
+        support_tiles.update({
+            'flop_per_pose_iter_it_runs': round(fl), 'achieved_tflops': round(fl * B / (support_tiles['ms_per_step'] * 1e-3) / 1e12, 2),
+            'frac_of_f32_mfma_peak': round(fl * B / (support_tiles['ms_per_step'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            'note': 'joint-loss iterations read the vertices through the regressor only: a 32-vertex tile without a positive regressor entry '
+                    'adds exact zeros to the joints and receives a zero vertex adjoint, so forward, backward and blend adjoint skip it '
+                    '(same kernels, tile list from the device-side support lists; results equal the all-tiles run up to the order of '
+                    'the sums, tests/test_gpu_round4.py).  NOT the headline: `value` runs all 216 tiles.'})
+        if B >= 1024 and a.config == 3 and not a.no_config2:
+            c2t = side_run(eng_mod.FLAG_KEEP_VERTS, Bs=1024, disc=False, tiles=True)
+            support_tiles['config2_batch1024_joint_loss_only'] = c2t
     # ---- BASELINE configs[4]: + soft-silhouette loss inside the inner loop, separately timed ----
     config5 = None
     if not a.no_config5 and not use_sil and use_disc:
@@ -744,6 +768,8 @@ def main():
                          'j_allreduce_bytes': xch.nbytes, 'pose_d_allreduce_bytes': 1840153 * 4 if use_disc else 0}
     if folded is not None:
         out['folded_mode'] = folded
+    if support_tiles is not None:
+        out['support_tiles'] = support_tiles
     if config2 is not None:
         out['config2'] = config2
     if config5 is not None:

@@ -42,6 +42,8 @@ def build_parser() -> argparse.ArgumentParser:
                         help='inner iterations per J_regressor step (100 = reference cadence: once per outer batch)')
     parser.add_argument('--j_allreduce', type=str, default='support', choices=['support', 'dense'],
                         help='payload of the in-loop J step all-reduce under data parallelism: the regressor\'s support (8 704 B) or the dense (17,6890) gradient')
+    parser.add_argument('--all_vertex_tiles', action='store_true',
+                        help='run every joint-loss iteration on all 216 vertex tiles (default: only the tiles that hold an entry of the J_regressor\'s support; same results up to summation order)')
     parser.add_argument('--no_pose_disc', action='store_true', help='drop the pose-discriminator term (BASELINE config 2)')
     parser.add_argument('--shape_disc', action='store_true', help='add the shape-discriminator term (optimize.py:244,249-250)')
     parser.add_argument('--reprojection', action='store_true',

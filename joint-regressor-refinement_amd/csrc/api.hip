@@ -366,6 +366,7 @@ struct jrr_engine {
   float *rowsum, *Jraw, *Jmask, *Jn, *Jn_vi, *Jn_iv, *Jn_q;
   bool tab_static;                                   // the W parts of the backward operand records are in place
   float *FT, *FTq, *AT, *VPb, *JP, *dJT, *DVP, *dATp, *dFTp, *joints, *sqerr, *Jsum, *dA, *dF, *R0T, *dRT, *dbT;
+  unsigned* dmask;                                   // [slab][BP / 64] joint masks of the dA slabs (k_lbs_bwd16 -> k_chain_bwd)
   float *convL;                                      // LDS image of the per-joint MLP parameters (k_conv_image)
   float *W2s, *zpart;                                // fc2.w rows scaled by fc4.w; partial fc4 dots [16][BP]
   float *W0Tq, *W2Tq, *W2sq, *W0q;                   // the four GEMM weight operands in quads [k/4][m][4]
@@ -467,6 +468,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->dJT = c.take((size_t)3 * NHP * BP);
     t->DVP = c.take((size_t)3 * VP * BP);
     t->dATp = c.take((size_t)(nvcb > nvcb16 ? nvcb : nvcb16) * 12 * NJ * BP);     // slabs of either backward kernel
+    t->dmask = (unsigned*)c.take((size_t)(nvcb > nvcb16 ? nvcb : nvcb16) * (BP / 64));   // joints present in each slab (k_lbs_bwd16)
     t->dFTp = c.take((size_t)nsplit * KFP * BP);
     t->Jsum = c.take((size_t)3 * NH * BP);
     t->dA = c.take((size_t)12 * NJ * BP);
@@ -803,9 +805,14 @@ static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s, const float* c
   if (e->nvcb > MAX_SLABS_IN_CONSUMER)
     launch_reduce_slabs(e->dATp, e->nvcb, (size_t)12 * NJ * e->BP, e->dA, (size_t)12 * NJ * e->BP, s);
 }
+// k_lbs_bwd16's slabs carry joint masks instead of zero rows when k_chain_bwd sums them itself (a slab-sum launch reads every row)
+static unsigned* slab_masks(jrr_engine* e) {
+  return (e->m.kjs && e->m.bwd16 && e->nvcb <= MAX_SLABS_IN_CONSUMER) ? e->dmask : nullptr;
+}
 static void set_adjoint_slabs(jrr_engine* e, PrepBwdLaunch& L) {
   const bool pre = e->nvcb > MAX_SLABS_IN_CONSUMER;
   L.dATp = pre ? e->dA : e->dATp; L.nslabA = pre ? 1 : e->nvcb; L.strideA = (size_t)12 * NJ * e->BP; L.dFTp = e->dF;
+  L.dmaskA = slab_masks(e);
 }
 
 static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,
@@ -852,7 +859,7 @@ extern "C" int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d, const
   e->fwd_cached = false;
   launch_joints_loss(nullptr, 0, nullptr, djoints, 0.f, nullptr, nullptr, e->dJT, e->B, e->BP, s);   // (B,17,3) -> [3][18][BP]
   if (dx6d || dR || dbetas) {
-    launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s);
+    launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s, nullptr, 0, slab_masks(e));
     int rc = blend_adjoint_gemm(e, s);
     if (rc) return rc;
     reduce_adjoint_partials(e, s);
@@ -880,7 +887,7 @@ extern "C" int jrr_smpl_vertices_backward(jrr_engine_t* e, const float* x6d, con
   e->fwd_cached = false;
   // the caller's adjoint, transposed into its own [3][VP][BP] buffer (the stored vertices stay valid for a later dJ)
   launch_dverts_transpose(dverts, V * 3, e->dVTb, e->B, e->BP, s, e->m.p2v);
-  launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, nullptr, e->dVTb, e->DVP, e->dATp, e->BP, e->nvcb, s);
+  launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, nullptr, e->dVTb, e->DVP, e->dATp, e->BP, e->nvcb, s, nullptr, 0, slab_masks(e));
   int rc = blend_adjoint_gemm(e, s);
   if (rc) return rc;
   reduce_adjoint_partials(e, s);
@@ -1381,7 +1388,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     prof_mark(e, 3, s);
     if (folded) launch_fold_bwd(e->dJT, e->AT, e->MT, e->G0, e->dMT, e->dA, e->BP, s);
     else {
-      int rcb = launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, sil ? e->VTb : nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s, tl, ntl);
+      int rcb = launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, sil ? e->VTb : nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s, tl, ntl, slab_masks(e));
       if (rcb) return rcb;
     }
     prof_mark(e, 3, s);
@@ -1609,7 +1616,7 @@ static int j_step_local(jrr_engine* e, const float* x6d, const float* betas, con
   // the lists, both consumers (k_jgrad_sparse here, k_rejoints_sparse in the reusing iteration) read support rows only -- the forward
   // stores the tiles that hold one (a few dozen of 216) instead of 340 MB at 4096 poses
   const bool few = support_verts && e->have_jsup && e->jsup_fits_known;
-  const bool listed = few && use_tile_list(e);      // ... and with JRR_FLAG_SUPPORT_TILES nothing but those tiles is computed
+  const bool listed = use_tile_list(e);             // ... and with JRR_FLAG_SUPPORT_TILES nothing but those tiles is computed (any caller: the engine was created for it)
   smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s, few ? e->jsup.tmask : nullptr, listed ? e->act_list : nullptr, listed ? e->nact : 0);
   e->fwd_cached = true; e->fc_x6d = x6d; e->fc_betas = betas;
   const float scale = (float)(2.0 * 1.0 / ((double)e->bnorm * 51.0));   // optimize.py:307 unweighted MSE

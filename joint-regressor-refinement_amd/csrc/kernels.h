@@ -36,6 +36,7 @@ struct PrepBwdLaunch {
   const float* x6d_in = nullptr; const float* R_in = nullptr; const float* betas_in = nullptr;
   const float* dATp = nullptr; const float* dFTp = nullptr;    // adjoints dA^T [nslabA][288][BP] (partial slabs, summed
   int nslabA = 1; size_t strideA = 0;                           // by k_chain_bwd), dF^T [224][BP] (reduced)
+  const unsigned* dmaskA = nullptr;                             // [nslabA][BP / 64] valid-joint masks of the slabs (NULL: all rows valid)
   const float* FT = nullptr; const float* R0T = nullptr; const float* AT = nullptr;   // saved by k_prep_fwd
   float* dRT = nullptr; float* dbT = nullptr;                   // scratch [216][BP], [10][BP]
   const float* gx_extra = nullptr; const float* gb_extra = nullptr;
@@ -91,7 +92,10 @@ int launch_verts_untranspose(const float* VTb, float* verts, int ldv, int vlimit
                              hipStream_t s, const int* p2v = nullptr);
 int launch_bwd_tab_static(const Model& m, float* Tb, hipStream_t s);
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
-                   const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s, const int* tl = nullptr, int ntl = 0);
+                   const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s, const int* tl = nullptr, int ntl = 0,
+                   unsigned* dmask = nullptr);
+// dmask (nullable; k_lbs_bwd16 only -- ignored by the role kernel, which fills its slabs): [nvc][BP / 64] joint masks of the rows written
+// (rows of untouched joints are then not zero-filled; consumer: PrepBwdLaunch::dmaskA)
 int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int BP, hipStream_t s, const int* p2v = nullptr);
 // Support of the normalised regressor (the J step's products only need it: ReLU' makes dJ exactly zero elsewhere).
 // JSupport lives in the engine workspace: cnt[i] positive entries of row i, their internal vertex rows / weights in ascending

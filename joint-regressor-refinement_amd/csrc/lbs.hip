@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
   int g = 0;   // global stage counter: ring slot = g & 1
   for (int ix = t_begin; ix < t_end; ++ix) {
     const int vt = LIST ? tl[ix] : ix;                                       // the tile (wave-uniform)
-    const int vtn = (ix + 1 < t_end) ? (LIST ? tl[ix + 1] : ix + 1) : 0;     // the next one
+    const int vtn = LIST ? ((ix + 1 < t_end) ? tl[ix + 1] : 0) : ix + 1;      // the next one (used under ix + 1 < t_end only)
     const float* ldsW = wj + (ix & 1) * WJ_FLOATS;
     const float* ldsJ = ldsW + W_FLOATS;
     const bool stv = STORE_VERTS && (!vmask || vmask[vt] != 0);      // wave-uniform
@@ -861,7 +861,11 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
                                                       const float* __restrict__ dVT, float* __restrict__ DVP,
                                                       float* __restrict__ dATp, int BP, int nvc, int n_bt,
                                                       const int* __restrict__ segid, const int* __restrict__ segj, int paired,
-                                                      const int* __restrict__ tnj, const int* __restrict__ tl, int ntl) {
+                                                      const int* __restrict__ tnj, const int* __restrict__ tl, int ntl,
+                                                      unsigned* __restrict__ dmask) {
+  // dmask (nullable): [chunk][64-pose group] bit j = this workgroup wrote the rows of joint j of its dA slab.  The rows of the joints
+  // no tile of the chunk touches are then NOT zero-filled (and not read: k_chain_bwd takes the mask) -- at 4096 poses the eight slabs
+  // are 37.7 MB, about half of it rows of zeros (timing-only ablation of flush + fill: 18 us of the launch).
   // LIST: the ntl tiles tl[] only.  A tile without a support entry of the regressor has a zero vertex adjoint (DV == 0: no adjoint
   // from outside): its dvp and its dA contributions are exact zeros, and the blend adjoint skips its rows of DVP as well.
   const int NT = LIST ? ntl : VT;
@@ -955,18 +959,33 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
     // last dvp stores
     if (seen != 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int* sj = segj + seg_tile * 16;
+    // rows an earlier flush of this workgroup stored are read back FIRST, all of them in flight together (one agent-scope load per
+    // row and entry: issued one by one between the stores they feed, 48 dependent L2 round trips made the flush the largest fixed
+    // cost of the launch), then everything is stored
+    int jr[4];
+    float* rowp[4];
+    float oldv[4][12];
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int j = sj[4 * g + i];
-      if (j >= 0) {
-        const bool add = (seen >> j) & 1u;
+      jr[i] = sj[4 * g + i];
+      rowp[i] = dATp + ((size_t)(vc * 12) * NJ + (jr[i] >= 0 ? jr[i] : 0)) * BP + bcol;
+      const bool add = jr[i] >= 0 && ((seen >> jr[i]) & 1u);
+#pragma unroll
+      for (int e = 0; e < 12; ++e) {
+        const int ent = e < 9 ? (e / 3) * 4 + e % 3 : (e - 9) * 4 + 3;
+        // L1 bypassed: an earlier flush of this wave stored it, possibly from another lane
+        oldv[i][e] = add ? __hip_atomic_load(rowp[i] + (size_t)ent * NJ * BP, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.f;
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      if (jr[i] >= 0) {
+        const bool add = (seen >> jr[i]) & 1u;
 #pragma unroll
         for (int e = 0; e < 12; ++e) {
           const int ent = e < 9 ? (e / 3) * 4 + e % 3 : (e - 9) * 4 + 3;
-          float* dst = dATp + ((size_t)(vc * 12 + ent) * NJ + j) * BP + bcol;
-          float val = acc[e][i];
-          if (add) val += __hip_atomic_load(dst, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // L1 bypassed: an earlier flush of this wave stored it, possibly from another lane
-          __hip_atomic_store(dst, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // paired with the agent-scope re-read of a later flush
+          const float val = add ? acc[e][i] + oldv[i][e] : acc[e][i];
+          __hip_atomic_store(rowp[i] + (size_t)ent * NJ * BP, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // paired with the agent-scope re-read of a later flush
         }
       }
     }
@@ -1083,6 +1102,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
     if (ix + 1 < t_end) tile(ix + 1, vpB, vpA);
   }
   flush_window();
+  if (dmask) {
+    if (tid == 0) dmask[vc * n_bt + bt] = seen;
+    return;
+  }
   // joints no tile of this chunk touches: zero rows
 #pragma unroll 1
   for (int j = 0; j < NJ; ++j) {
@@ -1562,7 +1585,7 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
 }
 
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
-                   const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s, const int* tl, int ntl) {
+                   const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s, const int* tl, int ntl, unsigned* dmask) {
   if (tl && !(m.kjs && m.bwd16 && !dVT)) { jrr_set_error("lbs_bwd: the tile list serves k_lbs_bwd16 without an outside vertex adjoint"); return JRR_ERR_ARG; }
   if (m.kjs && m.bwd16) {                       // four symmetric waves of 16 poses: one workgroup per (64 poses, vertex chunk)
     const int n_bt16 = BP / 64;
@@ -1575,10 +1598,10 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
     const int paired16 = (pair_env > 0) ? ((grid16.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? pair_env : 0) : pair_env;
 #define JRR_LBS_BWD16_K(DVM, KJV, WD)                                                                                           \
   hipLaunchKernelGGL((k_lbs_bwd16<DVM, KJV, WD>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, \
-                     m.segj, paired16, m.tnj, nullptr, 0)
+                     m.segj, paired16, m.tnj, nullptr, 0, dmask)
 #define JRR_LBS_BWD16_L(KJV, WD)                                                                                                \
   hipLaunchKernelGGL((k_lbs_bwd16<0, KJV, WD, true>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, \
-                     m.segj, paired16, m.tnj, tl, ntl)
+                     m.segj, paired16, m.tnj, tl, ntl, dmask)
 #define JRR_LBS_BWD16(DVM)                                                                                                      \
   do {                                                                                                                          \
     if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_BWD16_K(DVM, 8, false);                                                            \

@@ -671,7 +671,8 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
                                                         const float* __restrict__ AT, const float* __restrict__ Jt,
                                                         const float* __restrict__ JS, Parents par,
                                                         const float* __restrict__ dA_, int nslabA, size_t strideA,
-                                                        const float* __restrict__ dF_, PoseUpdateArgs ua, int B, int BP) {
+                                                        const float* __restrict__ dF_, PoseUpdateArgs ua, int B, int BP,
+                                                        const unsigned* __restrict__ dmask) {
   constexpr int PP = PPB;
   __shared__ AdamScalars adam_sc;
   // one thread per (pose, joint); levels of the kinematic tree are processed deepest first.  Each child
@@ -713,35 +714,29 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
   const unsigned opj = (unsigned)(p > 0 ? p : 0) * pitch + lane_b;          // row of the parent
   const unsigned ofj = (unsigned)(j > 0 ? (j - 1) * 9 : 0) * pitch + lane_b;   // first pose-feature row of joint j
   // dA^T arrives as per-vertex-chunk partial slabs [nslabA][12][24][BP]: summed here, in slab order (deterministic)
-  // (two slabs' loads -- 24 -- in flight together)
+  // (two slabs' loads -- 24 -- in flight together).  dmask (k_lbs_bwd16): bit j of word [slab][b / 64] says whether the slab holds
+  // rows for joint j at all -- rows of joints its chunk never touched are neither written nor read (x + 0 = x: same sums)
   {
-    float t[12];
+    const int n_bt = BP / 64, bt = (int)(blockIdx.x * PP) / 64;
 #pragma unroll
-    for (int e = 0; e < 12; ++e) dA[e] = ld(dA_, oj + (unsigned)(e * NJ) * pitch);
-    if (nslabA > 1) {
-      const float* s1 = dA_ + strideA;
+    for (int e = 0; e < 12; ++e) dA[e] = 0.f;
+    for (int sl = 0; sl < nslabA; sl += 2) {
+      float t[12], u[12];
+      const bool two = sl + 1 < nslabA;
+      const bool v0 = !dmask || ((dmask[sl * n_bt + bt] >> j) & 1u);
+      const bool v1 = two && (!dmask || ((dmask[(sl + 1) * n_bt + bt] >> j) & 1u));
+      const float* s0 = dA_ + (size_t)sl * strideA;
+      const float* s1 = s0 + strideA;
 #pragma unroll
-      for (int e = 0; e < 12; ++e) t[e] = ld(s1, oj + (unsigned)(e * NJ) * pitch);
+      for (int e = 0; e < 12; ++e) t[e] = v0 ? ld(s0, oj + (unsigned)(e * NJ) * pitch) : 0.f;
+#pragma unroll
+      for (int e = 0; e < 12; ++e) u[e] = v1 ? ld(s1, oj + (unsigned)(e * NJ) * pitch) : 0.f;
 #pragma unroll
       for (int e = 0; e < 12; ++e) dA[e] += t[e];
-    }
-  }
-  for (int sl = 2; sl < nslabA; sl += 2) {
-    float t[12], u[12];
-    const bool two = sl + 1 < nslabA;
-    const float* s0 = dA_ + (size_t)sl * strideA;
-    const float* s1 = s0 + strideA;
+      if (two) {
 #pragma unroll
-    for (int e = 0; e < 12; ++e) t[e] = ld(s0, oj + (unsigned)(e * NJ) * pitch);
-    if (two) {
-#pragma unroll
-      for (int e = 0; e < 12; ++e) u[e] = ld(s1, oj + (unsigned)(e * NJ) * pitch);
-    }
-#pragma unroll
-    for (int e = 0; e < 12; ++e) dA[e] += t[e];
-    if (two) {
-#pragma unroll
-      for (int e = 0; e < 12; ++e) dA[e] += u[e];
+        for (int e = 0; e < 12; ++e) dA[e] += u[e];
+      }
     }
   }
 #pragma unroll
@@ -1010,7 +1005,7 @@ int launch_prep_bwd(const PrepBwdLaunch& L, const Model& m, hipStream_t s) {
   a.lr = L.lr; a.beta1 = L.beta1; a.beta2 = L.beta2; a.eps = L.eps;
   a.gcam = L.gcam; a.cam_io = L.cam_io; a.cam_m = L.cam_m; a.cam_v = L.cam_v;
   hipLaunchKernelGGL(k_chain_bwd, dim3((L.B + PPB - 1) / PPB), dim3(PPB * NJ), 0, s, L.FT, L.R0T, L.AT, m.Jt, m.JS, m.parents,
-                     L.dATp, L.nslabA, L.strideA, L.dFTp, a, L.B, L.BP);
+                     L.dATp, L.nslabA, L.strideA, L.dFTp, a, L.B, L.BP, L.dmaskA);
   return 0;
 }
 

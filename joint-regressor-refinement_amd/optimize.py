@@ -157,7 +157,11 @@ def optimize_pose_refiner(log=print) -> Dict:
     J_opt = AdamState(J_regressor, args.j_reg_lr)                                          # :125-126
 
     flags = _engine.FLAG_KEEP_VERTS | (_engine.FLAG_POSE_DISC if use_pd else 0) | (_engine.FLAG_SHAPE_DISC if use_sd else 0) \
-        | (_engine.FLAG_SILHOUETTE if args.silhouette else 0)
+        | (_engine.FLAG_SILHOUETTE if args.silhouette else 0) | (0 if args.all_vertex_tiles else _engine.FLAG_SUPPORT_TILES)
+    # FLAG_SUPPORT_TILES: iterations whose loss reads the joints only run their skinning kernels on the 32-vertex tiles that hold an
+    # entry of the regressor's support (51 of 216 for the shipped checkpoint's structure); the other tiles meet a zero block of the
+    # regressor (scripts/utils.py:87-92 multiplies them anyway) and a zero vertex adjoint.  Engaged by eng.j_support_info() below
+    # when the support fits the device lists; with the silhouette term every vertex is needed and every tile runs.
     engines: Dict = {}
     n_hist = (args.inner_iters + 9) // 10                                                  # :255 `if i % 10 == 0`
     bucket = SharedBucket(device, use_pd, use_sd, n_hist)

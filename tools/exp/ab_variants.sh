@@ -4,7 +4,7 @@ TAG=$1; shift
 LIB=joint-regressor-refinement_amd/libjrr_hip.so
 mkdir -p gpurun_out/$TAG
 cp $LIB /tmp/lib_base.so
-FLAGS="--no_cpu_baseline --no_folded --no_config5 --no_config2 --no_rccl_one_rank --min_timed_ms 800"
+FLAGS="--no_cpu_baseline --no_folded --no_config5 --no_config2 --no_rccl_one_rank --no_support_tiles --min_timed_ms 800"
 for round in 1 2; do
   for which in base "$@"; do
     if [ $which = base ]; then cp /tmp/lib_base.so $LIB; else cp tools/probe/libjrr_$which.so $LIB; fi

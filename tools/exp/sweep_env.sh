@@ -3,7 +3,7 @@
 # one short bench per value of an environment knob, two rounds interleaved; prints the per-kernel times
 TAG=$1; NAME=$2; BF=$3; shift; shift; shift
 mkdir -p gpurun_out/$TAG
-FLAGS="--no_cpu_baseline --no_folded --no_config5 --no_skin_variants --no_config2 --no_rccl_one_rank --min_timed_ms 1000 $BF"
+FLAGS="--no_cpu_baseline --no_folded --no_config5 --no_skin_variants --no_config2 --no_rccl_one_rank --no_support_tiles --min_timed_ms 1000 $BF"
 for round in 1 2; do
   for val in "$@"; do
     env $NAME=$val python bench.py $FLAGS > gpurun_out/$TAG/${val}_${round}.json 2>/dev/null
