@@ -561,8 +561,15 @@ def main():
     #      headline, which keeps running all 6890 vertices (north_star: "linear blend skinning over 6890 vertices") ----
     support_tiles = None
     if not a.no_support_tiles and not use_sil:
-        support_tiles = side_run(eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0), tiles=True)
+        # the body uploaded as optimize.py uploads it: with the regressor's positive columns as a hint for the library's internal vertex
+        # order (jrr_model_create_hinted: the support stored first -- ceil(58 / 32) = 2 tiles instead of one per entry)
+        hmodel = eng_mod.DeviceModel(model_np, dev, hint_vertices=np.nonzero((J_np > 0).any(0))[0])
+        support_tiles = side_run(eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0), tiles=True, model=hmodel)
+        support_tiles['model'] = hmodel.info
+        unhinted = side_run(eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0), tiles=True)
+        support_tiles['without_vertex_order_hint'] = {k: unhinted[k] for k in ('value', 'ms_per_step', 'vertex_tiles', 'kernels_ms')}
         nt = support_tiles['vertex_tiles']['run']
+        # FLOP it runs: the listed tiles at the 8-slot rate + a second pass for each of them that is wide (all, with the hint)
         fl = (flop_lbs_fwd(dmodel.info) + flop_lbs_bwd(dmodel.info) + FLOP_BLEND_ADJ_PER_POSE) * nt / 216 + (FLOP_DISC_PER_POSE if use_disc else 0)
         support_tiles.update({
             'flop_per_pose_iter_it_runs': round(fl), 'achieved_tflops': round(fl * B / (support_tiles['ms_per_step'] * 1e-3) / 1e12, 2),
@@ -572,7 +579,7 @@ def main():
                     '(same kernels, tile list from the device-side support lists; results equal the all-tiles run up to the order of '
                     'the sums, tests/test_gpu_round4.py).  NOT the headline: `value` runs all 216 tiles.'})
         if B >= 1024 and a.config == 3 and not a.no_config2:
-            c2t = side_run(eng_mod.FLAG_KEEP_VERTS, Bs=1024, disc=False, tiles=True)
+            c2t = side_run(eng_mod.FLAG_KEEP_VERTS, Bs=1024, disc=False, tiles=True, model=hmodel)
             support_tiles['config2_batch1024_joint_loss_only'] = c2t
     # ---- BASELINE configs[4]: + soft-silhouette loss inside the inner loop, separately timed ----
     config5 = None

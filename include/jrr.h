@@ -95,11 +95,21 @@ size_t jrr_model_bytes(void);
 int jrr_model_create_in(const float* v_template_host, const float* shapedirs_host, const float* posedirs_host,
                         const float* J_regressor_host, const float* lbs_weights_host, const int32_t* parents_host,
                         void* buffer_dev, size_t buffer_bytes, jrr_model_t** out);
+/* ... with a HINT for the internal vertex order: hint_vertices_host[n_hint] (file indices; duplicates ignored) are the vertices the
+ * caller's H36M regressor will read -- the columns where it is positive.  They are stored first (ceil(n / 32) tiles instead of
+ * up to one tile per vertex), which is what the iterations of JRR_FLAG_SUPPORT_TILES run; everything visible at the API keeps the
+ * file's vertex order.  The hint is dropped (jrr_model_info out[29] = 0) when one of those tiles would see more than 16 joints.
+ * A regressor with OTHER positive columns works as before, on more tiles.  No reference counterpart: the reference multiplies
+ * all 6890 vertices by the regressor (scripts/utils.py:87-92).                                                              */
+int jrr_model_create_hinted(const float* v_template_host, const float* shapedirs_host, const float* posedirs_host,
+                            const float* J_regressor_host, const float* lbs_weights_host, const int32_t* parents_host,
+                            const int32_t* hint_vertices_host, int n_hint, void* buffer_dev, size_t buffer_bytes, jrr_model_t** out);
 /* What the LBS kernels will run for this body (measurement / diagnostics; the reference has no counterpart):
  * out[0] = joint slots per 32-vertex tile and pass of the joint-sparse kernels (8 or 12; 0 = the dense kernels),
  * out[1] = WIDE tiles (more joints than that: each runs a second pass -- it costs itself, not the model),
  * out[2] = most joints of any tile, out[3] = 1 when the vertices are stored in the library's own joint-sorted order
- * (invisible at the API), out[4 + k] = number of tiles with k joints, k = 0 .. 24.                                      */
+ * (invisible at the API), out[4 + k] = number of tiles with k joints, k = 0 .. 24, out[29] = vertices stored first on the
+ * caller's hint (jrr_model_create_hinted; 0 = no hint or hint dropped).                                                  */
 int jrr_model_info(const jrr_model_t* m, int32_t* out, int n);
 /* triangle list of the mesh (SMPL `f`, 13776 x 3 int32; the reference reads it from data/body_model/smpl_uv.obj,
  * scripts/mesh_renderer.py:40-41); needed by the silhouette renderer only.  Synchronous.                  */

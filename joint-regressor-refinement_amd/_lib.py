@@ -24,6 +24,7 @@ SIGNATURES = {
     'jrr_model_destroy': (None, [_P]),
     'jrr_model_bytes': (c_size_t, []),
     'jrr_model_create_in': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_size_t, POINTER(_P)]),
+    'jrr_model_create_hinted': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_int, _P, c_size_t, POINTER(_P)]),
     'jrr_model_info': (c_int, [_P, POINTER(c_int32), c_int]),
     'jrr_model_set_faces': (c_int, [_P, _P, c_int]),
     'jrr_engine_workspace_bytes': (c_size_t, [c_int, c_int]),

@@ -51,6 +51,15 @@ extern "C" int jrr_model_create(const float* vt, const float* sd, const float* p
 
 extern "C" int jrr_model_create_in(const float* vt, const float* sd, const float* pd, const float* Jr, const float* W,
                                    const int32_t* parents, void* buffer_dev, size_t buffer_bytes, jrr_model_t** out) {
+  return jrr_model_create_hinted(vt, sd, pd, Jr, W, parents, nullptr, 0, buffer_dev, buffer_bytes, out);
+}
+
+extern "C" int jrr_model_create_hinted(const float* vt, const float* sd, const float* pd, const float* Jr, const float* W,
+                                       const int32_t* parents, const int32_t* hint_vertices, int n_hint, void* buffer_dev,
+                                       size_t buffer_bytes, jrr_model_t** out) {
+  if (n_hint < 0 || n_hint > V || (n_hint > 0 && !hint_vertices)) { jrr_set_error("jrr_model_create_hinted: bad hint"); return JRR_ERR_ARG; }
+  for (int i = 0; i < n_hint; ++i)
+    if (hint_vertices[i] < 0 || hint_vertices[i] >= V) { jrr_set_error("jrr_model_create_hinted: hint vertex %d out of range", hint_vertices[i]); return JRR_ERR_ARG; }
   if (!vt || !sd || !pd || !Jr || !W || !parents || !out) { jrr_set_error("jrr_model_create: null argument"); return JRR_ERR_ARG; }
   if (buffer_dev && (buffer_bytes < jrr_model_bytes() || ((uintptr_t)buffer_dev & 255) != 0)) {
     jrr_set_error("jrr_model_create_in: the model buffer needs jrr_model_bytes() = %zu bytes, 256-byte aligned", jrr_model_bytes());
@@ -102,11 +111,12 @@ extern "C" int jrr_model_create_in(const float* vt, const float* sd, const float
   std::vector<int> order(V);
   for (int v = 0; v < V; ++v) order[v] = v;
   bool permuted = false;
+  int hint_applied = 0;
   {
     const char* ask = getenv("JRR_VERTEX_ORDER");
     const bool force = ask && strcmp(ask, "sorted") == 0;
     const long cost_file = order_cost(order);
-    if (force || cost_file > (long)VT * 423) {      // some tile of the file order is wide: would a joint-sorted order be cheaper?
+    if (force || n_hint > 0 || cost_file > (long)VT * 423) {      // some tile of the file order is wide: would a joint-sorted order be cheaper?
       // joints of each vertex by descending weight (dominant joint first)
       std::vector<std::array<int, 4>> inf4(V);
       for (int v = 0; v < V; ++v) {
@@ -152,6 +162,46 @@ extern "C" int jrr_model_create_in(const float* vt, const float* sd, const float
       const long cost_lex = order_cost(lex), cost_chain = order_cost(chain);
       const std::vector<int>& best = cost_chain <= cost_lex ? chain : lex;
       if (force || std::min(cost_chain, cost_lex) < cost_file) { order = best; permuted = true; }
+      // HINT (jrr_model_create_hinted): the vertices the caller's regressor will read -- its support -- are stored FIRST, packed into
+      // as few tiles as the joint-sparse kernels like: groups of hinted vertices along the kinematic chains whose joints number at
+      // most 8 (one pass of the 8-slot kernels), each group topped up to a full tile with other vertices of the same joints; the
+      // rest follows in the order chosen above.  The iterations of JRR_FLAG_SUPPORT_TILES then run one tile per group instead of
+      // up to one per support entry.  Dropped (no effect) when a group cannot be completed within the 16-joint window.
+      if (n_hint > 0) {
+        std::vector<char> is_hint(V, 0), used(V, 0);
+        std::vector<int> hinted;
+        for (int i = 0; i < n_hint; ++i) if (!is_hint[hint_vertices[i]]) { is_hint[hint_vertices[i]] = 1; hinted.push_back(hint_vertices[i]); }
+        std::sort(hinted.begin(), hinted.end(), [&](int x, int y) { return ckey[x] < ckey[y]; });
+        auto joints_of = [&](int v) { unsigned m_ = 0; for (int j = 0; j < NJ; ++j) if (W[(size_t)v * NJ + j] != 0.f) m_ |= 1u << j; return m_; };
+        std::vector<int> with_hint;
+        bool ok = true;
+        size_t at = 0;
+        while (at < hinted.size() && ok) {
+          unsigned uni = 0;
+          std::vector<int> tile;
+          while (at < hinted.size() && tile.size() < 32) {      // the next group: joints <= 8 (a single vertex may bring up to 4)
+            const unsigned grown = uni | joints_of(hinted[at]);
+            if (!tile.empty() && __builtin_popcount(grown) > 8) break;
+            uni = grown; tile.push_back(hinted[at]); used[hinted[at]] = 1; ++at;
+          }
+          for (int limit : {0, 8, KJS_TILE_MAX}) {               // fillers: joints inside the group's, then anything that keeps <= 8, <= 16
+            for (int v : order) {
+              if (tile.size() == 32) break;
+              if (used[v] || is_hint[v]) continue;
+              const unsigned grown = uni | joints_of(v);
+              if (limit == 0 ? grown != uni : __builtin_popcount(grown) > limit) continue;
+              uni = grown; tile.push_back(v); used[v] = 1;
+            }
+            if (tile.size() == 32) break;
+          }
+          ok = tile.size() == 32;
+          with_hint.insert(with_hint.end(), tile.begin(), tile.end());
+        }
+        if (ok) {
+          for (int v : order) if (!used[v]) with_hint.push_back(v);
+          if ((int)with_hint.size() == V && order_cost(with_hint) < ((long)1 << 40)) { order = with_hint; permuted = true; hint_applied = (int)hinted.size(); }
+        }
+      }
     }
   }
   for (int p_ = 0; p_ < VP; ++p_) P2V[p_] = p_ < V ? order[p_] : -1;
@@ -287,6 +337,7 @@ extern "C" int jrr_model_create_in(const float* vt, const float* sd, const float
   m->d.most_joints = most_joints;
   for (int n = 0; n <= NJ; ++n) m->d.tile_hist[n] = hist[n];
   m->d.permuted = permuted ? 1 : 0;
+  m->d.hint_applied = hint_applied;
   m->v2p_host = nullptr;
   if (permuted) { m->v2p_host = new int[V]; memcpy(m->v2p_host, V2P, (size_t)V * sizeof(int)); }
   m->d.p2v = permuted ? reinterpret_cast<int*>(m->d.jl + nJl) : nullptr;
@@ -347,9 +398,10 @@ extern "C" void jrr_model_destroy(jrr_model_t* m) {
 
 extern "C" int jrr_model_info(const jrr_model_t* m, int32_t* out, int n) {
   if (!m || !out) return JRR_ERR_ARG;
-  int32_t v[4 + NJ + 1] = {m->d.kjs, m->d.wide_tiles, m->d.most_joints, m->d.permuted};
+  int32_t v[4 + NJ + 2] = {m->d.kjs, m->d.wide_tiles, m->d.most_joints, m->d.permuted};
   for (int k = 0; k <= NJ; ++k) v[4 + k] = m->d.tile_hist[k];
-  for (int i = 0; i < n && i < 4 + NJ + 1; ++i) out[i] = v[i];
+  v[4 + NJ + 1] = m->d.hint_applied;
+  for (int i = 0; i < n && i < 4 + NJ + 2; ++i) out[i] = v[i];
   return JRR_OK;
 }
 

@@ -162,6 +162,7 @@ struct Model {
   int* tnj;     // [VT] joints of the tile
   int kjs;
   int wide_tiles, most_joints, permuted;      // tiles above kjs joints; most joints of any tile; internal order != file order
+  int hint_applied;                           // vertices stored first on the caller's hint (jrr_model_create_hinted)
   int tile_hist[NJ + 1];                      // tiles by joint count (jrr_model_info)
   // Joint WINDOWS of the backward kernel's dA products (kjs > 0).  dA_{r,c}[j][pose] = sum_v W[v][j] (...) only has
   // non-zero rows for the joints that skin the tile; it is accumulated over the tiles of a vertex chunk, so the rows must

@@ -58,7 +58,9 @@ def _f32c(a) -> np.ndarray:
 class DeviceModel:
     """SMPL constants uploaded in the kernels' tile-major layouts (jrr_model_create)."""
 
-    def __init__(self, model: Dict[str, np.ndarray], device='cuda:0'):
+    def __init__(self, model: Dict[str, np.ndarray], device='cuda:0', hint_vertices=None):
+        """hint_vertices (optional): file indices of the vertices the H36M regressor reads (its positive columns); the library stores
+        them first internally, so that the iterations of FLAG_SUPPORT_TILES run ceil(n / 32) tiles (jrr_model_create_hinted)"""
         self.lib = _lib.load()
         self.device = torch.device(device)
         vt, sd, pd = _f32c(model['v_template']), _f32c(model['shapedirs']), _f32c(model['posedirs'])
@@ -73,15 +75,22 @@ class DeviceModel:
         self.buffer = torch.zeros(nbytes + 256, dtype=torch.uint8, device=self.device)
         base = (self.buffer.data_ptr() + 255) // 256 * 256
         with torch.cuda.device(self.device):
-            check(self.lib.jrr_model_create_in(vt.ctypes.data, sd.ctypes.data, pd.ctypes.data, jr.ctypes.data,
-                                               w.ctypes.data, par.ctypes.data, c_void_p(base), nbytes, byref(h)), 'jrr_model_create_in')
+            if hint_vertices is not None and len(hint_vertices):
+                hv = np.ascontiguousarray(np.asarray(hint_vertices, dtype=np.int32).ravel())
+                check(self.lib.jrr_model_create_hinted(vt.ctypes.data, sd.ctypes.data, pd.ctypes.data, jr.ctypes.data, w.ctypes.data,
+                                                       par.ctypes.data, hv.ctypes.data, int(hv.size), c_void_p(base), nbytes, byref(h)),
+                      'jrr_model_create_hinted')
+            else:
+                check(self.lib.jrr_model_create_in(vt.ctypes.data, sd.ctypes.data, pd.ctypes.data, jr.ctypes.data,
+                                                   w.ctypes.data, par.ctypes.data, c_void_p(base), nbytes, byref(h)), 'jrr_model_create_in')
         self.handle = h
-        info = (c_int32 * 29)()
-        check(self.lib.jrr_model_info(self.handle, info, 29), 'jrr_model_info')
+        info = (c_int32 * 30)()
+        check(self.lib.jrr_model_info(self.handle, info, 30), 'jrr_model_info')
         # what the LBS kernels run for this body: joint slots per tile and pass (0: dense kernels), tiles that need a second
         # pass, the most joints of any tile, whether the library re-ordered the vertices internally, tiles by joint count
         self.info = {'joint_slots': int(info[0]), 'wide_tiles': int(info[1]), 'most_joints_per_tile': int(info[2]),
-                     'internal_vertex_order': bool(info[3]), 'tile_joint_histogram': [int(x) for x in info[4:29]]}
+                     'internal_vertex_order': bool(info[3]), 'tile_joint_histogram': [int(x) for x in info[4:29]],
+                     'hinted_vertices_stored_first': int(info[29])}
         if self.faces is not None:
             f = np.ascontiguousarray(np.asarray(self.faces, dtype=np.int32))
             check(self.lib.jrr_model_set_faces(self.handle, f.ctypes.data, int(f.shape[0])), 'jrr_model_set_faces')

@@ -141,9 +141,13 @@ def optimize_pose_refiner(log=print) -> Dict:
     torch.cuda.set_device(device)
     utils.set_seed(args.seed)
 
-    smpl = SMPL(args.smpl_dir, batch_size=1, allow_synthetic=args.synthetic or args.smpl_dir == 'SPIN/data/smpl').to(device)   # :96-99
+    smpl = SMPL(args.smpl_dir, batch_size=1, allow_synthetic=args.synthetic or args.smpl_dir == 'SPIN/data/smpl')              # :96-99
     J_np = smpl_model.default_h36m_regressor(args.j_regressor_init,
                                              allow_default=args.synthetic or args.j_regressor_init == 'SPIN/data/J_regressor_h36m.npy')
+    # the body goes to the device with the regressor's positive columns as a hint for the library's internal vertex order: the
+    # support is stored first, so the joint-loss iterations (FLAG_SUPPORT_TILES below) run a handful of tiles
+    tiles_mode = not args.all_vertex_tiles and not args.silhouette
+    smpl = smpl.to(device, hint_vertices=np.nonzero((J_np > 0).any(0))[0] if tiles_mode else None)
     J_regressor = torch.from_numpy(J_np).float().to(device).contiguous()                   # :105-107
     j_reg_mask = utils.find_j_reg_mask(J_regressor).contiguous()                           # :130
 

@@ -76,13 +76,15 @@ class SMPL:
         self.device_model = None
         self._engines: Dict = {}
 
-    def to(self, device):
+    def to(self, device, hint_vertices=None):
+        """hint_vertices (optional, this build's): the vertices an H36M regressor reads (its positive columns) -- a hint for the
+        library's internal vertex order (engine.DeviceModel); results and every index at the API are unaffected"""
         device = torch.device(device)
         if device.type != 'cuda':
             raise RuntimeError('the HIP SMPL operator has no CPU path (device must be a ROCm "cuda" device)')
-        if self.device_model is None or self.device != device:
+        if self.device_model is None or self.device != device or hint_vertices is not None:
             self.device = device
-            self.device_model = _engine.DeviceModel(self.model_np, device)
+            self.device_model = _engine.DeviceModel(self.model_np, device, hint_vertices=hint_vertices)
             self._engines = {}
         return self
 

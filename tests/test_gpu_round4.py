@@ -50,6 +50,8 @@ VARIANTS = {
     'wide13': ({}, 'wide13', 8, True),                                         # ONE 13-joint tile in the file order
     'wide13_role_bwd': ({'JRR_BWD16': '0'}, 'wide13', 8, True),                # a wide tile + role kernel: its dense form
     'wide13_skin12': ({'JRR_SKIN_JOINTS': '12'}, 'wide13', 12, True),          # ... under the 12-slot kernels: second pass over slots 12..
+    'hinted': ({}, 'hinted', 8, False),                                        # the regressor's support stored FIRST (jrr_model_create_hinted), packed into tiles of <= 8 joints
+    'hinted_capsules': ({}, 'hinted_capsules', 8, True),                       # ... on the capsule body (100 support vertices; one tile behind them ends up with 9 joints)
 }
 
 
@@ -59,15 +61,18 @@ def variant(request, smpl_model_np, j_h36m_np):
         pytest.skip('the suite itself runs under a forced skinning variant')
     env, body, slots, wide = VARIANTS[request.param]
     sm, eng_mod = _mod('smpl_model'), _mod('engine')
-    if body == 'capsules':
+    if body in ('capsules', 'hinted_capsules'):
         model = sm.synthetic_smpl(1234, kind='capsules')
     elif body == 'wide13':
         model = sm.with_wide_tile(smpl_model_np, 100, 13)
     else:
         model = smpl_model_np
+    # a regressor with the shipped checkpoint's structure on THIS body's vertices (the capsule body has its own vertex order)
+    J = j_h36m_np if 'capsules' not in body else sm.synthetic_h36m_regressor(model, seed=7, support=8)
+    hint = np.nonzero((J > 0).any(0))[0] if body.startswith('hinted') else None
     os.environ.update(env)          # the knobs are read by jrr_model_create
     try:
-        dm = eng_mod.DeviceModel(model, DEV)
+        dm = eng_mod.DeviceModel(model, DEV, hint_vertices=hint)
     finally:
         for k in env:
             os.environ.pop(k, None)
@@ -77,8 +82,10 @@ def variant(request, smpl_model_np, j_h36m_np):
         assert dm.info['internal_vertex_order'] and dm.info['most_joints_per_tile'] <= 8
     if body == 'wide13':
         assert dm.info['most_joints_per_tile'] == 13 and dm.info['wide_tiles'] == 1 and not dm.info['internal_vertex_order']
-    # a regressor with the shipped checkpoint's structure on THIS body's vertices (the capsule body has its own vertex order)
-    J = j_h36m_np if body != 'capsules' else sm.synthetic_h36m_regressor(model, seed=7, support=8)
+    if hint is not None:
+        assert dm.info['hinted_vertices_stored_first'] == len(hint) and dm.info['internal_vertex_order'], dm.info
+    else:
+        assert dm.info['hinted_vertices_stored_first'] == 0
     return dict(name=request.param, model=model, dm=dm, J=np.ascontiguousarray(J), eng_mod=eng_mod, sm=sm)
 
 
@@ -191,6 +198,8 @@ def _tiles_engine(v, B, extra=0):
     assert on == listable, (v['name'], on, n)
     if on:
         assert 0 < n <= min(216, sum(counts)), (n, counts)        # at most one tile per support entry
+    if v['name'].startswith('hinted'):                            # the support was stored first, a few tiles of <= 8 joints each
+        assert on and n <= 4 * ((v['dm'].info['hinted_vertices_stored_first'] + 31) // 32), (n, v['dm'].info)
     return eng, on
 
 
@@ -254,7 +263,7 @@ def test_support_tiles_with_j_steps_equal_the_all_tiles_run(variant, every):
 
 def test_support_tiles_batch_4096_strided_subset_vs_oracle(variant):
     v = variant
-    if v['name'] not in ('default', 'capsules', 'wide13', 'skin12'):
+    if v['name'] not in ('default', 'capsules', 'wide13', 'skin12', 'hinted'):
         pytest.skip('the benchmarked size on the variants that differ in the listed kernels')
     B, sub = 4096, slice(5, 4096, 128)
     batch = v['sm'].synthetic_batch(v['model'], v['J'], B, seed=63)

@@ -19,10 +19,13 @@ model = sm.synthetic_smpl(1234)
 J_np = sm.default_h36m_regressor()
 batch = sm.synthetic_batch(model, J_np, B, seed=5)
 dm = em.DeviceModel(model, dev)
+import numpy as np
+dm_hint = em.DeviceModel(model, dev, hint_vertices=np.nonzero((J_np > 0).any(0))[0])
+print('hinted model', dm_hint.info)
 disc = torch.randn(em.DISC_PARAMS if hasattr(em, 'DISC_PARAMS') else 1840153, device=dev) * 0.02
 res = {}
-for name, fl in (('dense', 0), ('tiles', em.FLAG_SUPPORT_TILES)):
-    eng = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS | em.FLAG_POSE_DISC | fl)
+for name, fl in (('dense', 0), ('tiles', em.FLAG_SUPPORT_TILES), ('hinted', em.FLAG_SUPPORT_TILES)):
+    eng = em.RefineEngine(dm_hint if name == 'hinted' else dm, B, flags=em.FLAG_KEEP_VERTS | em.FLAG_POSE_DISC | fl)
     J = torch.from_numpy(J_np).to(dev).clone()
     eng.set_j_regressor(J)
     eng.set_pose_disc(disc)
@@ -48,6 +51,7 @@ for name, fl in (('dense', 0), ('tiles', em.FLAG_SUPPORT_TILES)):
     eng.refine_run(x, b, gt, m, v, st, 1e-2, 10)
     print(name, {k: round(t, 4) for k, (t, n) in eng.profile_read().items() if n})
     eng.set_profiling(False)
-for i, k in enumerate(('x6d', 'betas', 'J')):
-    d = (res['dense'][i] - res['tiles'][i]).abs()
-    print(k, 'max abs diff', d.max().item(), 'mean', d.mean().item())
+for other in ('tiles', 'hinted'):
+    for i, k in enumerate(('x6d', 'betas', 'J')):
+        d = (res['dense'][i] - res[other][i]).abs()
+        print(other, k, 'max abs diff', d.max().item(), 'mean', d.mean().item())
