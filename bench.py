@@ -693,6 +693,8 @@ def main():
                    'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in regions],
                    'host_calls_per_region': 'one C call (jrr_refine_run_j_steps)' if dist is None else 'refine_run + j_regressor_grad + all_reduce + j_step_apply per J step',
                    'forward_reuse_after_j_step': False,
+                   'vertex_tiles': 'all 216 (every iteration skins all 6890 vertices; the iteration restricted to the tiles of the '
+                                   'regressor\'s support -- what optimize.py runs by default -- is the separate block `support_tiles`)',
                    'geometry': dict(eng.info, **dmodel.info)},
         'collective': collective,
         'roofline': {'bound': 'mfma', 'kernel': 'k_lbs_fwd<true,false>', 'achieved': round(achieved, 2),
