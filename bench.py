@@ -225,7 +225,7 @@ def main():
     if world != a.gpus:
         raise SystemExit(f'bench.py: --gpus {a.gpus} but the launcher started {world} rank(s)')
     if not torch.cuda.is_available():
-        raise SystemExit('bench.py needs an MI355X (the HIP path has no CPU fallback)')
+        raise SystemExit(f'bench.py needs an MI355X (the HIP path has no CPU fallback) [rank {rank} of {world}]')
     if a.single_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
