@@ -628,7 +628,9 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_disc_gemm(GemmArgs g
 #pragma unroll
         for (int u = 0; u < 4; ++u) v[u] = (v[u] > 0.f) ? 1.f : 0.f;
       }
-      reinterpret_cast<f32x4*>(g.Out)[qi] = v;
+      // streamed: the next launch reads it from the Infinity Cache either way, and what is written through during the launch is not
+      // left for the write-back at its end (measured: the four GEMMs 0.2596 -> 0.2553 ms)
+      __builtin_nontemporal_store(v, &reinterpret_cast<f32x4*>(g.Out)[qi]);
     }
   if (EPI == EPI_BIAS_RELU_DOT) {      // rows of the two lane halves are disjoint: add them, one store per column
     const float t = dot + __shfl_xor(dot, 32);
