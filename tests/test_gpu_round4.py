@@ -282,6 +282,30 @@ def test_support_tiles_batch_4096_strided_subset_vs_oracle(variant):
     assert d.max().item() < 6e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
 
 
+def test_vertex_order_hint_is_invisible_at_the_api(smpl_model_np, j_h36m_np):
+    """jrr_model_create_hinted only changes the library's INTERNAL vertex order: vertices come back in the file's order and equal
+    the un-hinted model's (same per-vertex arithmetic), joints to rounding (another order of the sum over the vertices); duplicate
+    hint entries are ignored, an index outside the mesh is refused"""
+    sm, em = _mod('smpl_model'), _mod('engine')
+    hint = np.nonzero((j_h36m_np > 0).any(0))[0]
+    plain = em.DeviceModel(smpl_model_np, DEV)
+    hinted = em.DeviceModel(smpl_model_np, DEV, hint_vertices=np.concatenate([hint, hint[:7]]))
+    assert hinted.info['hinted_vertices_stored_first'] == len(hint) and plain.info['hinted_vertices_stored_first'] == 0
+    with pytest.raises(Exception):
+        em.DeviceModel(smpl_model_np, DEV, hint_vertices=np.array([3, 6890]))
+    B = 33
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=77)
+    xd, bd = T(batch['pose6d']).to(DEV).contiguous(), T(batch['betas']).to(DEV).contiguous()
+    outs = []
+    for dm in (plain, hinted):
+        eng = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS)
+        eng.set_j_regressor(T(j_h36m_np))
+        outs.append(eng.find_joints_forward(bd, x6d=xd, return_verts=True))
+    (j0, v0), (j1, v1) = outs
+    assert (v0 - v1).abs().max().item() < 2e-6
+    assert (j0 - j1).abs().max().item() < 2e-6
+
+
 # ---- forward reuse after a J step where BP is an odd multiple of 128 ---------------------------------------------------------
 @pytest.mark.parametrize('B', [300, 600])
 def test_forward_reuse_after_j_step_at_odd_multiples_of_128(smpl_model_np, j_h36m_np, B):
