@@ -1590,11 +1590,12 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
   if (m.kjs && m.bwd16) {                       // four symmetric waves of 16 poses: one workgroup per (64 poses, vertex chunk)
     const int n_bt16 = BP / 64;
     dim3 grid16(n_bt16 * nvc), block16(256);
-    // JRR_BWD16_PAIRED (experiments): share of the first-dispatched workgroup of a CU in thousandths (default 520: round 4, with
+    // JRR_BWD16_PAIRED (experiments): share of the first-dispatched workgroup of a CU in thousandths (default 540 since the slab flush
+    // reads back in one batch: 0.1777 ms against 0.1797 at 520, 0.1782 at 560; before that 520: round 4, with
     // the non-temporal streams -- 0.1797 ms against 0.1815 at 480, 0.186 at 560; shader-clock stamps: the first-dispatched workgroup's
     // tiles take ~12 300 clocks, its partner's ~14 000 while both run and 7 400 once it is alone), 0 = no
     // pairing, -2 = chunk-major mapping without pairing
-    static const int pair_env = [] { const char* e = getenv("JRR_BWD16_PAIRED"); return e ? atoi(e) : 520; }();
+    static const int pair_env = [] { const char* e = getenv("JRR_BWD16_PAIRED"); return e ? atoi(e) : 540; }();
     const int paired16 = (pair_env > 0) ? ((grid16.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? pair_env : 0) : pair_env;
 #define JRR_LBS_BWD16_K(DVM, KJV, WD)                                                                                           \
   hipLaunchKernelGGL((k_lbs_bwd16<DVM, KJV, WD>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, \
