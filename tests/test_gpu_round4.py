@@ -261,6 +261,34 @@ def test_support_tiles_with_j_steps_equal_the_all_tiles_run(variant, every):
     assert torch.equal(Ja != T(v['J']), Jt != T(v['J']))
 
 
+@pytest.mark.parametrize('B', [1, 37])
+def test_support_tiles_ragged_batches_vs_oracle(smpl_model_np, j_h36m_np, B):
+    """batches far below one pose group (padded to 128 columns): three listed iterations + a J step against the oracle, on the body
+    uploaded with the vertex-order hint (what optimize.py does)"""
+    sm, em = _mod('smpl_model'), _mod('engine')
+    dm = em.DeviceModel(smpl_model_np, DEV, hint_vertices=np.nonzero((j_h36m_np > 0).any(0))[0])
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=90 + B)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    o, p, b_, _ = oracle.refine_poses(smpl, T(j_h36m_np), x6[:, :1], x6[:, 1:], betas, gt_c, 3)
+    eng = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS | em.FLAG_SUPPORT_TILES)
+    J = T(j_h36m_np).to(DEV).clone()
+    eng.set_j_regressor(J)
+    assert eng.j_support_info()[1] and eng.support_tiles()[0]
+    xd, bd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous()
+    m, vv, step = _fresh_state(B)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, vv, step, 1e-2, 3)
+    d = (xd.cpu() - torch.cat([o, p], 1)).abs()
+    assert d.max().item() < 6e-4 and d.mean().item() < 1e-5, (d.max().item(), d.mean().item())
+    assert (bd.cpu() - b_).abs().max().item() < 3e-4
+    # the J step's gradient on the refined poses (listed forward), against the oracle on the same poses
+    _, dJ_ref, _ = oracle.j_regressor_loss_and_grad(smpl, T(j_h36m_np), xd.cpu()[:, :1], xd.cpu()[:, 1:], bd.cpu(), gt_c)
+    dJ = eng.j_regressor_grad(xd, bd, gt_c.to(DEV).contiguous())
+    assert _relerr(dJ, dJ_ref) < 5e-4
+    assert torch.equal(dJ.cpu() != 0, dJ_ref != 0)
+
+
 def test_support_tiles_batch_4096_strided_subset_vs_oracle(variant):
     v = variant
     if v['name'] not in ('default', 'capsules', 'wide13', 'skin12', 'hinted'):
