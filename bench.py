@@ -541,6 +541,20 @@ def main():
         if tiles:
             on, nt = e2.support_tiles()
             out_['vertex_tiles'] = {'run': nt, 'of': 216, 'restricted_to_regressor_support': on}
+            # ... and with a J step (+ forward reuse) after EVERY iteration, one C call (BASELINE configs[3]'s pattern on this engine)
+            Jc = J.clone()
+            Jm2, Jv2, Js2 = torch.zeros_like(Jc), torch.zeros_like(Jc), torch.zeros(1, dtype=torch.int32, device=dev)
+            e2.set_j_regressor(Jc)
+            e2.j_support_info()
+
+            def go1(n, _c):
+                e2.refine_run_j_steps(fx, fb, fgt, fm, fv, fstep, 1e-2, n, 1, Jc, Jm2, Jv2, Js2, 1e-2, reuse_forward=True)
+                return n
+            timed_region(a.steps, 0, go1)
+            c1t = statistics.median([timed_region(a.steps, 0, go1)[0] for _ in range(3)])
+            out_['cadence1_ms_per_step'] = round(c1t / a.steps * 1e3, 4)
+            e2.set_j_regressor(J)
+            e2.j_support_info()
         if setup is silhouette_setup or Bs != B or tiles:
             e2.set_profiling(True)
             e2.refine_run(fx, fb, fgt, fm, fv, fstep, 1e-2, max(2, min(a.steps, 10)))
