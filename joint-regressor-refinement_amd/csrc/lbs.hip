@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     // wins the issue arbitration and would finish ~20 % earlier, leaving its partner alone (one wave per SIMD) for
     // the tail (measured with per-workgroup s_memrealtime stamps).  So the two workgroups of a CU
     // -- dispatch slots j and j + per_xcd/2 of an XCD -- share one PAIR of vertex chunks of the same pose group and
-    // the first one takes 5/9 of the pair's tiles (15 : 12 at B = 4096).  Static, hence still bitwise reproducible;
+    // the first one takes the larger share of the pair's tiles (16 : 11 at B = 4096, launcher).  Static, hence still bitwise reproducible;
     // if the hardware paired differently the split would merely be uneven.
     const int per_xcd = gridDim.x >> 3, xcd = blockIdx.x & 7, j = blockIdx.x >> 3;
     const int p = j % (per_xcd / 2), slot = j / (per_xcd / 2);
@@ -1544,7 +1544,7 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
   dim3 grid((BP / BG) * nvc), block(256);
   if (tl && !(m.kjs && VPb)) { jrr_set_error("lbs_fwd: the tile list serves the joint-sparse kernels with v_posed kept"); return JRR_ERR_ARG; }
   // exactly one round of two workgroups per CU, an even number of chunks and whole pose groups per XCD
-  static const int fwd_split = [] { const char* e = getenv("JRR_FWD_SPLIT"); return e ? atoi(e) : 556; }();   // 5/9 (15 : 12 tiles at B = 4096)
+  static const int fwd_split = [] { const char* e = getenv("JRR_FWD_SPLIT"); return e ? atoi(e) : 593; }();   // 16 : 11 tiles at B = 4096 (re-swept late in round 4: 0.3613 ms against 0.3633 at 15 : 12 and 0.3630 at 17 : 10)
   const int paired = (grid.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? fwd_split : 0;
 #define JRR_LBS_FWD_K(SVP, SVT, KJV, WD, WT)                                                                                      \
   hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, KJV, WD>), grid, block, 0, s, m.Dk, WT, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe,  \
