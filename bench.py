@@ -411,6 +411,7 @@ def main():
     # ---- the same cadence through the call sequence N > 1 ranks execute (host-driven segments, the support-sized payload, a
     #      no-op in place of the collective at world size 1): bounds the multi-GPU cadence-1 cost before any 8-GPU box sees it ----
     c1h_el, c1h_regions, c1r = None, [], None
+    rccl_hung = [False]
     if dist is None:
         run_c1h = lambda n, c: run_host_driven(n, c, reuse=True)      # noqa: E731
         it_count[0] = 0
@@ -429,21 +430,44 @@ def main():
             os.dup2(2, 1)
             try:
                 import socket
+                import threading
                 import torch.distributed as tdist
                 with socket.socket() as so:
                     so.bind(('127.0.0.1', 0))
                     port = so.getsockname()[1]
-                tdist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
-                keep = xch.reduce
-                xch.reduce = lambda t: tdist.all_reduce(t)
-                it_count[0] = 0
-                timed_region(a.steps, 1, run_c1h)
-                c1r_regions = [timed_region(a.steps, 1, run_c1h)[0] for _ in range(5)]
-                xch.reduce = keep
-                torch.cuda.synchronize()
-                tdist.destroy_process_group()
-                c1r = {'ms_per_step': round(statistics.median(c1r_regions) / a.steps * 1e3, 4),
-                       'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1r_regions], 'backend': 'nccl (RCCL), one rank'}
+                up = {}
+
+                def bring_up():      # the part that talks to the outside (bootstrap sockets): under a watchdog, so that a box whose
+                    try:             # RCCL cannot start costs this block, not the bench line
+                        torch.cuda.set_device(dev)
+                        tdist.init_process_group('nccl', init_method=f'tcp://127.0.0.1:{port}', rank=0, world_size=1, device_id=dev)
+                        t0_ = torch.zeros(8, device=dev)
+                        tdist.all_reduce(t0_)
+                        torch.cuda.synchronize()
+                        up['ok'] = True
+                    except Exception as ex_:      # noqa: BLE001
+                        up['err'] = repr(ex_)[:200]
+                th = threading.Thread(target=bring_up, daemon=True)
+                th.start()
+                th.join(90.0)
+                if th.is_alive():
+                    rccl_hung[0] = True
+                    c1r = {'ms_per_step': None, 'error': 'the one-rank RCCL group did not come up within 90 s'}
+                elif 'err' in up:
+                    c1r = {'ms_per_step': None, 'error': up['err']}
+                else:
+                    keep = xch.reduce
+                    xch.reduce = lambda t: tdist.all_reduce(t)
+                    try:
+                        it_count[0] = 0
+                        timed_region(a.steps, 1, run_c1h)
+                        c1r_regions = [timed_region(a.steps, 1, run_c1h)[0] for _ in range(5)]
+                    finally:
+                        xch.reduce = keep
+                    torch.cuda.synchronize()
+                    tdist.destroy_process_group()
+                    c1r = {'ms_per_step': round(statistics.median(c1r_regions) / a.steps * 1e3, 4),
+                           'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1r_regions], 'backend': 'nccl (RCCL), one rank'}
             except Exception as ex:      # the bench line survives a box whose RCCL cannot start
                 c1r = {'ms_per_step': None, 'error': repr(ex)[:200]}
             finally:
@@ -814,6 +838,9 @@ def main():
                                          f'iteration at batch {B} itself, `config1_forward_b4` = BASELINE configs[0]',
                                'variants': variants}
     print(json.dumps(out))
+    if rccl_hung[0]:      # a bootstrap thread is still stuck inside RCCL: leave without waiting for it
+        sys.stdout.flush()
+        os._exit(0)
     if dist is not None:
         dist.destroy_process_group()
 
