@@ -88,7 +88,8 @@ def pytest_collection_finish(session):
     for name, cmd in runs.items():
         try:
             run_env = dict(env, JRR_DIST_SINGLE_RANK='1') if name.endswith('_1rank') else env
-            r = subprocess.run(cmd, env=run_env, cwd=ROOT, capture_output=True, text=True, timeout=1500)
+            # (the RCCL bring-up is the one step that talks to the box's network stack: bounded tightly)
+            r = subprocess.run(cmd, env=run_env, cwd=ROOT, capture_output=True, text=True, timeout=300 if name.endswith('_1rank') else 1500)
             DP_RUNS[name] = dict(rc=r.returncode, out=r.stdout, err=r.stderr[-4000:])
         except subprocess.TimeoutExpired as e:
             DP_RUNS[name] = dict(rc=-999, out=str(e.stdout)[-2000:], err='timeout: ' + str(e.stderr)[-2000:])
