@@ -120,3 +120,39 @@ def test_k8_two_independent_restatements_agree(smpl_model_np):
         verts, _ = oracle.smpl_lbs(m, R, betas)
         ref = sm._lbs_np(body, R.numpy(), betas.numpy())
         assert np.abs(verts.numpy() - ref).max() < 1e-9
+
+
+def test_k9_joint_loss_reads_the_vertices_through_the_regressor_support_only(smpl_model_np, j_h36m_np):
+    """What JRR_FLAG_SUPPORT_TILES rests on, stated on the REFERENCE algorithm (scripts/utils.py:85-103, scripts/optimize.py:228-239):
+    pred_joints = normalise(relu(J * mask)) @ vertices, so (a) the joints -- hence every loss term of configs 2-4 and every gradient --
+    do not change by one bit when the vertices OUTSIDE the regressor's positive columns are replaced by anything finite, and (b) the
+    gradient of the joint loss w.r.t. the vertices is exactly zero there.  62 positive entries on 58 vertices for the shipped
+    checkpoint's structure: the other 6832 vertices of a joint-loss iteration are computed for nothing."""
+    B = 3
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    J = T(j_h36m_np)
+    support = (J > 0).any(0)
+    assert int(support.sum()) == 58 and int((J > 0).sum()) == 62
+    g = torch.Generator().manual_seed(11)
+    x6 = torch.randn(B, 24, 6, generator=g)
+    betas = torch.randn(B, 10, generator=g)
+    R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(B, 24, 3, 3)
+    gt = torch.randn(B, 17, 3, generator=g)
+
+    class Perturbed:
+        def __call__(self, **kw):
+            out = smpl(**kw)
+            v = out.vertices.clone()
+            v[:, ~support] = torch.randn(B, int((~support).sum()), 3, generator=g) * 100.0      # anything finite
+            return oracle.SMPLOutput(vertices=v, joints=out.joints)
+    mask = oracle.find_j_reg_mask(J)
+    ja = oracle.find_joints(smpl, betas, R[:, :1], R[:, 1:], J, mask)
+    jb = oracle.find_joints(Perturbed(), betas, R[:, :1], R[:, 1:], J, mask)
+    assert torch.equal(ja, jb)
+    # (b) d(joint loss) / d(vertices) is exactly zero outside the support
+    _, verts = oracle.find_joints(smpl, betas, R[:, :1], R[:, 1:], J, mask, return_verts=True)
+    v = verts.detach().clone().requires_grad_(True)
+    joints = torch.matmul(oracle.normalize_j_regressor(J, mask)[None].expand(B, -1, -1), v)
+    loss = ((oracle.move_pelvis(joints) - gt) ** 2).mean()
+    loss.backward()
+    assert (v.grad[:, ~support] == 0).all() and (v.grad[:, support] != 0).any()
