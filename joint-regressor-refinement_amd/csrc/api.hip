@@ -845,15 +845,16 @@ extern "C" int jrr_rodrigues_backward(const float* aa, const float* dR, float* d
 // them (small batches: 16 slabs at 1024 poses, where k_chain_bwd has only 32 blocks to sum them with).
 constexpr int MAX_SLABS_IN_CONSUMER = 8;
 // conv_x6d != NULL (fused loop with the pose discriminator): the per-joint MLP adjoint shares the launch of the dF^T sum.
-static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s, const float* conv_x6d = nullptr, float dscale = 0.f) {
+static void reduce_adjoint_partials(jrr_engine* e, hipStream_t s, const float* conv_x6d = nullptr, float dscale = 0.f, int nsplit = 0) {
+  if (nsplit <= 0) nsplit = e->nsplit;      // (the support-tile iterations split the blend adjoint's short K range fewer ways)
   if (conv_x6d)
-    launch_dconv_bwd_reduce(e->convL, conv_x6d, e->dH2T, nullptr, dscale, 1.f, e->gx, e->dsq, e->B, e->BP, e->dFTp, e->nsplit,
+    launch_dconv_bwd_reduce(e->convL, conv_x6d, e->dH2T, nullptr, dscale, 1.f, e->gx, e->dsq, e->B, e->BP, e->dFTp, nsplit,
                             (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
   else if (e->nvcb > MAX_SLABS_IN_CONSUMER) {      // both slab sums in one launch
-    launch_reduce_slabs2(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, e->dATp, e->nvcb, (size_t)12 * NJ * e->BP, e->dA,
+    launch_reduce_slabs2(e->dFTp, nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, e->dATp, e->nvcb, (size_t)12 * NJ * e->BP, e->dA,
                          (size_t)12 * NJ * e->BP, s);
     return;
-  } else launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
+  } else launch_reduce_slabs(e->dFTp, nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
   if (e->nvcb > MAX_SLABS_IN_CONSUMER)
     launch_reduce_slabs(e->dATp, e->nvcb, (size_t)12 * NJ * e->BP, e->dA, (size_t)12 * NJ * e->BP, s);
 }
@@ -891,8 +892,8 @@ extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const 
   return JRR_OK;
 }
 
-static int blend_adjoint_gemm(jrr_engine* e, hipStream_t s, const int* tl = nullptr, int ntl = 0) {
-  return launch_blend_adjoint(e->m.Dq, e->DVP, e->dFTp, (size_t)KFP * e->BP, e->BP, e->nsplit, s, tl, ntl);
+static int blend_adjoint_gemm(jrr_engine* e, hipStream_t s, const int* tl = nullptr, int ntl = 0, int nsplit = 0) {
+  return launch_blend_adjoint(e->m.Dq, e->DVP, e->dFTp, (size_t)KFP * e->BP, e->BP, nsplit > 0 ? nsplit : e->nsplit, s, tl, ntl);
 }
 // the joint-loss iteration on the regressor's support tiles only (JRR_FLAG_SUPPORT_TILES)
 static bool use_tile_list(const jrr_engine* e) {
@@ -1386,6 +1387,11 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     const bool listed = use_tile_list(e);
     const int* tl = listed ? e->act_list : nullptr;
     const int ntl = listed ? e->nact : 0;
+    // split-K of the blend adjoint: its K range is 6 chunks per listed tile -- at least JRR_ADJ_CHUNKS (6) chunks per split, so that a
+    // handful of tiles does not leave 16 slabs of 3.7 MB (at 4096 poses) for the slab sum to read (6 tiles, 4096 poses: 6 splits
+    // 0.3575 ms per iteration, 16 splits 0.3623, 4 splits 0.3618, 2 splits 0.377)
+    static const int adj_chunks = [] { const char* v = getenv("JRR_ADJ_CHUNKS"); return v ? std::max(1, atoi(v)) : 6; }();
+    const int ns_adj = listed ? std::max(1, std::min(e->nsplit, (6 * ntl + adj_chunks - 1) / adj_chunks)) : 0;
     // The J step that preceded this call ran the SMPL forward on exactly these poses (jrr_j_regressor_grad keeps
     // v_posed, the skinning transforms and the vertices): the first iteration re-regresses the joints with the NEW
     // regressor from the stored vertices instead of repeating the 0.47 ms forward (jrr_refine_run_after_j_step).
@@ -1451,7 +1457,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       g.bias = nullptr; g.mask = nullptr; g.split_stride = (size_t)KFP * e->BP; g.M = KFP; g.N = e->BP; g.K = FOLD_M;
       rc = launch_gemm_224(g, EPI_STORE, e->nsplit, s);
     } else {
-      rc = blend_adjoint_gemm(e, s, tl, ntl);
+      rc = blend_adjoint_gemm(e, s, tl, ntl, ns_adj);
     }
     prof_mark(e, 4, s);
     if (rc) return rc;
@@ -1470,7 +1476,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     }
     prof_mark(e, 7, s);
     if (folded) launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
-    else reduce_adjoint_partials(e, s, pd ? x6d : nullptr, dscale);
+    else reduce_adjoint_partials(e, s, pd ? x6d : nullptr, dscale, ns_adj);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.betas_in = betas;
     if (folded) { L.dATp = e->dA; L.dFTp = e->dF; } else set_adjoint_slabs(e, L);
