@@ -1391,7 +1391,8 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     // handful of tiles does not leave 16 slabs of 3.7 MB (at 4096 poses) for the slab sum to read (6 tiles, 4096 poses: 6 splits
     // 0.3575 ms per iteration, 16 splits 0.3623, 4 splits 0.3618, 2 splits 0.377)
     static const int adj_chunks = [] { const char* v = getenv("JRR_ADJ_CHUNKS"); return v ? std::max(1, atoi(v)) : 6; }();
-    const int ns_adj = listed ? std::max(1, std::min(e->nsplit, (6 * ntl + adj_chunks - 1) / adj_chunks)) : 0;
+    // (and never fewer than ~128 workgroups in the launch: small batches have few 128-pose tiles)
+    const int ns_adj = listed ? std::max(1, std::min(e->nsplit, std::max((6 * ntl + adj_chunks - 1) / adj_chunks, (128 * 128 + e->BP - 1) / e->BP))) : 0;
     // The J step that preceded this call ran the SMPL forward on exactly these poses (jrr_j_regressor_grad keeps
     // v_posed, the skinning transforms and the vertices): the first iteration re-regresses the joints with the NEW
     // regressor from the stored vertices instead of repeating the 0.47 ms forward (jrr_refine_run_after_j_step).
