@@ -47,6 +47,8 @@ FLOP_LBS_FWD_PER_POSE = 2 * 20670 * 10 + 2 * 207 * 20670 + 2 * 6890 * 24 * 12 + 
 FLOP_LBS_BWD_PER_POSE = 2 * 17 * 6890 * 3 + 2 * 6890 * 24 * 9 + 2 * 6890 * 9 + 2 * 6890 * 24 * 12   # dverts, T, dvp, dA
 FLOP_BLEND_ADJ_PER_POSE = 2 * 217 * 20670                                                             # dF = D . dvp
 FLOP_DISC_PER_POSE = 2 * 2 * (24 * (192 + 1024) + 786432 + 1048576 + 1024 + 768)                     # fwd + input-grad
+FLOP_DISC_GEMMS_PER_POSE = 2 * 2 * (786432 + 1048576)      # what the four k_disc_gemm launches execute (fc0, fc2, their input adjoints); the
+#                                                            per-joint MLP and the heads run in k_prep_fwd_dconv / k_dconv_bwd_reduce
 # Joint-sparse skinning (engine info `joint_sparse`): every SMPL vertex has <= 4 skinning influences and a
 # tile of 32 consecutive vertices few joints in total, so the skinning products run over the tile's own joint SLOTS instead of 24.
 # ONE rule for every roofline figure of this file: the FLOP of the formulation that actually RUNS -- multiplications the kernels
@@ -101,6 +103,8 @@ def parse():
     ap.add_argument('--no_support_tiles', action='store_true', help='skip the side run restricted to the vertex tiles of the regressor\'s support')
     ap.add_argument('--no_skin_variants', action='store_true',
                     help='skip the separately reported 12-joint / dense skinning runs (what a body model with a less coherent vertex order runs)')
+    ap.add_argument('--no_driver_blocks', action='store_true',
+                    help='skip `driver_outer_batch` / `reference_default` (the real optimize_pose_refiner() timed per outer batch)')
     ap.add_argument('--no_rccl_one_rank', action='store_true', help='skip the cadence-1 host-driven run whose all-reduce is executed by a one-rank RCCL group')
     ap.add_argument('--backend', type=str, default='nccl', help='torch.distributed backend (nccl = RCCL); gloo for debugging')
     ap.add_argument('--single_device', action='store_true',
@@ -159,8 +163,10 @@ def cpu_baseline(model_np, J_np, batch_np, disc_sd, B, budget_s, use_disc, B_ful
                 'smpl_evals_per_iter': evals, 'batch': B}
 
     ncpu = os.cpu_count() or 1
+    phys = physical_cores() or ncpu
     best_t, best_n = None, 1
-    for nt in sorted({min(ncpu, n) for n in (8, 16, 32, 64)}):
+    sweep = sorted({min(ncpu, n) for n in (8, 16, 32, 64, 128, phys, ncpu) if n <= max(phys, 8) or n == phys})
+    for nt in sweep:
         torch.set_num_threads(nt)
         run(1)
         dt = run(1)
@@ -188,7 +194,22 @@ def cpu_baseline(model_np, J_np, batch_np, disc_sd, B, budget_s, use_disc, B_ful
     dt4 = time.perf_counter() - t0
     out['config1_forward_b4'] = {'evals_per_s': round(n4 / dt4, 2), 'ms_per_eval': round(dt4 / n4 * 1e3, 3), 'batch': 4,
                                  'threads': best_n, 'workload': 'BASELINE configs[0]: SMPL forward + J_regressor eval, batch 4'}
+    out['thread_sweep'] = {'tried': sweep, 'physical_cores': phys, 'logical_cpus': ncpu, 'picked': best_n}
     return out, best_n
+
+
+def physical_cores():
+    """distinct (physical id, core id) pairs of /proc/cpuinfo (SMT siblings counted once)"""
+    try:
+        cores, pid = set(), None
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('physical id'):
+                pid = line.split(':', 1)[1].strip()
+            elif line.startswith('core id'):
+                cores.add((pid, line.split(':', 1)[1].strip()))
+        return len(cores) or None
+    except OSError:
+        return None
 
 
 def self_launch(a):
@@ -357,12 +378,16 @@ def main():
         if dist is not None:
             dist.barrier()
 
+    own_times = []      # this rank's OWN time to finish each timed region (before the closing barrier): the per-rank spread of the line
+
     def timed_region(n, cadence, fn=None):
         """EXACTLY n steps between barrier + synchronize pairs; max over ranks"""
         barrier(); torch.cuda.synchronize()
         t0 = time.perf_counter()
         nj = (fn or run)(n, cadence)
-        torch.cuda.synchronize(); barrier()
+        torch.cuda.synchronize()
+        own_times.append(time.perf_counter() - t0)
+        barrier()
         el = time.perf_counter() - t0
         if dist is not None:
             t = torch.tensor([el], device=dev, dtype=torch.float64)
@@ -385,6 +410,7 @@ def main():
     timed_region(max(a.steps, cadence), cadence)  # untimed: loads the code objects of the J step path (holds >= 1 J step)
     it_count[0] = 0
     regions, region_nj = [], []
+    del own_times[:]
     el, nj0 = timed_region(a.steps, cadence)
     regions.append(el); region_nj.append(nj0)
     # whole cadences: the timed regions together hold the reference's share of J steps exactly (1 per `cadence` iterations)
@@ -397,6 +423,11 @@ def main():
     # `value`: every timed step over every timed second (the J steps amortised at the reference cadence)
     elapsed = sum(regions) / len(regions)
     nj_region = sum(region_nj)
+    own_ms = sum(own_times) / len(own_times) / a.steps * 1e3     # this rank alone, mean over the headline's regions
+    per_rank_ms = [own_ms]
+    if dist is not None:
+        per_rank_ms = [None] * world
+        dist.all_gather_object(per_rank_ms, own_ms)
     loss_joint = float(sq.sum().item()) / (B * 51)
 
     # ---- BASELINE configs[3] "all-reduce on the J_regressor gradient EACH step": J step after every iteration,
@@ -408,6 +439,56 @@ def main():
     for _ in range(max(4, min(repeats_for(c1_regions[0]), 10) - 1)):
         c1_regions.append(timed_region(a.steps, 1, run_c1)[0])
     c1_el = statistics.median(c1_regions)
+    # ---- N > 1: what the collective itself costs.  (a) stand-alone all-reduces of the three payloads of this path (median of 50 after
+    #      a warm-up; barrier + synchronize around each one, max over ranks is what the slowest rank sees); (b) the cadence-1 regions
+    #      again with a no-op in place of the all-reduce (each rank steps J with its local gradient: timing only, J restored after) ----
+    collective_cost = None
+    if dist is not None:
+        def ar_time(nfloats):
+            buf = torch.zeros(nfloats, device=dev)
+            for _ in range(5):
+                dist.all_reduce(buf)
+            ts = []
+            for _ in range(50):
+                torch.cuda.synchronize(); dist.barrier()
+                t0 = time.perf_counter()
+                dist.all_reduce(buf)
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter() - t0)
+            t = torch.tensor([statistics.median(ts)], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            # ... and 20 back to back in the stream (what a loop that does not synchronise per step pays)
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(20):
+                dist.all_reduce(buf)
+            torch.cuda.synchronize()
+            t2 = torch.tensor([(time.perf_counter() - t0) / 20], device=dev, dtype=torch.float64)
+            dist.all_reduce(t2, op=dist.ReduceOp.MAX)
+            return {'bytes': nfloats * 4, 'median_us_synchronised': round(float(t.item()) * 1e6, 1), 'us_back_to_back': round(float(t2.item()) * 1e6, 1)}
+        opt_mod = importlib.import_module(PKG + '.optimize')
+        n_bucket = opt_mod.SharedBucket(dev, True, False, 10).flat.numel()
+        collective_cost = {'standalone_allreduce': {'j_step_support_17x128': ar_time(17 * 128), 'j_step_dense_17x6890': ar_time(17 * 6890),
+                                                    'outer_step_flat_bucket': ar_time(n_bucket)}}
+        keepJ = [t.clone() for t in (J, Jm, Jv, Jstep)]
+        keep_reduce = xch.reduce
+        xch.reduce = lambda t: t
+        try:
+            it_count[0] = 0
+            timed_region(a.steps, 1, run_c1)
+            noop_regions = [timed_region(a.steps, 1, run_c1)[0] for _ in range(5)]
+        finally:
+            xch.reduce = keep_reduce
+            for dst, src in zip((J, Jm, Jv, Jstep), keepJ):
+                dst.copy_(src)
+            eng.set_j_regressor(J)
+            eng.j_support_info()
+            after_j[0] = False
+        noop_ms = statistics.median(noop_regions) / a.steps * 1e3
+        collective_cost.update({'cadence1_ms_per_step': round(c1_el / a.steps * 1e3, 4), 'cadence1_noop_collective_ms_per_step': round(noop_ms, 4),
+                                'collective_us_per_step': round((c1_el / a.steps * 1e3 - noop_ms) * 1e3, 1),
+                                'note': 'cadence-1 iteration (J step + all-reduce after every iteration) minus its twin with a no-op in place of '
+                                        'the all-reduce = what the collective costs in the loop, launch + wait for the slowest rank included'})
     # ---- the same cadence through the call sequence N > 1 ranks execute (host-driven segments, the support-sized payload, a
     #      no-op in place of the collective at world size 1): bounds the multi-GPU cadence-1 cost before any 8-GPU box sees it ----
     c1h_el, c1h_regions, c1r = None, [], None
@@ -419,9 +500,14 @@ def main():
         c1h_regions = [timed_region(a.steps, 1, run_c1h)[0] for _ in range(5)]
         c1h_el = statistics.median(c1h_regions)
         after_j[0] = False
-        # ... and with the collective EXECUTED: a one-rank RCCL group on this GPU (a sum over one rank is the identity; what is timed
-        # is RCCL's own enqueue + kernel on the 8 704-byte device buffer between the two halves of every J step)
-        if not a.no_rccl_one_rank and a.backend == 'nccl':
+
+    def rccl_one_rank_block():
+        """cadence-1 host-driven regions with the collective EXECUTED: a one-rank RCCL group on this GPU (a sum over one rank is the
+        identity; what is timed is RCCL's own enqueue + kernel on the 8 704-byte device buffer between the two halves of every J step).
+        Runs LAST, after every other measurement and the CPU baseline: if the bring-up hangs, nothing else shares the GPU with a
+        half-initialised communicator, the line is printed with the error and the process exits non-zero (status 3)."""
+        c1r = None
+        if dist is None and not a.no_rccl_one_rank and a.backend == 'nccl':
             # (RCCL prints a version banner through C stdio on stdout: this program's stdout is ONE JSON line, so fd 1 points at
             # stderr while the group lives, and C stdio is flushed before it is restored)
             import ctypes
@@ -478,6 +564,8 @@ def main():
                 os.dup2(fd1, 1)
                 os.close(fd1)
             after_j[0] = False
+
+        return c1r
 
     # ---- the inner iteration ALONE (no J step in the region, no forward reuse): the denominator of roofline.whole_step ----
     def run_inner(n, _cadence):
@@ -678,6 +766,53 @@ def main():
             skin_variants[name] = r
             del mdl
 
+    # ---- the ENTRY POINT, per outer batch (/root/reference/scripts/optimize.py:144-337 is one call of optimize_pose_refiner() per run:
+    #      H->D copy, [camera pre-fit], 100 inner iterations, D updates, J step, two evaluations, a log record).  The real driver of the
+    #      package on synthetic batches; the first batch (engine set-up, code-object loads) is discarded ----
+    def driver_run(batch, extra, n_batches=3, inner=100):
+        argsmod = importlib.import_module(PKG + '.args')
+        argsmod._LazyArgs._ns = argsmod.get_args(['--batch_size', str(batch), '--synthetic_batches', str(n_batches), '--inner_iters', str(inner),
+                                                   '--synthetic', '--device', str(dev), '--smpl_dir', '/nonexistent', '--j_regressor_init',
+                                                   '/nonexistent'] + list(extra))
+        optm = importlib.import_module(PKG + '.optimize')
+        recs = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        optm.optimize_pose_refiner(log=recs.append)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kept = recs[1:] or recs
+        sec = statistics.median([r['seconds_batch'] for r in kept])
+        return {'flags': ' '.join(extra) or '(defaults)', 'batch': batch, 'inner_iters': inner, 'outer_batches_run': len(recs), 'first_batch_discarded': len(recs) > 1,
+                'seconds_per_outer_batch': round(sec, 5), 'seconds_per_outer_batch_each': [round(r['seconds_batch'], 5) for r in recs],
+                'loop_and_outer_step_seconds': round(statistics.median([r['seconds'] for r in kept]), 5),
+                'it_s_through_the_entry_point': round(inner / sec, 2), 'vertex_tiles_run': kept[-1]['vertex_tiles_run'],
+                'whole_call_seconds_incl_synthetic_batch_generation_and_setup': round(wall, 3),
+                'joint_loss_last': kept[-1]['joint_loss'], 'mpjpe_last': kept[-1].get('mpjpe')}
+
+    driver_outer, ref_default = None, None
+    if dist is None and not a.no_driver_blocks and a.config == 3 and not use_sil:
+        outer_ms = (d_ms or 0.0) + j_ms                  # pose-D update + J step as timed above (stand-alone, this engine)
+        driver_outer = {}
+        for name, extra, step_ms in (('all_vertex_tiles', ['--all_vertex_tiles'], inner_ms),
+                                     ('support_tiles_default', [], support_tiles['ms_per_step'] if support_tiles else None)):
+            r = driver_run(B, extra)
+            if step_ms:
+                kern = (r['inner_iters'] * step_ms + outer_ms) * 1e-3
+                r.update({'inner_ms_per_step_of_this_mode': round(step_ms, 4), 'outer_step_ms': round(outer_ms, 3),
+                          'kernel_seconds_expected': round(kern, 5),
+                          'share_not_inner_loop_or_outer_step': round(1.0 - kern / r['seconds_per_outer_batch'], 4)})
+            driver_outer[name] = r
+        driver_outer['note'] = ('optimize_pose_refiner() of this package (the reference entry point restated) on 3 synthetic outer batches, first one '
+                                'discarded; seconds_per_outer_batch = wall time from the batch arriving to its record (H->D copies, fresh Adam '
+                                'state, 100 inner iterations in ONE C call, D update, J step, evaluations, the one read-back); '
+                                'share_not_inner_loop_or_outer_step = 1 - (100 x ms_per_step + pose-D update + J step) / that')
+        # the reference's OWN default run (scripts/args.py:8 batch 256; all five terms of scripts/optimize.py:252-253 with the 1000-step
+        # camera pre-fit of :187-199)
+        ref_default = driver_run(256, ['--shape_disc', '--reprojection', '--silhouette'])
+        ref_default['workload'] = ('scripts/args.py:8 default batch 256, all five loss terms (2-D joints, silhouette, 3-D joints, pose-D, shape-D), '
+                                   '1000-step camera pre-fit, 100 inner iterations, D updates + J step per outer batch')
+
     if rank != 0:
         if dist is not None:
             dist.destroy_process_group()
@@ -735,6 +870,9 @@ def main():
                                    'regressor\'s support -- what optimize.py runs by default -- is the separate block `support_tiles`)',
                    'geometry': dict(eng.info, **dmodel.info)},
         'collective': collective,
+        'per_rank_ms_per_step': {'min': round(min(per_rank_ms), 4), 'median': round(statistics.median(per_rank_ms), 4), 'max': round(max(per_rank_ms), 4),
+                                 'each': [round(x, 4) for x in per_rank_ms],
+                                 'note': 'every rank\'s own time per step over the headline regions (before the closing barrier); `ms_per_step` is the max over ranks incl. barriers'},
         'roofline': {'bound': 'mfma', 'kernel': 'k_lbs_fwd<true,false>', 'achieved': round(achieved, 2),
                      'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
                      'traffic': traffic,
@@ -780,7 +918,7 @@ def main():
                                     'issued_work': issued(pm_name, prof[cls][0])}
                              for name, cls, fl, pm_name in (('k_lbs_bwd', 'k_lbs_bwd', flop_bwd, 'k_lbs_bwd'),
                                                             ('k_blend_adjoint', 'k_gemm_tn_blend_adjoint', FLOP_BLEND_ADJ_PER_POSE, 'k_blend_adjoint'),
-                                                            ('pose_disc_gemms (4 launches)', 'pose_disc_gemms', FLOP_DISC_PER_POSE, 'pose_disc_gemms'))
+                                                            ('pose_disc_gemms (4 launches)', 'pose_disc_gemms', FLOP_DISC_GEMMS_PER_POSE, 'pose_disc_gemms'))
                              if prof.get(cls, (0, 0))[1] and prof[cls][0] > 0},
         'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
                    'allreduce_bytes': xch.nbytes, 'allreduce_payload': 'regressor support [17][128]' if xch.compact else 'dense (17,6890)',
@@ -801,7 +939,7 @@ def main():
             'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1h_regions],
             'spread_frac': round((max(c1h_regions) - min(c1h_regions)) / c1h_el, 4),
             'allreduce_bytes_it_would_send': xch.nbytes,
-            'with_rccl_one_rank_allreduce': c1r,
+            'with_rccl_one_rank_allreduce': None,
             'note': 'cadence 1 through the call sequence N > 1 ranks execute (refine_run_after_j_step -> j_regressor_grad_support -> '
                     '[all-reduce: a no-op at world size 1] -> j_step_apply_support per iteration, host-driven): bounds the multi-GPU '
                     'cadence-1 cost of everything but the collective itself'}
@@ -813,6 +951,12 @@ def main():
                          'it_s_incl_pose_d_update_at_cadence': round(world / ((ms_per_step + (d_ms or 0.0) / cadence) * 1e-3), 3),
                          'it_s_all_outer_work_every_iteration': round(world / ((c1_ms + (d_ms or 0.0)) * 1e-3), 3),
                          'j_allreduce_bytes': xch.nbytes, 'pose_d_allreduce_bytes': 1840153 * 4 if use_disc else 0}
+    if collective_cost is not None:
+        out['collective_cost'] = collective_cost
+    if driver_outer is not None:
+        out['driver_outer_batch'] = driver_outer
+    if ref_default is not None:
+        out['reference_default'] = ref_default
     if folded is not None:
         out['folded_mode'] = folded
     if support_tiles is not None:
@@ -826,21 +970,24 @@ def main():
     if not a.no_cpu_baseline and world == 1:   # the CPU baseline leg runs at N = 1 only
         cb = min(a.cpu_batch or B, B)
         variants, nthreads = cpu_baseline(model_np, J_np, batch_np, disc_sd, cb, a.cpu_seconds, use_disc, B)
+        sweep_info = variants.pop('thread_sweep', None)
         for vv in variants.values():
             if 'it_s_at_sample_batch' in vv:
                 vv['value_batch4096_units'] = round(vv['it_s_at_sample_batch'] * vv['batch'] / B, 5)
         out['cpu_baseline'] = {'value': variants['one_eval']['value_batch4096_units'], 'unit': f'it/s (x{B} poses)', 'cores': nthreads,
-                               'kind': 'port', 'cpu_model': cpu_model_name(), 'host_threads': os.cpu_count(),
+                               'kind': 'port', 'cpu_model': cpu_model_name(), 'host_threads': os.cpu_count(), 'thread_sweep': sweep_info,
                                'sample': f"{variants['one_eval']['iterations']} inner iterations at batch {cb} of the same workload "
                                          f'(oracle/reference_port.py: torch-CPU ops in the reference order, autograd, torch.optim.Adam; '
                                          f"1 SMPL eval/iter), {variants['one_eval']['seconds']} s on {nthreads} threads picked from a "
-                                         f'1-iteration sweep over 8/16/32/64, scaled x{cb}/{B} to batch-{B} units; `full_batch` = one '
+                                         f'1-iteration sweep up to all physical cores (`thread_sweep`), scaled x{cb}/{B} to batch-{B} units; `full_batch` = one '
                                          f'iteration at batch {B} itself, `config1_forward_b4` = BASELINE configs[0]',
                                'variants': variants}
+    if c1h_el is not None:       # LAST: the one measurement that brings up a communicator (see rccl_one_rank_block)
+        out['cadence1_host_driven']['with_rccl_one_rank_allreduce'] = rccl_one_rank_block()
     print(json.dumps(out))
-    if rccl_hung[0]:      # a bootstrap thread is still stuck inside RCCL: leave without waiting for it
+    if rccl_hung[0]:      # a bootstrap thread is still stuck inside RCCL: the line is out; leave without waiting for it, and say so
         sys.stdout.flush()
-        os._exit(0)
+        os._exit(3)
     if dist is not None:
         dist.destroy_process_group()
 

@@ -35,6 +35,8 @@ extern "C" int jrr_version(void) { return 100; }
 // =============================================================================================
 // model
 // =============================================================================================
+constexpr size_t SIL_SCRATCH_STRIDE = 27584;      // floats per pose of Engine::ndc: >= 4 V (the NdcV records) and >= 3 x 6912 (sil.hip SF_SCRATCH), a multiple of 32
+static_assert(SIL_SCRATCH_STRIDE >= (size_t)4 * V && SIL_SCRATCH_STRIDE >= (size_t)3 * 6912 && SIL_SCRATCH_STRIDE % 32 == 0, "silhouette scratch");
 constexpr int MAX_FACES = 14336;       // the rasteriser's capacity: 1024 threads x 14 faces (sil.hip)
 static size_t model_floats() {
   const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nDq = nDn, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
@@ -569,7 +571,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   }
   if (flags & (JRR_FLAG_SILHOUETTE | JRR_FLAG_KEEP_VERTS)) t->VTb = c.take((size_t)3 * VP * BP);
   if (flags & JRR_FLAG_SILHOUETTE) {
-    t->ndc = c.take((size_t)BP * V * 4);
+    t->ndc = c.take((size_t)BP * SIL_SCRATCH_STRIDE);      // stand-alone API: projected vertices [B][V] x 16 bytes; fused loop: the rasteriser's pose-private scratch
     const size_t S = (flags & JRR_FLAG_SIL_256) ? 256 : 224;
     t->cover = (unsigned*)c.take((size_t)BP * S * S);
     t->ncover = (int*)c.take((size_t)BP);
@@ -1291,7 +1293,7 @@ extern "C" int jrr_silhouette_loss_grad(jrr_engine_t* e, const float* x6d, const
   e->smask_valid = false;
   const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * (double)e->sil * (double)e->sil));      // optimize.py:252 weight 100
   launch_sil_raster_adj(e->VTb, e->BP, cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, mask, e->smask, e->cover,
-                        e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s, e->sil);
+                        e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s, e->sil, e->ndc, SIL_SCRATCH_STRIDE);
   if (sqsil) JRR_HIP(hipMemcpyAsync(sqsil, e->sqsil, (size_t)e->B * 4, hipMemcpyDeviceToDevice, s));
   if (dverts) launch_verts_untranspose(e->VTb, dverts, V * 3, V, nullptr, nullptr, e->B, e->BP, s, e->m.p2v);
   if (dcam) JRR_HIP(hipMemcpyAsync(dcam, e->gcam, (size_t)e->B * 3 * 4, hipMemcpyDeviceToDevice, s));
@@ -1441,7 +1443,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       if (!e->smask_valid) { launch_mask_sq(e->sil_mask, e->smask, e->B, s, e->sil); e->smask_valid = true; }
       // projection, rasterisation, loss and adjoint in one kernel, straight from / into the row-quad vertex buffer
       launch_sil_raster_adj(e->VTb, e->BP, e->cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil,
-                            silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s, e->sil);
+                            silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s, e->sil, e->ndc, SIL_SCRATCH_STRIDE);
       prof_mark(e, 8, s);
     }
     prof_mark(e, 3, s);

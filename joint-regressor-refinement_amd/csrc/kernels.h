@@ -153,7 +153,7 @@ int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* 
 int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s, int S = 224);
 int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
                           unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
-                          hipStream_t s, int S = 224);
+                          hipStream_t s, int S, float* scratch, size_t scratch_stride);
 int launch_sil_pix_to_face(const unsigned* cover, const int* ncover, int* p2f, int B, hipStream_t s, int S = 224);
 int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, const int* ncover, const float* mask,
                    const float* galpha, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,

@@ -48,6 +48,18 @@ def all_reduce_sum_(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+def agree_max(value: int, device=None) -> int:
+    """MAX of a small integer over the ranks (the identity without a process group): how the ranks agree on a per-batch
+    outcome -- e.g. "this batch failed to load on some rank" -- before they enter the next collective together."""
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(value)
+    on_gpu = dist.get_backend() == 'nccl'
+    t = torch.tensor([int(value)], dtype=torch.int32, device=device if on_gpu else 'cpu')
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return int(t.item())
+
+
 class JStepExchange:
     """The J step between two segments of the inner loop under data parallelism (scripts/optimize.py:300-312 sharded):
     local gradient -> ONE sum-all-reduce -> replicated Adam + re-normalisation, no allocation, nothing read back.

@@ -94,12 +94,20 @@ def _dataset_batches(root: str, B_global: int, seed: int, device, drop_last: boo
     loader = torch.utils.data.DataLoader(ds, batch_size=B_global, num_workers=0, shuffle=True, drop_last=drop_last, generator=g)
     iterator = iter(loader)
     for it in range(len(loader)):
+        failed = 0
         try:                                           # scripts/optimize.py:150-156: a batch that fails to load is reported and skipped
             batch = next(iterator)
         except StopIteration:
-            return
+            failed = 2
         except Exception as exc:                       # noqa: BLE001  (the reference catches everything here)
             print(f'problem loading batch {it}: {type(exc).__name__}: {exc}')
+            failed = 1
+        # under data parallelism every rank loads on its own: the ranks agree on the outcome before going on, or a transient
+        # error on one rank would pair different batches in the all-reduces that follow (one MAX over a single int per batch)
+        failed = jdist.agree_max(failed, device)
+        if failed == 2:
+            return
+        if failed:
             continue
         x6 = pose_to_rot6d(batch['orient'].to(device), batch['pose'].to(device)).cpu()
         yield {'pose6d': x6, 'betas': batch['betas'].float(), 'gt_j3d': batch['gt_j3d'].float(), 'cam': batch['cam'].float(),
@@ -193,7 +201,7 @@ def optimize_pose_refiner(log=print) -> Dict:
 
     history = []
     pending = None             # the previous batch's record, waiting for its after-the-J-step metrics
-    x6d = betas = None
+    x6d = betas = cam = None
     lo = hi = 0
 
     def finish(rec, B_global, after):
@@ -213,6 +221,7 @@ def optimize_pose_refiner(log=print) -> Dict:
                     pass
 
     for it, full in enumerate(source):                                                     # :144-148
+        t_batch = time.perf_counter()
         B_global = int(full['pose6d'].shape[0])
         lo, hi = jdist.shard_bounds(B_global, rank, world)
         B = hi - lo
@@ -259,6 +268,7 @@ def optimize_pose_refiner(log=print) -> Dict:
                 eng.refine_run(x6d, betas, gt_j3d, m, v, step, 1e-2, args.j_step_every, sqerr=sq, after_j_step=done > 0)
                 xch.step(J_regressor, J_opt.m, J_opt.v, J_opt.step, J_opt.lr, x6d, betas, gt_j3d, mask=j_reg_mask)
         eng.refine_run(x6d, betas, gt_j3d, m, v, step, 1e-2, args.inner_iters - n_inloop, sqerr=sq, after_j_step=n_inloop > 0)
+        tiles_run = eng.support_tiles()[1]          # vertex tiles the inner iterations ran (asked while the silhouette term is still set)
         bucket.flat.zero_()
         bucket.put(0, sq)                                                                   # joint_loss (:238-239)
         pose_disc_sq, shape_disc_sq = eng.refine_aux_losses(use_pd, use_sd) if args.inner_iters > 0 else (None, None)
@@ -318,7 +328,9 @@ def optimize_pose_refiner(log=print) -> Dict:
                'j_regressor_error': sc[5] / (B_global * 51),
                '_mpjpe_before': sc[6] * 1000 / B_global, '_pampjpe_before': sc[7] * 1000 / B_global,
                'loss_history': [[float(x) for x in row] for row in hist_np],                # :255-261, every 10th iteration
-               'seconds': time.perf_counter() - t0,
+               'seconds': time.perf_counter() - t0,                                         # inner loop + outer step, as the reference times nothing finer
+               'seconds_batch': time.perf_counter() - t_batch,                              # + H->D copies, camera pre-fit, target set-up
+               'vertex_tiles_run': tiles_run,     # 216, or the tiles of the regressor's support (FLAG_SUPPORT_TILES engaged)
                'body_model': smpl.provenance, 'data': 'dataset' if args.data_root else 'synthetic'}
         rec = {k: (float(x) if isinstance(x, np.floating) else x) for k, x in rec.items()}
         pending = (rec, B_global)
@@ -329,7 +341,7 @@ def optimize_pose_refiner(log=print) -> Dict:
     if args.save_j_regressor and rank == 0:
         checkpoint.save_j_regressor(J_regressor, args.save_j_regressor)
     return {'history': history, 'J_regressor': J_regressor, 'disc_flat': disc_flat, 'sdisc_flat': sdisc_flat,
-            'x6d': x6d, 'betas': betas, 'shard': (lo, hi)}
+            'x6d': x6d, 'betas': betas, 'cam': cam, 'shard': (lo, hi)}
 
 
 def _synthetic_gt_j2d(eng, x6d, betas, cam, seed, lo, hi, B_global):

@@ -28,6 +28,11 @@ DP_FLAGS = ['--batch_size', '256', '--synthetic_batches', '1', '--inner_iters', 
             '--reprojection', '--camera_iters', '20', '--synthetic', '--device', 'cuda:0']
 
 
+# BASELINE configs[4] through the driver: all five loss terms + the camera pre-fit (silhouette => every vertex tile)
+SIL_FLAGS = ['--batch_size', '64', '--synthetic_batches', '1', '--inner_iters', '3', '--j_step_every', '2', '--shape_disc', '--reprojection',
+             '--camera_iters', '20', '--silhouette', '--synthetic', '--device', 'cuda:0']
+
+
 BIG_FLAGS = ['--batch_size', '32768', '--synthetic_batches', '1', '--inner_iters', '3', '--j_step_every', '1', '--synthetic', '--device', 'cuda:0']
 
 
@@ -52,6 +57,12 @@ def pytest_collection_finish(session):
         'w2': _torchrun(2, 29541, [worker, os.path.join(tmp, 'w2')] + DP_FLAGS + ['--dist_backend', 'gloo', '--single_device']),
         # the node's world size (BASELINE configs[3]: 8 ranks), 32 poses per rank, still on one GPU over gloo
         'w8': _torchrun(8, 29544, [worker, os.path.join(tmp, 'w8')] + DP_FLAGS + ['--dist_backend', 'gloo', '--single_device']),
+        # the kernel configuration the bench headline measures (every iteration on all 216 vertex tiles) through the driver
+        'w1a': [sys.executable, worker, os.path.join(tmp, 'w1a')] + DP_FLAGS + ['--all_vertex_tiles'],
+        'w2a': _torchrun(2, 29550, [worker, os.path.join(tmp, 'w2a')] + DP_FLAGS + ['--all_vertex_tiles', '--dist_backend', 'gloo', '--single_device']),
+        # --silhouette --reprojection --shape_disc together
+        'w1s': [sys.executable, worker, os.path.join(tmp, 'w1s')] + SIL_FLAGS,
+        'w2s': _torchrun(2, 29551, [worker, os.path.join(tmp, 'w2s')] + SIL_FLAGS + ['--dist_backend', 'gloo', '--single_device']),
         # bench.py --gpus 2 WITHOUT torchrun: bench.py starts its own 2-rank child (what the driver's command line does)
         'bench2': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--j_step_every', '2', '--batch', '256',
                    '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5',

@@ -30,7 +30,7 @@ def main():
     rank = int(os.environ.get('RANK', '0'))
     lo, hi = res['shard']
     np.savez(f'{out}.rank{rank}.npz', J=res['J_regressor'].cpu().numpy(), disc=res['disc_flat'].cpu().numpy(),
-             sdisc=res['sdisc_flat'].cpu().numpy(), x6d=res['x6d'].cpu().numpy(), betas=res['betas'].cpu().numpy(),
+             sdisc=res['sdisc_flat'].cpu().numpy(), x6d=res['x6d'].cpu().numpy(), betas=res['betas'].cpu().numpy(), cam=res['cam'].cpu().numpy(),
              lo=lo, hi=hi, history=json.dumps(res['history']))
     import torch.distributed as dist
     if dist.is_available() and dist.is_initialized():

@@ -75,6 +75,54 @@ def test_eight_rank_driver_equals_single_process():
     np.testing.assert_allclose(np.array(h8['loss_history']), np.array(h1['loss_history']), rtol=2e-3, atol=1e-6)
 
 
+def test_two_rank_driver_all_vertex_tiles_equals_single_process():
+    """--all_vertex_tiles (what the bench headline runs: every iteration skins all 216 vertex tiles) through the driver on two
+    ranks against one rank, and against the default run on the regressor's support tiles (same results up to summation order)"""
+    _run('w1a'); _run('w2a'); _run('w1')
+    (one,) = _load('w1a', 1)
+    two = _load('w2a', 2)
+    (dflt,) = _load('w1', 1)
+    h1 = json.loads(str(one['history']))[0]
+    assert h1['vertex_tiles_run'] == 216 and 0 < json.loads(str(dflt['history']))[0]['vertex_tiles_run'] < 60
+    x2 = np.concatenate([two[0]['x6d'], two[1]['x6d']])
+    b2 = np.concatenate([two[0]['betas'], two[1]['betas']])
+    assert np.abs(x2 - one['x6d']).max() < 2e-4 and np.abs(b2 - one['betas']).max() < 2e-4
+    for k in ('J', 'disc', 'sdisc'):
+        assert np.array_equal(two[0][k], two[1][k]), k
+        assert np.abs(two[0][k] - one[k]).max() < 5e-5, k
+    h2 = json.loads(str(two[0]['history']))[0]
+    for k in ('joint_loss', 'pose_discriminated_loss', 'shape_discriminated_loss', 'pose_discriminator_loss',
+              'shape_discriminator_loss', 'j_regressor_error', 'mpjpe', 'pampjpe'):
+        np.testing.assert_allclose(h2[k], h1[k], rtol=2e-3, err_msg=k)
+    # all tiles vs the support's tiles: the sums over the tiles associate differently (DESIGN.md section 0: 1e-4 max / 2e-8 mean measured)
+    dx = np.abs(one['x6d'] - dflt['x6d'])
+    assert dx.max() < 6e-4 and dx.mean() < 1e-6, (dx.max(), dx.mean())
+    assert np.abs(one['J'] - dflt['J']).max() < 5e-6
+
+
+def test_two_rank_driver_with_silhouette_reprojection_shape_disc_equals_single_process():
+    """BASELINE configs[4] through the driver under sharding: --silhouette --reprojection --shape_disc, 64 poses, a J step inside the
+    loop; the synthetic masks / 2-D targets are drawn for the global batch and sliced, so the two shards see the 1-rank targets"""
+    _run('w1s'); _run('w2s')
+    (one,) = _load('w1s', 1)
+    two = _load('w2s', 2)
+    assert (int(two[0]['lo']), int(two[0]['hi']), int(two[1]['lo']), int(two[1]['hi'])) == (0, 32, 32, 64)
+    h1, h2 = json.loads(str(one['history']))[0], json.loads(str(two[0]['history']))[0]
+    assert h1['vertex_tiles_run'] == h2['vertex_tiles_run'] == 216
+    # per pose the rasteriser and its fixed-point adjoint do not depend on the batch: only the launch geometry of the LBS
+    # kernels differs between 32 and 64 poses (last-bit summation order, Adam-amplified)
+    for k in ('x6d', 'betas', 'cam'):
+        d = np.abs(np.concatenate([two[0][k], two[1][k]]) - one[k])
+        assert d.max() < 2e-3 and d.mean() < 2e-5, (k, d.max(), d.mean())
+    for k in ('J', 'disc', 'sdisc'):
+        assert np.array_equal(two[0][k], two[1][k]), k
+        assert np.abs(two[0][k] - one[k]).max() < 5e-5, k
+    for k in ('joint_loss', 'pose_discriminated_loss', 'shape_discriminated_loss', 'pose_discriminator_loss',
+              'shape_discriminator_loss', 'j_regressor_error', 'mpjpe', 'pampjpe'):
+        np.testing.assert_allclose(h2[k], h1[k], rtol=5e-3, err_msg=k)
+    np.testing.assert_allclose(np.array(h2['loss_history'])[0], np.array(h1['loss_history'])[0], rtol=2e-4)
+
+
 def test_one_rank_over_rccl_runs_the_collective_call_sites():
     """backend nccl (= RCCL) with a one-rank group on this box's GPU: the driver takes its N > 1 branch (refine_run ->
     jrr_j_regressor_grad_support -> all-reduce -> jrr_j_step_apply_support per J step; ONE flat all-reduce per outer step) and
@@ -170,6 +218,17 @@ def test_bench_n_ranks(name, world, batch):
     assert c['allreduce_check'] == c['allreduce_expected'] == world * (world - 1) / 2     # sum of ranks over the collective
     assert c['backend'] == 'gloo' and c['single_device_debug'] is True
     assert j['cadence1']['timed_regions'] >= 5 and j['cadence1']['value'] > 0
+    # the first N > 1 run explains itself: per-rank spread, the collective on its own, the collective's share of a cadence-1 step
+    pr = j['per_rank_ms_per_step']
+    assert len(pr['each']) == world and 0 < pr['min'] <= pr['median'] <= pr['max'] <= j['ms_per_step'] * 1.05
+    cc = j['collective_cost']
+    sa = cc['standalone_allreduce']
+    assert sa['j_step_support_17x128']['bytes'] == 8704 and sa['j_step_dense_17x6890']['bytes'] == 468520
+    assert 7.8e6 < sa['outer_step_flat_bucket']['bytes'] < 7.9e6
+    for rec in sa.values():
+        assert rec['median_us_synchronised'] > 0 and rec['us_back_to_back'] > 0
+    assert cc['cadence1_ms_per_step'] > 0 and cc['cadence1_noop_collective_ms_per_step'] > 0
+    assert abs(cc['collective_us_per_step'] - (cc['cadence1_ms_per_step'] - cc['cadence1_noop_collective_ms_per_step']) * 1e3) < 0.2
 
 
 def test_bench_rejects_a_world_that_contradicts_gpus():

@@ -1,0 +1,42 @@
+"""Where an outer batch of optimize_pose_refiner() spends its time: every engine method / host helper the driver calls is wrapped with a
+synchronising timer (so the numbers add up to MORE than the un-instrumented batch: the syncs serialise host and device).
+    python tools/exp/driver_sections.py [--all_vertex_tiles] [driver flags ...]"""
+import importlib, os, sys, time, collections
+import torch
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+PKG = 'joint-regressor-refinement_amd'
+argsmod = importlib.import_module(PKG + '.args')
+flags = ['--batch_size', '4096', '--synthetic_batches', '3', '--inner_iters', '100', '--synthetic', '--smpl_dir', '/nonexistent',
+         '--j_regressor_init', '/nonexistent'] + sys.argv[1:]
+argsmod._LazyArgs._ns = argsmod.get_args(flags)
+eng_mod = importlib.import_module(PKG + '.engine')
+opt = importlib.import_module(PKG + '.optimize')
+utils = importlib.import_module(PKG + '.utils')
+T = collections.defaultdict(list)
+
+def wrap(obj, name, label=None):
+    fn = getattr(obj, name)
+    def w(*a, **k):
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        r = fn(*a, **k)
+        torch.cuda.synchronize(); T[label or name].append(time.perf_counter() - t0)
+        return r
+    setattr(obj, name, w)
+
+for n in ('refine_run', 'refine_run_j_steps', 'pose_disc_backward_params', 'shape_disc_backward_params', 'j_regressor_grad', 'j_step_apply',
+          'find_joints_forward', 'set_j_regressor', 'j_support_info', 'set_pose_disc', 'refine_aux_losses', 'camera_prefit', 'set_loss_history'):
+    wrap(eng_mod.RefineEngine, n)
+wrap(utils, 'evaluate_sums'); wrap(utils, 'move_pelvis'); wrap(eng_mod, 'adam_step')
+recs = []
+t0 = time.perf_counter()
+opt.optimize_pose_refiner(log=recs.append)
+torch.cuda.synchronize()
+print('whole call %.3f s; seconds_batch per batch: %s' % (time.perf_counter() - t0, [round(r['seconds_batch'], 4) for r in recs]))
+nb = len(recs)
+tot = 0.0
+for k, v in sorted(T.items(), key=lambda kv: -sum(kv[1])):
+    last = v[len(v) * (nb - 1) // nb:]          # the calls of the last batch
+    print(f'{k:32s} calls/batch {len(v) / nb:4.1f}   last batch: {sum(last) * 1e3:8.3f} ms')
+    tot += sum(last)
+print(f'sum of the wrapped calls, last batch: {tot * 1e3:.3f} ms of {recs[-1]["seconds_batch"] * 1e3:.3f} ms')
