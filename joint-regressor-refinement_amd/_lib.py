@@ -13,7 +13,9 @@ from ctypes import POINTER, c_char_p, c_float, c_int, c_int32, c_size_t, c_void_
 import torch  # noqa: F401  (must precede CDLL, see module docstring)
 
 HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(HERE, 'libjrr_hip.so')
+# JRR_LIB (experiments only, tools/exp/ab_libs.sh): load a variant library built by tools/exp/build_variant.py instead of the
+# in-tree one -- the in-tree file is never overwritten by an experiment
+LIB_PATH = os.environ.get('JRR_LIB') or os.path.join(HERE, 'libjrr_hip.so')
 
 # every exported symbol of include/jrr.h with (restype, argtypes)
 _P = c_void_p

@@ -17,6 +17,10 @@ SOURCES = ['api.hip', 'prep.hip', 'lbs.hip', 'gemm.hip', 'disc.hip', 'eval.hip',
 
 def main():
     name, fname, pairs = sys.argv[1], sys.argv[2], sys.argv[3:]
+    # the other objects the variant links against must be those of the CURRENT tree: bring the in-tree build up to date first
+    sys.path.insert(0, PKG)
+    import build as _build
+    _build.build(verbose=False)
     tmp = tempfile.mkdtemp(prefix='jrr_var_')
     csrc = os.path.join(tmp, 'pkg', 'csrc')
     shutil.copytree(os.path.join(PKG, 'csrc'), csrc)
