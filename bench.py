@@ -746,7 +746,9 @@ def main():
                     # kinematic chains (invisible at the API); tiles that are still wide would pay a second pass themselves
                     ('capsules_random_file_order', {}, sm.synthetic_smpl(1234, kind='capsules')),
                     # the benchmarked body with ONE tile skinned by 13 joints: it pays a second pass itself, the model stays in its class
-                    ('one_13_joint_tile', {}, sm.with_wide_tile(model_np, 100, 13))]
+                    ('one_13_joint_tile', {}, sm.with_wide_tile(model_np, 100, 13)),
+                    # ... and both together: the 12-slot kernels WITH a wide tile (the instantiation that used to spill registers)
+                    ('one_13_joint_tile_skin12', {'JRR_SKIN_JOINTS': '12'}, sm.with_wide_tile(model_np, 100, 13))]
         for name, env, mnp in variants:
             old = {k: os.environ.get(k) for k in env}
             os.environ.update(env)                       # read by jrr_model_create

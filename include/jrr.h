@@ -170,6 +170,12 @@ int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d_dev, const float*
                              const float* betas_dev, const float* djoints_dev, float* dx6d_dev,
                              float* dR_dev, float* dbetas_dev, float* dJ_dev, void* stream);
 
+/* The `joints` field of the SMPL operator's output (scripts/smpl.py:69-84: smplx's 24 posed joints J_transformed = G_j[:3, 3] of the
+ * kinematic chain head the list the wrapper re-maps).  Must follow a forward on this engine (jrr_find_joints_forward,
+ * jrr_refine_run, ...) with the SAME betas: reads the stored skinning transforms.  joints24_dev (B,24,3).  Not differentiated
+ * (dead on the hot path: every caller of the reference reads `.vertices` only).        */
+int jrr_smpl_posed_joints(jrr_engine_t* e, const float* betas_dev, float* joints24_dev, void* stream);
+
 /* SMPL operator on its own: smpl(global_orient, body_pose, betas, pose2rot=False).vertices
  * (call sites scripts/utils.py:94-95, scripts/optimize.py:78-79, scripts/renderer.py:32-33).
  * Forward = jrr_find_joints_forward with verts_dev != NULL.  This is the adjoint w.r.t. the

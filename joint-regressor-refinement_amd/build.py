@@ -36,6 +36,49 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
+def resource_rows(sources=None):
+    """Per-kernel resource usage of the CURRENT sources (compiled into a scratch directory with
+    -Rpass-analysis=kernel-resource-usage; the in-tree objects are not touched): a list of dicts with the demangled kernel
+    name and integer vgpr / agpr / scratch / vspill / occ / lds.  tests/test_host_logic.py fails on any spilled register."""
+    import tempfile
+    tmp = tempfile.mkdtemp(prefix='jrr_report_')
+    jobs = [[_hipcc()] + FLAGS + ['-c', os.path.join(CSRC, src), '-o', os.path.join(tmp, src.replace('.hip', '.o')),
+                                  '-Rpass-analysis=kernel-resource-usage'] for src in (sources or SOURCES)]
+    with ThreadPoolExecutor(max_workers=min(len(jobs), 8)) as ex:
+        outs = list(ex.map(lambda cmd: subprocess.run(cmd, capture_output=True, text=True), jobs))
+    import shutil
+    shutil.rmtree(tmp, ignore_errors=True)
+    rows = []
+    for p in outs:
+        if p.returncode != 0:
+            raise RuntimeError('hipcc failed:\n' + p.stderr[-2000:])
+        rows += _parse(p.stdout + p.stderr)
+    return rows
+
+
+def _parse(out: str):
+    import re
+    rows, cur = [], None
+    for line in out.splitlines():
+        m = re.search(r'remark: Function Name: (\S+)', line)
+        if m:
+            name = m.group(1)
+            try:
+                name = subprocess.run(['c++filt', name], capture_output=True, text=True).stdout.strip() or name
+            except OSError:
+                pass
+            cur = {'name': name.split('(')[0]}
+            rows.append(cur)
+            continue
+        for key, pat in (('vgpr', r'remark:\s+VGPRs: (\d+)'), ('agpr', r'AGPRs: (\d+)'), ('scratch', r'ScratchSize \[bytes/lane\]: (\d+)'),
+                         ('occ', r'Occupancy \[waves/SIMD\]: (\d+)'), ('lds', r'LDS Size \[bytes/block\]: (\d+)'),
+                         ('vspill', r'VGPRs Spill: (\d+)')):
+            m = re.search(pat, line)
+            if m and cur is not None:
+                cur[key] = int(m.group(1))
+    return [r for r in rows if 'vgpr' in r]
+
+
 def _summarise(out: str) -> str:
     """Condense -Rpass-analysis=kernel-resource-usage remarks to one line per kernel."""
     import re

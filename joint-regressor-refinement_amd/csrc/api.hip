@@ -35,8 +35,6 @@ extern "C" int jrr_version(void) { return 100; }
 // =============================================================================================
 // model
 // =============================================================================================
-constexpr size_t SIL_SCRATCH_STRIDE = 27584;      // floats per pose of Engine::ndc: >= 4 V (the NdcV records) and >= 3 x 6912 (sil.hip SF_SCRATCH), a multiple of 32
-static_assert(SIL_SCRATCH_STRIDE >= (size_t)4 * V && SIL_SCRATCH_STRIDE >= (size_t)3 * 6912 && SIL_SCRATCH_STRIDE % 32 == 0, "silhouette scratch");
 constexpr int MAX_FACES = 14336;       // the rasteriser's capacity: 1024 threads x 14 faces (sil.hip)
 static size_t model_floats() {
   const size_t nDk = (size_t)VT * KFP * 96, nDn = (size_t)3 * VP * KFP, nDq = nDn, nWjv = (size_t)VT * NJ * 32, nWvj = (size_t)VT * 1024;
@@ -571,7 +569,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   }
   if (flags & (JRR_FLAG_SILHOUETTE | JRR_FLAG_KEEP_VERTS)) t->VTb = c.take((size_t)3 * VP * BP);
   if (flags & JRR_FLAG_SILHOUETTE) {
-    t->ndc = c.take((size_t)BP * SIL_SCRATCH_STRIDE);      // stand-alone API: projected vertices [B][V] x 16 bytes; fused loop: the rasteriser's pose-private scratch
+    t->ndc = c.take((size_t)BP * V * 4);
     const size_t S = (flags & JRR_FLAG_SIL_256) ? 256 : 224;
     t->cover = (unsigned*)c.take((size_t)BP * S * S);
     t->ncover = (int*)c.take((size_t)BP);
@@ -596,6 +594,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->jsup.col = (int*)c.take((size_t)NH * JSUP_CAP);
     t->jsup.val = c.take((size_t)NH * JSUP_CAP);
     t->jsup.tmask = (int*)c.take(256);
+    t->jsup.tknown = (int*)c.take(256);
     t->act_list = (int*)c.take(256);
   }
   if (e) {
@@ -757,6 +756,7 @@ static int set_j_regressor_impl(jrr_engine_t* e, const float* J, const float* ma
   e->jsup_fits_known = false;      // a regressor from outside: its support is not known to fit until jrr_j_support_info says so
   if (e->verts_partial) e->fwd_cached = false;      // the stored vertices cover the OLD regressor's support tiles only
   e->act_valid = false;
+  if (e->have_jsup && !step_inc) JRR_HIP(hipMemsetAsync(e->jsup.flag + JSUP_KNOWN, 0, sizeof(int32_t), s));   // (a J step keeps the baseline: step_inc != NULL)
   JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   e->have_mask = mask != nullptr;
@@ -952,6 +952,14 @@ extern "C" int jrr_smpl_vertices_backward(jrr_engine_t* e, const float* x6d, con
   L.dx6d = dx6d; L.dR = dR; L.dbetas = dbetas;
   L.B = e->B; L.BP = e->BP;
   launch_prep_bwd(L, e->m, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
+extern "C" int jrr_smpl_posed_joints(jrr_engine_t* e, const float* betas, float* joints24, void* stream) {
+  if (!e || !betas || !joints24) { jrr_set_error("smpl_posed_joints: null"); return JRR_ERR_ARG; }
+  if (e->flags & JRR_FLAG_NO_MODEL) { jrr_set_error("smpl_posed_joints: engine created without a body model"); return JRR_ERR_STATE; }
+  launch_posed_joints(e->m, e->AT, betas, joints24, e->B, e->BP, (hipStream_t)stream);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -1293,7 +1301,7 @@ extern "C" int jrr_silhouette_loss_grad(jrr_engine_t* e, const float* x6d, const
   e->smask_valid = false;
   const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * (double)e->sil * (double)e->sil));      // optimize.py:252 weight 100
   launch_sil_raster_adj(e->VTb, e->BP, cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, mask, e->smask, e->cover,
-                        e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s, e->sil, e->ndc, SIL_SCRATCH_STRIDE);
+                        e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s, e->sil);
   if (sqsil) JRR_HIP(hipMemcpyAsync(sqsil, e->sqsil, (size_t)e->B * 4, hipMemcpyDeviceToDevice, s));
   if (dverts) launch_verts_untranspose(e->VTb, dverts, V * 3, V, nullptr, nullptr, e->B, e->BP, s, e->m.p2v);
   if (dcam) JRR_HIP(hipMemcpyAsync(dcam, e->gcam, (size_t)e->B * 3 * 4, hipMemcpyDeviceToDevice, s));
@@ -1443,7 +1451,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       if (!e->smask_valid) { launch_mask_sq(e->sil_mask, e->smask, e->B, s, e->sil); e->smask_valid = true; }
       // projection, rasterisation, loss and adjoint in one kernel, straight from / into the row-quad vertex buffer
       launch_sil_raster_adj(e->VTb, e->BP, e->cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil,
-                            silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s, e->sil, e->ndc, SIL_SCRATCH_STRIDE);
+                            silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s, e->sil);
       prof_mark(e, 8, s);
     }
     prof_mark(e, 3, s);
@@ -1583,10 +1591,29 @@ extern "C" int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t
   JRR_HIP(hipStreamSynchronize((hipStream_t)stream));
   JRR_HIP(hipMemcpy(cnt, e->jsup.cnt, NH * sizeof(int32_t), hipMemcpyDeviceToHost));
   JRR_HIP(hipMemcpy(&flag, e->jsup.flag, sizeof(int32_t), hipMemcpyDeviceToHost));
+  {   // sticky device error: since the last call the support left the tiles reported then / stopped fitting the lists, while the engine
+      // enqueued support-restricted work only (the caller changed J or the mask IN PLACE instead of announcing it through
+      // jrr_engine_set_j_regressor): every result since then is suspect.  Cleared by reporting it.
+    int32_t err = 0;
+    JRR_HIP(hipMemcpy(&err, e->jsup.flag + JSUP_ERR, sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (err) {
+      JRR_HIP(hipMemset(e->jsup.flag + JSUP_ERR, 0, 2 * sizeof(int32_t)));      // error word and KNOWN
+      e->jsup_fits_known = false; e->act_valid = false; e->fwd_cached = false;
+      jrr_set_error("the J_regressor's support GREW behind the engine's back (%s): J or its mask was edited in place after "
+                    "jrr_j_support_info; results since then are invalid -- announce a changed regressor with jrr_engine_set_j_regressor",
+                    (err & 2) ? "a row no longer fits the support lists" : "entries outside the reported tiles");
+      return JRR_ERR_STATE;
+    }
+  }
   if (counts_host) for (int i = 0; i < NH; ++i) counts_host[i] = cnt[i];
   *fits_host = flag;
   e->jsup_fits_known = flag != 0;      // stays true under J steps (ReLU' = 0: Adam never re-activates an entry); cleared by set_j_regressor
   e->act_valid = false;
+  {   // the baseline the device checks later supports against (k_jsup_tilemask)
+    const int32_t known = flag ? 1 : 0;
+    if (flag) JRR_HIP(hipMemcpy(e->jsup.tknown, e->jsup.tmask, VT * sizeof(int32_t), hipMemcpyDeviceToDevice));
+    JRR_HIP(hipMemcpy(e->jsup.flag + JSUP_KNOWN, &known, sizeof(int32_t), hipMemcpyHostToDevice));
+  }
   if (flag && (e->flags & JRR_FLAG_SUPPORT_TILES)) {      // the support's tiles, for the kernels of the joint-loss iteration
     int32_t tm[VT], list[VT];
     JRR_HIP(hipMemcpy(tm, e->jsup.tmask, VT * sizeof(int32_t), hipMemcpyDeviceToHost));
@@ -1641,6 +1668,7 @@ extern "C" int jrr_j_step_apply(jrr_engine_t* e, float* J, const float* dJ, floa
 static int j_step_apply(jrr_engine* e, float* J, const float* dJ, float* m, float* v, int32_t* step, float lr, const float* mask,
                         hipStream_t s, const float* dJs) {
   const bool cached = e->fwd_cached, known = e->jsup_fits_known && mask == e->jsup_mask;
+  if (!known && e->have_jsup) JRR_HIP(hipMemsetAsync(e->jsup.flag + JSUP_KNOWN, 0, sizeof(int32_t), s));   // (another mask: no baseline to hold the new support against)
   if (e->have_jsup && e->have_J && e->tab_static) {
     // Adam, the engine's copy, the row sums, the normalised layouts and the support lists in ONE launch (lbs.hip k_jstep_update)
     JStepUpdate a;

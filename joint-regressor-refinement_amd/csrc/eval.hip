@@ -5,6 +5,7 @@
 // K^T K (V, sigma^2) followed by U = K V / sigma, with the reference's det-sign fix on the last axis.
 #include "jrr_common.h"
 #include "kernels.h"
+#include <type_traits>
 
 namespace jrr {
 
@@ -38,7 +39,7 @@ __device__ __forceinline__ float det3(const float M[3][3]) {
          M[0][2] * (M[1][0] * M[2][1] - M[1][1] * M[2][0]);
 }
 
-__global__ void k_evaluate(const float* __restrict__ pred, const float* __restrict__ target_mm, float* __restrict__ err,
+__global__ __launch_bounds__(64) void k_evaluate(const float* __restrict__ pred, const float* __restrict__ target_mm, float* __restrict__ err,
                            float* __restrict__ err_pa, int B) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
@@ -95,24 +96,28 @@ __global__ void k_evaluate(const float* __restrict__ pred, const float* __restri
     jacobi_rotate(S, V, 0, 2);
     jacobi_rotate(S, V, 1, 2);
   }
-  // sort singular values descending (torch.svd order): the det fix applies to the SMALLEST axis
+  // sort singular values descending (torch.svd order): the det fix applies to the SMALLEST axis.  A compare-exchange network on
+  // (sigma^2, column of V) with static indices (an index array would put sigma^2 and V into scratch memory)
   float sig2[3] = {S[0][0], S[1][1], S[2][2]};
-  int order[3] = {0, 1, 2};
+  auto cswap = [&](auto A_, auto B_) __attribute__((always_inline)) {
+    constexpr int a = decltype(A_)::value, c = decltype(B_)::value;
+    if (sig2[a] < sig2[c]) {
+      const float t = sig2[a]; sig2[a] = sig2[c]; sig2[c] = t;
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int c = 0; c < 2 - a; ++c)
-      if (sig2[order[c]] < sig2[order[c + 1]]) { const int t = order[c]; order[c] = order[c + 1]; order[c + 1] = t; }
+      for (int r = 0; r < 3; ++r) { const float u = V[r][a]; V[r][a] = V[r][c]; V[r][c] = u; }
+    }
+  };
+  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>; using I2 = std::integral_constant<int, 2>;
+  cswap(I0{}, I1{}); cswap(I1{}, I2{}); cswap(I0{}, I1{});
   float Vs[3][3], U[3][3];
 #pragma unroll
   for (int k = 0; k < 3; ++k) {
-    const int src = order[k];
-    const float sg = sqrtf(fmaxf(sig2[src], 0.f));
+    const float sg = sqrtf(fmaxf(sig2[k], 0.f));
 #pragma unroll
-    for (int r = 0; r < 3; ++r) Vs[r][k] = V[r][src];
+    for (int r = 0; r < 3; ++r) Vs[r][k] = V[r][k];
 #pragma unroll
     for (int r = 0; r < 3; ++r)
-      U[r][k] = (K[r][0] * V[0][src] + K[r][1] * V[1][src] + K[r][2] * V[2][src]) / fmaxf(sg, 1e-20f);
+      U[r][k] = (K[r][0] * V[0][k] + K[r][1] * V[1][k] + K[r][2] * V[2][k]) / fmaxf(sg, 1e-20f);
   }
   // R = V Z U^T with Z = diag(1, 1, sign(det(U V^T)))   (eval_utils.py:38-44)
   float UVt[3][3];

@@ -58,6 +58,7 @@ int launch_rodrigues_bwd(const float* aa, const float* dR, float* daa, int n, hi
 // FT: blend features row-major [KFP][BP] (chain adjoint, folded product); FTq: the same in K-quads [KFP/4][BP][4] (k_lbs_fwd)
 int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* FTq, float* AT,
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s);
+int launch_posed_joints(const Model& m, const float* AT, const float* betas, float* out, int B, int BP, hipStream_t s);
 // horizontally fused launches of the inner loop (prep.hip): chain forward || per-joint MLP forward, and
 // per-joint MLP adjoint || dF^T slab sum
 int launch_prep_fwd_dconv(const Model& m, const float* x6d, const float* betas, float* FT, float* FTq, float* AT, float* R0T, int B,
@@ -101,7 +102,11 @@ int launch_dverts_transpose(const float* dverts, int ldv, float* dVT, int B, int
 // JSupport lives in the engine workspace: cnt[i] positive entries of row i, their internal vertex rows / weights in ascending
 // vertex order, flag[0] = 1 when every row has at most JSUP_CAP of them (else the dense products run).
 constexpr int JSUP_CAP = 128;
-struct JSupport { int* flag; int* cnt; int* col; float* val; int* tmask; };     // flag[1], cnt[32], col[17][JSUP_CAP], val[17][JSUP_CAP], tmask[VT]
+struct JSupport { int* flag; int* cnt; int* col; float* val; int* tmask; int* tknown; };     // flag[64], cnt[32], col[17][JSUP_CAP], val[17][JSUP_CAP], tmask[VT], tknown[VT]
+// flag[0] fits, flag[1..2] counters of k_jstep_update, flag[JSUP_ERR] STICKY error word, flag[JSUP_KNOWN] = 1 while the host relies on
+// tknown = the tile mask jrr_j_support_info reported: a support that then leaves it (bit 0) or stops fitting the lists (bit 1) --
+// only possible when the caller edits J or the mask in place behind the engine's back -- sets the error word (k_jsup_tilemask)
+constexpr int JSUP_ERR = 3, JSUP_KNOWN = 4;
 // tmask[tile] = 1 when a support entry lives in that 32-vertex tile (rebuilt with the lists)
 int launch_jreg_normalize(const float* J, const float* mask, float* rowsum, float* Jn, float* Jn_vi, float* Jn_iv, float* Jn_q,
                           const int* p2v, hipStream_t s, int r16 = 0, const int* v2p = nullptr, const JSupport* sup = nullptr,
@@ -153,7 +158,7 @@ int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* 
 int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s, int S = 224);
 int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
                           unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
-                          hipStream_t s, int S, float* scratch, size_t scratch_stride);
+                          hipStream_t s, int S = 224);
 int launch_sil_pix_to_face(const unsigned* cover, const int* ncover, int* p2f, int B, hipStream_t s, int S = 224);
 int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, const int* ncover, const float* mask,
                    const float* galpha, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,

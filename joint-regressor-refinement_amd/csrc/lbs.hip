@@ -334,26 +334,33 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         const float* ab = buf + half * BG + wave * BT + l31;             // block ci at + ci * KJS * BG, row pair p at + 2 p BG
         float w[KJS / 2], x0[KJS / 2], x1[KJS / 2];
 #pragma unroll
-        for (int pq = 0; pq < KJS / 2; ++pq) { w[pq] = wp[2 * pq * 32]; x0[pq] = ab[2 * pq * BG]; x1[pq] = ab[KJS * BG + 2 * pq * BG]; }
+        for (int pq = 0; pq < KJS / 2; ++pq) { w[pq] = wp[2 * pq * 32]; x0[pq] = ab[2 * pq * BG]; x1[pq] = (WIDE && KJS > 8) ? 0.f : ab[KJS * BG + 2 * pq * BG]; }
         f32x16 T = zero16(), U = zero16();
+        // TIGHT (12 slots AND wide tiles: a body whose best order still has a 13-joint tile): 30 operand registers per block pair
+        // and the regressor operands held across the second-pass branch do not fit 256 registers (7 .. 12 spilled) -- that one
+        // instantiation reads the second block pair's operands where they are used and requests the regressor operands behind the
+        // branch (exposed LDS latency instead of scratch traffic; no other instantiation changes)
+        constexpr bool TIGHT = WIDE && KJS > 8;
         float y0[KJS / 2], y1[KJS / 2];
 #pragma unroll
         for (int pq = 0; pq < KJS / 2; ++pq) {                            // T_{r,3}, T_{r,0}; the next two blocks' operands meanwhile
           T = mfma(w[pq], x0[pq], T);
-          y0[pq] = ab[2 * KJS * BG + 2 * pq * BG]; y1[pq] = ab[3 * KJS * BG + 2 * pq * BG];
+          if (!TIGHT) { y0[pq] = ab[2 * KJS * BG + 2 * pq * BG]; y1[pq] = ab[3 * KJS * BG + 2 * pq * BG]; }
+          else x1[pq] = ab[KJS * BG + 2 * pq * BG];
           U = mfma(w[pq], x1[pq], U);
         }
         vr = T + U * vp[0];                      // T_{r,3} + T_{r,0} v_x
         T = zero16(); U = zero16();
 #pragma unroll
         for (int pq = 0; pq < KJS / 2; ++pq) {                            // T_{r,1}, T_{r,2}
+          if (TIGHT) { y0[pq] = ab[2 * KJS * BG + 2 * pq * BG]; y1[pq] = ab[3 * KJS * BG + 2 * pq * BG]; }
           T = mfma(w[pq], y0[pq], T);
           U = mfma(w[pq], y1[pq], U);
         }
         vr += T * vp[1];                         // T_{r,1} v_y
         vr += U * vp[2];                         // T_{r,2} v_z
         float ra[4];
-        regress_operands(ldsJ, ra);
+        if (!TIGHT) regress_operands(ldsJ, ra);
         if (WIDE && wide) {
           // ---- second pass of a WIDE tile (more than KJS joints): the same four products over slots KJS .. 2 KJS - 1,
           //      added to vr.  Its own ring stage: every copy and store of this wave is drained at its barrier (rare path).
@@ -391,6 +398,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
             *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g4, BP, qoff) = t;
           }
         }
+        if (TIGHT) regress_operands(ldsJ, ra);
         regress(std::integral_constant<int, r>{}, ldsJ, ra);
         // after a second pass the next stage's counted wait (which assumes this stage's stores are all younger than its
         // copies) no longer holds: drain
@@ -448,19 +456,25 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
       ++g;
     });
   }
+  // (the output addresses are formed HERE, from a laundered lane index: hoisted above the tile loop they cost the 12-slot WIDE
+  // instantiation four spilled registers)
+  int te = tid;
+  asm volatile("" : "+v"(te));
+  const int le = te & 63;
+  const size_t b0e = (size_t)(bg * BG + (te >> 6) * BT);
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
     for (int u = 0; u < 4; ++u) {        // block layout: register 4 blk + u = joint 4 (lane / 16) + u, pose column lane % 16 (+ 16)
-      const int i = 4 * (lane >> 4) + u;
-      float* dst = JP + ((size_t)(vc * 3 + r) * NH + i) * BP + (size_t)b0 + (lane & 15);
+      const int i = 4 * (le >> 4) + u;
+      float* dst = JP + ((size_t)(vc * 3 + r) * NH + i) * BP + b0e + (le & 15);
       dst[0] = jacc[r][u] + jacc[r][8 + u];
       dst[16] = jacc[r][4 + u] + jacc[r][12 + u];
     }
 #pragma unroll
   for (int r = 0; r < 3; ++r) {          // joint 16: the two lane halves hold the partial sums over their rows
     const float t = j16[r] + __shfl_xor(j16[r], 32);
-    if (lane < 32) JP[((size_t)(vc * 3 + r) * NH + 16) * BP + bcol] = t;
+    if (le < 32) JP[((size_t)(vc * 3 + r) * NH + 16) * BP + b0e + (le & 31)] = t;
   }
   if (probe && blockIdx.x == 0 && tid == 0) {
     probe[0] = clock64() - probe_t0;                 // shader clocks this wave was resident
@@ -1321,7 +1335,15 @@ __global__ __launch_bounds__(256) void k_jsup_tilemask(JSupport sup) {
     if (e < sup.cnt[i]) m[sup.col[idx] >> 5] = 1;
   }
   __syncthreads();
-  for (int t = threadIdx.x; t < VT; t += 256) sup.tmask[t] = m[t];
+  const bool known = sup.flag[JSUP_KNOWN] != 0;
+  for (int t = threadIdx.x; t < VT; t += 256) {
+    sup.tmask[t] = m[t];
+    // the host has been told which tiles hold the support (and enqueues support-restricted work only): a J step can only shrink
+    // it (ReLU' = 0 outside it) -- unless the caller changed J or the mask in place.  Loud, not silently wrong: sticky error word,
+    // reported by the next jrr_j_support_info
+    if (known && m[t] && !sup.tknown[t]) atomicOr(&sup.flag[JSUP_ERR], 1);
+  }
+  if (known && threadIdx.x == 0 && sup.flag[0] == 0) atomicOr(&sup.flag[JSUP_ERR], 2);
 }
 int launch_jsup_tilemask(const JSupport& sup, hipStream_t s) {
   hipLaunchKernelGGL(k_jsup_tilemask, dim3(1), dim3(256), 0, s, sup);

@@ -329,6 +329,32 @@ __global__ __launch_bounds__(PP * NJ) void k_prep_fwd(const float* __restrict__ 
   prep_fwd_body(blockIdx.x, x6d, Rin, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc, FTq);
 }
 
+// The 24 posed SMPL joints of the most recent chain forward (smplx lbs(): J_transformed = G_j[:3, 3], the `joints` field of the
+// operator's output, /root/reference/scripts/smpl.py:69-84): G_j t = A_j t + A_j R . J_j(beta) from the stored skinning transforms
+// AT [12][24][BP] and the folded rest-joint tables.  One thread per (pose, joint); out (B,24,3).
+__global__ __launch_bounds__(256) void k_posed_joints(const float* __restrict__ AT, const float* __restrict__ betas,
+                                                      const float* __restrict__ Jt, const float* __restrict__ JS,
+                                                      float* __restrict__ out, int B, int BP) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;      // b fastest: coalesced reads of AT
+  if (idx >= B * NJ) return;
+  const int b = idx % B, j = idx / B;
+  float beta[NB], J[3];
+#pragma unroll
+  for (int l = 0; l < NB; ++l) beta[l] = betas[(size_t)b * NB + l];
+  rest_joint(Jt, JS, j, beta, J);
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    float acc = AT[(size_t)((r * 4 + 3) * NJ + j) * BP + b];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) acc = fmaf(AT[(size_t)((r * 4 + c) * NJ + j) * BP + b], J[c], acc);
+    out[((size_t)b * NJ + j) * 3 + r] = acc;
+  }
+}
+int launch_posed_joints(const Model& m, const float* AT, const float* betas, float* out, int B, int BP, hipStream_t s) {
+  hipLaunchKernelGGL(k_posed_joints, dim3((B * NJ + 255) / 256), dim3(256), 0, s, AT, betas, m.Jt, m.JS, out, B, BP);
+  return 0;
+}
+
 // Horizontal fusion (fused inner loop with the pose discriminator): the chain forward and the discriminator's per-joint MLP
 // both depend on x6d only and are both latency-bound with few workgroups (128 + 256 at 4096 poses) -- one launch, different
 // CUs.  Every launch costs ~3.8 us of fixed time on this stack (a one-thread kernel measures that), so two independent small

@@ -411,310 +411,6 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   }
 }
 
-// ------------------------------------------------------------------------------------------------------------------
-// The FUSED rasteriser of the inner loop (round 5): TWO poses in flight per CU.
-//
-// k_sil_raster above keeps one pose's x, y, z (82.7 KB) and a 70 KB z-buffer strip in LDS: one 1024-thread workgroup per CU, and
-// while its 16 waves sit at a barrier or wait for a dependent global round trip nothing else runs (PMC, round 4: 54 % of the
-// wave-cycles parked, 0.23 of the VALU issue rate).  This kernel does the same arithmetic per face and per pixel with <= 80 KB of
-// LDS and 512 threads, so that two workgroups -- two poses -- share a CU and each fills the other's waits:
-//   * LDS holds (x_ndc, y_ndc) only, as float2 (one ds_read_b64 per corner): 55 KB.  The view depth z is needed by faces that
-//     have a pixel centre in their box; it lives in a pose-private GLOBAL scratch plane (27.6 KB, written at set-up, gathered
-//     through L1 / L2 while the face's set-up arithmetic runs).
-//   * the z-buffer strip is 2816 pixels (22 KB): ~5 strips for the ~81 x 144-pixel box of a person; a face is only touched in
-//     the strip(s) its rows fall into.
-//   * a thread keeps its 28 faces as TWO registers each -- three 13-bit vertex indices and the 8-bit first / last pixel row --
-//     so the sweep issues no index loads.
-//   * the adjoint accumulators (one 64-bit fixed-point word per vertex, 55 KB) take the (x, y) array's place once the last strip
-//     is resolved; the resolve pass gathers its corners from the scratch (float2) instead, and the write-out reads x, y, z from it.
-// Same results as k_sil_raster<true> up to the order of the float sums of the camera gradient / the squared error (the vertex
-// adjoint is integer: order-free); bitwise reproducible run to run.
-// ------------------------------------------------------------------------------------------------------------------
-constexpr int SF_T = 512;                  // threads per workgroup
-constexpr int SF_FPT = 28;                 // faces per thread (28 * 512 = 14336 = the model's face capacity)
-constexpr int SF_ZPIX = 2816;              // pixels of the z-buffer strip (22 KB of 64-bit keys)
-constexpr int SF_VS = 6912;                // scratch plane stride in floats (>= V, a multiple of 32: 128-byte lines are not shared)
-constexpr int SF_SCRATCH = 3 * SF_VS;      // floats of scratch per pose: float2 xy[SF_VS] | float z[SF_VS]
-static_assert(SF_VS >= V && SF_VS % 32 == 0 && SF_FPT % 7 == 0, "scratch stride / face groups");
-constexpr int SF_LDS_BYTES = V * 8 + SF_ZPIX * 8;
-
-template <int SIL>
-__global__ __launch_bounds__(SF_T, 4) void k_sil_fused(const int* __restrict__ faces, int nfaces, const float* __restrict__ mask,
-                                                        unsigned* __restrict__ cover, int* __restrict__ ncover,
-                                                        float* __restrict__ sqsil, float scale, float* __restrict__ VQ, int BP,
-                                                        const float* __restrict__ cam, int B, float* __restrict__ gcam,
-                                                        int accumulate_cam, const float* __restrict__ smask,
-                                                        float* __restrict__ scratch, size_t scratch_stride) {
-  constexpr float SIL_F = 5000.f / (float)SIL;
-  extern __shared__ unsigned long long smem64[];
-  float2* xy = reinterpret_cast<float2*>(smem64);                 // [V]   (later: the adjoint accumulators, one u64 per vertex)
-  unsigned long long* zb = smem64 + V;                             // [SF_ZPIX]
-  __shared__ float red[SF_T];
-  __shared__ float pxt[SIL_MAX];
-  __shared__ float bbp[4][SF_T / 64];
-  __shared__ int ncov;
-  const int tid = threadIdx.x;
-  const int per = BP >> 3;
-  const int b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);       // poses [x per, (x + 1) per) on XCD x (8 poses share a 128-byte line of VQ)
-  f32x4* VQ4 = reinterpret_cast<f32x4*>(VQ);
-  if (b >= B) {                                                     // padded pose: its adjoint is zero
-    for (int q = tid; q < 3 * (VP / 4); q += SF_T) VQ4[(size_t)q * BP + b] = f32x4{0.f, 0.f, 0.f, 0.f};
-    return;
-  }
-  float* sxy = scratch + (size_t)b * scratch_stride;               // float2 [SF_VS]
-  float* sz = sxy + 2 * SF_VS;                                      // float  [SF_VS]
-  unsigned* lst = cover + (size_t)b * SIL * SIL;
-  if (tid == 0) ncov = 0;
-  if (tid < SIL) pxt[tid] = pix_x<SIL>(tid);
-  const float tcx = cam[(size_t)b * 3], tcy = cam[(size_t)b * 3 + 1], tcz = cam[(size_t)b * 3 + 2];
-  float bxn = 3e38f, bxx = -3e38f, byn = 3e38f, byx = -3e38f;
-  for (int q = tid; q < VP / 4; q += SF_T) {
-    const f32x4 t0 = VQ4[(size_t)q * BP + b], t1 = VQ4[((size_t)(VP / 4) + q) * BP + b], t2 = VQ4[((size_t)2 * (VP / 4) + q) * BP + b];
-    f32x4 oz, oxy0, oxy1;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int v = 4 * q + u;
-      // scripts/optimize.py:80-82 flip / scale + mesh_renderer.py:52-57 camera (k_sil_project's arithmetic)
-      const float X = -2.f * t0[u] + tcx, Y = -2.f * t1[u] + tcy, Z = 2.f * t2[u] + tcz;
-      const float xn = SIL_F * X / Z, yn = SIL_F * Y / Z;
-      oz[u] = Z;
-      if (u < 2) { oxy0[2 * u] = xn; oxy0[2 * u + 1] = yn; } else { oxy1[2 * (u - 2)] = xn; oxy1[2 * (u - 2) + 1] = yn; }
-      if (v < V) {
-        xy[v] = make_float2(xn, yn);
-        bxn = fminf(bxn, xn); bxx = fmaxf(bxx, xn); byn = fminf(byn, yn); byx = fmaxf(byx, yn);
-      }
-    }
-    reinterpret_cast<f32x4*>(sz)[q] = oz;                           // rows >= V of the last quad: padding of the planes
-    reinterpret_cast<f32x4*>(sxy)[2 * q] = oxy0;
-    reinterpret_cast<f32x4*>(sxy)[2 * q + 1] = oxy1;
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    bxn = fminf(bxn, __shfl_xor(bxn, o)); bxx = fmaxf(bxx, __shfl_xor(bxx, o));
-    byn = fminf(byn, __shfl_xor(byn, o)); byx = fmaxf(byx, __shfl_xor(byx, o));
-  }
-  if ((tid & 63) == 0) {
-    const int w = tid >> 6;
-    bbp[0][w] = bxn; bbp[1][w] = bxx; bbp[2][w] = byn; bbp[3][w] = byx;
-  }
-  __syncthreads();                        // xy in LDS, the scratch planes in L2 (workgroup-scope release: the stores are acknowledged)
-  // two registers per face: r0 = i0 | i1 << 13, r1 = i2 | first row << 13 | last row << 21 (an empty range: first 1, last 0);
-  // built in four groups of seven faces (the index loads of a group fly together; groups are kept apart so that the 84 indices
-  // are never live at once)
-  unsigned fr0[SF_FPT], fr1[SF_FPT];
-#pragma unroll
-  for (int g = 0; g < SF_FPT / 7; ++g) {
-    int fi[7][3];
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int f = min(tid + (7 * g + u) * SF_T, nfaces - 1);      // (a slot past the last face reads the last face and is marked empty below)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) fi[u][k] = faces[f * 3 + k];
-    }
-#pragma unroll
-    for (int u = 0; u < 7; ++u) {
-      const int f = tid + (7 * g + u) * SF_T;
-      const float y0v = xy[fi[u][0]].y, y1v = xy[fi[u][1]].y, y2v = xy[fi[u][2]].y;
-      const float ymax = fmaxf(y0v, fmaxf(y1v, y2v)), ymin = fminf(y0v, fminf(y1v, y2v));
-      int ylo = (int)ceilf((SIL * (1.f - ymax) - 1.f) * 0.5f - 1e-3f), yhi = (int)floorf((SIL * (1.f - ymin) - 1.f) * 0.5f + 1e-3f);
-      ylo = max(ylo, 0); yhi = min(yhi, SIL - 1);
-      if (f >= nfaces || !(ymax == ymax) || !(ymin == ymin) || ylo > yhi) { ylo = 1; yhi = 0; }
-      fr0[7 * g + u] = (unsigned)fi[u][0] | ((unsigned)fi[u][1] << 13);
-      fr1[7 * g + u] = (unsigned)fi[u][2] | ((unsigned)ylo << 13) | ((unsigned)yhi << 21);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-  }
-  int bx0, bx1, by0, by1;
-  {
-    float xn = 3e38f, xx = -3e38f, yn = 3e38f, yx = -3e38f;
-#pragma unroll
-    for (int w = 0; w < SF_T / 64; ++w) {
-      xn = fminf(xn, bbp[0][w]); xx = fmaxf(xx, bbp[1][w]); yn = fminf(yn, bbp[2][w]); yx = fmaxf(yx, bbp[3][w]);
-    }
-    const float fx0 = (SIL * (1.f - xx) - 1.f) * 0.5f - 1e-3f, fx1 = (SIL * (1.f - xn) - 1.f) * 0.5f + 1e-3f;
-    const float fy0 = (SIL * (1.f - yx) - 1.f) * 0.5f - 1e-3f, fy1 = (SIL * (1.f - yn) - 1.f) * 0.5f + 1e-3f;
-    bx0 = (fx0 > 0.f) ? (int)ceilf(fminf(fx0, (float)SIL)) : 0;
-    bx1 = (fx1 < (float)(SIL - 1)) ? (int)floorf(fmaxf(fx1, -1.f)) : SIL - 1;
-    by0 = (fy0 > 0.f) ? (int)ceilf(fminf(fy0, (float)SIL)) : 0;
-    by1 = (fy1 < (float)(SIL - 1)) ? (int)floorf(fmaxf(fy1, -1.f)) : SIL - 1;
-  }
-  const int bw = bx1 - bx0 + 1;
-  const int rows_per = (bw > 0) ? max(SF_ZPIX / bw, 1) : SIL;
-  for (int y0 = by0; y0 <= by1 && bw > 0; y0 += rows_per) {
-    const int y1 = min(y0 + rows_per, by1 + 1);
-    const int npx = (y1 - y0) * bw;
-    for (int i = tid; i < npx; i += SF_T) zb[i] = ~0ull;
-    __syncthreads();
-#pragma unroll
-    for (int u = 0; u < SF_FPT; ++u) {
-      unsigned r0 = fr0[u], r1 = fr1[u];
-      asm volatile("" : "+v"(r0), "+v"(r1));     // unpacked HERE, per strip: hoisted out of the strip loop the 28 x 6 fields would not fit the registers
-      const int ylo = max((int)((r1 >> 13) & 255u), y0), yhi = min((int)(r1 >> 21), y1 - 1);
-      if (ylo > yhi) continue;                                         // no pixel centre of this face in the strip
-      int to = tid;
-      asm volatile("" : "+v"(to));                // (the 28 face numbers are not loop invariants worth a register each either)
-      const int f = to + u * SF_T;
-      const int i0 = (int)(r0 & 8191u), i1 = (int)(r0 >> 13), i2 = (int)(r1 & 8191u);
-      const float2 pa = xy[i0], pb = xy[i1], pc = xy[i2];
-      const float az = sz[i0], bz = sz[i1], cz = sz[i2];               // global gathers: consumed after the set-up arithmetic
-      const float ax = pa.x, ay = pa.y, bx = pb.x, by = pb.y, cx = pc.x, cy = pc.y;
-      const float xmax = fmaxf(ax, fmaxf(bx, cx)), xmin = fminf(ax, fminf(bx, cx));
-      int xlo = (int)ceilf((SIL * (1.f - xmax) - 1.f) * 0.5f - 1e-3f), xhi = (int)floorf((SIL * (1.f - xmin) - 1.f) * 0.5f + 1e-3f);
-      xlo = max(xlo, bx0); xhi = min(xhi, bx1);
-      if (xlo > xhi) continue;
-      const float area = edge_fn(cx, cy, ax, ay, bx, by);
-      if (!(fabsf(area) > SIL_EPS)) continue;                    // also rejects NaN
-      const float inv = 1.f / area;
-      const float a1x = (ay - cy) * inv, a1y = -(ax - cx) * inv;         // d w1 / d (px, py)
-      const float a2x = (by - ay) * inv, a2y = -(bx - ax) * inv;         // d w2 / d (px, py)
-      if (fmaxf(az, fmaxf(bz, cz)) < 0.f) continue;              // behind the camera
-      const float dzb = bz - az, dzc = cz - az;
-      for (int xi = xlo, yi = ylo; yi <= yhi;) {
-        const float dx = pxt[xi] - ax, dy = pxt[yi] - ay;
-        const float w1 = fmaf(dx, a1x, dy * a1y);
-        const float w2 = fmaf(dx, a2x, dy * a2y);
-        const float w0 = 1.f - w1 - w2;
-        const float pz = fmaf(w1, dzb, fmaf(w2, dzc, az));
-        if (w0 > 0.f && w1 > 0.f && w2 > 0.f && pz >= 0.f) {
-          const unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
-          atomicMin(&zb[(yi - y0) * bw + (xi - bx0)], key);
-        }
-        const bool wrap = xi >= xhi;
-        xi = wrap ? xlo : xi + 1;
-        yi += wrap ? 1 : 0;
-      }
-    }
-    __syncthreads();
-    {     // covered pixels of the strip -> the pose's list (pixel << 14 | face): one box row per wave and step, lanes over the columns
-      const int wave = tid >> 6, lane = tid & 63;
-      for (int r = wave; r < y1 - y0; r += SF_T / 64) {
-        for (int x0 = 0; x0 < bw; x0 += 64) {
-          const int x = x0 + lane;
-          const unsigned long long key = (x < bw) ? zb[r * bw + x] : ~0ull;
-          const bool cov = key != ~0ull;
-          const unsigned long long bal = __ballot(cov);
-          if (bal) {
-            const int leader = __ffsll((long long)bal) - 1;
-            int base = 0;
-            if (lane == leader) base = atomicAdd(&ncov, __popcll(bal));
-            base = __shfl(base, leader);
-            if (cov) lst[base + __popcll(bal & ((1ull << lane) - 1ull))] = ((unsigned)((y0 + r) * SIL + bx0 + x) << SIL_FBITS) | (unsigned)(key & 0xffffffffu);
-          }
-        }
-      }
-    }
-    __syncthreads();
-  }
-  const int n = ncov;
-  if (tid == 0) ncover[b] = n;
-  // the (x, y) array is dead: its LDS now holds the adjoint accumulators (fixed point, see k_sil_raster)
-  unsigned long long* acc = smem64;
-  const float fq = scale * (1.f / 131072.f), fqi = (scale > 0.f) ? 131072.f / scale : 0.f;
-  auto pack2 = [&](float gx, float gy) {
-    const long long ix = (long long)__float2int_rn(gx * fqi), iy = (long long)__float2int_rn(gy * fqi);
-    return (unsigned long long)((ix << 32) + iy);
-  };
-  for (int i = tid; i < V; i += SF_T) acc[i] = 0ull;
-  __syncthreads();                                                     // (also: the list stores of the last strip are acknowledged)
-  float err = 0.f;
-  const float2* sxy2 = reinterpret_cast<const float2*>(sxy);
-  for (int e0 = tid; e0 < n; e0 += SF_T * SIL_EB) {
-    unsigned ent[SIL_EB];
-    int id[SIL_EB][3];
-    float tg[SIL_EB];
-    float2 pv[SIL_EB][3];
-#pragma unroll
-    for (int u = 0; u < SIL_EB; ++u) ent[u] = (e0 + u * SF_T < n) ? lst[e0 + u * SF_T] : 0u;
-#pragma unroll
-    for (int u = 0; u < SIL_EB; ++u) {
-      const int f = (int)(ent[u] & ((1u << SIL_FBITS) - 1));
-#pragma unroll
-      for (int k = 0; k < 3; ++k) id[u][k] = faces[f * 3 + k];
-      tg[u] = mask[(size_t)b * SIL * SIL + (ent[u] >> SIL_FBITS)];
-    }
-#pragma unroll
-    for (int u = 0; u < SIL_EB; ++u)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) pv[u][k] = sxy2[id[u][k]];
-#pragma unroll
-    for (int u = 0; u < SIL_EB; ++u) {
-      if (e0 + u * SF_T >= n) continue;
-      const int pix = (int)(ent[u] >> SIL_FBITS);
-      const float px = pxt[pix % SIL], py = pxt[pix / SIL];
-      const float x[3] = {pv[u][0].x, pv[u][1].x, pv[u][2].x}, y[3] = {pv[u][0].y, pv[u][1].y, pv[u][2].y};
-      int ka;
-      float tt;
-      const float dist = sil_nearest_edge(px, py, x, y, ka, tt);
-      const float al = sil_alpha(dist);
-      const float dm = al - tg[u];
-      err += dm * dm - tg[u] * tg[u];                                  // (the pixel's background share is in smask)
-      const float gd = scale * (al - tg[u]) * al * (1.f - al) * SIL_ISIGMA;          // d loss / d dist
-      if (gd == 0.f) continue;
-      const int ida = ka == 0 ? id[u][0] : ka == 1 ? id[u][1] : id[u][2], idb = ka == 0 ? id[u][1] : ka == 1 ? id[u][2] : id[u][0];
-      const float xa = ka == 0 ? x[0] : ka == 1 ? x[1] : x[2], xb = ka == 0 ? x[1] : ka == 1 ? x[2] : x[0];
-      const float ya = ka == 0 ? y[0] : ka == 1 ? y[1] : y[2], yb = ka == 0 ? y[1] : ka == 1 ? y[2] : y[0];
-      const float rx = px - (xa + tt * (xb - xa)), ry = py - (ya + tt * (yb - ya));
-      const float ca = -2.f * (1.f - tt) * gd, cb = -2.f * tt * gd;
-      if (ca != 0.f) atomicAdd(&acc[ida], pack2(ca * rx, ca * ry));
-      if (cb != 0.f) atomicAdd(&acc[idb], pack2(cb * rx, cb * ry));
-    }
-  }
-  __syncthreads();
-  float gc[3] = {0.f, 0.f, 0.f};
-  for (int q = tid; q < VP / 4; q += SF_T) {       // the pose's pieces of VQ now take the vertex adjoint
-    const f32x4 z4 = reinterpret_cast<const f32x4*>(sz)[q];
-    const f32x4 xy0 = reinterpret_cast<const f32x4*>(sxy)[2 * q], xy1 = reinterpret_cast<const f32x4*>(sxy)[2 * q + 1];
-    f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, o2 = o0;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int v = 4 * q + u;
-      if (v < V) {
-        const long long sum = (long long)acc[v];
-        const int iy = (int)(unsigned)(sum & 0xffffffffll);                  // low word, sign-extended
-        const int ix = (int)((sum - (long long)iy) >> 32);
-        const float Gx = (float)ix * fq, Gy = (float)iy * fq;
-        float g[3] = {0.f, 0.f, 0.f};
-        if (Gx != 0.f || Gy != 0.f) {
-          const float vxn = (u < 2) ? xy0[2 * u] : xy1[2 * (u - 2)], vyn = (u < 2) ? xy0[2 * u + 1] : xy1[2 * (u - 2) + 1];
-          const float iz = 1.f / z4[u];
-          g[0] = SIL_F * iz * Gx; g[1] = SIL_F * iz * Gy; g[2] = -(vxn * Gx + vyn * Gy) * iz;
-        }
-        o0[u] = -2.f * g[0]; o1[u] = -2.f * g[1]; o2[u] = 2.f * g[2];
-#pragma unroll
-        for (int c = 0; c < 3; ++c) gc[c] += g[c];
-      }
-    }
-    VQ4[(size_t)q * BP + b] = o0; VQ4[((size_t)(VP / 4) + q) * BP + b] = o1; VQ4[((size_t)2 * (VP / 4) + q) * BP + b] = o2;
-  }
-  if (gcam) {                                                          // wave sums, added in wave order (deterministic)
-#pragma unroll
-    for (int c = 0; c < 3; ++c) {
-      float w = gc[c];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
-      if ((tid & 63) == 0) red[c * (SF_T / 64) + (tid >> 6)] = w;
-    }
-    __syncthreads();
-    if (tid < 3) {
-      float t = 0.f;
-#pragma unroll
-      for (int w = 0; w < SF_T / 64; ++w) t += red[tid * (SF_T / 64) + w];
-      if (accumulate_cam) gcam[(size_t)b * 3 + tid] += t;
-      else gcam[(size_t)b * 3 + tid] = t;
-    }
-    __syncthreads();
-  }
-  if (sqsil) {
-    red[tid] = err;
-    __syncthreads();
-    for (int s = SF_T / 2; s > 0; s >>= 1) {
-      if (tid < s) red[tid] += red[tid + s];
-      __syncthreads();
-    }
-    if (tid == 0) sqsil[b] = red[0] + (smask ? smask[b] : 0.f);
-  }
-}
-
 // adjoint for an arbitrary upstream gradient: g_alpha = galpha[pixel] if given, else scale * (alpha - mask[pixel]).
 // One workgroup per pose walks the pose's covered-pixel list (dense lanes) and accumulates the NDC-space vertex
 // adjoints (G_x, G_y) in LDS (2 x 6890 floats, ds_add_f32), exactly as k_sil_raster<true> does; the projection's
@@ -860,8 +556,6 @@ static void sil_attrs() {
   (void)hipFuncSetAttribute((const void*)k_sil_raster<true, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
   (void)hipFuncSetAttribute((const void*)k_sil_raster<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
   (void)hipFuncSetAttribute((const void*)k_sil_raster<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
-  (void)hipFuncSetAttribute((const void*)k_sil_fused<224>, hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
-  (void)hipFuncSetAttribute((const void*)k_sil_fused<256>, hipFuncAttributeMaxDynamicSharedMemorySize, SF_LDS_BYTES);
   (void)hipFuncSetAttribute((const void*)k_sil_bwd<224>, hipFuncAttributeMaxDynamicSharedMemorySize, V * 2 * 4);
   (void)hipFuncSetAttribute((const void*)k_sil_bwd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, V * 2 * 4);
   g_sil_attr = true;
@@ -890,33 +584,20 @@ int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* 
 }
 // fused loop: project the pose's vertices from the row-quad buffer VQ [3][VP/4][BP][4], rasterise, squared error against
 // mask, and the adjoint of scale/2 * sum((alpha - mask)^2) written back over the same pieces of VQ; gcam: overwrite or
-// accumulate.  scratch: >= BP * scratch_stride floats, scratch_stride >= SF_SCRATCH and a multiple of 32 (pose-private planes,
-// 128-byte lines not shared between poses).  JRR_SIL_V1=1 (experiments): the round-2..4 kernel, one pose per CU.
+// accumulate
 int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
                           unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
-                          hipStream_t s, int S, float* scratch, size_t scratch_stride) {
+                          hipStream_t s, int S) {
   sil_attrs();
   if (sil_size_ok(S)) return JRR_ERR_ARG;
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
-  if (!mask) { jrr_set_error("silhouette: the fused rasteriser needs a target mask"); return JRR_ERR_ARG; }
   const int grid = BP;                     // pose = (block % 8) * (BP / 8) + block / 8; blocks of padded poses zero their pieces
-  static const bool v1 = [] { const char* v = getenv("JRR_SIL_V1"); return v && v[0] == '1'; }();
-  if (v1 || !scratch || scratch_stride < (size_t)SF_SCRATCH || scratch_stride % 32 != 0) {
-    if (!v1) { jrr_set_error("silhouette: scratch of %zu floats per pose (need %d, a multiple of 32)", scratch_stride, SF_SCRATCH); return JRR_ERR_ARG; }
-    if (S == 224)
-      hipLaunchKernelGGL((k_sil_raster<true, 224>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, faces, nfaces, mask, cover,
-                         ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask);
-    else
-      hipLaunchKernelGGL((k_sil_raster<true, 256>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, faces, nfaces, mask, cover,
-                         ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask);
-    return 0;
-  }
   if (S == 224)
-    hipLaunchKernelGGL((k_sil_fused<224>), dim3(grid), dim3(SF_T), SF_LDS_BYTES, s, faces, nfaces, mask, cover, ncover, sqsil, scale, VQ, BP, cam, B,
-                       gcam, accumulate_cam, smask, scratch, scratch_stride);
+    hipLaunchKernelGGL((k_sil_raster<true, 224>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, faces, nfaces, mask, cover,
+                       ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask);
   else
-    hipLaunchKernelGGL((k_sil_fused<256>), dim3(grid), dim3(SF_T), SF_LDS_BYTES, s, faces, nfaces, mask, cover, ncover, sqsil, scale, VQ, BP, cam, B,
-                       gcam, accumulate_cam, smask, scratch, scratch_stride);
+    hipLaunchKernelGGL((k_sil_raster<true, 256>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, faces, nfaces, mask, cover,
+                       ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask);
   return 0;
 }
 // writes ALL of dverts[b][0 .. 6890*3) (no zero-fill needed); gcam: overwrite or accumulate

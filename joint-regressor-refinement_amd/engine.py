@@ -279,6 +279,13 @@ class RefineEngine:
         check(self.lib.jrr_pose_disc_vjp_input(self.handle, ptr(x6d), ptr(gout), ptr(dx), self._s()), 'pose_disc_vjp_input')
         return dx
 
+    def posed_joints(self, betas):
+        """(B,24,3) posed SMPL joints (smplx J_transformed) of the most recent forward on this engine with these betas"""
+        self._chk(betas, (self.batch, NUM_BETAS), 'betas')
+        out = torch.empty(self.batch, NUM_JOINTS, 3, device=self.device)
+        check(self.lib.jrr_smpl_posed_joints(self.handle, ptr(betas), ptr(out), self._s()), 'smpl_posed_joints')
+        return out
+
     def smpl_vertices_backward(self, betas, dverts, x6d=None, R=None):
         B = self.batch
         self._chk(dverts, (B, NUM_VERTS, 3), 'dverts')

@@ -4,8 +4,10 @@ Mirrors the wrapper the reference constructs as `SMPL("SPIN/data/smpl", batch_si
 (/root/reference/scripts/optimize.py:96-99; scripts/smpl.py:61-85) and calls as
     smpl(global_orient=(B,1,3,3), body_pose=(B,23,3,3), betas=(B,10), pose2rot=False).vertices
 (scripts/utils.py:94-95, scripts/optimize.py:78-79, scripts/renderer.py:32-33).  Only `.vertices`
-is consumed on this path; the wrapper's 49 extra regressed joints are dead code there and are not
-produced.  `.vertices` is differentiable w.r.t. all three inputs (analytic adjoint kernels).
+is consumed on this path.  `.vertices` is differentiable w.r.t. all three inputs (analytic adjoint kernels).
+`.joints` (dead on the path: no caller of the reference reads it) holds the 24 posed joints of the kinematic chain
+(jrr_smpl_posed_joints) and -- when the wrapper's `J_regressor_extra.npy` is found -- the reference's 49 re-mapped joints
+(scripts/smpl.py:61-84); it is not differentiated.
 """
 from __future__ import annotations
 
@@ -17,13 +19,24 @@ from . import engine as _engine
 from . import smpl_model as _smpl_model
 
 
+# scripts/smpl.py:12-51 as data: [JOINT_MAP[name] for name in JOINT_NAMES] -- indices into cat(24 posed joints, smplx's 21 vertex
+# joints, 9 extra regressed joints) for the 49 joints the wrapper returns
+JOINT_MAP_49 = (24, 12, 17, 19, 21, 16, 18, 20, 0, 2, 5, 8, 1, 4, 7, 25, 26, 27, 28, 29, 30, 31, 32, 33, 34, 8, 5, 45, 46, 4, 7, 21, 19, 17, 16,
+                18, 20, 47, 48, 49, 50, 51, 52, 53, 24, 26, 25, 28, 27)
+# smplx 0.1.26 VertexJointSelector for SMPL (vertex_ids['smplh']; [3P-memory], like SURVEY.md Appendix A): nose, right / left eye,
+# right / left ear; left big toe, small toe, heel, right big toe, small toe, heel; left thumb .. pinky tips, right thumb .. pinky tips
+SMPL_VERTEX_JOINTS = (332, 6260, 2800, 4071, 583, 3216, 3226, 3387, 6617, 6624, 6787, 2746, 2319, 2445, 2556, 2673, 6191, 5782, 5905,
+                      6016, 6133)
+JOINT_REGRESSOR_TRAIN_EXTRA = 'data/vibe_data/J_regressor_extra.npy'      # scripts/smpl.py:54
+
+
 class SMPLOutput:
-    def __init__(self, vertices, global_orient=None, body_pose=None, betas=None):
+    def __init__(self, vertices, global_orient=None, body_pose=None, betas=None, joints=None):
         self.vertices = vertices
         self.global_orient = global_orient
         self.body_pose = body_pose
         self.betas = betas
-        self.joints = None
+        self.joints = joints
 
 
 class _SMPLVerticesFn(torch.autograd.Function):
@@ -68,8 +81,17 @@ class SMPL:
     """smpl = SMPL(model_dir, batch_size=1).to(device)"""
 
     def __init__(self, model_path: Optional[str] = None, batch_size: int = 1, model: Optional[Dict] = None,
-                 allow_synthetic: bool = True, **_):
+                 allow_synthetic: bool = True, joint_regressor_extra: Optional[str] = None, **_):
         self.model_np = model if model is not None else _smpl_model.load_smpl_model(model_path, allow_synthetic)
+        # scripts/smpl.py:66-69: the (9,6890) extra joint regressor; without the file `.joints` is the 24 posed joints only
+        self.J_regressor_extra = None
+        import os
+        for cand in (joint_regressor_extra, JOINT_REGRESSOR_TRAIN_EXTRA,
+                     os.path.join(model_path, 'J_regressor_extra.npy') if model_path else None):
+            if cand and os.path.isfile(cand):
+                import numpy as np
+                self.J_regressor_extra = torch.from_numpy(np.load(cand).astype('float32'))
+                break
         self.provenance = str(self.model_np.get('provenance', 'caller-supplied arrays'))
         self.faces = self.model_np.get('faces')
         self.device = None
@@ -114,4 +136,9 @@ class SMPL:
             R = torch.cat([global_orient.reshape(B, 1, 3, 3), body_pose.reshape(B, 23, 3, 3)], dim=1).float()
         eng = self.engine(B)
         verts = _SMPLVerticesFn.apply(R, betas.float(), eng)
-        return SMPLOutput(verts, global_orient, body_pose, betas)
+        joints = eng.posed_joints(betas.detach().float().contiguous())      # the chain's 24 posed joints of THIS forward
+        if self.J_regressor_extra is not None:                               # scripts/smpl.py:75-78
+            v = verts.detach()
+            extra = torch.einsum('jv,bvc->bjc', self.J_regressor_extra.to(v.device), v)
+            joints = torch.cat([joints, v[:, list(SMPL_VERTEX_JOINTS)], extra], dim=1)[:, list(JOINT_MAP_49)]
+        return SMPLOutput(verts, global_orient, body_pose, betas, joints)

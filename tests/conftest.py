@@ -106,10 +106,14 @@ def pytest_collection_finish(session):
             DP_RUNS[name] = dict(rc=-999, out=str(e.stdout)[-2000:], err='timeout: ' + str(e.stderr)[-2000:])
 
 
-def write_chumpy_style_pickle(model, path):
+def write_chumpy_style_pickle(model, path, protocol=2):
     """SMPL_NEUTRAL.pkl as distributed: chumpy.ch.Ch arrays, scipy.sparse J_regressor, (6890,3,207) posedirs, 300 shape
-    components, uint32 kintree_table -- written with a stand-in `chumpy` package that is removed again afterwards"""
+    components, uint32 kintree_table -- written with a stand-in `chumpy` package that is removed again afterwards.  The stand-in
+    mimics the state layout of a real chumpy.ch.Ch: its __dict__ (`x`, `_dirty_vars`, `_itr`, `_depends_on_deps`, `_status`, ...)
+    WITHOUT the two WeakKeyDictionary members `_parents` / `_cache`, which chumpy's __getstate__ drops and __setstate__ rebuilds;
+    `protocol` 0 (text pickles, as Python 2 wrote them by default) or 2."""
     import scipy.sparse as sp
+    import weakref
     mods = {n: types.ModuleType(n) for n in ('chumpy', 'chumpy.ch', 'chumpy.reordering')}
 
     class Ch(object):
@@ -117,9 +121,15 @@ def write_chumpy_style_pickle(model, path):
             self.x = np.asarray(x)
             self._dirty_vars = set()
             self._itr = None
+            self._depends_on_deps = False
+            self._status = 'new'
+            self._parents = weakref.WeakKeyDictionary()
+            self._cache = {'drs': weakref.WeakKeyDictionary()}
 
         def __getstate__(self):
-            return self.__dict__.copy()
+            d = self.__dict__.copy()
+            d.pop('_parents', None); d.pop('_cache', None)
+            return d
 
         def __setstate__(self, d):
             self.__dict__.update(d)
@@ -127,6 +137,8 @@ def write_chumpy_style_pickle(model, path):
 
     class transpose(Ch):
         def __init__(self, a, axes=None):
+            Ch.__init__(self, np.zeros(0))
+            del self.__dict__['x']
             self.a, self.axes = a, axes
     transpose.__module__, transpose.__qualname__ = 'chumpy.reordering', 'transpose'
     mods['chumpy.ch'].Ch = Ch
@@ -145,7 +157,7 @@ def write_chumpy_style_pickle(model, path):
     sys.modules.update(mods)
     try:
         with open(path, 'wb') as f:
-            pickle.dump(d, f, protocol=2)
+            pickle.dump(d, f, protocol=protocol)
     finally:
         for n in mods:
             sys.modules.pop(n, None)

@@ -143,7 +143,17 @@ def test_fused_silhouette_gradient_ragged_67(smpl_hip, smpl_model_np, j_h36m_np)
     # (measured with tools/exp/sil_grad_truth.py: the fp32 ORACLE itself is off by 3.4e-2 / 1.1e-2 from its own float64
     # evaluation on two poses of this batch, the HIP kernel on those two and one more)
     pp = per_pose(dv_f, vr.grad)
-    assert pp.median().item() < 1e-4 and (pp > 2e-3).sum().item() <= 3 and pp.max().item() < 3e-2, (pp.median().item(), pp.topk(4))
+    # WHICH poses those are is determined explicitly: the oracle is evaluated once more in float64 on the same fp32 vertices and
+    # targets; a pose whose fp32 ORACLE gradient is itself > 5e-4 away from that evaluation is rounding-sensitive (a pixel on a tie).
+    # Every other pose keeps the strict bound; only the tie poses get the wide one.
+    v64, c64 = verts_h.cpu().double().clone().requires_grad_(True), cam.double().clone().requires_grad_(True)
+    ref64 = sp.soft_silhouette(v64, smpl_model_np['faces'], c64)[:, 0]
+    (100.0 * ((ref64 - mask_o.double()) ** 2).sum() / (B * 224 * 224)).backward()
+    own = per_pose(vr.grad, v64.grad)
+    tie = own > 5e-4
+    assert tie.sum().item() <= 6, own.topk(8)
+    assert pp[~tie].max().item() < 2e-3 and pp.median().item() < 1e-4, (pp[~tie].topk(3), pp.median().item())
+    assert pp.max().item() < 3e-2, pp.topk(4)
     # fused kernel == stand-alone rasteriser + adjoint on the same target (float LDS atomics there: last bits vary)
     dv_s, dc_s = eng.silhouette_backward(((eng.silhouette_forward(verts_h, cd) - mh) * (2.0 * 100.0 / (B * 224 * 224))).contiguous())
     assert rel(dv_f, dv_s) < 2e-5 and rel(dc_f, dc_s) < 2e-5 and per_pose(dv_f, dv_s).max().item() < 5e-5

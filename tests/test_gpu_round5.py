@@ -150,3 +150,75 @@ def test_driver_silhouette_reprojection_shape_disc_vs_oracle(smpl_model_np, j_h3
     J1 = J0.clone()
     oracle.adam_step(J1, gJ, torch.zeros_like(J1), torch.zeros_like(J1), 1, 1e-2)
     assert (res['J_regressor'].cpu() - J1).abs().max().item() < 2e-5
+
+
+def test_smpl_output_joints(smpl_model_np, tmp_path):
+    """`smpl(...).joints` (/root/reference/scripts/smpl.py:69-84): the 24 posed joints of the kinematic chain against the oracle's
+    G_j[:3, 3]; with a J_regressor_extra.npy the 49 re-mapped joints = cat(24 posed, smplx's 21 vertex joints, 9 extra regressed)
+    [JOINT_MAP] rebuilt here from the oracle's vertices and posed joints (the map itself is the reference's table: spot-checked)."""
+    smpl_mod = _mod('smpl')
+    B = 5
+    gen = torch.Generator().manual_seed(21)
+    aa = torch.randn(B, 24, 3, generator=gen) * 0.4
+    betas = torch.randn(B, 10, generator=gen)
+    R = oracle.rodrigues(aa.reshape(-1, 3)).view(B, 24, 3, 3).float()
+    ref = oracle.OracleSMPL(smpl_model_np)(R[:, :1], R[:, 1:], betas)
+    smpl = smpl_mod.SMPL(model=smpl_model_np).to(DEV)
+    out = smpl(global_orient=R[:, :1].to(DEV), body_pose=R[:, 1:].to(DEV), betas=betas.to(DEV), pose2rot=False)
+    assert out.joints.shape == (B, 24, 3)
+    assert (out.joints.cpu() - ref.joints).abs().max().item() < 2e-5
+    assert (out.vertices.cpu() - ref.vertices).abs().max().item() < 2e-5
+    # ... and the wrapper's 49 joints when the extra regressor exists
+    rng = np.random.RandomState(3)
+    Jx = np.zeros((9, 6890), np.float32)
+    for r in range(9):
+        cols = rng.choice(6890, 12, replace=False)
+        Jx[r, cols] = rng.dirichlet(np.ones(12)).astype(np.float32)
+    path = str(tmp_path / 'J_regressor_extra.npy')
+    np.save(path, Jx)
+    smpl49 = smpl_mod.SMPL(model=smpl_model_np, joint_regressor_extra=path).to(DEV)
+    out49 = smpl49(global_orient=R[:, :1].to(DEV), body_pose=R[:, 1:].to(DEV), betas=betas.to(DEV), pose2rot=False)
+    assert out49.joints.shape == (B, 49, 3)
+    full = torch.cat([ref.joints, ref.vertices[:, list(smpl_mod.SMPL_VERTEX_JOINTS)], torch.einsum('jv,bvc->bjc', T(Jx), ref.vertices)], 1)
+    assert full.shape == (B, 54, 3)
+    want = full[:, list(smpl_mod.JOINT_MAP_49)]
+    assert (out49.joints.cpu() - want).abs().max().item() < 2e-5
+    m = smpl_mod.JOINT_MAP_49            # scripts/smpl.py:12-51: 'OP MidHip' -> 0, 'OP Nose' -> 24, 'Right Hip' -> 45, 'Head (H36M)' -> 53
+    assert len(m) == 49 and m[8] == 0 and m[0] == 24 and m[27] == 45 and m[43] == 53 and m[44] == 24
+
+
+def test_support_growing_behind_the_engines_back_is_reported(smpl_model_np, j_h36m_np):
+    """The engine enqueues support-restricted J-step work only once jrr_j_support_info has said the support fits (J steps can only
+    shrink it).  A caller that edits J IN PLACE afterwards -- new positive entries in tiles the engine does not run -- used to get
+    silently wrong gradients; now the device sets a sticky error word and the next jrr_j_support_info raises (and re-baselines)."""
+    eng_mod, lib_mod = _mod('engine'), _mod('_lib')
+    B = 40
+    sm = _mod('smpl_model')
+    dm = eng_mod.DeviceModel(smpl_model_np, DEV)
+    eng = eng_mod.RefineEngine(dm, B, flags=eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_SUPPORT_TILES)
+    J = T(j_h36m_np).to(DEV).contiguous()
+    eng.set_j_regressor(J)
+    counts, fits = eng.j_support_info()
+    assert fits and sum(counts) == 62
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=3)
+    x6, betas = T(batch['pose6d']).to(DEV), T(batch['betas']).to(DEV)
+    gt = oracle.move_pelvis(T(batch['gt_j3d'])).to(DEV).contiguous()
+    Jm, Jv, Js = torch.zeros_like(J), torch.zeros_like(J), torch.zeros(1, dtype=torch.int32, device=DEV)
+    buf = torch.zeros(17, 128, device=DEV)
+    # a legitimate J step: nothing to report
+    eng.j_regressor_grad_support(x6, betas, gt, out=buf)
+    eng.j_step_apply_support(J, buf, Jm, Jv, Js, 1e-2)
+    counts2, fits2 = eng.j_support_info()
+    assert fits2 and sum(counts2) <= 62
+    # the caller grows the support in place: positive entries in vertices far from the support's tiles
+    used = (J > 0).any(0).nonzero().flatten().cpu().numpy()
+    free = [v for v in range(0, 6890, 97) if abs(used - v).min() > 64][:5]
+    J[3, free] = 0.05
+    eng.j_regressor_grad_support(x6, betas, gt, out=buf)
+    eng.j_step_apply_support(J, buf, Jm, Jv, Js, 1e-2)          # k_jstep_update rebuilds the lists from the edited J
+    with pytest.raises(lib_mod.JrrError, match='GREW behind'):
+        eng.j_support_info()
+    # reported once; announcing the regressor properly gives a fresh baseline
+    eng.set_j_regressor(J)
+    counts3, fits3 = eng.j_support_info()
+    assert fits3 and counts3[3] >= 5
