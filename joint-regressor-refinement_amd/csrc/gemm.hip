@@ -502,16 +502,20 @@ int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t
 // exact tiles, 3-deep LDS-DMA ring with counted waits, operand prefetch one quad pair ahead.
 //   tile (32 WM WAVES_M) x (32 WAVES_N), 32-deep chunks (8 quads); EPI / BTR as in k_gemm_tn.
 // ------------------------------------------------------------------------------------------------------------------
-template <int WM, int WAVES_M, int WAVES_N, int EPI, int BTR>
-__global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_disc_gemm(GemmArgs g) {
-  constexpr int NW = WAVES_M * WAVES_N, BM = 32 * WM * WAVES_M, BN = 32 * WAVES_N;
+// KS = 2: two waves per (wm, wn) position split every 32-deep chunk's K steps between them (quad pairs 0-1 / 2-3) and add their
+// accumulators through LDS at the end -- twice the waves on the same tile and the same LDS footprint: the 96 x 64 tile (M = 768:
+// 512 workgroups of two waves = ONE wave per SIMD) gets the second wave per SIMD that covers an LDS wait.
+template <int WM, int WAVES_M, int WAVES_N, int EPI, int BTR, int KS = 1>
+__global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KS) void k_disc_gemm(GemmArgs g) {
+  constexpr int NW = WAVES_M * WAVES_N * KS, BM = 32 * WM * WAVES_M, BN = 32 * WAVES_N;
   constexpr int SA = 8 * BM * 4, SB = 8 * BN * 4, SLOT = SA + SB;            // floats per ring slot
   constexpr int OPA = SA / 256, OPB = SB / 256, PA = OPA / NW, PB = OPB / NW;  // 1 KB copies per chunk / per wave
   static_assert(OPA % NW == 0 && OPB % NW == 0, "exact tiling required");
   __shared__ __attribute__((aligned(16))) float lds[3 * SLOT];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
-  const int wm = wave / WAVES_N, wn = wave % WAVES_N;
+  const int ks = wave / (WAVES_M * WAVES_N), wpos = wave % (WAVES_M * WAVES_N);
+  const int wm = wpos / WAVES_N, wn = wpos % WAVES_N;
   const int n_mt = g.M / BM;
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   const int mt = L % n_mt, nt = L / n_mt;     // consecutive blocks share the activation panel
@@ -559,9 +563,16 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_disc_gemm(GemmArgs g
       if (g.out0) g.out0[(size_t)n * g.out0_ld] = sg;
     }
   }
-  f32x16 acc[WM];
+  // Every variant sums K in the SAME order -- per chunk the quad pairs 0-1 into one accumulator set and 2-3 into another, the two
+  // added at the end -- so that the K-split tile (KS = 2: the two sets live in two waves) and the one-wave-per-position tiles give
+  // bit-identical results: which tile shape a product gets depends on the batch size, and engines of different batch sizes are
+  // compared bit for bit (tests/test_gpu_parity.py)
+  constexpr int NACC = (KS == 1) ? 2 : 1;
+  f32x16 accs[NACC][WM];
 #pragma unroll
-  for (int i = 0; i < WM; ++i) acc[i] = zero16();
+  for (int a = 0; a < NACC; ++a)
+#pragma unroll
+    for (int i = 0; i < WM; ++i) accs[a][i] = zero16();
   int slot = 0;
   for (int ch = 0; ch < nch; ++ch) {
     if (ch + 1 < nch) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PA + PB) : "memory");
@@ -571,24 +582,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_disc_gemm(GemmArgs g
     const f32x4* la = reinterpret_cast<const f32x4*>(lds + slot * SLOT) + wm * WM * 32 + l31;
     const f32x4* lb = reinterpret_cast<const f32x4*>(lds + slot * SLOT + SA) + wn * 32 + l31;
     slot = (slot == 2) ? 0 : slot + 1;
+    constexpr int GQ = 4 / KS;                            // quad pairs of a chunk this wave multiplies: ks GQ .. ks GQ + GQ - 1
+    const int gq0 = ks * GQ;
     f32x4 a4[WM], b4;
 #pragma unroll
-    for (int i = 0; i < WM; ++i) a4[i] = la[half * BM + 32 * i];
-    b4 = lb[half * BN];
+    for (int i = 0; i < WM; ++i) a4[i] = la[(2 * gq0 + half) * BM + 32 * i];
+    b4 = lb[(2 * gq0 + half) * BN];
 #pragma unroll
-    for (int gq = 0; gq < 4; ++gq) {
+    for (int gq = 0; gq < GQ; ++gq) {
       f32x4 ca[WM], cb;
 #pragma unroll
       for (int i = 0; i < WM; ++i) ca[i] = a4[i];
 #pragma unroll
       for (int t = 0; t < 4; ++t) cb[t] = b4[t];
+      f32x16 (&acc)[WM] = accs[(KS == 1) ? gq / 2 : 0];
       __builtin_amdgcn_sched_barrier(0);
       acc[0] = mfma(ca[0][0], cb[0], acc[0]);
       __builtin_amdgcn_sched_barrier(0);
-      if (gq + 1 < 4) {
+      if (gq + 1 < GQ) {
 #pragma unroll
-        for (int i = 0; i < WM; ++i) a4[i] = la[(2 * gq + 2 + half) * BM + 32 * i];
-        b4 = lb[(2 * gq + 2 + half) * BN];
+        for (int i = 0; i < WM; ++i) a4[i] = la[(2 * (gq0 + gq) + 2 + half) * BM + 32 * i];
+        b4 = lb[(2 * (gq0 + gq) + 2 + half) * BN];
       }
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -597,6 +611,27 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N) void k_disc_gemm(GemmArgs g
         for (int i = 0; i < WM; ++i)
           if (t + i > 0) acc[i] = mfma(ca[i][t], cb[t], acc[i]);
     }
+  }
+  f32x16 (&acc)[WM] = accs[0];
+  if (KS == 1) {
+#pragma unroll
+    for (int i = 0; i < WM; ++i) acc[i] += accs[NACC - 1][i];
+  }
+  if (KS == 2) {      // the K halves meet: the ks = 1 waves leave their tiles in the (now idle) ring, the ks = 0 waves add and finish
+    __syncthreads();                                      // every wave is done reading the last chunk
+    float* red = lds + wpos * (WM * 16 * 64);
+    if (ks == 1) {
+#pragma unroll
+      for (int i = 0; i < WM; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) red[(i * 16 + q) * 64 + lane] = acc[i][q];
+    }
+    __syncthreads();
+    if (ks == 1) return;
+#pragma unroll
+    for (int i = 0; i < WM; ++i)
+#pragma unroll
+      for (int q = 0; q < 16; ++q) acc[i][q] += red[(i * 16 + q) * 64 + lane];
   }
   // epilogue: registers 4q4 .. 4q4+3 of tile i = rows r0 + {0..3}, r0 = m0 + (wm WM + i) 32 + 8 q4 + 4 half: one output quad
   const int n = n0 + wn * 32 + l31;
@@ -646,11 +681,17 @@ int launch_disc_gemm_q(const GemmArgs& g, int epi, int btr, hipStream_t s, int* 
   if (!t96 && g.M % 128 != 0) { jrr_set_error("disc_gemm_q: M=%d is neither a multiple of 128 nor of 96", g.M); return JRR_ERR_ARG; }
   if (ndot) *ndot = t96 ? g.M / 96 : (g.M / 128) * 2;
   if (t96) {
-    dim3 grid((g.M / 96) * (g.N / 64)), block(128);
-    if (epi == EPI_STORE && !btr) hipLaunchKernelGGL((k_disc_gemm<3, 1, 2, EPI_STORE, 0>), grid, block, 0, s, g);
+    // the 96-row tile on four waves, two per (row block, column half), splitting K inside the workgroup: two waves per SIMD instead of
+    // one (round 5: the four launches 0.2685 -> 0.2646 ms); JRR_DISC_KS=1 (experiments): two waves, as in rounds 2-4
+    static const bool ks2 = [] { const char* e = getenv("JRR_DISC_KS"); return !(e && atoi(e) == 1); }();
+    dim3 grid((g.M / 96) * (g.N / 64)), block(ks2 ? 256 : 128);
+    if (epi == EPI_STORE && !btr && ks2) hipLaunchKernelGGL((k_disc_gemm<3, 1, 2, EPI_STORE, 0, 2>), grid, block, 0, s, g);
+    else if (epi == EPI_STORE && !btr) hipLaunchKernelGGL((k_disc_gemm<3, 1, 2, EPI_STORE, 0>), grid, block, 0, s, g);
     else { jrr_set_error("disc_gemm_q: 96-row tiles serve the plain store epilogue only"); return JRR_ERR_ARG; }
     return 0;
   }
+  // (256 x 64 tiles on eight waves -- one workgroup per CU, two waves per SIMD behind ONE barrier -- measured equal: 0.2676-0.2689 vs
+  // 0.2684-0.2685 ms for the four launches, round 5; not kept)
   dim3 grid((g.M / 128) * (g.N / 64)), block(256);
   if (epi == EPI_BIAS_RELU && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_BIAS_RELU, 0>), grid, block, 0, s, g);
   else if (epi == EPI_BIAS_RELU_DOT && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_BIAS_RELU_DOT, 0>), grid, block, 0, s, g);

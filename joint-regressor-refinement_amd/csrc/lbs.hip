@@ -869,8 +869,14 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd(const float* __restrict__ Tb
 __device__ __forceinline__ f32x4 mfma4(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
 
-template <int DV, int KJ, bool WIDE, bool LIST = false>      // WIDE, LIST: as in k_lbs_fwd (WIDE: 0.184 vs 0.187 ms)
-__global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ Tb, const float* __restrict__ AT,
+// NG (round 5): 16-pose column groups per wave.  1: the round-3 shape -- two workgroups per CU, two waves per SIMD at 256 registers.
+// 2: ONE workgroup per CU, one wave per SIMD with the 512-register budget, each wave holding TWO column groups: every A operand of
+// the three products (Jn, the tile's W^T rows, the W16 window) is pose-independent, so one LDS read feeds two matrix instructions
+// (28 -> 14 LDS reads per 162 instructions), the two groups are two independent accumulator chains the wave interleaves itself --
+// what the SIMD's second wave did, without its duplicate barrier, prologue and flush -- and the next tile's v_posed quads of both
+// groups wait in registers.  A workgroup then covers 128 poses.
+template <int DV, int KJ, bool WIDE, bool LIST = false, int NG = 1>      // WIDE, LIST: as in k_lbs_fwd (WIDE: 0.184 vs 0.187 ms)
+__global__ __launch_bounds__(256, NG == 2 ? 1 : 2) void k_lbs_bwd16(const float* __restrict__ Tb, const float* __restrict__ AT,
                                                       const float* __restrict__ VPb, const float* __restrict__ dJT,
                                                       const float* __restrict__ dVT, float* __restrict__ DVP,
                                                       float* __restrict__ dATp, int BP, int nvc, int n_bt,
@@ -885,12 +891,12 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
   const int NT = LIST ? ntl : VT;
   constexpr int S = KJ / 4;                          // K steps of the T product (4 joint slots each)
   constexpr int ASL = 9 * NJ * 16;                   // floats of one wave's A^T slice [(r,c)][24 joints][16 poses]
-  __shared__ __attribute__((aligned(16))) float lds[BWD_RING * R16_FLOATS + 4 * ASL];
+  __shared__ __attribute__((aligned(16))) float lds[BWD_RING * R16_FLOATS + 4 * NG * ASL];
   float* const ring = lds;
   const int tid = threadIdx.x;
   const int lane = tid & 63, n = lane & 15, g = lane >> 4;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
-  float* const ldsA = lds + BWD_RING * R16_FLOATS + wv * ASL;
+  float* const ldsA = lds + BWD_RING * R16_FLOATS + wv * NG * ASL;      // group gi at + gi * ASL
   const int L = xcd_remap(blockIdx.x, gridDim.x);
   // default mapping: an XCD's contiguous range of L = one vertex chunk x all pose groups (paired == -2: chunk-major inside a
   // pose group instead; measured equal or slower: 0.200 vs 0.203 ms at B = 4096, 0.069 vs 0.066 ms at B = 1024)
@@ -913,7 +919,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
     t_begin = slot_ ? mid : P0;
     t_end = slot_ ? P1 : mid;
   }
-  const size_t bcol = (size_t)bt * 64 + wv * 16 + n;          // this lane's pose column
+  size_t bcol[NG];                                            // this lane's pose column in each of the wave's groups
+#pragma unroll
+  for (int gi = 0; gi < NG; ++gi) bcol[gi] = (size_t)bt * (64 * NG) + wv * (16 * NG) + gi * 16 + n;
   const unsigned lane_ln = (unsigned)lane * 4u;
 
   auto issue = [&](int vt, int slot) {
@@ -935,33 +943,40 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
 #pragma unroll
     for (int jj = 0; jj < NJ / 4; ++jj) {
       const int j = 4 * jj + g;
-      ldsA[(rc * NJ + j) * 16 + n] = AT[(size_t)(((rc / 3) * 4 + rc % 3) * NJ + j) * BP + bcol];
+#pragma unroll
+      for (int gi = 0; gi < NG; ++gi) ldsA[gi * ASL + (rc * NJ + j) * 16 + n] = AT[(size_t)(((rc / 3) * 4 + rc % 3) * NJ + j) * BP + bcol[gi]];
     }
   // joint adjoint as B operands of the vertex-adjoint product: dj[r][s] = dJ^T[r][i = 4 s + g][pose]
-  float dj[3][5];
+  float dj[NG][3][5];
 #pragma unroll
-  for (int r = 0; r < 3; ++r)
+  for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
-    for (int s5 = 0; s5 < 5; ++s5) {
-      const int i = 4 * s5 + g;
-      dj[r][s5] = (DV != 1 && i < NHP) ? dJT[(size_t)(r * NHP + i) * BP + bcol] : 0.f;
-    }
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s5 = 0; s5 < 5; ++s5) {
+        const int i = 4 * s5 + g;
+        dj[gi][r][s5] = (DV != 1 && i < NHP) ? dJT[(size_t)(r * NHP + i) * BP + bcol[gi]] : 0.f;
+      }
 
   // row quad (plane, tile, blk) of this lane: rows 32 vt + 16 blk + 4 g + 0..3 of its pose
-  auto qidx = [&](int plane, int vt, int blk) { return ((size_t)plane * (VP / 4) + vt * 8 + 4 * blk + g) * BP + bcol; };
+  auto qidx = [&](int plane, int vt, int blk, int gi) { return ((size_t)plane * (VP / 4) + vt * 8 + 4 * blk + g) * BP + bcol[gi]; };
   const f32x4* const VP4 = reinterpret_cast<const f32x4*>(VPb);
   const f32x4* const dV4 = reinterpret_cast<const f32x4*>(dVT);
   f32x4* const DVP4 = reinterpret_cast<f32x4*>(DVP);
-  auto load_vp = [&](int vt, f32x4 (&dst)[3][2]) __attribute__((always_inline)) {
+  auto load_vp = [&](int vt, f32x4 (&dst)[NG][3][2]) __attribute__((always_inline)) {
 #pragma unroll
-    for (int c = 0; c < 3; ++c)
+    for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk) dst[c][blk] = __builtin_nontemporal_load(&VP4[qidx(c, vt, blk)]);   // read once: do not displace the operands in L2
+      for (int c = 0; c < 3; ++c)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) dst[gi][c][blk] = __builtin_nontemporal_load(&VP4[qidx(c, vt, blk, gi)]);   // read once: do not displace the operands in L2
   };
 
-  f32x4 acc[12];                                   // dA_{r,c} at 3 r + c (c < 3), dA_{r,3} at 9 + r: 16 window rows x 16 poses
+  f32x4 acc[NG][12];                               // dA_{r,c} at 3 r + c (c < 3), dA_{r,3} at 9 + r: 16 window rows x 16 poses
 #pragma unroll
-  for (int e = 0; e < 12; ++e) acc[e] = zero4();
+  for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[gi][e] = zero4();
   int cur_seg = (t_begin < t_end) ? segid[tile_of(t_begin)] : 0;
   int seg_tile = (t_begin < t_end) ? tile_of(t_begin) : 0;
   unsigned seen = 0u;
@@ -973,6 +988,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
     // last dvp stores
     if (seen != 0u) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int* sj = segj + seg_tile * 16;
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
     // rows an earlier flush of this workgroup stored are read back FIRST, all of them in flight together (one agent-scope load per
     // row and entry: issued one by one between the stores they feed, 48 dependent L2 round trips made the flush the largest fixed
     // cost of the launch), then everything is stored
@@ -982,7 +999,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       jr[i] = sj[4 * g + i];
-      rowp[i] = dATp + ((size_t)(vc * 12) * NJ + (jr[i] >= 0 ? jr[i] : 0)) * BP + bcol;
+      rowp[i] = dATp + ((size_t)(vc * 12) * NJ + (jr[i] >= 0 ? jr[i] : 0)) * BP + bcol[gi];
       const bool add = jr[i] >= 0 && ((seen >> jr[i]) & 1u);
 #pragma unroll
       for (int e = 0; e < 12; ++e) {
@@ -998,39 +1015,42 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
 #pragma unroll
         for (int e = 0; e < 12; ++e) {
           const int ent = e < 9 ? (e / 3) * 4 + e % 3 : (e - 9) * 4 + 3;
-          const float val = add ? acc[e][i] + oldv[i][e] : acc[e][i];
+          const float val = add ? acc[gi][e][i] + oldv[i][e] : acc[gi][e][i];
           __hip_atomic_store(rowp[i] + (size_t)ent * NJ * BP, val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // paired with the agent-scope re-read of a later flush
         }
       }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[gi][e] = zero4();
     }
 #pragma unroll
     for (int k = 0; k < 16; ++k) {
       const int j = sj[k];
       if (j >= 0) seen |= 1u << j;
     }
-#pragma unroll
-    for (int e = 0; e < 12; ++e) acc[e] = zero4();
   };
 
-  f32x4 vpA[3][2], vpB[3][2];
+  f32x4 vpA[NG][3][2], vpB[NG][3][2];
   if (t_begin < t_end) load_vp(tile_of(t_begin), vpA);
   int slot = 0;
-  auto tile = [&](int ix, const f32x4 (&vpc)[3][2], f32x4 (&vpn)[3][2]) __attribute__((always_inline)) {
+  auto tile = [&](int ix, const f32x4 (&vpc)[NG][3][2], f32x4 (&vpn)[NG][3][2]) __attribute__((always_inline)) {
     const int vt = tile_of(ix);
     // record vt has landed (it was issued two tiles ago: older than the 6 prefetch loads and the 6 dvp stores of the previous
     // tile, which stay in flight) and every wave is done with the slot the next copy overwrites
-    barrier_keep_vm<12>();
+    barrier_keep_vm<12 * NG>();
     const int slot1 = (slot + 1 == BWD_RING) ? 0 : slot + 1, slot2 = (slot1 + 1 == BWD_RING) ? 0 : slot1 + 1;
     if (ix + 2 < t_end) issue(tile_of(ix + 2), slot2);
     __builtin_amdgcn_sched_barrier(0);
     const float* tab = ring + slot * R16_FLOATS;
     if (ix + 1 < t_end) load_vp(tile_of(ix + 1), vpn);
     // ---- vertex adjoint of the tile: dverts_r = Jn^T dj_r and / or the caller's ----
-    f32x4 dv[3][2];
+    f32x4 dv[NG][3][2];
 #pragma unroll
-    for (int r = 0; r < 3; ++r)
+    for (int gi = 0; gi < NG; ++gi)
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk) dv[r][blk] = (DV != 0) ? dV4[qidx(r, vt, blk)] : zero4();
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) dv[gi][r][blk] = (DV != 0) ? dV4[qidx(r, vt, blk, gi)] : zero4();
     if (DV != 1) {
 #pragma unroll
       for (int s5 = 0; s5 < 5; ++s5)
@@ -1038,7 +1058,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
         for (int blk = 0; blk < 2; ++blk) {
           const float a = tab[R16_JN + (blk * 5 + s5) * 64 + lane];
 #pragma unroll
-          for (int r = 0; r < 3; ++r) dv[r][blk] = mfma4(a, dj[r][s5], dv[r][blk]);
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) dv[gi][r][blk] = mfma4(a, dj[gi][r][s5], dv[gi][r][blk]);
         }
     }
     // ---- operands shared by the planes: W^T (A of T), W16 (A of dA), the A^T row offsets of the tile's joint slots ----
@@ -1063,51 +1085,56 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
 #pragma unroll
       for (int i = 0; i < 4; ++i)
 #pragma unroll
-        for (int r = 0; r < 3; ++r) acc[9 + r] = mfma4(wd[blk][i], dv[r][blk][i], acc[9 + r]);
+        for (int r = 0; r < 3; ++r)
+#pragma unroll
+          for (int gi = 0; gi < NG; ++gi) acc[gi][9 + r] = mfma4(wd[blk][i], dv[gi][r][blk][i], acc[gi][9 + r]);
     // ---- per plane c: T_{r,c} (recomputed), dvp_c = sum_r T_{r,c} dverts_r, dA_{r,c} += W16^T (dverts_r * vp_c) ----
 #pragma unroll
     for (int c = 0; c < 3; ++c) {
-      f32x4 T[3][2];
 #pragma unroll
-      for (int r = 0; r < 3; ++r) { T[r][0] = zero4(); T[r][1] = zero4(); }
+      for (int gi = 0; gi < NG; ++gi) {      // (one group's T at a time: 24 live registers, not 24 NG -- the W^T operands stay in registers)
+        f32x4 T[3][2];
 #pragma unroll
-      for (int s = 0; s < S; ++s)
+        for (int r = 0; r < 3; ++r) { T[r][0] = zero4(); T[r][1] = zero4(); }
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-          const float at = ldsA[(r * 3 + c) * (NJ * 16) + jo[s] + n];
-          T[r][0] = mfma4(wt[0][s], at, T[r][0]);
-          T[r][1] = mfma4(wt[1][s], at, T[r][1]);
-        }
-      if (WIDE && s_tile > S) {                                     // WIDE tile: the K steps beyond the kernel's S (slots 4 S .. 15)
-#pragma unroll 1
-        for (int s = S; s < s_tile && s < 4; ++s) {
-          const int jox = reinterpret_cast<const int*>(tab + R16_JL)[4 * s + g];
-          const float w0 = s < 3 ? tab[R16_WT + (0 * 3 + s) * 64 + lane] : tab[R16_WX + lane];
-          const float w1 = s < 3 ? tab[R16_WT + (1 * 3 + s) * 64 + lane] : tab[R16_WX + 64 + lane];
+        for (int s = 0; s < S; ++s)
 #pragma unroll
           for (int r = 0; r < 3; ++r) {
-            const float at = ldsA[(r * 3 + c) * (NJ * 16) + jox + n];
-            T[r][0] = mfma4(w0, at, T[r][0]);
-            T[r][1] = mfma4(w1, at, T[r][1]);
+            const float at = ldsA[gi * ASL + (r * 3 + c) * (NJ * 16) + jo[s] + n];
+            T[r][0] = mfma4(wt[0][s], at, T[r][0]);
+            T[r][1] = mfma4(wt[1][s], at, T[r][1]);
+          }
+        if (WIDE && s_tile > S) {                                     // WIDE tile: the K steps beyond the kernel's S (slots 4 S .. 15)
+#pragma unroll 1
+          for (int s = S; s < s_tile && s < 4; ++s) {
+            const int jox = reinterpret_cast<const int*>(tab + R16_JL)[4 * s + g];
+            const float w0 = s < 3 ? tab[R16_WT + (0 * 3 + s) * 64 + lane] : tab[R16_WX + lane];
+            const float w1 = s < 3 ? tab[R16_WT + (1 * 3 + s) * 64 + lane] : tab[R16_WX + 64 + lane];
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+              const float at = ldsA[gi * ASL + (r * 3 + c) * (NJ * 16) + jox + n];
+              T[r][0] = mfma4(w0, at, T[r][0]);
+              T[r][1] = mfma4(w1, at, T[r][1]);
+            }
           }
         }
-      }
 #pragma unroll
-      for (int blk = 0; blk < 2; ++blk) {
-        f32x4 t;
+        for (int blk = 0; blk < 2; ++blk) {
+          f32x4 t;
 #pragma unroll
-        for (int i = 0; i < 4; ++i)
-          t[i] = fmaf(T[2][blk][i], dv[2][blk][i], fmaf(T[1][blk][i], dv[1][blk][i], T[0][blk][i] * dv[0][blk][i]));
-        __builtin_nontemporal_store(t, &DVP4[qidx(c, vt, blk)]);      // streamed (340 MB per launch): nt, measured -2.5 us
+          for (int i = 0; i < 4; ++i)
+            t[i] = fmaf(T[2][blk][i], dv[gi][2][blk][i], fmaf(T[1][blk][i], dv[gi][1][blk][i], T[0][blk][i] * dv[gi][0][blk][i]));
+          __builtin_nontemporal_store(t, &DVP4[qidx(c, vt, blk, gi)]);      // streamed (340 MB per launch): nt, measured -2.5 us
+        }
       }
 #pragma unroll
       for (int blk = 0; blk < 2; ++blk)
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          const float v = vpc[c][blk][i];
+        for (int i = 0; i < 4; ++i)
 #pragma unroll
-          for (int r = 0; r < 3; ++r) acc[3 * r + c] = mfma4(wd[blk][i], dv[r][blk][i] * v, acc[3 * r + c]);
-        }
+          for (int r = 0; r < 3; ++r)
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) acc[gi][3 * r + c] = mfma4(wd[blk][i], dv[gi][r][blk][i] * vpc[gi][c][blk][i], acc[gi][3 * r + c]);
     }
     slot = slot1;
   };
@@ -1116,8 +1143,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
     if (ix + 1 < t_end) tile(ix + 1, vpB, vpA);
   }
   flush_window();
-  if (dmask) {
-    if (tid == 0) dmask[vc * n_bt + bt] = seen;
+  if (dmask) {      // one word per (chunk, 64-pose group): this workgroup's NG groups of 64 poses touched the same joints
+    if (tid < NG) dmask[vc * (n_bt * NG) + bt * NG + tid] = seen;
     return;
   }
   // joints no tile of this chunk touches: zero rows
@@ -1126,7 +1153,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_bwd16(const float* __restrict__ 
     if ((seen >> j) & 1u) continue;
     if (lane < 16) {
 #pragma unroll
-      for (int ent = 0; ent < 12; ++ent) dATp[((size_t)(vc * 12 + ent) * NJ + j) * BP + bcol] = 0.f;
+      for (int gi = 0; gi < NG; ++gi)
+#pragma unroll
+        for (int ent = 0; ent < 12; ++ent) dATp[((size_t)(vc * 12 + ent) * NJ + j) * BP + bcol[gi]] = 0.f;
     }
   }
 }
@@ -1609,22 +1638,47 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
 int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float* VPb, const float* dJT,
                    const float* dVT, float* DVP, float* dATp, int BP, int nvc, hipStream_t s, const int* tl, int ntl, unsigned* dmask) {
   if (tl && !(m.kjs && m.bwd16 && !dVT)) { jrr_set_error("lbs_bwd: the tile list serves k_lbs_bwd16 without an outside vertex adjoint"); return JRR_ERR_ARG; }
-  if (m.kjs && m.bwd16) {                       // four symmetric waves of 16 poses: one workgroup per (64 poses, vertex chunk)
-    const int n_bt16 = BP / 64;
+  if (m.kjs && m.bwd16) {                       // four symmetric waves: one workgroup per (64 NG poses, vertex chunk)
+    // JRR_BWD16_NG (experiments): 16-pose column groups per wave -- 1 (default): the round-3 shape, two workgroups of 64 poses per CU;
+    // 2: one workgroup of 128 poses per CU, one wave per SIMD with 512 registers (round 5: built, parity-green, measured SLOWER --
+    // 0.251 vs 0.178 ms at 4096 poses: a lone wave per SIMD does not cover its own LDS / VALU latencies with the compiler's schedule)
+    // (NG = 2 is built for the loop's own case -- vertex adjoint from the joints only, no wide tile; with a vertex adjoint from outside or
+    // the wide-tile branch the two groups' registers no longer fit the 512 and the compiler spills 8 .. 53 of them: those run NG = 1)
+    static const int ng_env = [] { const char* e = getenv("JRR_BWD16_NG"); return (e && e[0] == '2') ? 2 : 1; }();
+    const int ng = (ng_env == 2 && !dVT && !m.wide_tiles && m.kjs == 8) ? 2 : 1;
+    const int n_bt16 = BP / (64 * ng);
     dim3 grid16(n_bt16 * nvc), block16(256);
-    // JRR_BWD16_PAIRED (experiments): share of the first-dispatched workgroup of a CU in thousandths (default 540 since the slab flush
+    // JRR_BWD16_PAIRED (experiments, NG = 1): share of the first-dispatched workgroup of a CU in thousandths (default 540 since the slab flush
     // reads back in one batch: 0.1777 ms against 0.1797 at 520, 0.1782 at 560; before that 520: round 4, with
     // the non-temporal streams -- 0.1797 ms against 0.1815 at 480, 0.186 at 560; shader-clock stamps: the first-dispatched workgroup's
     // tiles take ~12 300 clocks, its partner's ~14 000 while both run and 7 400 once it is alone), 0 = no
     // pairing, -2 = chunk-major mapping without pairing
     static const int pair_env = [] { const char* e = getenv("JRR_BWD16_PAIRED"); return e ? atoi(e) : 540; }();
-    const int paired16 = (pair_env > 0) ? ((grid16.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? pair_env : 0) : pair_env;
+    const int paired16 = ng == 2 ? 0 : (pair_env > 0) ? ((grid16.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? pair_env : 0) : pair_env;
 #define JRR_LBS_BWD16_K(DVM, KJV, WD)                                                                                           \
-  hipLaunchKernelGGL((k_lbs_bwd16<DVM, KJV, WD>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, \
-                     m.segj, paired16, m.tnj, nullptr, 0, dmask)
+  do {                                                                                                                          \
+    if constexpr (DVM == 0 && !WD) {                                                                                            \
+      if (ng == 2) {                                                                                                            \
+        hipLaunchKernelGGL((k_lbs_bwd16<0, 8, false, false, 2>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, \
+                           m.segid, m.segj, paired16, m.tnj, nullptr, 0, dmask);                                                \
+        break;                                                                                                                  \
+      }                                                                                                                         \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((k_lbs_bwd16<DVM, KJV, WD, false, 1>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, \
+                       m.segid, m.segj, paired16, m.tnj, nullptr, 0, dmask);                                                    \
+  } while (0)
 #define JRR_LBS_BWD16_L(KJV, WD)                                                                                                \
-  hipLaunchKernelGGL((k_lbs_bwd16<0, KJV, WD, true>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, m.segid, \
-                     m.segj, paired16, m.tnj, tl, ntl, dmask)
+  do {                                                                                                                          \
+    if constexpr (!WD) {                                                                                                        \
+      if (ng == 2) {                                                                                                            \
+        hipLaunchKernelGGL((k_lbs_bwd16<0, 8, false, true, 2>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, \
+                           m.segid, m.segj, paired16, m.tnj, tl, ntl, dmask);                                                   \
+        break;                                                                                                                  \
+      }                                                                                                                         \
+    }                                                                                                                           \
+    hipLaunchKernelGGL((k_lbs_bwd16<0, KJV, WD, true, 1>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, \
+                       m.segid, m.segj, paired16, m.tnj, tl, ntl, dmask);                                                       \
+  } while (0)
 #define JRR_LBS_BWD16(DVM)                                                                                                      \
   do {                                                                                                                          \
     if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_BWD16_K(DVM, 8, false);                                                            \

@@ -119,6 +119,23 @@ def test_fused_silhouette_gradient_ragged_67(smpl_hip, smpl_model_np, j_h36m_np)
     agree = (p2f_h == p2f_o) & ((alpha - ref.detach()).abs() < 2e-3)
     covered = (p2f_o >= 0).sum().item()
     assert (~agree).sum().item() < 5e-3 * covered, ((~agree).sum().item(), covered)      # the winning faces differ on < 0.5 %
+    # ... and the pixels ON A TIE are taken out the same way, explicitly: a pixel whose two nearest edges of the winning face are
+    # equidistant to within 1e-3 (relative; float64 evaluation on the fp32 vertices) gets its gradient through whichever edge the
+    # rounding of |p - q|^2 picks -- different vertices, same alpha.  (Round 4 allowed "up to three poses off by up to 3e-2" instead.)
+    ndc64 = sp.project_mesh(verts_h.cpu().double(), cam.double())
+    ft = torch.as_tensor(np.asarray(smpl_model_np['faces']), dtype=torch.long)
+    tie = torch.zeros_like(agree)
+    for bi in range(B):
+        pix = torch.nonzero(p2f_o[bi].reshape(-1) >= 0).flatten()
+        f = ft[p2f_o[bi].reshape(-1)[pix].long()]
+        px = 1 - (2 * (pix % 224).double() + 1) / 224
+        py = 1 - (2 * (pix // 224).double() + 1) / 224
+        vx, vy = ndc64[bi, :, 0], ndc64[bi, :, 1]
+        d = torch.stack([sp._seg_dist2(px, py, vx[f[:, k]], vy[f[:, k]], vx[f[:, (k + 1) % 3]], vy[f[:, (k + 1) % 3]]) for k in range(3)], 1)
+        ds = d.sort(1).values
+        tie[bi].view(-1)[pix] = (ds[:, 1] - ds[:, 0]) < 1e-3 * ds[:, 0].clamp_min(1e-30)
+    assert tie.sum().item() < 5e-3 * covered, (tie.sum().item(), covered)
+    agree = agree & ~tie
     mask_o = torch.where(agree, mask, ref.detach())
     mask_h = torch.where(agree, mask, alpha)
     loss = 100.0 * ((ref - mask_o) ** 2).sum() / (B * 224 * 224)
@@ -135,25 +152,11 @@ def test_fused_silhouette_gradient_ragged_67(smpl_hip, smpl_model_np, j_h36m_np)
 
     def per_pose(a, b):
         return ((a.double().cpu() - b.double().cpu()).flatten(1).norm(dim=1) / b.double().cpu().flatten(1).norm(dim=1))
-    # (the norm over the batch is dominated by the one to three poses with a pixel on a tie, see below: which poses those are changes
-    # with the last bit of the vertices -- 2.0e-3 with round 3's forward kernel, 2.9e-3 with round 4's K-quad summation order)
-    assert rel(dv_f, vr.grad) < 5e-3 and rel(dc_f, cr.grad) < 5e-3, (rel(dv_f, vr.grad), rel(dc_f, cr.grad))
-    # per pose: typically 2e-5; a pose is off by up to ~1e-2 when ONE of its pixels sits on a tie -- equidistant from two
-    # edges of its face, or at a clamp boundary of the closest-point parameter -- that fp32 rounding breaks differently
-    # (measured with tools/exp/sil_grad_truth.py: the fp32 ORACLE itself is off by 3.4e-2 / 1.1e-2 from its own float64
-    # evaluation on two poses of this batch, the HIP kernel on those two and one more)
+    # with the tie pixels out of the comparison EVERY pose keeps the strict bound (tools/exp/sil_grad_truth.py measured what a tie
+    # costs: the fp32 ORACLE itself is 3.4e-2 / 1.1e-2 from its own float64 evaluation on two poses of this batch)
+    assert rel(dv_f, vr.grad) < 2e-3 and rel(dc_f, cr.grad) < 2e-3, (rel(dv_f, vr.grad), rel(dc_f, cr.grad))
     pp = per_pose(dv_f, vr.grad)
-    # WHICH poses those are is determined explicitly: the oracle is evaluated once more in float64 on the same fp32 vertices and
-    # targets; a pose whose fp32 ORACLE gradient is itself > 5e-4 away from that evaluation is rounding-sensitive (a pixel on a tie).
-    # Every other pose keeps the strict bound; only the tie poses get the wide one.
-    v64, c64 = verts_h.cpu().double().clone().requires_grad_(True), cam.double().clone().requires_grad_(True)
-    ref64 = sp.soft_silhouette(v64, smpl_model_np['faces'], c64)[:, 0]
-    (100.0 * ((ref64 - mask_o.double()) ** 2).sum() / (B * 224 * 224)).backward()
-    own = per_pose(vr.grad, v64.grad)
-    tie = own > 5e-4
-    assert tie.sum().item() <= 6, own.topk(8)
-    assert pp[~tie].max().item() < 2e-3 and pp.median().item() < 1e-4, (pp[~tie].topk(3), pp.median().item())
-    assert pp.max().item() < 3e-2, pp.topk(4)
+    assert pp.median().item() < 1e-4 and pp.max().item() < 2e-3, (pp.median().item(), pp.topk(4))
     # fused kernel == stand-alone rasteriser + adjoint on the same target (float LDS atomics there: last bits vary)
     dv_s, dc_s = eng.silhouette_backward(((eng.silhouette_forward(verts_h, cd) - mh) * (2.0 * 100.0 / (B * 224 * 224))).contiguous())
     assert rel(dv_f, dv_s) < 2e-5 and rel(dc_f, dc_s) < 2e-5 and per_pose(dv_f, dv_s).max().item() < 5e-5

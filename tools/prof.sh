@@ -6,8 +6,8 @@ OUT=$PWD/gpurun_out/prof_$TAG
 mkdir -p $OUT
 export TMPDIR=/tmp
 # kernel trace: the default bench command itself (100 timed steps); PMC passes: a short run (counters serialise kernels)
-FULL="python3 $PWD/bench.py --no_cpu_baseline --min_timed_ms 600 --no_config2 --no_rccl_one_rank"
-CMD="python3 $PWD/bench.py --steps 5 --warmup 2 --no_cpu_baseline --min_timed_ms 1 --no_skin_variants --no_folded --no_config2 --no_rccl_one_rank --no_support_tiles"
+FULL="python3 $PWD/bench.py --no_cpu_baseline --min_timed_ms 600 --no_config2 --no_rccl_one_rank --no_driver_blocks"
+CMD="python3 $PWD/bench.py --steps 5 --warmup 2 --no_cpu_baseline --min_timed_ms 1 --no_skin_variants --no_folded --no_config2 --no_rccl_one_rank --no_support_tiles --no_driver_blocks"
 cd /tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- $FULL > $OUT/trace.log 2>&1
 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA SQ_LDS_BANK_CONFLICT --output-format csv -d $OUT/pmc_sq -o pmc -- $CMD > $OUT/pmc_sq.log 2>&1
@@ -56,14 +56,14 @@ if f is not None and w is not None:
     issued = {}
     n = mf('k_lbs_fwd<true, false, 8, false, false>')
     if n: issued['k_lbs_fwd'] = {'sq_insts_mfma': int(n), 'flop_per_launch': int(n * (378 * 4096 + 48 * 2048) / 426)}
-    n = mf('k_lbs_bwd16<0, 8, false, false>')
+    n = mf('k_lbs_bwd16<0, 8, false, false, 1>')
     if n: issued['k_lbs_bwd'] = {'sq_insts_mfma': int(n), 'flop_per_launch': int(n * 2048)}
     n = mf('k_blend_adjoint')
     if n: issued['k_blend_adjoint'] = {'sq_insts_mfma': int(n), 'flop_per_launch': int(n * 4096)}
     nd = [v.get('SQ_INSTS_MFMA') for k, v in sq.items() if 'k_disc_gemm' in k]
     if nd and all(nd): issued['pose_disc_gemms'] = {'sq_insts_mfma': int(sum(nd)), 'flop_per_launch': int(sum(nd) * 4096), 'launches': len(nd)}
     out['traffic']['mfma_issued_b4096'] = issued
-    for key, name in (('k_lbs_fwd<true, false, 8, false, false>', 'k_lbs_fwd'), ('k_lbs_bwd16<0, 8, false, false>', 'k_lbs_bwd'), ('k_blend_adjoint', 'k_blend_adjoint')):
+    for key, name in (('k_lbs_fwd<true, false, 8, false, false>', 'k_lbs_fwd'), ('k_lbs_bwd16<0, 8, false, false, 1>', 'k_lbs_bwd'), ('k_blend_adjoint', 'k_blend_adjoint')):
         d = pick(sq, key)
         if d: out['traffic'][name + '_sq_per_launch'] = {c: int(v) for c, v in d.items()}
     json.dump(out['traffic'], open('pmc_traffic.json', 'w'), indent=1)
