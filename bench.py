@@ -811,7 +811,7 @@ def main():
                                 'share_not_inner_loop_or_outer_step = 1 - (100 x ms_per_step + pose-D update + J step) / that')
         # the reference's OWN default run (scripts/args.py:8 batch 256; all five terms of scripts/optimize.py:252-253 with the 1000-step
         # camera pre-fit of :187-199)
-        ref_default = driver_run(256, ['--shape_disc', '--reprojection', '--silhouette'])
+        ref_default = driver_run(256, ['--shape_disc', '--reprojection', '--silhouette'], n_batches=6)
         ref_default['workload'] = ('scripts/args.py:8 default batch 256, all five loss terms (2-D joints, silhouette, 3-D joints, pose-D, shape-D), '
                                    '1000-step camera pre-fit, 100 inner iterations, D updates + J step per outer batch')
 
