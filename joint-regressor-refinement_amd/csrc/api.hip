@@ -426,7 +426,7 @@ struct jrr_engine {
   float *Ps, *gb;
   float *dsq, *ssq;                                  // per-pose squared adversarial errors of the last iteration [25][BP], [BP]
   long long* probe;                                  // shader-clock probe of k_lbs_fwd (profiling)
-  float *ndc, *sqsil; unsigned* cover; int* ncover;   // soft silhouette (JRR_FLAG_SILHOUETTE)
+  float *ndc, *sqsil, *VPM; unsigned* cover; int* ncover;   // soft silhouette (JRR_FLAG_SILHOUETTE)
   const float* sil_mask; float* smask; bool smask_valid;     // target masks, per-pose sum(mask^2)
   float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
   bool folded, fold_valid;
@@ -575,6 +575,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->ncover = (int*)c.take((size_t)BP);
     t->sqsil = c.take((size_t)BP);
     t->smask = c.take((size_t)BP);
+    t->VPM = c.take((size_t)BP * 3 * VP);      // the vertices of a silhouette iteration, pose-major (k_lbs_fwd -> fused rasteriser)
   }
   if (flags & JRR_FLAG_FOLDED) {
     t->JW = c.take((size_t)VP * FOLD_MJ);
@@ -870,12 +871,14 @@ static void set_adjoint_slabs(jrr_engine* e, PrepBwdLaunch& L) {
   L.dmaskA = slab_masks(e);
 }
 
+// verts_pm: the vertices go pose-major into e->VPM (what the fused rasteriser reads) instead of the row quads of e->VTb
 static int smpl_forward(jrr_engine* e, const float* x6d, const float* R, const float* betas, bool keep_vp,
-                        bool keep_verts, int32_t* step_inc, hipStream_t s, const int* vmask = nullptr, const int* tl = nullptr, int ntl = 0) {
+                        bool keep_verts, int32_t* step_inc, hipStream_t s, const int* vmask = nullptr, const int* tl = nullptr, int ntl = 0,
+                        bool verts_pm = false) {
   launch_prep_fwd(e->m, x6d, R, betas, e->FT, e->FTq, e->AT, e->R0T, e->B, e->BP, step_inc, s);
-  launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, keep_vp ? e->VPb : nullptr, e->JP, keep_verts ? e->VTb : nullptr, e->B, e->BP,
-                 e->nvc, s, nullptr, tl ? nullptr : vmask, tl, ntl);
-  if (keep_verts) e->verts_partial = vmask != nullptr || tl != nullptr;
+  launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, keep_vp ? e->VPb : nullptr, e->JP, verts_pm ? e->VPM : keep_verts ? e->VTb : nullptr, e->B, e->BP,
+                 e->nvc, s, nullptr, tl ? nullptr : vmask, tl, ntl, verts_pm ? 1 : 0);
+  if (keep_verts && !verts_pm) e->verts_partial = vmask != nullptr || tl != nullptr;
   return 0;
 }
 
@@ -1296,12 +1299,12 @@ extern "C" int jrr_silhouette_loss_grad(jrr_engine_t* e, const float* x6d, const
   if (!e->VTb) { jrr_set_error("silhouette_loss_grad needs JRR_FLAG_KEEP_VERTS"); return JRR_ERR_STATE; }
   hipStream_t s = (hipStream_t)stream;
   e->fwd_cached = false;
-  smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s);
+  smpl_forward(e, x6d, nullptr, betas, true, true, nullptr, s, nullptr, nullptr, 0, true);      // vertices pose-major, as in the loop
   launch_mask_sq(mask, e->smask, e->B, s, e->sil);
   e->smask_valid = false;
   const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * (double)e->sil * (double)e->sil));      // optimize.py:252 weight 100
   launch_sil_raster_adj(e->VTb, e->BP, cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, mask, e->smask, e->cover,
-                        e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s, e->sil);
+                        e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s, e->sil, e->VPM);
   if (sqsil) JRR_HIP(hipMemcpyAsync(sqsil, e->sqsil, (size_t)e->B * 4, hipMemcpyDeviceToDevice, s));
   if (dverts) launch_verts_untranspose(e->VTb, dverts, V * 3, V, nullptr, nullptr, e->B, e->BP, s, e->m.p2v);
   if (dcam) JRR_HIP(hipMemcpyAsync(dcam, e->gcam, (size_t)e->B * 3 * 4, hipMemcpyDeviceToDevice, s));
@@ -1431,10 +1434,11 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       launch_fold_fwd(e->MT, e->AT, e->G0, e->Jsum, e->BP, s);
     } else {
       const bool silf = e->sil_mask != nullptr;      // the silhouette term needs the vertices
-      int rcl = launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, e->VPb, e->JP, silf ? e->VTb : nullptr, e->B, e->BP, e->nvc, s,
-                               e->profiling ? e->probe : nullptr, nullptr, tl, ntl);
+      // (silhouette iterations: the vertices go to the pose-major buffer the rasteriser reads; VTb then only receives the
+      // rasteriser's vertex adjoint -- its stored vertices are no longer those of this forward: verts_partial)
+      int rcl = launch_lbs_fwd(e->m, e->Jn_vi, e->FTq, e->AT, e->VPb, e->JP, silf ? e->VPM : nullptr, e->B, e->BP, e->nvc, s,
+                               e->profiling ? e->probe : nullptr, nullptr, tl, ntl, silf ? 1 : 0);
       if (rcl) return rcl;
-      if (silf) e->verts_partial = false;
     }
     prof_mark(e, 1, s);
     prof_mark(e, 2, s);
@@ -1451,7 +1455,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       if (!e->smask_valid) { launch_mask_sq(e->sil_mask, e->smask, e->B, s, e->sil); e->smask_valid = true; }
       // projection, rasterisation, loss and adjoint in one kernel, straight from / into the row-quad vertex buffer
       launch_sil_raster_adj(e->VTb, e->BP, e->cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil,
-                            silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s, e->sil);
+                            silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s, e->sil, e->VPM);
       prof_mark(e, 8, s);
     }
     prof_mark(e, 3, s);

@@ -85,7 +85,8 @@ int launch_adam_flat(float* p, const float* g, float* m, float* v, size_t n, con
 // lbs.hip
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
                    float* VTb, int B, int BP, int nvc, hipStream_t s, long long* probe = nullptr, const int* vmask = nullptr,
-                   const int* tl = nullptr, int ntl = 0);
+                   const int* tl = nullptr, int ntl = 0, int verts_pose_major = 0);
+// verts_pose_major: VTb is [BP][3][VP] (a pose's vertices contiguous: the fused rasteriser's input) instead of row quads
 // tl / ntl (nullable; joint-sparse classes, VPb kept): run the ntl listed tiles only (the regressor's support tiles: every other
 // tile adds exact zeros to the joints); also launch_lbs_bwd and launch_blend_adjoint
 // vmask (nullable, with VTb): store the vertices of the tiles with vmask[tile] != 0 only (JSupport::tmask)
@@ -158,7 +159,8 @@ int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* 
 int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s, int S = 224);
 int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
                           unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
-                          hipStream_t s, int S = 224);
+                          hipStream_t s, int S = 224, const float* VPM = nullptr);
+// VPM (nullable): the vertices pose-major [BP][3][VP] (launch_lbs_fwd with verts_pose_major); NULL: read from the row quads of VQ
 int launch_sil_pix_to_face(const unsigned* cover, const int* ncover, int* p2f, int B, hipStream_t s, int S = 224);
 int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, const int* ncover, const float* mask,
                    const float* galpha, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,

@@ -86,7 +86,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
                                                     float* __restrict__ JP, float* __restrict__ VTb, int B, int BP,
                                                     int nvc, long long* __restrict__ probe, int paired,
                                                     const int* __restrict__ jl, const int* __restrict__ tnj,
-                                                    const int* __restrict__ vmask, const int* __restrict__ tl, int ntl) {
+                                                    const int* __restrict__ vmask, const int* __restrict__ tl, int ntl, int vpm) {
+  // vpm (STORE_VERTS only): VTb is a POSE-MAJOR buffer [BP][3][VP] -- what the fused rasteriser reads (round 5).  A pose's 32 rows of
+  // a tile sit in two lanes (l and l + 32: rows 8 g + 4 half + 0..3), whose four 16-byte stores per plane complete one 128-byte
+  // line of that pose; the rasteriser then loads a pose's 83 KB contiguously instead of 5184 pieces out of 5184 cache lines.
   // LIST: the launch covers the ntl tiles tl[0 .. ntl) only (ascending) -- the tiles that hold an entry of the regressor's support.
   // Every other tile multiplies its vertices by a zero block of the regressor: it adds exact zeros to the joints, and nothing else
   // of it is read by the joint-loss iteration (the backward kernels skip the same tiles).
@@ -230,6 +233,15 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     j16[r] += p16;
   };
 
+  // pose-major vertex store (vpm): wave-uniform row base + a 32-bit lane offset formed AT the store from a laundered lane index
+  // (hoisted out of the tile loop it costs the WIDE instantiations registers they do not have)
+  auto pm_store = [&](int r, int vt, int g4, const f32x4& t) __attribute__((always_inline)) {
+    const int ln = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned lo = ((unsigned)b0 + (unsigned)(ln & 31)) * (3u * VP) + 4u * (unsigned)(ln >> 5);
+    float* base = VTb + ((size_t)r * VP + vt * 32 + 8 * g4);
+    asm volatile("" : "+s"(base));
+    *reinterpret_cast<f32x4*>(base + lo) = t;
+  };
   const int t_first = (t_begin < t_end) ? (LIST ? tl[t_begin] : t_begin) : 0;
   if (SPARSE && WIDE && t_begin < t_end) wide_next = tnj[t_first] > KJS;
   if (t_begin < t_end) issue(t_first, 0, 0, 0, wide_next, t_begin & 1);
@@ -334,7 +346,11 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         const float* ab = buf + half * BG + wave * BT + l31;             // block ci at + ci * KJS * BG, row pair p at + 2 p BG
         float w[KJS / 2], x0[KJS / 2], x1[KJS / 2];
 #pragma unroll
-        for (int pq = 0; pq < KJS / 2; ++pq) { w[pq] = wp[2 * pq * 32]; x0[pq] = ab[2 * pq * BG]; x1[pq] = (WIDE && KJS > 8) ? 0.f : ab[KJS * BG + 2 * pq * BG]; }
+        for (int pq = 0; pq < KJS / 2; ++pq) {
+          w[pq] = wp[2 * pq * 32];
+          x0[pq] = (WIDE && KJS > 8) ? 0.f : ab[2 * pq * BG];
+          x1[pq] = (WIDE && KJS > 8) ? 0.f : ab[KJS * BG + 2 * pq * BG];
+        }
         f32x16 T = zero16(), U = zero16();
         // TIGHT (12 slots AND wide tiles: a body whose best order still has a 13-joint tile): 30 operand registers per block pair
         // and the regressor operands held across the second-pass branch do not fit 256 registers (7 .. 12 spilled) -- that one
@@ -344,9 +360,9 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
         float y0[KJS / 2], y1[KJS / 2];
 #pragma unroll
         for (int pq = 0; pq < KJS / 2; ++pq) {                            // T_{r,3}, T_{r,0}; the next two blocks' operands meanwhile
+          if (TIGHT) { x0[pq] = ab[2 * pq * BG]; x1[pq] = ab[KJS * BG + 2 * pq * BG]; }
           T = mfma(w[pq], x0[pq], T);
           if (!TIGHT) { y0[pq] = ab[2 * KJS * BG + 2 * pq * BG]; y1[pq] = ab[3 * KJS * BG + 2 * pq * BG]; }
-          else x1[pq] = ab[KJS * BG + 2 * pq * BG];
           U = mfma(w[pq], x1[pq], U);
         }
         vr = T + U * vp[0];                      // T_{r,3} + T_{r,0} v_x
@@ -395,7 +411,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
 #pragma unroll
           for (int g4 = 0; g4 < 4; ++g4) {
             const f32x4 t = {vr[4 * g4], vr[4 * g4 + 1], vr[4 * g4 + 2], vr[4 * g4 + 3]};
-            *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g4, BP, qoff) = t;
+            if (vpm) pm_store(r, vt, g4, t);
+            else *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g4, BP, qoff) = t;
           }
         }
         if (TIGHT) regress_operands(ldsJ, ra);
@@ -445,7 +462,8 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const f32x4 t = {vr[4 * g], vr[4 * g + 1], vr[4 * g + 2], vr[4 * g + 3]};
-              *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g, BP, qoff) = t;
+              if (vpm) pm_store(r, vt, g, t);
+              else *quad_ptr(VTb, (size_t)r * (VP / 4) + vt * 8, g, BP, qoff) = t;
             }
           }
           float ra[4];
@@ -456,12 +474,10 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
       ++g;
     });
   }
-  // (the output addresses are formed HERE, from a laundered lane index: hoisted above the tile loop they cost the 12-slot WIDE
-  // instantiation four spilled registers)
-  int te = tid;
-  asm volatile("" : "+v"(te));
-  const int le = te & 63;
-  const size_t b0e = (size_t)(bg * BG + (te >> 6) * BT);
+  // (the output addresses are formed HERE, from the hardware lane count and the scalar wave index: hoisted above the tile loop --
+  // or from a thread index kept alive across it -- they cost the 12-slot WIDE instantiations spilled registers)
+  const int le = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));      // the lane index, from no live register
+  const size_t b0e = (size_t)(bg * BG + wv * BT);
 #pragma unroll
   for (int r = 0; r < 3; ++r)
 #pragma unroll
@@ -476,7 +492,7 @@ __global__ __launch_bounds__(256, 2) void k_lbs_fwd(const float* __restrict__ Dk
     const float t = j16[r] + __shfl_xor(j16[r], 32);
     if (le < 32) JP[((size_t)(vc * 3 + r) * NH + 16) * BP + b0e + (le & 31)] = t;
   }
-  if (probe && blockIdx.x == 0 && tid == 0) {
+  if (probe && blockIdx.x == 0 && wv == 0 && le == 0) {
     probe[0] = clock64() - probe_t0;                 // shader clocks this wave was resident
     probe[1] = (long long)(t_end - t_begin) * (SPARSE ? (KF / 2) * 3 + 3 * 2 * KJS + 3 * 16 : LBS_FWD_MFMA_PER_TILE) + n_extra * 3 * 2 * KJS;   // MFMA instructions it issued
     probe[2] = wall_clock64() - probe_w0;            // the same interval on the constant 100 MHz counter
@@ -1591,7 +1607,8 @@ int launch_jstep_update(const JStepUpdate& a, hipStream_t s) {
 // launchers
 // ------------------------------------------------------------------------------------------
 int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const float* AT, float* VPb, float* JP,
-                   float* verts, int B, int BP, int nvc, hipStream_t s, long long* probe, const int* vmask, const int* tl, int ntl) {
+                   float* verts, int B, int BP, int nvc, hipStream_t s, long long* probe, const int* vmask, const int* tl, int ntl,
+                   int verts_pose_major) {
   dim3 grid((BP / BG) * nvc), block(256);
   if (tl && !(m.kjs && VPb)) { jrr_set_error("lbs_fwd: the tile list serves the joint-sparse kernels with v_posed kept"); return JRR_ERR_ARG; }
   // exactly one round of two workgroups per CU, an even number of chunks and whole pose groups per XCD
@@ -1599,10 +1616,10 @@ int launch_lbs_fwd(const Model& m, const float* Jn_vi, const float* FT, const fl
   const int paired = (grid.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? fwd_split : 0;
 #define JRR_LBS_FWD_K(SVP, SVT, KJV, WD, WT)                                                                                      \
   hipLaunchKernelGGL((k_lbs_fwd<SVP, SVT, KJV, WD>), grid, block, 0, s, m.Dk, WT, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc, probe,  \
-                     paired, m.jl, m.tnj, verts ? vmask : nullptr, nullptr, 0)
+                     paired, m.jl, m.tnj, verts ? vmask : nullptr, nullptr, 0, verts_pose_major)
 #define JRR_LBS_FWD_L(SVT, KJV, WD)                                                                                               \
   hipLaunchKernelGGL((k_lbs_fwd<true, SVT, KJV, WD, true>), grid, block, 0, s, m.Dk, m.Wc, Jn_vi, FT, AT, VPb, JP, verts, B, BP, nvc,  \
-                     probe, paired, m.jl, m.tnj, nullptr, tl, ntl)
+                     probe, paired, m.jl, m.tnj, nullptr, tl, ntl, verts_pose_major)
 #define JRR_LBS_FWD(SVP, SVT)                                                                                                     \
   do {                                                                                                                            \
     if (m.kjs == 8 && !m.wide_tiles) JRR_LBS_FWD_K(SVP, SVT, 8, false, m.Wc);                                                     \

@@ -33,6 +33,7 @@ constexpr int SIL_FPT = 14;              // faces per thread, kept in registers 
 constexpr int SIL_FBITS = 14;             // covered-pixel list entry = pixel << 14 | face (faces < 16384, pixels < 65536)
 constexpr int SIL_EB = 6;                 // list entries fetched together per thread in the resolve
 static_assert((3 * V + 2) % 2 == 0, "z-buffer alignment");
+static_assert(SIL_FPT % 7 == 0 && V <= 8192 && SIL_MAX <= 256, "face records: 13-bit vertex indices, 8-bit pixel rows");
 static_assert(V * 8 <= SIL_ZPIX * 8, "adjoint accumulators must fit the z-buffer");
 constexpr int SIL_VPAD = 3 * V + 2;      // floats of the LDS vertex arrays, padded so the u64 z-buffer is 8-byte aligned
 // BlendParams sigma = 1e-4 (mesh_renderer.py:28); only its reciprocal is used
@@ -102,16 +103,29 @@ __device__ __forceinline__ float sil_alpha(float dist) { return 1.f / (1.f + exp
 // same pieces with the vertex adjoint -- the layout k_lbs_bwd<2> consumes.  No pose-major copies of the vertices or of
 // their adjoint exist (two transposes of 0.35 ms and 0.8 GB of buffers gone).  A 128-byte line of VQ holds 8 consecutive
 // poses, so consecutive poses are given to the SAME XCD (blockIdx % 8 selects the XCD) and meet in its L2.
+// the lane index, recomputed from the hardware lane count on an operand the compiler cannot see through: neither hoisted out of a
+// loop nor kept alive across one
+__device__ __forceinline__ int fresh_lane() {
+  unsigned z = 0u;
+  asm volatile("" : "+v"(z));
+  return (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, z));
+}
+
 template <bool ADJ, int SIL>
-__global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ ndc, const int* __restrict__ faces,
-                                                       int nfaces, const float* __restrict__ mask,
-                                                       unsigned* __restrict__ cover, int* __restrict__ ncover,
-                                                       float* __restrict__ alpha_out, float* __restrict__ sqsil,
-                                                       float scale, float* __restrict__ VQ, int BP,
-                                                       const float* __restrict__ cam, int B,
-                                                       float* __restrict__ gcam, int accumulate_cam,
-                                                       const float* __restrict__ smask) {
+__device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, const NdcV* __restrict__ ndc, const int* __restrict__ faces,
+                                                int nfaces, const float* __restrict__ mask,
+                                                unsigned* __restrict__ cover, int* __restrict__ ncover,
+                                                float* __restrict__ alpha_out, float* __restrict__ sqsil,
+                                                float scale, float* __restrict__ VQ, int BP,
+                                                const float* __restrict__ cam, int B,
+                                                float* __restrict__ gcam, int accumulate_cam,
+                                                const float* __restrict__ smask, const float* __restrict__ VPM) {
   constexpr float SIL_F = 5000.f / (float)SIL;        // NDC focal length (mesh_renderer.py:52-53)
+  // every per-thread quantity below derives from `tix`, a laundered copy of the thread index: loop-invariant address arithmetic and
+  // loads (the face indices!) then cannot be hoisted out of the persistent kernel's pose loop, where they would cost ~140 spilled registers
+  // (formed from the hardware lane count and the wave index in a scalar register, so that no copy of threadIdx.x has to stay alive
+  // across the poses of the persistent kernel)
+  int tix = wave_s * 64 + fresh_lane();
   extern __shared__ unsigned long long smem64[];      // 8-byte aligned whatever static LDS precedes it
   float* vx = reinterpret_cast<float*>(smem64);       // [V]; the vertex arrays first: ds offsets stay < 64 KB
   unsigned long long* zb = smem64 + SIL_VPAD / 2;     // [SIL_ZPIX]
@@ -120,38 +134,33 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   __shared__ float red[SIL_RT];
   __shared__ float pxt[SIL_MAX];      // pixel centres
   __shared__ int ncov;
-  int b = blockIdx.x;
-  if (ADJ) {                                 // poses [x per, (x + 1) per) on XCD x; BP is a multiple of 128
-    const int per = BP >> 3;
-    b = (blockIdx.x & 7) * per + (blockIdx.x >> 3);
-    if (b >= B) {                            // padded pose (whole workgroup): its adjoint is zero
-      f32x4* P4 = reinterpret_cast<f32x4*>(VQ);
-      for (int q = threadIdx.x; q < 3 * (VP / 4); q += SIL_RT) P4[(size_t)q * BP + b] = f32x4{0.f, 0.f, 0.f, 0.f};
-      return;
-    }
+  if (ADJ && b >= B) {                       // padded pose (whole workgroup): its adjoint is zero
+    f32x4* P4 = reinterpret_cast<f32x4*>(VQ);
+    for (int q = tix; q < 3 * (VP / 4); q += SIL_RT) P4[(size_t)q * BP + b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    return;
   }
+  // (the fused kernel is PERSISTENT: this function runs once per pose of the workgroup's list.  The face indices below do not depend
+  // on the pose -- laundering the pointer keeps the compiler from hoisting their loads out of the pose loop)
+  asm volatile("" : "+s"(faces));
   const NdcV* vb = ndc + (size_t)b * V;
   unsigned* lst = cover + (size_t)b * SIL * SIL;
   __shared__ float bbp[4][SIL_RT / 64];   // per-wave partial bounding box of the projected vertices
-  if (threadIdx.x == 0) ncov = 0;
-  if (threadIdx.x < SIL) pxt[threadIdx.x] = pix_x<SIL>(threadIdx.x);
+  if (tix == 0) ncov = 0;
+  if (tix < SIL) pxt[tix] = pix_x<SIL>(tix);
   float bxn = 3e38f, bxx = -3e38f, byn = 3e38f, byx = -3e38f;
-  // this thread's faces: vertex indices now (requested BEFORE the vertex loads below: both batches of loads fly together),
-  // pixel-row range after the vertices have landed
-  int fi[SIL_FPT][3];
-  int frow[SIL_FPT];                  // first row | last row << 16
-#pragma unroll
-  for (int u = 0; u < SIL_FPT; ++u) {
-    const int f = threadIdx.x + u * SIL_RT;
-#pragma unroll
-    for (int k = 0; k < 3; ++k) fi[u][k] = (f < nfaces) ? faces[f * 3 + k] : 0;
-  }
+  // after the set-up a face is TWO registers: fr0 = i0 | i1 << 13, fr1 = i2 | first row << 13 | last row << 21 (vertex indices < 8192,
+  // pixel rows < 256) -- 28 registers for the 14 faces instead of 56, which is what lets the persistent kernel stay inside 128
+  unsigned fr0[SIL_FPT], fr1[SIL_FPT];
   f32x4* VQ4 = reinterpret_cast<f32x4*>(VQ);
   float tcam[3] = {0.f, 0.f, 0.f};
   if (ADJ) {
     tcam[0] = cam[(size_t)b * 3]; tcam[1] = cam[(size_t)b * 3 + 1]; tcam[2] = cam[(size_t)b * 3 + 2];
-    for (int q = threadIdx.x; q < VP / 4; q += SIL_RT) {
-      const f32x4 t0 = VQ4[(size_t)q * BP + b], t1 = VQ4[((size_t)(VP / 4) + q) * BP + b], t2 = VQ4[((size_t)2 * (VP / 4) + q) * BP + b];
+    // VPM (round 5): the forward kernel left this pose's vertices contiguous, [3][VP] -- three coalesced 16-byte loads per thread
+    // and quad instead of three pieces out of three different cache lines (the set-up phase was 25.6 of a pose's 80 us)
+    const f32x4* PM4 = VPM ? reinterpret_cast<const f32x4*>(VPM) + (size_t)b * 3 * (VP / 4) : nullptr;
+    for (int q = tix; q < VP / 4; q += SIL_RT) {
+      const f32x4 t0 = PM4 ? PM4[q] : VQ4[(size_t)q * BP + b], t1 = PM4 ? PM4[(VP / 4) + q] : VQ4[((size_t)(VP / 4) + q) * BP + b],
+                  t2 = PM4 ? PM4[2 * (VP / 4) + q] : VQ4[((size_t)2 * (VP / 4) + q) * BP + b];
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int v = 4 * q + u;
@@ -164,35 +173,46 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
       }
     }
   } else {
-    for (int v = threadIdx.x; v < V; v += SIL_RT) {
+    for (int v = tix; v < V; v += SIL_RT) {
       const NdcV p = vb[v];
       vx[v] = p.x; vy[v] = p.y; vz[v] = p.z;
       bxn = fminf(bxn, p.x); bxx = fmaxf(bxx, p.x); byn = fminf(byn, p.y); byx = fmaxf(byx, p.y);
     }
   }
   if (alpha_out)                      // stand-alone forward: background alpha; covered pixels are overwritten in pass 2
-    for (int i = threadIdx.x; i < SIL * SIL; i += SIL_RT) alpha_out[(size_t)b * SIL * SIL + i] = 0.f;
+    for (int i = tix; i < SIL * SIL; i += SIL_RT) alpha_out[(size_t)b * SIL * SIL + i] = 0.f;
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     bxn = fminf(bxn, __shfl_xor(bxn, o)); bxx = fmaxf(bxx, __shfl_xor(bxx, o));
     byn = fminf(byn, __shfl_xor(byn, o)); byx = fmaxf(byx, __shfl_xor(byx, o));
   }
-  if ((threadIdx.x & 63) == 0) {
-    const int w = threadIdx.x >> 6;
+  if ((tix & 63) == 0) {
+    const int w = tix >> 6;
     bbp[0][w] = bxn; bbp[1][w] = bxx; bbp[2][w] = byn; bbp[3][w] = byx;
   }
   __syncthreads();
+  // this thread's faces: vertex indices -> pixel-row range of the face -> the two-register record
+  {
+    int fi[SIL_FPT][3];
 #pragma unroll
-  for (int u = 0; u < SIL_FPT; ++u) {
-    const int f = threadIdx.x + u * SIL_RT;
-    const float y0v = vy[fi[u][0]], y1v = vy[fi[u][1]], y2v = vy[fi[u][2]];
-    const float ymax = fmaxf(y0v, fmaxf(y1v, y2v)), ymin = fminf(y0v, fminf(y1v, y2v));
-    // pixel centres inside the bounding box: yf = 1 - (2 yi + 1)/H in [ymin, ymax]  <=>
-    // yi in [ceil((H (1 - ymax) - 1)/2), floor((H (1 - ymin) - 1)/2)]; 1e-3 px of slack, the inside test is exact.
-    int ylo = (int)ceilf((SIL * (1.f - ymax) - 1.f) * 0.5f - 1e-3f), yhi = (int)floorf((SIL * (1.f - ymin) - 1.f) * 0.5f + 1e-3f);
-    ylo = max(ylo, 0); yhi = min(yhi, SIL - 1);
-    if (f >= nfaces || !(ymax == ymax) || !(ymin == ymin)) { ylo = 1; yhi = 0; }     // empty range
-    frow[u] = ylo | (yhi << 16);
+    for (int u = 0; u < SIL_FPT; ++u) {
+      const int f = min(tix + u * SIL_RT, nfaces - 1);      // (a slot past the last face reads the last face; it is marked empty below)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fi[u][k] = faces[f * 3 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < SIL_FPT; ++u) {
+      const int f = tix + u * SIL_RT;
+      const float y0v = vy[fi[u][0]], y1v = vy[fi[u][1]], y2v = vy[fi[u][2]];
+      const float ymax = fmaxf(y0v, fmaxf(y1v, y2v)), ymin = fminf(y0v, fminf(y1v, y2v));
+      // pixel centres inside the bounding box: yf = 1 - (2 yi + 1)/H in [ymin, ymax]  <=>
+      // yi in [ceil((H (1 - ymax) - 1)/2), floor((H (1 - ymin) - 1)/2)]; 1e-3 px of slack, the inside test is exact.
+      int ylo = (int)ceilf((SIL * (1.f - ymax) - 1.f) * 0.5f - 1e-3f), yhi = (int)floorf((SIL * (1.f - ymin) - 1.f) * 0.5f + 1e-3f);
+      ylo = max(ylo, 0); yhi = min(yhi, SIL - 1);
+      if (f >= nfaces || !(ymax == ymax) || !(ymin == ymin) || ylo > yhi) { ylo = 1; yhi = 0; }     // empty range
+      fr0[u] = (unsigned)fi[u][0] | ((unsigned)fi[u][1] << 13);
+      fr1[u] = (unsigned)fi[u][2] | ((unsigned)ylo << 13) | ((unsigned)yhi << 21);
+    }
   }
   float err = 0.f;
   // The z-buffer only ever holds the pixel bounding box of the projected mesh (a person covers 8-9 % of the crop and
@@ -220,16 +240,19 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   for (int y0 = by0; y0 <= by1 && bw > 0; y0 += rows_per) {
     const int y1 = min(y0 + rows_per, by1 + 1);                        // rows [y0, y1) of the box columns [bx0, bx1]
     const int npx = (y1 - y0) * bw;
-    for (int i = threadIdx.x; i < npx; i += SIL_RT) zb[i] = ~0ull;
+    for (int i = tix; i < npx; i += SIL_RT) zb[i] = ~0ull;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SIL_FPT; ++u) {
-      const int ylo = max(frow[u] & 0xffff, y0), yhi = min(frow[u] >> 16, y1 - 1);
+      unsigned r0 = fr0[u], r1 = fr1[u];
+      asm volatile("" : "+v"(r0), "+v"(r1));     // unpacked HERE, per strip: hoisted out of the strip loop the fields would be registers again
+      const int ylo = max((int)((r1 >> 13) & 255u), y0), yhi = min((int)(r1 >> 21), y1 - 1);
       if (ylo > yhi) continue;                                         // no pixel centre of this face in the strip
-      const int f = threadIdx.x + u * SIL_RT;
-      const float ax = vx[fi[u][0]], ay = vy[fi[u][0]], az = vz[fi[u][0]];
-      const float bx = vx[fi[u][1]], by = vy[fi[u][1]], bz = vz[fi[u][1]];
-      const float cx = vx[fi[u][2]], cy = vy[fi[u][2]], cz = vz[fi[u][2]];
+      const int f = tix + u * SIL_RT;
+      const int i0 = (int)(r0 & 8191u), i1 = (int)(r0 >> 13), i2 = (int)(r1 & 8191u);
+      const float ax = vx[i0], ay = vy[i0], az = vz[i0];
+      const float bx = vx[i1], by = vy[i1], bz = vz[i1];
+      const float cx = vx[i2], cy = vy[i2], cz = vz[i2];
       const float xmax = fmaxf(ax, fmaxf(bx, cx)), xmin = fminf(ax, fminf(bx, cx));
       int xlo = (int)ceilf((SIL * (1.f - xmax) - 1.f) * 0.5f - 1e-3f), xhi = (int)floorf((SIL * (1.f - xmin) - 1.f) * 0.5f + 1e-3f);
       xlo = max(xlo, bx0); xhi = min(xhi, bx1);
@@ -267,7 +290,7 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
     // handled densely in pass 2 instead of under divergence here; one LDS atomic per wave reserves the list slots.
     // One box row per wave and step, lanes over the columns.
     {
-      const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+      const int wave = tix >> 6, lane = tix & 63;
       for (int r = wave; r < y1 - y0; r += SIL_RT / 64) {
         for (int x0 = 0; x0 < bw; x0 += 64) {
           const int x = x0 + lane;
@@ -288,7 +311,7 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
   }
   // resolve, pass 2: alpha of the covered pixels from the edge distances of their winning faces
   const int n = ncov;
-  if (threadIdx.x == 0) ncover[b] = n;
+  if (tix == 0) ncover[b] = n;
   // ADJ: the adjoint is accumulated per vertex in NDC space, (G_x, G_y) = sum of d loss / d (x_ndc, y_ndc), in the
   // z-buffer's LDS (2 x 6890 floats); the chain through x_ndc = f X / Z, y_ndc = f Y / Z is linear in (G_x, G_y)
   // with per-VERTEX coefficients and is applied once per vertex at write-out:
@@ -312,10 +335,10 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
     return (unsigned long long)((ix << 32) + iy);
   };
   if (ADJ) {
-    for (int i = threadIdx.x; i < V; i += SIL_RT) acc[i] = 0ull;
+    for (int i = tix; i < V; i += SIL_RT) acc[i] = 0ull;
     __syncthreads();
   }
-  for (int e0 = threadIdx.x; e0 < n; e0 += SIL_RT * SIL_EB) {
+  for (int e0 = tix; e0 < n; e0 += SIL_RT * SIL_EB) {
     unsigned ent[SIL_EB];
     int id[SIL_EB][3];
     float tg[SIL_EB];
@@ -355,10 +378,12 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
       }
     }
   }
+  // (a FRESH laundered thread index for the write-out and the reductions: nothing derived from `tix` has to survive the resolve pass)
+  int tq = wave_s * 64 + fresh_lane();
   if (ADJ) {
     __syncthreads();
     float gc[3] = {0.f, 0.f, 0.f};
-    for (int q = threadIdx.x; q < VP / 4; q += SIL_RT) {       // the pose's pieces of VQ now take the vertex adjoint
+    for (int q = tq; q < VP / 4; q += SIL_RT) {       // the pose's pieces of VQ now take the vertex adjoint
       f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, o2 = o0;
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
@@ -385,29 +410,57 @@ __global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ 
 #pragma unroll
       for (int c = 0; c < 3; ++c) {
         float w = gc[c];
+        // (shuffle addresses from the FRESH lane index: shared with the bounding-box reduction of the set-up they would be six
+        // registers alive across the whole pose)
 #pragma unroll
-        for (int o = 32; o > 0; o >>= 1) w += __shfl_xor(w, o);
-        if ((threadIdx.x & 63) == 0) red[c * (SIL_RT / 64) + (threadIdx.x >> 6)] = w;
+        for (int o = 32; o > 0; o >>= 1) w += __int_as_float(__builtin_amdgcn_ds_bpermute(((tq & 63) ^ o) << 2, __float_as_int(w)));
+        if ((tq & 63) == 0) red[c * (SIL_RT / 64) + (tq >> 6)] = w;
       }
       __syncthreads();
-      if (threadIdx.x < 3) {
+      if (tq < 3) {
         float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < SIL_RT / 64; ++w) t += red[threadIdx.x * (SIL_RT / 64) + w];
-        if (accumulate_cam) gcam[(size_t)b * 3 + threadIdx.x] += t;
-        else gcam[(size_t)b * 3 + threadIdx.x] = t;
+        for (int w = 0; w < SIL_RT / 64; ++w) t += red[tq * (SIL_RT / 64) + w];
+        if (accumulate_cam) gcam[(size_t)b * 3 + tq] += t;
+        else gcam[(size_t)b * 3 + tq] = t;
       }
       __syncthreads();                                                   // red is reused by the error sum below
     }
   }
   if (sqsil) {
-    red[threadIdx.x] = err;
+    red[tq] = err;
     __syncthreads();
     for (int s = SIL_RT / 2; s > 0; s >>= 1) {
-      if (threadIdx.x < s) red[threadIdx.x] += red[threadIdx.x + s];
+      if (tq < s) red[tq] += red[tq + s];
       __syncthreads();
     }
-    if (threadIdx.x == 0) sqsil[b] = red[0] + (smask ? smask[b] : 0.f);
+    if (tq == 0) sqsil[b] = red[0] + (smask ? smask[b] : 0.f);
+  }
+}
+
+// The kernels.  <false> (stand-alone forward): one workgroup per pose.  <true> (fused loop): PERSISTENT -- one workgroup per CU walks
+// its poses (round 5: in-kernel stamps put a pose at 67 us where the launch averaged 83 us per pose and CU: the turnover of a
+// 1024-thread / 155 KB workgroup is not free).  XCD x (workgroups with blockIdx % 8 == x) takes the poses [x per, (x + 1) per) and
+// its workgroups take consecutive poses in every step: the 8 poses whose adjoint pieces share a 128-byte line of VQ are written by
+// one XCD at about the same time and meet in its L2.
+template <bool ADJ, int SIL>
+__global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ ndc, const int* __restrict__ faces,
+                                                       int nfaces, const float* __restrict__ mask,
+                                                       unsigned* __restrict__ cover, int* __restrict__ ncover,
+                                                       float* __restrict__ alpha_out, float* __restrict__ sqsil,
+                                                       float scale, float* __restrict__ VQ, int BP,
+                                                       const float* __restrict__ cam, int B,
+                                                       float* __restrict__ gcam, int accumulate_cam,
+                                                       const float* __restrict__ smask, const float* __restrict__ VPM) {
+  const int wave_s = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);      // the wave's index, in a scalar register for the whole kernel
+  if (!ADJ) {
+    sil_raster_pose<ADJ, SIL>(blockIdx.x, wave_s, ndc, faces, nfaces, mask, cover, ncover, alpha_out, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask, VPM);
+    return;
+  }
+  const int per = BP >> 3, nw = gridDim.x >> 3, xcd = blockIdx.x & 7;
+  for (int i = blockIdx.x >> 3; i < per; i += nw) {
+    sil_raster_pose<ADJ, SIL>(xcd * per + i, wave_s, ndc, faces, nfaces, mask, cover, ncover, alpha_out, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask, VPM);
+    __syncthreads();                          // the pose's last reads of LDS before the next pose's first writes
   }
 }
 
@@ -576,10 +629,10 @@ int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* 
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
   if (S == 224)
     hipLaunchKernelGGL((k_sil_raster<false, 224>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc, faces, nfaces, nullptr, cover,
-                       ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr);
+                       ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr, nullptr);
   else
     hipLaunchKernelGGL((k_sil_raster<false, 256>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc, faces, nfaces, nullptr, cover,
-                       ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr);
+                       ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr, nullptr);
   return 0;
 }
 // fused loop: project the pose's vertices from the row-quad buffer VQ [3][VP/4][BP][4], rasterise, squared error against
@@ -587,17 +640,17 @@ int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* 
 // accumulate
 int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
                           unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
-                          hipStream_t s, int S) {
+                          hipStream_t s, int S, const float* VPM) {
   sil_attrs();
   if (sil_size_ok(S)) return JRR_ERR_ARG;
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
-  const int grid = BP;                     // pose = (block % 8) * (BP / 8) + block / 8; blocks of padded poses zero their pieces
+  const int grid = BP < 256 ? BP : 256;    // persistent: one workgroup per CU (a multiple of 8: BP is a multiple of 128); padded poses zero their pieces
   if (S == 224)
     hipLaunchKernelGGL((k_sil_raster<true, 224>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, faces, nfaces, mask, cover,
-                       ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask);
+                       ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask, VPM);
   else
     hipLaunchKernelGGL((k_sil_raster<true, 256>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, faces, nfaces, mask, cover,
-                       ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask);
+                       ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask, VPM);
   return 0;
 }
 // writes ALL of dverts[b][0 .. 6890*3) (no zero-fill needed); gcam: overwrite or accumulate
