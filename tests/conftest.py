@@ -164,6 +164,13 @@ def write_chumpy_style_pickle(model, path, protocol=2):
 
 
 
+def support_tiles_available():
+    """the iterations restricted to the regressor's support tiles (FLAG_SUPPORT_TILES) exist in the joint-sparse kernels with the
+    16-pose backward only: when the whole suite is run with the dense or the role kernels forced (JRR_DENSE_SKINNING=1, JRR_BWD16=0;
+    profiles/gpu_suite_r05_variants.txt) the engine runs all 216 tiles, by design"""
+    return os.environ.get('JRR_DENSE_SKINNING') != '1' and os.environ.get('JRR_BWD16') != '0'
+
+
 def load_golden(name):
     return dict(np.load(os.path.join(GOLDEN, name)))
 

@@ -83,7 +83,8 @@ def test_two_rank_driver_all_vertex_tiles_equals_single_process():
     two = _load('w2a', 2)
     (dflt,) = _load('w1', 1)
     h1 = json.loads(str(one['history']))[0]
-    assert h1['vertex_tiles_run'] == 216 and 0 < json.loads(str(dflt['history']))[0]['vertex_tiles_run'] < 60
+    nd = json.loads(str(dflt['history']))[0]['vertex_tiles_run']
+    assert h1['vertex_tiles_run'] == 216 and (0 < nd < 60 if conftest.support_tiles_available() else nd == 216)
     x2 = np.concatenate([two[0]['x6d'], two[1]['x6d']])
     b2 = np.concatenate([two[0]['betas'], two[1]['betas']])
     assert np.abs(x2 - one['x6d']).max() < 2e-4 and np.abs(b2 - one['betas']).max() < 2e-4

@@ -275,7 +275,8 @@ def test_support_tiles_ragged_batches_vs_oracle(smpl_model_np, j_h36m_np, B):
     eng = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS | em.FLAG_SUPPORT_TILES)
     J = T(j_h36m_np).to(DEV).clone()
     eng.set_j_regressor(J)
-    assert eng.j_support_info()[1] and eng.support_tiles()[0]
+    import conftest
+    assert eng.j_support_info()[1] and eng.support_tiles()[0] == conftest.support_tiles_available()
     xd, bd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous()
     m, vv, step = _fresh_state(B)
     eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, vv, step, 1e-2, 3)

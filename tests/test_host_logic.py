@@ -326,4 +326,7 @@ def test_no_kernel_spills_registers():
     assert not bad, bad
     for r in rows:
         if any(k in r['name'] for k in ('k_lbs_fwd', 'k_lbs_bwd', 'k_blend_adjoint')):
+            if 'k_lbs_bwd16' in r['name'] and r['name'].rstrip().endswith(', 2>'):
+                assert r['occ'] == 1                        # the JRR_BWD16_NG=2 experiment: ONE 512-register wave per SIMD, by design
+                continue
             assert r['occ'] >= 2 and r['vgpr'] <= 256, r
