@@ -170,6 +170,12 @@ int jrr_find_joints_backward(jrr_engine_t* e, const float* x6d_dev, const float*
                              const float* betas_dev, const float* djoints_dev, float* dx6d_dev,
                              float* dR_dev, float* dbetas_dev, float* dJ_dev, void* stream);
 
+/* find_joints (scripts/utils.py:85-103) of the poses of the J step that PRECEDED -- jrr_j_regressor_grad[_support] followed by
+ * jrr_j_step_apply[_support] on the same x6d / betas buffers, nothing else in between -- with the stepped regressor, re-regressed from
+ * that step's stored vertices instead of a second SMPL forward: the joints the driver evaluates after the step
+ * (scripts/optimize.py:317-321).  joints_dev (B,17,3).  A mismatch the engine can detect returns JRR_ERR_STATE.          */
+int jrr_find_joints_after_j_step(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev, float* joints_dev, void* stream);
+
 /* The `joints` field of the SMPL operator's output (scripts/smpl.py:69-84: smplx's 24 posed joints J_transformed = G_j[:3, 3] of the
  * kinematic chain head the list the wrapper re-maps).  Must follow a forward on this engine (jrr_find_joints_forward,
  * jrr_refine_run, ...) with the SAME betas: reads the stored skinning transforms.  joints24_dev (B,24,3).  Not differentiated

@@ -45,6 +45,7 @@ SIGNATURES = {
     'jrr_find_joints_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_smpl_vertices_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_smpl_posed_joints': (c_int, [_P, _P, _P, _P]),
+    'jrr_find_joints_after_j_step': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_pose_disc_vjp_input': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_joint_loss': (c_int, [_P, _P, c_float, c_int, c_int, _P, _P, _P]),
     'jrr_pose_disc_forward': (c_int, [_P, _P, _P, _P]),

@@ -1587,6 +1587,26 @@ extern "C" int jrr_j_regressor_grad(jrr_engine_t* e, const float* x6d, const flo
   return j_step_local(e, x6d, betas, gt_mm, dJ, sqerr, (hipStream_t)stream, joints);
 }
 
+// find_joints on the poses of the J step that preceded, with the CURRENT (stepped) regressor, from that step's stored vertices: the
+// joints the driver evaluates after the step (scripts/optimize.py:317-321) without a second SMPL forward
+extern "C" int jrr_find_joints_after_j_step(jrr_engine_t* e, const float* x6d, const float* betas, float* joints, void* stream) {
+  if (!e || !x6d || !betas || !joints) { jrr_set_error("find_joints_after_j_step: null"); return JRR_ERR_ARG; }
+  if (!e->have_J) { jrr_set_error("J_regressor not set"); return JRR_ERR_STATE; }
+  const bool ok = e->fwd_cached && e->fc_x6d == x6d && e->fc_betas == betas && e->VTb != nullptr &&
+                  !(e->verts_partial && !(e->have_jsup && e->jsup_fits_known));
+  if (!ok) {
+    jrr_set_error("find_joints_after_j_step: the previous forward on this engine was not a J step (jrr_j_regressor_grad*) on the same pose buffers");
+    return JRR_ERR_STATE;
+  }
+  hipStream_t s = (hipStream_t)stream;
+  int rc = joints_from_stored_verts(e, s);
+  if (rc) return rc;
+  launch_joints_loss(e->dFTp, e->nsplit, nullptr, nullptr, 0.f, joints, nullptr, nullptr, e->B, e->BP, s, nullptr, 32,
+                     e->have_jsup ? e->jsup.flag : nullptr);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
 // ---- the J step's all-reduce payload restricted to the regressor's support (include/jrr.h) ----
 extern "C" int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t* fits_host, void* stream) {
   if (!e || !fits_host) return JRR_ERR_ARG;

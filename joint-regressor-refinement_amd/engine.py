@@ -279,6 +279,13 @@ class RefineEngine:
         check(self.lib.jrr_pose_disc_vjp_input(self.handle, ptr(x6d), ptr(gout), ptr(dx), self._s()), 'pose_disc_vjp_input')
         return dx
 
+    def find_joints_after_j_step(self, betas, x6d):
+        """joints (B,17,3) of the poses of the J step that preceded (j_regressor_grad* + j_step_apply* on these very buffers) with the
+        stepped regressor, from that step's stored vertices -- no second SMPL forward (jrr_find_joints_after_j_step)"""
+        joints = torch.empty(self.batch, NUM_H36M, 3, device=self.device)
+        check(self.lib.jrr_find_joints_after_j_step(self.handle, ptr(x6d), ptr(betas), ptr(joints), self._s()), 'find_joints_after_j_step')
+        return joints
+
     def posed_joints(self, betas):
         """(B,24,3) posed SMPL joints (smplx J_transformed) of the most recent forward on this engine with these betas"""
         self._chk(betas, (self.batch, NUM_BETAS), 'betas')

@@ -304,17 +304,18 @@ def optimize_pose_refiner(log=print) -> Dict:
 
         jdist.all_reduce_sum_(bucket.flat)                                                  # THE collective of the outer step
 
-        # ---- replicated Adam steps (identical on every rank) ----
+        # ---- replicated Adam steps (identical on every rank; the three parameter sets are independent: the J step goes first so that
+        #      the joints after it come from the vertices its forward stored -- uploading discriminator weights drops that state) ----
+        eng.j_step_apply(J_regressor, bucket.dJ, J_opt.m, J_opt.v, J_opt.step, J_opt.lr, mask=j_reg_mask)
+        joints_after = eng.find_joints_after_j_step(betas, x6d)                            # :317-321 with the stepped regressor (re-regressed from the J step's vertices)
+        e_a, epa_a = utils.evaluate_sums(joints_after, gt_mm)
+        after_sums = torch.stack([e_a, epa_a])
         if use_pd:
             disc_opt.apply(disc_flat, bucket.dD)
             eng.set_pose_disc(disc_flat)
         if use_sd:
             sdisc_opt.apply(sdisc_flat, bucket.dS)
             eng.set_shape_disc(sdisc_flat)
-        eng.j_step_apply(J_regressor, bucket.dJ, J_opt.m, J_opt.v, J_opt.step, J_opt.lr, mask=j_reg_mask)
-        joints_after = eng.find_joints_forward(betas, x6d=x6d)                              # :317-321 with the stepped regressor
-        e_a, epa_a = utils.evaluate_sums(joints_after, gt_mm)
-        after_sums = torch.stack([e_a, epa_a])
 
         tail = bucket.tail.cpu().double().numpy()                                           # the ONE read-back of this batch
         sc, hist_np = tail[:N_SCALARS], tail[N_SCALARS:].reshape(-1, 5)

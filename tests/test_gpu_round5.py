@@ -241,3 +241,31 @@ def test_support_growing_behind_the_engines_back_is_reported(smpl_model_np, j_h3
     eng.set_j_regressor(J)
     counts3, fits3 = eng.j_support_info()
     assert fits3 and counts3[3] >= 5
+
+
+def test_find_joints_after_j_step_equals_a_fresh_forward(smpl_model_np, j_h36m_np):
+    """the joints the driver evaluates after the J step (scripts/optimize.py:317-321): re-regressed from the step's stored vertices with
+    the stepped regressor = a fresh find_joints forward = the oracle; refused when the preceding forward was something else"""
+    eng_mod, lib_mod, sm = _mod('engine'), _mod('_lib'), _mod('smpl_model')
+    B = 45
+    dm = eng_mod.DeviceModel(smpl_model_np, DEV)
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=8)
+    x6, betas = T(batch['pose6d']).to(DEV), T(batch['betas']).to(DEV)
+    gt = oracle.move_pelvis(T(batch['gt_j3d'])).to(DEV).contiguous()
+    for flags in (eng_mod.FLAG_KEEP_VERTS, eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_SUPPORT_TILES):
+        eng = eng_mod.RefineEngine(dm, B, flags=flags)
+        J = T(j_h36m_np).to(DEV).contiguous().clone()
+        eng.set_j_regressor(J)
+        eng.j_support_info()
+        Jm, Jv, Js = torch.zeros_like(J), torch.zeros_like(J), torch.zeros(1, dtype=torch.int32, device=DEV)
+        dJ = eng.j_regressor_grad(x6, betas, gt)
+        eng.j_step_apply(J, dJ, Jm, Jv, Js, 1e-2)
+        got = eng.find_joints_after_j_step(betas, x6)
+        fresh = eng.find_joints_forward(betas, x6d=x6)
+        assert (got - fresh).abs().max().item() < 2e-6
+        R = oracle.rot6d_to_rotmat(x6.cpu().reshape(-1, 6)).view(B, 24, 3, 3)
+        ref = oracle.find_joints(oracle.OracleSMPL(smpl_model_np), betas.cpu(), R[:, :1], R[:, 1:], J.cpu())
+        assert (got.cpu() - ref).abs().max().item() < 2e-5
+        assert (J.cpu() != T(j_h36m_np)).sum().item() == 62                       # the step did move the regressor
+        with pytest.raises(lib_mod.JrrError):                                     # after a plain forward there is no J step to reuse
+            eng.find_joints_after_j_step(betas, x6)
