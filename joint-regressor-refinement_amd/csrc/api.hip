@@ -21,7 +21,7 @@ void jrr_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* jrr_last_error(void) { return g_err; }
-extern "C" int jrr_version(void) { return 100; }
+extern "C" int jrr_version(void) { return 105; }      // 100 + round: entry points were added in rounds 2-5, none changed or removed
 
 #define CHECK_LAUNCH()                                                            \
   do {                                                                            \
