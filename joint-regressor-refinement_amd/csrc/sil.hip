@@ -33,7 +33,7 @@ constexpr int SIL_FPT = 14;              // faces per thread, kept in registers 
 constexpr int SIL_FBITS = 14;             // covered-pixel list entry = pixel << 14 | face (faces < 16384, pixels < 65536)
 constexpr int SIL_EB = 6;                 // list entries fetched together per thread in the resolve
 static_assert((3 * V + 2) % 2 == 0, "z-buffer alignment");
-static_assert(SIL_FPT % 7 == 0 && V <= 8192 && SIL_MAX <= 256, "face records: 13-bit vertex indices, 8-bit pixel rows");
+static_assert(V <= 8192 && SIL_MAX <= 256, "face records: 13-bit vertex indices, 8-bit pixel rows");
 static_assert(V * 8 <= SIL_ZPIX * 8, "adjoint accumulators must fit the z-buffer");
 constexpr int SIL_VPAD = 3 * V + 2;      // floats of the LDS vertex arrays, padded so the u64 z-buffer is 8-byte aligned
 // BlendParams sigma = 1e-4 (mesh_renderer.py:28); only its reciprocal is used
