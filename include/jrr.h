@@ -54,7 +54,9 @@ enum {
   JRR_FLAG_SHAPE_DISC = 2,  /* shape-discriminator term (optimize.py:244,249-250) */
   JRR_FLAG_KEEP_VERTS = 4,  /* reserve a (B,6890,3) vertex buffer for return_verts / J step */
   JRR_FLAG_FOLDED = 8,      /* reserve the folded-regressor tables (jrr_engine_set_folded) */
-  JRR_FLAG_SILHOUETTE = 16, /* reserve the soft-silhouette buffers (needs JRR_FLAG_KEEP_VERTS and model faces) */
+  JRR_FLAG_SILHOUETTE = 16, /* reserve the soft-silhouette buffers (needs JRR_FLAG_KEEP_VERTS and model faces): per pose the projected
+                               vertices of the stand-alone API (110 KB), the covered-pixel list (200 KB at 224 x 224) and a pose-major
+                               copy of the vertices for the fused rasteriser (83 KB) */
   JRR_FLAG_NO_MODEL = 32,   /* discriminator-only engine (model == NULL): the SMPL sections (~230 KB per pose) are not
                                part of the workspace; only JRR_FLAG_POSE_DISC / JRR_FLAG_SHAPE_DISC may accompany it */
   JRR_FLAG_SIL_256 = 64,    /* with JRR_FLAG_SILHOUETTE: 256 x 256 silhouettes (the reference constructor's default,
