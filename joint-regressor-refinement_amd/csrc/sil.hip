@@ -29,6 +29,8 @@ namespace jrr {
 constexpr int SIL_MAX = 256;
 constexpr int SIL_ZPIX = 40 * 224;       // z-buffer capacity in pixels (8960 * 8 B = 70 KB); strips cover the mesh's pixel box
 constexpr int SIL_RT = 1024;             // threads of the raster workgroup (one workgroup per pose and per CU: LDS-bound)
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) unsigned long long lds_u64;
 constexpr int SIL_FPT = 14;              // faces per thread, kept in registers (14 * 1024 >= 13776)
 constexpr int SIL_FBITS = 14;             // covered-pixel list entry = pixel << 14 | face (faces < 16384, pixels < 65536)
 constexpr int SIL_EB = 6;                 // list entries fetched together per thread in the resolve
@@ -267,22 +269,49 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
       const float a1x = (ay - cy) * inv, a1y = -(ax - cx) * inv;         // d w1 / d (px, py)
       const float a2x = (by - ay) * inv, a2y = -(bx - ax) * inv;         // d w2 / d (px, py)
       const float dzb = bz - az, dzc = cz - az;
-      // one flat loop over the bounding box (xi fastest): a wave runs max-over-lanes(nx * ny) trips, not
-      // sum-over-rows(max nx)
-      for (int xi = xlo, yi = ylo; yi <= yhi;) {
-        const float dx = pxt[xi] - ax, dy = pxt[yi] - ay;
-        // edge(p; c, a) = (p - c) x (a - c); with p - c = (p - a) + (a - c) the constant term vanishes: = (p - a) x (a - c)
-        const float w1 = fmaf(dx, a1x, dy * a1y);
-        const float w2 = fmaf(dx, a2x, dy * a2y);
-        const float w0 = 1.f - w1 - w2;
-        const float pz = fmaf(w1, dzb, fmaf(w2, dzc, az));
-        if (w0 > 0.f && w1 > 0.f && w2 > 0.f && pz >= 0.f) {
-          const unsigned long long key = ((unsigned long long)__float_as_uint(pz) << 32) | (unsigned)f;
-          atomicMin(&zb[(yi - y0) * bw + (xi - bx0)], key);
+      // One flat loop over the bounding box in blocks of 2 x 2 pixel centres (x fastest).  Stamps and no-op variants (round 5) put
+      // 25 of the sweep's 32 us in this loop and showed it bound by instruction ISSUE (four waves per SIMD, ~2.6 clocks per
+      // instruction), not by latency, the LDS gathers or the atomics: what counts is instructions per trip x trips of the
+      // longest lane.  2 x 2 blocks cut the trips from 2027 to 692 per pose; per block the two columns go through packed
+      // fp32 arithmetic (v_pk_fma_f32: one instruction for both), the three edge tests are one v_min3 + compare, and a block
+      // hanging over the box's edge REPEATS its last column / row instead of testing bounds (atomicMin is idempotent).
+      // Per pixel the arithmetic is what it was one pixel at a time (dy * a1y shared by a row, nothing incremental).
+      // The loop variables are BYTE offsets into pxt (4 x the pixel index): no shifts for the table reads, one shift-add for a
+      // z-buffer address, one multiply-add for a row's base.
+      {
+        const char* const pxb = reinterpret_cast<const char*>(pxt);
+        // (the z-buffer is addressed through its 32-bit LDS offset: + row * bw * 8 + column * 8, the row term from a 24-bit
+        // multiply -- the compiler's own address arithmetic used the quarter-rate 32-bit multiply)
+        const unsigned zrow = (unsigned)(size_t)(lds_u64*)zb - (unsigned)(bx0 * 8) - (unsigned)(y0 * bw * 8);
+        const unsigned long long keyf = (unsigned long long)(unsigned)f;
+        const int xlo4 = xlo * 4, xhi4 = xhi * 4, yhi4 = yhi * 4, bw2 = bw * 2;
+        for (int xi = xlo4, yi = ylo * 4; yi <= yhi4;) {
+          const int xj = min(xi + 4, xhi4), yj = min(yi + 4, yhi4);
+          const f32x2 DX = f32x2{*reinterpret_cast<const float*>(pxb + xi), *reinterpret_cast<const float*>(pxb + xj)} - ax;
+          const float dyr[2] = {*reinterpret_cast<const float*>(pxb + yi) - ay, *reinterpret_cast<const float*>(pxb + yj) - ay};
+          unsigned zr[2];
+          asm("v_mul_u32_u24 %0, %1, %2" : "=v"(zr[0]) : "s"(bw2), "v"(yi));
+          asm("v_mul_u32_u24 %0, %1, %2" : "=v"(zr[1]) : "s"(bw2), "v"(yj));
+          zr[0] += zrow; zr[1] += zrow;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            // edge(p; c, a) = (p - c) x (a - c); with p - c = (p - a) + (a - c) the constant term vanishes: = (p - a) x (a - c)
+            const float t1 = dyr[j] * a1y, t2 = dyr[j] * a2y;
+            const f32x2 W1 = __builtin_elementwise_fma(DX, f32x2{a1x, a1x}, f32x2{t1, t1});
+            const f32x2 W2 = __builtin_elementwise_fma(DX, f32x2{a2x, a2x}, f32x2{t2, t2});
+            const f32x2 W0 = (1.f - W1) - W2;
+            const f32x2 PZ = __builtin_elementwise_fma(W1, f32x2{dzb, dzb}, __builtin_elementwise_fma(W2, f32x2{dzc, dzc}, f32x2{az, az}));
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+              // (a NaN weight makes pz NaN, so the min's NaN-dropping cannot let a pixel through)
+              if (__builtin_fminf(__builtin_fminf(W0[i], W1[i]), W2[i]) > 0.f && PZ[i] >= 0.f)
+                __hip_atomic_fetch_min((lds_u64*)(zr[j] + 2u * (unsigned)(i ? xj : xi)), ((unsigned long long)__float_as_uint(PZ[i]) << 32) | keyf,
+                                       __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          }
+          const bool wrap = xi + 8 > xhi4;
+          xi = wrap ? xlo4 : xi + 8;
+          yi += wrap ? 8 : 0;
         }
-        const bool wrap = xi >= xhi;
-        xi = wrap ? xlo : xi + 1;
-        yi += wrap ? 1 : 0;
       }
     }
     __syncthreads();
