@@ -133,7 +133,7 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
   unsigned long long* zb = smem64 + SIL_VPAD / 2;     // [SIL_ZPIX]
   float* vy = vx + V;
   float* vz = vx + 2 * V;
-  __shared__ float red[SIL_RT];
+  __shared__ float red[4 * (SIL_RT / 64)];   // wave partials of the four end-of-pose sums
   __shared__ float pxt[SIL_MAX];      // pixel centres
   __shared__ int ncov;
   if (ADJ && b >= B) {                       // padded pose (whole workgroup): its adjoint is zero
@@ -305,7 +305,7 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
             for (int i = 0; i < 2; ++i)
               // (a NaN weight makes pz NaN, so the min's NaN-dropping cannot let a pixel through)
               if (__builtin_fminf(__builtin_fminf(W0[i], W1[i]), W2[i]) > 0.f && PZ[i] >= 0.f)
-                __hip_atomic_fetch_min((lds_u64*)(zr[j] + 2u * (unsigned)(i ? xj : xi)), ((unsigned long long)__float_as_uint(PZ[i]) << 32) | keyf,
+                __hip_atomic_fetch_min((lds_u64*)(size_t)(zr[j] + 2u * (unsigned)(i ? xj : xi)), ((unsigned long long)__float_as_uint(PZ[i]) << 32) | keyf,
                                        __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
           }
           const bool wrap = xi + 8 > xhi4;
@@ -409,9 +409,9 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
   }
   // (a FRESH laundered thread index for the write-out and the reductions: nothing derived from `tix` has to survive the resolve pass)
   int tq = wave_s * 64 + fresh_lane();
+  float gc[3] = {0.f, 0.f, 0.f};
   if (ADJ) {
     __syncthreads();
-    float gc[3] = {0.f, 0.f, 0.f};
     for (int q = tq; q < VP / 4; q += SIL_RT) {       // the pose's pieces of VQ now take the vertex adjoint
       f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = o0, o2 = o0;
 #pragma unroll
@@ -434,36 +434,34 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
       }
       VQ4[(size_t)q * BP + b] = o0; VQ4[((size_t)(VP / 4) + q) * BP + b] = o1; VQ4[((size_t)2 * (VP / 4) + q) * BP + b] = o2;
     }
-    if (gcam) {                                                          // wave sums, added in wave order (deterministic)
-      __syncthreads();                                                   // (red is free: nobody reads it before this point)
-#pragma unroll
-      for (int c = 0; c < 3; ++c) {
-        float w = gc[c];
-        // (shuffle addresses from the FRESH lane index: shared with the bounding-box reduction of the set-up they would be six
-        // registers alive across the whole pose)
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) w += __int_as_float(__builtin_amdgcn_ds_bpermute(((tq & 63) ^ o) << 2, __float_as_int(w)));
-        if ((tq & 63) == 0) red[c * (SIL_RT / 64) + (tq >> 6)] = w;
-      }
-      __syncthreads();
-      if (tq < 3) {
-        float t = 0.f;
-#pragma unroll
-        for (int w = 0; w < SIL_RT / 64; ++w) t += red[tq * (SIL_RT / 64) + w];
-        if (accumulate_cam) gcam[(size_t)b * 3 + tq] += t;
-        else gcam[(size_t)b * 3 + tq] = t;
-      }
-      __syncthreads();                                                   // red is reused by the error sum below
-    }
   }
-  if (sqsil) {
-    red[tq] = err;
-    __syncthreads();
-    for (int s = SIL_RT / 2; s > 0; s >>= 1) {
-      if (tq < s) red[tq] += red[tq + s];
-      __syncthreads();
+  // the camera adjoint's three sums and the squared error: wave butterflies, one LDS row per quantity, rows added in wave order by
+  // one thread each (deterministic).  ONE barrier -- the shared-memory tree this replaces cost a pose twelve.
+  // (`red` is next written at the next pose's tail, many barriers after these reads)
+  if ((ADJ && gcam) || sqsil) {
+    const float rv[4] = {gc[0], gc[1], gc[2], err};
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      if (c < 3 && !(ADJ && gcam)) continue;
+      float w = rv[c];
+      // (shuffle addresses from the FRESH lane index: shared with the bounding-box reduction of the set-up they would be six
+      // registers alive across the whole pose)
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) w += __int_as_float(__builtin_amdgcn_ds_bpermute(((tq & 63) ^ o) << 2, __float_as_int(w)));
+      if ((tq & 63) == 0) red[c * (SIL_RT / 64) + (tq >> 6)] = w;
     }
-    if (tq == 0) sqsil[b] = red[0] + (smask ? smask[b] : 0.f);
+    __syncthreads();
+    if (tq < 4) {
+      float t = 0.f;
+#pragma unroll
+      for (int w = 0; w < SIL_RT / 64; ++w) t += red[tq * (SIL_RT / 64) + w];
+      if (tq < 3) {
+        if (ADJ && gcam) {
+          if (accumulate_cam) gcam[(size_t)b * 3 + tq] += t;
+          else gcam[(size_t)b * 3 + tq] = t;
+        }
+      } else if (sqsil) sqsil[b] = t + (smask ? smask[b] : 0.f);
+    }
   }
 }
 

@@ -23,8 +23,8 @@ pairs = [
     '  ' + ST(4),
     '  // (a FRESH laundered thread index for the write-out',
     ST(5) + '  // (a FRESH laundered thread index for the write-out',
-    '    if (tq == 0) sqsil[b] = red[0] + (smask ? smask[b] : 0.f);\n  }\n',
-    '    if (tq == 0) sqsil[b] = red[0] + (smask ? smask[b] : 0.f);\n  }\n  tix = tq;\n' + ST(6) + '  if (ADJ && tix == 0 && blockIdx.x == 0) g_sil_dbg[7] += 1;\n',
+    '      } else if (sqsil) sqsil[b] = t + (smask ? smask[b] : 0.f);\n    }\n  }\n',
+    '      } else if (sqsil) sqsil[b] = t + (smask ? smask[b] : 0.f);\n    }\n  }\n  tix = tq;\n' + ST(6) + '  if (ADJ && tix == 0 && blockIdx.x == 0) g_sil_dbg[7] += 1;\n',
     '// adjoint for an arbitrary upstream gradient',
     'extern "C" void jrr_debug_read(long long* out) { (void)hipDeviceSynchronize(); (void)hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sil_dbg), sizeof(long long) * 16); }\n// adjoint for an arbitrary upstream gradient',
 ]
