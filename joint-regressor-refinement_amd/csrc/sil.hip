@@ -193,29 +193,6 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
     bbp[0][w] = bxn; bbp[1][w] = bxx; bbp[2][w] = byn; bbp[3][w] = byx;
   }
   __syncthreads();
-  // this thread's faces: vertex indices -> pixel-row range of the face -> the two-register record
-  {
-    int fi[SIL_FPT][3];
-#pragma unroll
-    for (int u = 0; u < SIL_FPT; ++u) {
-      const int f = min(tix + u * SIL_RT, nfaces - 1);      // (a slot past the last face reads the last face; it is marked empty below)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) fi[u][k] = faces[f * 3 + k];
-    }
-#pragma unroll
-    for (int u = 0; u < SIL_FPT; ++u) {
-      const int f = tix + u * SIL_RT;
-      const float y0v = vy[fi[u][0]], y1v = vy[fi[u][1]], y2v = vy[fi[u][2]];
-      const float ymax = fmaxf(y0v, fmaxf(y1v, y2v)), ymin = fminf(y0v, fminf(y1v, y2v));
-      // pixel centres inside the bounding box: yf = 1 - (2 yi + 1)/H in [ymin, ymax]  <=>
-      // yi in [ceil((H (1 - ymax) - 1)/2), floor((H (1 - ymin) - 1)/2)]; 1e-3 px of slack, the inside test is exact.
-      int ylo = (int)ceilf((SIL * (1.f - ymax) - 1.f) * 0.5f - 1e-3f), yhi = (int)floorf((SIL * (1.f - ymin) - 1.f) * 0.5f + 1e-3f);
-      ylo = max(ylo, 0); yhi = min(yhi, SIL - 1);
-      if (f >= nfaces || !(ymax == ymax) || !(ymin == ymin) || ylo > yhi) { ylo = 1; yhi = 0; }     // empty range
-      fr0[u] = (unsigned)fi[u][0] | ((unsigned)fi[u][1] << 13);
-      fr1[u] = (unsigned)fi[u][2] | ((unsigned)ylo << 13) | ((unsigned)yhi << 21);
-    }
-  }
   float err = 0.f;
   // The z-buffer only ever holds the pixel bounding box of the projected mesh (a person covers 8-9 % of the crop and
   // its box ~23 %): strips of as many box rows as fit 70 KB -- 1.8 strips per pose on the synthetic batches instead of the
@@ -239,10 +216,40 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
   }
   const int bw = bx1 - bx0 + 1;
   const int rows_per = (bw > 0) ? SIL_ZPIX / bw : SIL;
+  // the first strip's z-buffer is cleared HERE, under the face records' index loads (which wait on the L2 with nothing else to do),
+  // not behind them
+  if (bw > 0) {
+    const int npx0 = (min(by0 + rows_per, by1 + 1) - by0) * bw;
+    for (int i = tix; i < npx0; i += SIL_RT) zb[i] = ~0ull;
+  }
+  // this thread's faces: vertex indices -> pixel-row range of the face -> the two-register record
+  {
+    int fi[SIL_FPT][3];
+#pragma unroll
+    for (int u = 0; u < SIL_FPT; ++u) {
+      const int f = min(tix + u * SIL_RT, nfaces - 1);      // (a slot past the last face reads the last face; it is marked empty below)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) fi[u][k] = faces[f * 3 + k];
+    }
+#pragma unroll
+    for (int u = 0; u < SIL_FPT; ++u) {
+      const int f = tix + u * SIL_RT;
+      const float y0v = vy[fi[u][0]], y1v = vy[fi[u][1]], y2v = vy[fi[u][2]];
+      const float ymax = fmaxf(y0v, fmaxf(y1v, y2v)), ymin = fminf(y0v, fminf(y1v, y2v));
+      // pixel centres inside the bounding box: yf = 1 - (2 yi + 1)/H in [ymin, ymax]  <=>
+      // yi in [ceil((H (1 - ymax) - 1)/2), floor((H (1 - ymin) - 1)/2)]; 1e-3 px of slack, the inside test is exact.
+      int ylo = (int)ceilf((SIL * (1.f - ymax) - 1.f) * 0.5f - 1e-3f), yhi = (int)floorf((SIL * (1.f - ymin) - 1.f) * 0.5f + 1e-3f);
+      ylo = max(ylo, 0); yhi = min(yhi, SIL - 1);
+      if (f >= nfaces || !(ymax == ymax) || !(ymin == ymin) || ylo > yhi) { ylo = 1; yhi = 0; }     // empty range
+      fr0[u] = (unsigned)fi[u][0] | ((unsigned)fi[u][1] << 13);
+      fr1[u] = (unsigned)fi[u][2] | ((unsigned)ylo << 13) | ((unsigned)yhi << 21);
+    }
+  }
   for (int y0 = by0; y0 <= by1 && bw > 0; y0 += rows_per) {
     const int y1 = min(y0 + rows_per, by1 + 1);                        // rows [y0, y1) of the box columns [bx0, bx1]
     const int npx = (y1 - y0) * bw;
-    for (int i = tix; i < npx; i += SIL_RT) zb[i] = ~0ull;
+    if (y0 != by0)
+      for (int i = tix; i < npx; i += SIL_RT) zb[i] = ~0ull;
     __syncthreads();
 #pragma unroll
     for (int u = 0; u < SIL_FPT; ++u) {

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Build tools/probe/libjrr_silstamp.so: the shipped rasteriser with wall_clock64() stamps (10 ns ticks) summed per phase over the
-poses of workgroup 0, read back through jrr_debug_read (tools/exp/sil_phases.py prints them).  Phases: 0 set-up (vertices, box),
-1 face records, 2 z-buffer clears, 3 face sweep, 4 resolve pass 1 (covered-pixel list), 5 resolve pass 2 (alpha, adjoint atomics),
+poses of workgroup 0, read back through jrr_debug_read (tools/exp/sil_phases.py prints them).  Phases: 0 set-up (vertices),
+1 mesh box (face records + first clear are inside 2), 2 z-buffer clears, 3 face sweep, 4 resolve pass 1 (covered-pixel list), 5 resolve pass 2 (alpha, adjoint atomics),
 6 write-out + reductions, 7 number of poses."""
 import os, subprocess, sys
 here = os.path.dirname(os.path.abspath(__file__))
@@ -11,12 +11,12 @@ pairs = [
     '__device__ long long g_sil_dbg[16];\n__device__ __forceinline__ int fresh_lane() {',
     '  int tix = wave_s * 64 + fresh_lane();\n',
     '  int tix = wave_s * 64 + fresh_lane();\n  long long t_last = wall_clock64();\n',
-    '  __syncthreads();\n  // this thread\'s faces:',
-    ST(0) + '  // this thread\'s faces:',
-    '  float err = 0.f;\n',
-    ST(1) + '  float err = 0.f;\n',
-    '    for (int i = tix; i < npx; i += SIL_RT) zb[i] = ~0ull;\n    __syncthreads();\n',
-    '    for (int i = tix; i < npx; i += SIL_RT) zb[i] = ~0ull;\n  ' + ST(2),
+    '  __syncthreads();\n  float err = 0.f;\n',
+    ST(0) + '  float err = 0.f;\n',
+    '  const int bw = bx1 - bx0 + 1;\n',
+    '  const int bw = bx1 - bx0 + 1;\n' + ST(1),
+    '      for (int i = tix; i < npx; i += SIL_RT) zb[i] = ~0ull;\n    __syncthreads();\n',
+    '      for (int i = tix; i < npx; i += SIL_RT) zb[i] = ~0ull;\n  ' + ST(2),
     '    __syncthreads();\n    // resolve, pass 1',
     '  ' + ST(3) + '    // resolve, pass 1',
     '    __syncthreads();                                                   // strip resolved before the z-buffer is reused\n',
