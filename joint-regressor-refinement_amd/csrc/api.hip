@@ -42,7 +42,7 @@ static size_t model_floats() {
   const size_t nW16 = (size_t)VT * 16 * 36, nSeg = (size_t)VT * 32;
   return nDk + nDn + nDq + nWjv + nWvj + nJt + nJS + nWc + nJl + nPerm + nW16 + nSeg;
 }
-extern "C" size_t jrr_model_bytes(void) { return round_up(model_floats() * sizeof(float), 256) + (size_t)2 * MAX_FACES * 3 * sizeof(int32_t); }
+extern "C" size_t jrr_model_bytes(void) { return round_up(model_floats() * sizeof(float), 256) + (size_t)2 * MAX_FACES * (3 + 2) * sizeof(int32_t); }
 
 extern "C" int jrr_model_create(const float* vt, const float* sd, const float* pd, const float* Jr, const float* W,
                                 const int32_t* parents, jrr_model_t** out) {
@@ -350,6 +350,8 @@ extern "C" int jrr_model_create_hinted(const float* vt, const float* sd, const f
   m->d.parents.maxd = 0;
   m->d.faces = nullptr;
   m->d.faces_int = nullptr;
+  m->d.faces_pk = nullptr;
+  m->d.faces_int_pk = nullptr;
   m->d.nfaces = 0;
   for (int j = 0; j < NJ; ++j) {
     m->d.parents.p[j] = parents[j];
@@ -384,6 +386,23 @@ extern "C" int jrr_model_set_faces(jrr_model_t* m, const int32_t* faces, int n_f
     for (size_t i = 0; i < fi.size(); ++i) fi[i] = m->v2p_host[faces[i]];
     m->d.faces_int = m->faces_area + (size_t)MAX_FACES * 3;
     JRR_HIP(hipMemcpy(m->d.faces_int, fi.data(), fi.size() * sizeof(int), hipMemcpyHostToDevice));
+  }
+  // the rasteriser reads a face as ONE 8-byte record (three 13-bit vertex indices): one gather per face where three strided
+  // 4-byte ones were the resolve pass's bound
+  auto pack = [&](const int32_t* f3, unsigned* dst) -> int {
+    std::vector<unsigned> pk((size_t)n_faces * 2);
+    for (int i = 0; i < n_faces; ++i) { pk[2 * i] = (unsigned)f3[3 * i] | ((unsigned)f3[3 * i + 1] << 13); pk[2 * i + 1] = (unsigned)f3[3 * i + 2]; }
+    return hipMemcpy(dst, pk.data(), pk.size() * sizeof(unsigned), hipMemcpyHostToDevice) == hipSuccess ? 0 : 1;
+  };
+  static_assert(V <= 8192, "packed face records hold 13-bit vertex indices");
+  m->d.faces_pk = reinterpret_cast<unsigned*>(m->faces_area + (size_t)2 * MAX_FACES * 3);
+  m->d.faces_int_pk = nullptr;
+  if (pack(faces, m->d.faces_pk)) { jrr_set_error("hipMemcpy(faces) failed"); return JRR_ERR_HIP; }
+  if (m->v2p_host) {
+    std::vector<int32_t> fi((size_t)n_faces * 3);
+    for (size_t i = 0; i < fi.size(); ++i) fi[i] = m->v2p_host[faces[i]];
+    m->d.faces_int_pk = m->d.faces_pk + (size_t)MAX_FACES * 2;
+    if (pack(fi.data(), m->d.faces_int_pk)) { jrr_set_error("hipMemcpy(faces) failed"); return JRR_ERR_HIP; }
   }
   m->d.nfaces = n_faces;
   return JRR_OK;
@@ -1251,7 +1270,7 @@ extern "C" int jrr_silhouette_forward(jrr_engine_t* e, const float* verts, const
   hipStream_t s = (hipStream_t)stream;
   e->fwd_cached = false;
   launch_sil_project(verts, V * 3, cam, e->ndc, e->B, s, e->sil);
-  launch_sil_raster(e->ndc, e->m.faces, e->m.nfaces, e->cover, e->ncover, alpha, e->B, s, e->sil);
+  launch_sil_raster(e->ndc, e->m.faces_pk, e->m.nfaces, e->cover, e->ncover, alpha, e->B, s, e->sil);
   CHECK_LAUNCH();
   return JRR_OK;
 }
@@ -1306,7 +1325,7 @@ extern "C" int jrr_silhouette_loss_grad(jrr_engine_t* e, const float* x6d, const
   launch_mask_sq(mask, e->smask, e->B, s, e->sil);
   e->smask_valid = false;
   const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * (double)e->sil * (double)e->sil));      // optimize.py:252 weight 100
-  launch_sil_raster_adj(e->VTb, e->BP, cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, mask, e->smask, e->cover,
+  launch_sil_raster_adj(e->VTb, e->BP, cam, e->m.faces_int_pk ? e->m.faces_int_pk : e->m.faces_pk, e->m.nfaces, mask, e->smask, e->cover,
                         e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s, e->sil, e->VPM);
   if (sqsil) JRR_HIP(hipMemcpyAsync(sqsil, e->sqsil, (size_t)e->B * 4, hipMemcpyDeviceToDevice, s));
   if (dverts) launch_verts_untranspose(e->VTb, dverts, V * 3, V, nullptr, nullptr, e->B, e->BP, s, e->m.p2v);
@@ -1457,7 +1476,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * (double)e->sil * (double)e->sil));
       if (!e->smask_valid) { launch_mask_sq(e->sil_mask, e->smask, e->B, s, e->sil); e->smask_valid = true; }
       // projection, rasterisation, loss and adjoint in one kernel, straight from / into the row-quad vertex buffer
-      launch_sil_raster_adj(e->VTb, e->BP, e->cam, e->m.faces_int ? e->m.faces_int : e->m.faces, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil,
+      launch_sil_raster_adj(e->VTb, e->BP, e->cam, e->m.faces_int_pk ? e->m.faces_int_pk : e->m.faces_pk, e->m.nfaces, e->sil_mask, e->smask, e->cover, e->ncover, e->sqsil,
                             silscale, e->gcam, e->gt_j2d ? 1 : 0, e->B, s, e->sil, e->VPM);
       prof_mark(e, 8, s);
     }

@@ -188,6 +188,8 @@ struct Model {
   Parents parents;
   int* faces;   // [nfaces][3] (device) or NULL; vertex indices of the caller's mesh
   int* faces_int;   // the same faces in internal row indices (only when p2v != NULL; fused rasteriser)
+  unsigned* faces_pk;      // the rasteriser's table: one 8-byte record per face, {i0 | i1 << 13, i2} (vertex indices < 8192)
+  unsigned* faces_int_pk;  // ... in internal row indices
   int nfaces;
 };
 
@@ -199,7 +201,7 @@ struct jrr_model {
   jrr::Model d;
   void* base;      // the model buffer (jrr_model_bytes): the caller's (jrr_model_create_in) or the library's own
   bool owns_base;
-  int* faces_area; // tail of the buffer: faces [MAX_FACES][3], faces in internal row indices [MAX_FACES][3]
+  int* faces_area; // tail of the buffer: faces [MAX_FACES][3], faces in internal row indices [MAX_FACES][3], the two packed tables [MAX_FACES][2] each
   int* v2p_host;   // host copy of Model::v2p (jrr_model_set_faces), NULL for the identity order
 };
 

@@ -153,11 +153,11 @@ int launch_jgrad_q(const float* dJT, const float* VTq, float* Out, int BP, int k
 int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s, int S = 224);
 // cover [B][S*S] / ncover [B]: the covered pixels of each pose (pixel << 14 | winning face), written by the
 // rasteriser and consumed by the adjoint
-int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* cover, int* ncover, float* alpha, int B,
+int launch_sil_raster(const float* ndc, const unsigned* faces_pk, int nfaces, unsigned* cover, int* ncover, float* alpha, int B,
                       hipStream_t s, int S = 224);
 // smask [B] = per-pose sum(mask^2) over the image (launch_mask_sq): the rasteriser only visits the mesh's pixel box
 int launch_mask_sq(const float* mask, float* smask, int B, hipStream_t s, int S = 224);
-int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
+int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const unsigned* faces_pk, int nfaces, const float* mask, const float* smask,
                           unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
                           hipStream_t s, int S = 224, const float* VPM = nullptr);
 // VPM (nullable): the vertices pose-major [BP][3][VP] (launch_lbs_fwd with verts_pose_major); NULL: read from the row quads of VQ

@@ -114,7 +114,7 @@ __device__ __forceinline__ int fresh_lane() {
 }
 
 template <bool ADJ, int SIL>
-__device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, const NdcV* __restrict__ ndc, const int* __restrict__ faces,
+__device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, const NdcV* __restrict__ ndc, const uint2* __restrict__ faces,
                                                 int nfaces, const float* __restrict__ mask,
                                                 unsigned* __restrict__ cover, int* __restrict__ ncover,
                                                 float* __restrict__ alpha_out, float* __restrict__ sqsil,
@@ -224,25 +224,24 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
   }
   // this thread's faces: vertex indices -> pixel-row range of the face -> the two-register record
   {
-    int fi[SIL_FPT][3];
+    uint2 fi[SIL_FPT];         // {i0 | i1 << 13, i2}: one 8-byte load per face
 #pragma unroll
     for (int u = 0; u < SIL_FPT; ++u) {
       const int f = min(tix + u * SIL_RT, nfaces - 1);      // (a slot past the last face reads the last face; it is marked empty below)
-#pragma unroll
-      for (int k = 0; k < 3; ++k) fi[u][k] = faces[f * 3 + k];
+      fi[u] = faces[f];
     }
 #pragma unroll
     for (int u = 0; u < SIL_FPT; ++u) {
       const int f = tix + u * SIL_RT;
-      const float y0v = vy[fi[u][0]], y1v = vy[fi[u][1]], y2v = vy[fi[u][2]];
+      const float y0v = vy[fi[u].x & 8191u], y1v = vy[fi[u].x >> 13], y2v = vy[fi[u].y];
       const float ymax = fmaxf(y0v, fmaxf(y1v, y2v)), ymin = fminf(y0v, fminf(y1v, y2v));
       // pixel centres inside the bounding box: yf = 1 - (2 yi + 1)/H in [ymin, ymax]  <=>
       // yi in [ceil((H (1 - ymax) - 1)/2), floor((H (1 - ymin) - 1)/2)]; 1e-3 px of slack, the inside test is exact.
       int ylo = (int)ceilf((SIL * (1.f - ymax) - 1.f) * 0.5f - 1e-3f), yhi = (int)floorf((SIL * (1.f - ymin) - 1.f) * 0.5f + 1e-3f);
       ylo = max(ylo, 0); yhi = min(yhi, SIL - 1);
       if (f >= nfaces || !(ymax == ymax) || !(ymin == ymin) || ylo > yhi) { ylo = 1; yhi = 0; }     // empty range
-      fr0[u] = (unsigned)fi[u][0] | ((unsigned)fi[u][1] << 13);
-      fr1[u] = (unsigned)fi[u][2] | ((unsigned)ylo << 13) | ((unsigned)yhi << 21);
+      fr0[u] = fi[u].x;
+      fr1[u] = fi[u].y | ((unsigned)ylo << 13) | ((unsigned)yhi << 21);
     }
   }
   for (int y0 = by0; y0 <= by1 && bw > 0; y0 += rows_per) {
@@ -383,8 +382,8 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
 #pragma unroll
     for (int u = 0; u < SIL_EB; ++u) {
       const int f = (int)(ent[u] & ((1u << SIL_FBITS) - 1));
-#pragma unroll
-      for (int k = 0; k < 3; ++k) id[u][k] = faces[f * 3 + k];
+      const uint2 fp = faces[f];
+      id[u][0] = (int)(fp.x & 8191u); id[u][1] = (int)(fp.x >> 13); id[u][2] = (int)fp.y;
       tg[u] = mask ? mask[(size_t)b * SIL * SIL + (ent[u] >> SIL_FBITS)] : 0.f;
     }
 #pragma unroll
@@ -478,7 +477,7 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
 // its workgroups take consecutive poses in every step: the 8 poses whose adjoint pieces share a 128-byte line of VQ are written by
 // one XCD at about the same time and meet in its L2.
 template <bool ADJ, int SIL>
-__global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ ndc, const int* __restrict__ faces,
+__global__ __launch_bounds__(SIL_RT) void k_sil_raster(const NdcV* __restrict__ ndc, const uint2* __restrict__ faces,
                                                        int nfaces, const float* __restrict__ mask,
                                                        unsigned* __restrict__ cover, int* __restrict__ ncover,
                                                        float* __restrict__ alpha_out, float* __restrict__ sqsil,
@@ -656,23 +655,23 @@ int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc
   hipLaunchKernelGGL(k_sil_project, dim3((B * V + 255) / 256), dim3(256), 0, s, verts, ldv, cam, (NdcV*)ndc, B, 5000.f / (float)S);
   return 0;
 }
-int launch_sil_raster(const float* ndc, const int* faces, int nfaces, unsigned* cover, int* ncover, float* alpha, int B,
+int launch_sil_raster(const float* ndc, const unsigned* faces_pk, int nfaces, unsigned* cover, int* ncover, float* alpha, int B,
                       hipStream_t s, int S) {
   sil_attrs();
   if (sil_size_ok(S)) return JRR_ERR_ARG;
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
   if (S == 224)
-    hipLaunchKernelGGL((k_sil_raster<false, 224>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc, faces, nfaces, nullptr, cover,
+    hipLaunchKernelGGL((k_sil_raster<false, 224>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc, reinterpret_cast<const uint2*>(faces_pk), nfaces, nullptr, cover,
                        ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr, nullptr);
   else
-    hipLaunchKernelGGL((k_sil_raster<false, 256>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc, faces, nfaces, nullptr, cover,
+    hipLaunchKernelGGL((k_sil_raster<false, 256>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc, reinterpret_cast<const uint2*>(faces_pk), nfaces, nullptr, cover,
                        ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr, nullptr);
   return 0;
 }
 // fused loop: project the pose's vertices from the row-quad buffer VQ [3][VP/4][BP][4], rasterise, squared error against
 // mask, and the adjoint of scale/2 * sum((alpha - mask)^2) written back over the same pieces of VQ; gcam: overwrite or
 // accumulate
-int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces, int nfaces, const float* mask, const float* smask,
+int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const unsigned* faces_pk, int nfaces, const float* mask, const float* smask,
                           unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
                           hipStream_t s, int S, const float* VPM) {
   sil_attrs();
@@ -680,10 +679,10 @@ int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const int* faces,
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
   const int grid = BP < 256 ? BP : 256;    // persistent: one workgroup per CU (a multiple of 8: BP is a multiple of 128); padded poses zero their pieces
   if (S == 224)
-    hipLaunchKernelGGL((k_sil_raster<true, 224>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, faces, nfaces, mask, cover,
+    hipLaunchKernelGGL((k_sil_raster<true, 224>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, reinterpret_cast<const uint2*>(faces_pk), nfaces, mask, cover,
                        ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask, VPM);
   else
-    hipLaunchKernelGGL((k_sil_raster<true, 256>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, faces, nfaces, mask, cover,
+    hipLaunchKernelGGL((k_sil_raster<true, 256>), dim3(grid), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)nullptr, reinterpret_cast<const uint2*>(faces_pk), nfaces, mask, cover,
                        ncover, nullptr, sqsil, scale, VQ, BP, cam, B, gcam, accumulate_cam, smask, VPM);
   return 0;
 }
