@@ -79,6 +79,7 @@ def fwd_pipe_clocks_per_tile(model_info):
     slots = skin_slots(model_info)[0]
     return (330 + 6 * slots) * 64 + 48 * 33 if model_info['joint_slots'] else 522 * 64
 PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak (= fp32 vector peak)
+PEAK_BF16_MFMA_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 matrix peak (the side mode's own denominator)
 
 
 def parse():
@@ -98,6 +99,7 @@ def parse():
     ap.add_argument('--cpu_batch', type=int, default=1024, help='cpu_baseline sample batch (scaled to batch-4096 units)')
     ap.add_argument('--cpu_seconds', type=float, default=8.0, help='time budget per cpu_baseline variant')
     ap.add_argument('--no_folded', action='store_true', help='skip the separately reported folded-regressor mode')
+    ap.add_argument('--no_bf16x3', action='store_true', help='skip the separately reported split-bf16 side mode of the blend adjoint')
     ap.add_argument('--no_config5', action='store_true', help='skip the separately reported BASELINE configs[4] block')
     ap.add_argument('--no_config2', action='store_true', help='skip the separately reported BASELINE configs[1] block (batch 1024, joint loss only)')
     ap.add_argument('--no_support_tiles', action='store_true', help='skip the side run restricted to the vertex tiles of the regressor\'s support')
@@ -623,7 +625,7 @@ def main():
         d_ms = (time.perf_counter() - td) / nj * 1e3
         eng.set_pose_disc(disc_flat.to(dev))
 
-    def side_run(flags_, setup=None, model=None, Bs=None, disc=None, tiles=False):
+    def side_run(flags_, setup=None, model=None, Bs=None, disc=None, tiles=False, force_profile=False):
         """a separately reported mode on a fresh copy of the same batch (its first Bs poses): warm-up, then --steps timed
         iterations (median of 3)"""
         Bs = Bs or B
@@ -667,7 +669,7 @@ def main():
             out_['cadence1_ms_per_step'] = round(c1t / a.steps * 1e3, 4)
             e2.set_j_regressor(J)
             e2.j_support_info()
-        if setup is silhouette_setup or Bs != B or tiles:
+        if setup is silhouette_setup or Bs != B or tiles or force_profile:
             e2.set_profiling(True)
             e2.refine_run(fx, fb, fgt, fm, fv, fstep, 1e-2, max(2, min(a.steps, 10)))
             pr = e2.profile_read()
@@ -682,6 +684,27 @@ def main():
         folded.update({'algorithmic_flop_per_pose_iter': 2 * (2 * 1224 * 218) + 4 * (17 * 3 * 24 * 4 * 2),
                        'note': 'joints = A.(H F) with H = sum_v Jn W D contracted once per J update (exact re-association, '
                                'same losses/updates; no vertices).  Separate mode, separate denominator: not the headline.'})
+    # ---- SIDE MODE, a different arithmetic type: the blend-basis adjoint as a split-bf16 product (JRR_FLAG_BLEND_BF16X3).  Reported
+    #      like folded_mode: separately labelled, its own denominator, NEVER `value` (the reference computes in fp32; so does the
+    #      headline).  Its parity bounds are its own: tests/test_gpu_bf16x3.py ----
+    bf16x3 = None
+    if not a.no_bf16x3 and not use_sil and use_disc and hasattr(eng_mod, 'FLAG_BLEND_BF16X3'):
+        bf16x3 = side_run(eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_POSE_DISC | eng_mod.FLAG_BLEND_BF16X3, force_profile=True)
+        adj_ms = bf16x3.get('kernels_ms', {}).get('k_gemm_tn_blend_adjoint')
+        # issued work of the kernel: three 32x32x16 bf16 matrix instructions per accumulator tile and 16 vertices
+        bf_flop = 3 * 2.0 * 224 * (3 * 6912) * B
+        bf16x3.update({
+            'dtype': 'bf16x3, f32 accumulate (blend adjoint only; every other kernel exact f32)',
+            'blend_adjoint': {'avg_launch_ms': adj_ms, 'exact_f32_kernel_ms': round(prof['k_gemm_tn_blend_adjoint'][0], 4),
+                              'issued_bf16_mfma_flop_per_launch': bf_flop,
+                              'achieved_tflops_bf16_issued': round(bf_flop / (adj_ms * 1e-3) / 1e12, 1) if adj_ms else None,
+                              'peak_bf16_mfma_tflops': PEAK_BF16_MFMA_TFLOPS,
+                              'frac_of_bf16_mfma_peak': round(bf_flop / (adj_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if adj_ms else None,
+                              'operand_bytes_through_lds_per_launch': int((B // 128) * 1296 * (14336 + 8192)),
+                              'bound': 'operand traffic (the split operands are as large as the f32 ones; the matrix part is 5.3 x shorter)'},
+            'note': 'NOT the headline and not the reference\'s arithmetic: operands of the blend-basis adjoint taken as bf16 hi + lo, three bf16 '
+                    'products per exact one, f32 accumulation (relative error of the product ~3e-5; joints after 100 iterations within 1e-4 m of '
+                    'the exact engine and of the oracle: tests/test_gpu_bf16x3.py).  `value` stays the exact-f32 run above.'})
     # ---- the same iteration on the vertex tiles of the regressor's SUPPORT only (JRR_FLAG_SUPPORT_TILES; what optimize.py runs by
     #      default).  Exact: the other tiles meet a zero block of the regressor and a zero vertex adjoint.  Reported beside the
     #      headline, which keeps running all 6890 vertices (north_star: "linear blend skinning over 6890 vertices") ----
@@ -961,6 +984,8 @@ def main():
         out['reference_default'] = ref_default
     if folded is not None:
         out['folded_mode'] = folded
+    if bf16x3 is not None:
+        out['bf16x3_mode'] = bf16x3
     if support_tiles is not None:
         out['support_tiles'] = support_tiles
     if config2 is not None:

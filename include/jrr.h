@@ -62,7 +62,7 @@ enum {
   JRR_FLAG_SIL_256 = 64,    /* with JRR_FLAG_SILHOUETTE: 256 x 256 silhouettes (the reference constructor's default,
                                scripts/mesh_renderer.py:25; focal length 5000 / 256) instead of 224 x 224 (scripts/optimize.py:110):
                                every (B,224,224) below then reads (B,256,256) */
-  JRR_FLAG_SUPPORT_TILES = 128 /* with JRR_FLAG_KEEP_VERTS: once jrr_j_support_info has reported that the regressor's support fits,
+  JRR_FLAG_SUPPORT_TILES = 128,/* with JRR_FLAG_KEEP_VERTS: once jrr_j_support_info has reported that the regressor's support fits,
                                the iterations of jrr_refine_run* whose loss reads the JOINTS only (no silhouette term) run their three
                                skinning kernels on the 32-vertex tiles that hold a support entry -- every other tile multiplies
                                its vertices by a zero block of the regressor and receives a zero vertex adjoint: exact zeros in
@@ -70,6 +70,12 @@ enum {
                                over the tiles; until jrr_j_support_info is called (and after a jrr_engine_set_j_regressor from
                                outside) the iterations run all 216 tiles.  v_posed / vertices of the other tiles are NOT
                                produced by those iterations (jrr_find_joints_forward and jrr_smpl_vertices* always are dense). */
+  JRR_FLAG_BLEND_BF16X3 = 256  /* SIDE MODE, not the reference's arithmetic (the reference computes in fp32 and so does every engine
+                               without this flag): the all-tiles blend-basis adjoint of jrr_refine_run* runs as a split-bf16 product
+                               -- operands taken as bf16 hi + lo, three bf16 matrix instructions per exact-fp32 eight, fp32
+                               accumulation; relative error of the product ~ 3e-5.  Reserves 18.6 MB for the split basis.  Every
+                               other kernel, and the support-tile iterations, are unchanged.  bench.py reports it as a separately
+                               labelled block (`bf16x3_mode`); it is never the headline. */
 };
 
 typedef struct jrr_model jrr_model_t;   /* device-resident, re-laid-out SMPL constants */

@@ -448,6 +448,7 @@ struct jrr_engine {
   float *ndc, *sqsil, *VPM; unsigned* cover; int* ncover;   // soft silhouette (JRR_FLAG_SILHOUETTE)
   const float* sil_mask; float* smask; bool smask_valid;     // target masks, per-pose sum(mask^2)
   float *JW, *Hm, *Hk, *G0, *MT, *dMT;      // folded regressor (JRR_FLAG_FOLDED)
+  float* Dsplit;                            // the blend basis as bf16 hi | lo chunks (JRR_FLAG_BLEND_BF16X3)
   bool folded, fold_valid;
   // forward reuse (jrr_refine_run_after_j_step): state left by jrr_j_regressor_grad's SMPL forward; dropped by every
   // entry point that overwrites FT / AT / VPb / VTb or may run between the two calls (drop_cached_forward)
@@ -607,6 +608,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->MT = c.take((size_t)FOLD_M * BP);
     t->dMT = c.take((size_t)FOLD_M * BP);
   }
+  if ((flags & JRR_FLAG_BLEND_BF16X3) && !(flags & JRR_FLAG_NO_MODEL)) t->Dsplit = c.take(blend_basis_split_bytes() / sizeof(float));
   if (flags & JRR_FLAG_KEEP_VERTS) {
     t->dVTb = c.take((size_t)3 * VP * BP);
     t->dJnp = c.take((size_t)3 * nsplitJ * 32 * VP);
@@ -654,6 +656,11 @@ extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_
   e->sil = (flags & JRR_FLAG_SIL_256) ? 256 : 224;
   carve(e, ws, batch, flags);
   e->have_jsup = (flags & JRR_FLAG_KEEP_VERTS) != 0;
+  if (flags & JRR_FLAG_BLEND_BF16X3) {      // side mode: the basis is split once, here
+    launch_split_blend_basis(e->m.Dq, e->Dsplit, nullptr);
+    const hipError_t he = hipStreamSynchronize(nullptr);
+    if (he != hipSuccess) { jrr_set_error("jrr_engine_create: splitting the blend basis failed: %s", hipGetErrorString(he)); delete e; return JRR_ERR_HIP; }
+  }
   *out = e;
   return JRR_OK;
 }
@@ -920,6 +927,8 @@ extern "C" int jrr_find_joints_forward(jrr_engine_t* e, const float* x6d, const 
 }
 
 static int blend_adjoint_gemm(jrr_engine* e, hipStream_t s, const int* tl = nullptr, int ntl = 0, int nsplit = 0) {
+  if ((e->flags & JRR_FLAG_BLEND_BF16X3) && !tl)      // side mode (include/jrr.h): split-bf16 operands, fp32 accumulation
+    return launch_blend_adjoint_bf16x3(e->Dsplit, e->DVP, e->dFTp, (size_t)KFP * e->BP, e->BP, nsplit > 0 ? nsplit : e->nsplit, s);
   return launch_blend_adjoint(e->m.Dq, e->DVP, e->dFTp, (size_t)KFP * e->BP, e->BP, nsplit > 0 ? nsplit : e->nsplit, s, tl, ntl);
 }
 // the joint-loss iteration on the regressor's support tiles only (JRR_FLAG_SUPPORT_TILES)

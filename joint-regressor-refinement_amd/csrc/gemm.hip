@@ -495,6 +495,124 @@ int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t
 }
 
 // ------------------------------------------------------------------------------------------------------------------
+// SIDE MODE (JRR_FLAG_BLEND_BF16X3) -- NOT the reference's arithmetic, never the default, never what bench.py's `value` runs.
+// The blend-basis adjoint as a SPLIT-bf16 product with fp32 accumulation: every fp32 operand x is taken as hi + lo,
+// hi = bf16(x), lo = bf16(x - hi) (both round-to-nearest-even; what is dropped is <= 2^-17 |x|), and
+//     dF^T += D_hi dvp_hi + D_hi dvp_lo + D_lo dvp_hi        (the lo x lo term, <= 2^-16 of the product, is dropped)
+// in three v_mfma_f32_32x32x16_bf16 per accumulator tile and 16 vertices -- where the exact-fp32 kernel above issues eight
+// 32x32x2 instructions of twice the duration each: 5.3 x less matrix-pipe time, which leaves this kernel bound by its operand
+// traffic (the same 22 KB per chunk through the same LDS-DMA ring).
+//   D is split ONCE (k_split_blend_basis, at engine creation) into the layout a lane reads with one ds_read_b128 per tile and part:
+//   chunk ch (16 vertices = one matrix-instruction K step) = [part hi | lo][K half h][224 rows][8 bf16], element j of (h, row m) = vertex
+//   16 ch + 8 h + j -- 14 336 bytes per chunk, the size of the fp32 chunk it replaces.  dvp is split in registers, per chunk:
+//   a lane's eight K values of its pose column are two 16-byte LDS reads (quads 2 h, 2 h + 1).
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+constexpr int BX_CHUNKS = 3 * (VP / 4) / BA_QUADS;            // 1296 chunks of 16 vertices over the three coordinate planes
+__global__ __launch_bounds__(256) void k_split_blend_basis(const float* __restrict__ Dq, bf16x8* __restrict__ Ds) {
+  const int i = blockIdx.x * 256 + threadIdx.x;               // (chunk, K half, row)
+  if (i >= BX_CHUNKS * 2 * KFP) return;
+  const int m = i % KFP, h = (i / KFP) & 1, ch = i / (2 * KFP);
+  const f32x4* q = reinterpret_cast<const f32x4*>(Dq) + ((size_t)ch * BA_QUADS + 2 * h) * KFP + m;
+  const f32x4 x0 = q[0], x1 = q[KFP];
+  bf16x8 hi, lo;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const float x = j < 4 ? x0[j] : x1[j - 4];
+    const __bf16 t = (__bf16)x;
+    hi[j] = t;
+    lo[j] = (__bf16)(x - (float)t);
+  }
+  bf16x8* o = Ds + (size_t)ch * (4 * KFP);
+  o[(0 * 2 + h) * KFP + m] = hi;
+  o[(1 * 2 + h) * KFP + m] = lo;
+}
+int launch_split_blend_basis(const float* Dq, void* Ds, hipStream_t s) {
+  hipLaunchKernelGGL(k_split_blend_basis, dim3((BX_CHUNKS * 2 * KFP + 255) / 256), dim3(256), 0, s, Dq, reinterpret_cast<bf16x8*>(Ds));
+  return 0;
+}
+size_t blend_basis_split_bytes() { return (size_t)BX_CHUNKS * 4 * KFP * sizeof(bf16x8); }
+
+__global__ __launch_bounds__(256, 2) void k_blend_adjoint_bf16x3(const bf16x8* __restrict__ Ds, const float* __restrict__ DVPq,
+                                                                 float* __restrict__ dFTp, size_t split_stride, int BP) {
+  static_assert(4 * KFP * sizeof(bf16x8) == BA_SA * sizeof(float), "a split chunk of D is as large as the fp32 chunk it replaces");
+  __shared__ __attribute__((aligned(16))) float lds[3 * BA_SLOT];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int nt = xcd_remap(blockIdx.x, gridDim.x);
+  const int n0 = nt * 128;
+  const int split = blockIdx.y, nsplit = gridDim.y;
+  const int c_begin = (int)((long)BX_CHUNKS * split / nsplit), c_end = (int)((long)BX_CHUNKS * (split + 1) / nsplit);
+  auto issue = [&](int ch, int slot) {        // the fp32 kernel's ring: A = 14 linear 1 KB pieces, B = 8 pieces (quad p / 2, poses (p % 2) * 64 + lane)
+    const float* a = reinterpret_cast<const float*>(Ds) + (size_t)ch * BA_SA;
+    const float* b = DVPq + ((size_t)ch * BA_QUADS * BP + n0) * 4;
+    asm volatile("" : "+s"(a));
+    asm volatile("" : "+s"(b));
+    float* dA = lds + slot * BA_SLOT;
+    float* dB = dA + BA_SA;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int p = wave + 4 * i;
+      if (p < 14) __builtin_amdgcn_global_load_lds(JRR_GLB(a + p * 256 + lane * 4), JRR_LDS(dA + p * 256), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int p = wave + 4 * i;
+      __builtin_amdgcn_global_load_lds(JRR_GLB(b + ((size_t)(p >> 1) * BP + (p & 1) * 64 + lane) * 4), JRR_LDS(dB + p * 256), 16, 0, 2);
+    }
+  };
+  f32x16 acc[7];
+#pragma unroll
+  for (int i = 0; i < 7; ++i) acc[i] = zero16();
+  if (c_begin < c_end) issue(c_begin, 0);
+  if (c_begin + 1 < c_end) issue(c_begin + 1, 1);
+  int slot = 0;
+  for (int ch = c_begin; ch < c_end; ++ch) {
+    if (ch + 1 < c_end) {
+      if (wave < 2) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __builtin_amdgcn_s_barrier();
+    if (ch + 2 < c_end) issue(ch + 2, slot >= 1 ? slot - 1 : 2);
+    const bf16x8* la = reinterpret_cast<const bf16x8*>(lds + slot * BA_SLOT) + half * KFP + l31;      // + part * 2 KFP + 32 i
+    const f32x4* lb = reinterpret_cast<const f32x4*>(lds + slot * BA_SLOT + BA_SA) + (2 * half) * 128 + wave * 32 + l31;
+    slot = (slot == 2) ? 0 : slot + 1;
+    const f32x4 b0 = lb[0], b1 = lb[128];
+    bf16x8 ah[7], al[7], bh, bl;
+#pragma unroll
+    for (int i = 0; i < 7; ++i) ah[i] = la[32 * i];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float x = j < 4 ? b0[j] : b1[j - 4];
+      const __bf16 t = (__bf16)x;
+      bh[j] = t;
+      bl[j] = (__bf16)(x - (float)t);
+    }
+#pragma unroll
+    for (int i = 0; i < 7; ++i) al[i] = la[2 * KFP + 32 * i];
+    // three rounds over the seven tiles: consecutive matrix instructions never share an accumulator
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, acc[i], 0, 0, 0);
+#pragma unroll
+    for (int i = 0; i < 7; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, acc[i], 0, 0, 0);
+  }
+  float* out = dFTp + (size_t)split * split_stride;
+  const unsigned lane_off = (unsigned)(4 * half) * (unsigned)BP + (unsigned)(n0 + wave * 32 + l31);
+#pragma unroll
+  for (int i = 0; i < 7; ++i)
+#pragma unroll
+    for (int q = 0; q < 16; ++q) urow(out, (size_t)(32 * i + acc_row_u(q)), BP)[lane_off] = acc[i][q];
+}
+int launch_blend_adjoint_bf16x3(const void* Ds, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s) {
+  hipLaunchKernelGGL(k_blend_adjoint_bf16x3, dim3(BP / 128, nsplit), dim3(256), 0, s, reinterpret_cast<const bf16x8*>(Ds), DVPq, dFTp, split_stride, BP);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Pose-discriminator layers on QUAD-layout operands: Out[m][n] = epilogue(sum_k A[k][m] B[k][n]) with every matrix stored
 // as [row/4][column][4] (weights re-laid once per upload; activations written that way by the producing epilogue, whose
 // lanes own four consecutive rows 8g + 4 half + {0..3} of their column = one quad = 16 bytes).  Same tricks as

@@ -142,6 +142,10 @@ int launch_gemm_224(const GemmArgs& g, int epi, int nsplit, hipStream_t s);
 // blend-basis adjoint dF^T[split][224][BP] = sum_{c, v in split} D_c[v][.] dvp_c[v][.], both operands in vertex quads
 int launch_blend_adjoint(const float* Dq, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s,
                          const int* tl = nullptr, int ntl = 0);
+// side mode JRR_FLAG_BLEND_BF16X3: the same product from split-bf16 operands (three bf16 matrix instructions, fp32 accumulation)
+int launch_split_blend_basis(const float* Dq, void* Ds, hipStream_t s);
+size_t blend_basis_split_bytes();
+int launch_blend_adjoint_bf16x3(const void* Ds, const float* DVPq, float* dFTp, size_t split_stride, int BP, int nsplit, hipStream_t s);
 // skip_flag (device, nullable): the launch returns at once when *skip_flag != 0 (the support-restricted kernels did the work)
 int launch_gemm_q32(const float* A, int ldA, size_t planeA, const float* Bm, int ldB, size_t planeB, float* Out, int ldo,
                     size_t ks_stride, size_t plane_stride, int N, int K, int nplanes, int ksplit, hipStream_t s,

@@ -23,6 +23,7 @@ FLAG_SILHOUETTE = 16
 FLAG_NO_MODEL = 32
 FLAG_SIL_256 = 64      # with FLAG_SILHOUETTE: 256 x 256 silhouettes (the reference constructor's default) instead of 224 x 224
 FLAG_SUPPORT_TILES = 128      # joint-loss iterations on the tiles of the regressor's support only (see include/jrr.h)
+FLAG_BLEND_BF16X3 = 256       # SIDE MODE, not the reference's arithmetic: split-bf16 blend adjoint (see include/jrr.h); never the default
 SIL = 224
 
 NUM_VERTS, NUM_JOINTS, NUM_H36M, NUM_BETAS = 6890, 24, 17, 10
