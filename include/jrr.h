@@ -71,7 +71,7 @@ enum {
                                outside) the iterations run all 216 tiles.  v_posed / vertices of the other tiles are NOT
                                produced by those iterations (jrr_find_joints_forward and jrr_smpl_vertices* always are dense). */
   JRR_FLAG_BLEND_BF16X3 = 256  /* SIDE MODE, not the reference's arithmetic (the reference computes in fp32 and so does every engine
-                               without this flag): the all-tiles blend-basis adjoint of jrr_refine_run* runs as a split-bf16 product
+                               without this flag): the all-tiles blend-basis adjoint (jrr_refine_run*, jrr_find_joints_backward, jrr_smpl_vertices_backward) runs as a split-bf16 product
                                -- operands taken as bf16 hi + lo, three bf16 matrix instructions per exact-fp32 eight, fp32
                                accumulation; relative error of the product ~ 3e-5.  Reserves 18.6 MB for the split basis.  Every
                                other kernel, and the support-tile iterations, are unchanged.  bench.py reports it as a separately
