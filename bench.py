@@ -718,6 +718,9 @@ def main():
         unhinted = side_run(eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0), tiles=True)
         support_tiles['without_vertex_order_hint'] = {k: unhinted[k] for k in ('value', 'ms_per_step', 'vertex_tiles', 'kernels_ms')}
         nt = support_tiles['vertex_tiles']['run']
+        km = support_tiles.get('kernels_ms', {})
+        support_tiles['small_launches_ms'] = round(sum(km.get(k_, 0.0) for k_ in ('k_prep_fwd', 'k_joints_loss', 'k_prep_bwd', 'k_shape_disc')), 4)
+        support_tiles['skinning_launches_ms'] = round(sum(km.get(k_, 0.0) for k_ in ('k_lbs_fwd', 'k_lbs_bwd', 'k_gemm_tn_blend_adjoint')), 4)
         # FLOP it runs: the listed tiles at the 8-slot rate + a second pass for each of them that is wide (all, with the hint)
         fl = (flop_lbs_fwd(dmodel.info) + flop_lbs_bwd(dmodel.info) + FLOP_BLEND_ADJ_PER_POSE) * nt / 216 + (FLOP_DISC_PER_POSE if use_disc else 0)
         support_tiles.update({
