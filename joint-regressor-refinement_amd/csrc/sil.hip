@@ -160,9 +160,7 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
     // VPM (round 5): the forward kernel left this pose's vertices contiguous, [3][VP] -- three coalesced 16-byte loads per thread
     // and quad instead of three pieces out of three different cache lines (the set-up phase was 25.6 of a pose's 80 us)
     const f32x4* PM4 = VPM ? reinterpret_cast<const f32x4*>(VPM) + (size_t)b * 3 * (VP / 4) : nullptr;
-    for (int q = tix; q < VP / 4; q += SIL_RT) {
-      const f32x4 t0 = PM4 ? PM4[q] : VQ4[(size_t)q * BP + b], t1 = PM4 ? PM4[(VP / 4) + q] : VQ4[((size_t)(VP / 4) + q) * BP + b],
-                  t2 = PM4 ? PM4[2 * (VP / 4) + q] : VQ4[((size_t)2 * (VP / 4) + q) * BP + b];
+    auto project4 = [&](int q, const f32x4& t0, const f32x4& t1, const f32x4& t2) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         const int v = 4 * q + u;
@@ -173,7 +171,17 @@ __device__ __forceinline__ void sil_raster_pose(const int b, const int wave_s, c
           bxn = fminf(bxn, xn); bxx = fmaxf(bxx, xn); byn = fminf(byn, yn); byx = fmaxf(byx, yn);
         }
       }
-    }
+    };
+    static_assert(VP / 4 <= 2 * SIL_RT, "two quads per thread cover the pose");
+    // both quads of a thread are requested before the first is projected: one round trip to the vertices, not two
+    const int q0 = tix, q1 = tix + SIL_RT;
+    const bool h1 = q1 < VP / 4;
+    const int q1c = h1 ? q1 : q0;
+    auto ldq = [&](int plane, int q) { return PM4 ? PM4[plane * (VP / 4) + q] : VQ4[((size_t)plane * (VP / 4) + q) * BP + b]; };
+    const f32x4 t0 = ldq(0, q0), t1 = ldq(1, q0), t2 = ldq(2, q0);
+    const f32x4 u0 = ldq(0, q1c), u1 = ldq(1, q1c), u2 = ldq(2, q1c);
+    project4(q0, t0, t1, t2);
+    if (h1) project4(q1, u0, u1, u2);
   } else {
     for (int v = tix; v < V; v += SIL_RT) {
       const NdcV p = vb[v];
