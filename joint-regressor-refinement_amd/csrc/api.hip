@@ -504,7 +504,7 @@ static void plan_geometry(int BP, int& nvc, int& nvcb, int& nvcb16, int& nsplit,
   if (nsplit > 32) nsplit = 32;
   if (nsplit < 1) nsplit = 1;
   // (experiment knobs, tools/exp: the split-K slab count of the blend adjoint and the vertex chunks of k_lbs_bwd16)
-  { const char* e = getenv("JRR_NSPLIT"); if (e && atoi(e) >= 1 && atoi(e) <= 64) nsplit = atoi(e); }
+  { const char* e = getenv("JRR_NSPLIT"); if (e && atoi(e) >= 1 && atoi(e) <= 256) nsplit = atoi(e); }
   { const char* e = getenv("JRR_NVCB16"); if (e && atoi(e) >= 1 && atoi(e) <= 36) nvcb16 = atoi(e); }
   nsplitJ = 3;                                      // pose splits per plane of the J-gradient product: 162 x 3 workgroups
   if (BP / 32 < nsplitJ) nsplitJ = BP / 32;         // = 0.95 of one round of the chip's 512 workgroup slots

@@ -40,3 +40,8 @@ for k, v in sorted(T.items(), key=lambda kv: -sum(kv[1])):
     print(f'{k:32s} calls/batch {len(v) / nb:4.1f}   last batch: {sum(last) * 1e3:8.3f} ms')
     tot += sum(last)
 print(f'sum of the wrapped calls, last batch: {tot * 1e3:.3f} ms of {recs[-1]["seconds_batch"] * 1e3:.3f} ms')
+# per batch: the sections that moved (ms), to tell a slow batch's cause
+for k, v in sorted(T.items(), key=lambda kv: -sum(kv[1])):
+    per = len(v) // nb
+    if per and sum(v) > 1e-3:
+        print(f'{k:32s}', ' '.join('%7.2f' % (sum(v[i * per:(i + 1) * per]) * 1e3) for i in range(nb)))
