@@ -28,6 +28,22 @@ for n in ('refine_run', 'refine_run_j_steps', 'pose_disc_backward_params', 'shap
           'find_joints_forward', 'set_j_regressor', 'j_support_info', 'set_pose_disc', 'refine_aux_losses', 'camera_prefit', 'set_loss_history'):
     wrap(eng_mod.RefineEngine, n)
 wrap(utils, 'evaluate_sums'); wrap(utils, 'move_pelvis'); wrap(eng_mod, 'adam_step')
+# a fixed calibration product timed right after every refine_run: does a slow batch's device state slow IT too?
+_A = torch.randn(2048, 2048, device='cuda:0')
+CAL = []
+_rr = eng_mod.RefineEngine.refine_run
+ENQ = []
+def _rr_cal(self, *a, **k):
+    torch.cuda.synchronize(); te = time.perf_counter()
+    r = _rr(self, *a, **k)
+    ENQ.append((time.perf_counter() - te) * 1e3)          # host time of the call itself (it returns after its last launch)
+    torch.cuda.synchronize(); t = time.perf_counter()
+    for _ in range(5):
+        _A @ _A
+    torch.cuda.synchronize(); CAL.append((time.perf_counter() - t) * 1e3)
+    return r
+if os.environ.get('JRR_SECTIONS_CAL') == '1':
+    eng_mod.RefineEngine.refine_run = _rr_cal
 recs = []
 t0 = time.perf_counter()
 opt.optimize_pose_refiner(log=recs.append)
@@ -40,6 +56,9 @@ for k, v in sorted(T.items(), key=lambda kv: -sum(kv[1])):
     print(f'{k:32s} calls/batch {len(v) / nb:4.1f}   last batch: {sum(last) * 1e3:8.3f} ms')
     tot += sum(last)
 print(f'sum of the wrapped calls, last batch: {tot * 1e3:.3f} ms of {recs[-1]["seconds_batch"] * 1e3:.3f} ms')
+if CAL:
+    print('host time inside refine_run (ms):', ' '.join('%.2f' % c for c in ENQ))
+    print('calibration product after each refine_run (ms):', ' '.join('%.2f' % c for c in CAL))
 # per batch: the sections that moved (ms), to tell a slow batch's cause
 for k, v in sorted(T.items(), key=lambda kv: -sum(kv[1])):
     per = len(v) // nb
