@@ -468,6 +468,34 @@ def synthetic_batch(model: Dict[str, np.ndarray], J_h36m: np.ndarray, B: int, se
 
     Ground truth is produced with a float64 numpy LBS of the same synthetic model (data
     generation, not the product path)."""
+    with _few_blas_threads():
+        return _synthetic_batch(model, J_h36m, B, seed)
+
+
+class _few_blas_threads:
+    """numpy's OpenBLAS starts one worker per logical CPU (256 on the GPU box) and the workers keep SPINNING for tens of
+    milliseconds after a product.  A 100-iteration jrr_refine_run that starts right after a batch was generated then shares the
+    host with 256 busy threads exactly when it has filled the device's queue and waits for room in it: the device was seen idle
+    for ~60 ms in the middle of 40 % of such calls at 256 poses (25 ms calls reading 90 ms; DESIGN.md section 0,
+    tools/exp/small_batch_triggers.py).  Data generation therefore runs its BLAS calls on at most 8 threads."""
+
+    def __enter__(self):
+        self._ctx = None
+        try:
+            import threadpoolctl
+            self._ctx = threadpoolctl.threadpool_limits(limits=8, user_api='blas')
+            self._ctx.__enter__()
+        except Exception:
+            self._ctx = None
+        return self
+
+    def __exit__(self, *exc):
+        if self._ctx is not None:
+            self._ctx.__exit__(*exc)
+        return False
+
+
+def _synthetic_batch(model, J_h36m, B, seed):
     rng = np.random.RandomState(seed)
     aa = rng.normal(0.0, 0.3, size=(B, NUM_JOINTS, 3))
     R = _rodrigues_np(aa.reshape(-1, 3)).reshape(B, NUM_JOINTS, 3, 3)
