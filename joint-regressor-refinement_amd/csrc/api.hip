@@ -501,7 +501,11 @@ static void plan_geometry(int BP, int& nvc, int& nvcb, int& nvcb16, int& nsplit,
   // one pose group (lbs.hip), which is worth more than the last per cent of tile balance
   if (512 % (BP / 64) == 0 && 512 / (BP / 64) <= 36 && ((512 / (BP / 64)) & 1) == 0 && 32 % (512 / (BP / 64) / 2) == 0) nvcb16 = 512 / (BP / 64);
   nsplit = (512 + nbg - 1) / nbg;
-  if (nsplit > 32) nsplit = 32;
+  // at most 32 slabs -- 64 for batches of up to 512 poses, whose 32 x (BP / 128) workgroups leave most of the chip idle (256 poses, the
+  // reference's default batch: blend adjoint 81 -> 46 us, the iteration 0.383 -> 0.357 ms; at 1024 poses 64 slabs gain the product
+  // nothing and cost the slab sum 10 us: DESIGN.md section 8)
+  const int cap = nbg <= 4 ? 64 : 32;
+  if (nsplit > cap) nsplit = cap;
   if (nsplit < 1) nsplit = 1;
   // (experiment knobs, tools/exp: the split-K slab count of the blend adjoint and the vertex chunks of k_lbs_bwd16)
   { const char* e = getenv("JRR_NSPLIT"); if (e && atoi(e) >= 1 && atoi(e) <= 256) nsplit = atoi(e); }

@@ -149,8 +149,10 @@ def test_three_iterations_with_pose_discriminator_vs_oracle(variant):
     eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, vv, step, 1e-2, 3)
     d = (xd.cpu() - torch.cat([o, p], 1)).abs()
     # Adam's first steps are lr * g / (|g| + eps): last-bit differences of the summation order are amplified wherever a gradient
-    # entry is ~ 0; the bound on the mean is what pins the trajectory
-    assert d.max().item() < 6e-4 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+    # entry is ~ 0; the bound on the mean is what pins the trajectory.  The maximum is ONE such entry and moves
+    # with every change of a summation order (64 instead of 32 split-K slabs at this batch size, round 5: 7.7e-4 on one of the 26
+    # variants, mean 4.6e-8): it is held to a tenth of a first Adam step (lr = 1e-2)
+    assert d.max().item() < 1e-3 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
     assert (bd.cpu() - b_).abs().max().item() < 3e-4
 
 
