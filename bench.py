@@ -797,7 +797,7 @@ def main():
     # ---- the ENTRY POINT, per outer batch (/root/reference/scripts/optimize.py:144-337 is one call of optimize_pose_refiner() per run:
     #      H->D copy, [camera pre-fit], 100 inner iterations, D updates, J step, two evaluations, a log record).  The real driver of the
     #      package on synthetic batches; the first batch (engine set-up, code-object loads) is discarded ----
-    def driver_run(batch, extra, n_batches=5, inner=100):
+    def driver_run(batch, extra, n_batches=7, inner=100):
         argsmod = importlib.import_module(PKG + '.args')
         argsmod._LazyArgs._ns = argsmod.get_args(['--batch_size', str(batch), '--synthetic_batches', str(n_batches), '--inner_iters', str(inner),
                                                    '--synthetic', '--device', str(dev), '--smpl_dir', '/nonexistent', '--j_regressor_init',
@@ -831,7 +831,7 @@ def main():
                           'kernel_seconds_expected': round(kern, 5),
                           'share_not_inner_loop_or_outer_step': round(1.0 - kern / r['seconds_per_outer_batch'], 4)})
             driver_outer[name] = r
-        driver_outer['note'] = ('optimize_pose_refiner() of this package (the reference entry point restated) on 5 synthetic outer batches, first one '
+        driver_outer['note'] = ('optimize_pose_refiner() of this package (the reference entry point restated) on 7 synthetic outer batches, first one '
                                 'discarded, median of the rest; seconds_per_outer_batch = wall time from the batch arriving to its record (H->D copies, fresh Adam '
                                 'state, 100 inner iterations in ONE C call, D update, J step, evaluations, the one read-back); '
                                 'share_not_inner_loop_or_outer_step = 1 - (100 x ms_per_step + pose-D update + J step) / that')
