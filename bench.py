@@ -87,7 +87,13 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=100)
     ap.add_argument('--warmup', type=int, default=10)
-    ap.add_argument('--batch', type=int, default=4096, help='poses per GPU (BASELINE metric: 4096)')
+    ap.add_argument('--batch', type=int, default=4096, help='poses per GPU under --scaling weak (BASELINE metric: 4096); the GLOBAL batch under --scaling strong')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='weak (default): every GPU refines --batch poses, the global batch grows with N.  strong: the GLOBAL batch is fixed '
+                         'at --batch and rank r refines its contiguous shard of --batch / N poses (BASELINE.json\'s metric string "batch 4096, '
+                         'at 1/2/4/8" read as one global batch); `value` then counts iterations of the global batch')
+    ap.add_argument('--allow_experiment_lib', action='store_true',
+                    help='accept a library named by JRR_LIB (tools/exp variants) instead of the in-tree libjrr_hip.so; the line then says so')
     ap.add_argument('--config', type=int, default=3, choices=[2, 3, 5],
                     help='BASELINE config: 2 = joint loss only, 3 = + pose discriminator (headline), 5 = + soft silhouette')
     ap.add_argument('--j_step_every', type=int, default=100,
@@ -214,6 +220,24 @@ def physical_cores():
         return None
 
 
+def provenance(allow_experiment_lib):
+    """which binary and which knobs this line measured: sha256 (first 16 hex digits) and path of the library the process loaded, every
+    JRR_* variable of the environment (api.hip reads its experiment knobs from there).  JRR_LIB -- a variant library of tools/exp --
+    is refused unless --allow_experiment_lib says the line is an experiment."""
+    import hashlib
+    lib_mod = importlib.import_module(PKG + '._lib')
+    env = {k: v for k, v in sorted(os.environ.items()) if k.startswith('JRR_')}
+    if 'JRR_LIB' in env and not allow_experiment_lib:
+        raise SystemExit('bench.py: JRR_LIB is set (an experiment library of tools/exp): pass --allow_experiment_lib to measure it, '
+                         'or unset it to measure the in-tree libjrr_hip.so')
+    path = os.path.abspath(lib_mod.LIB_PATH)
+    with open(path, 'rb') as f:
+        sha = hashlib.sha256(f.read()).hexdigest()[:16]
+    return {'lib_path': os.path.relpath(path, ROOT) if path.startswith(ROOT) else path, 'lib_sha16': sha, 'lib_bytes': os.path.getsize(path),
+            'in_tree_lib': path == os.path.join(ROOT, PKG, 'libjrr_hip.so'), 'jrr_env': env,
+            'note': 'sha256[:16] of the shared library this process loaded; jrr_env = every JRR_* variable set (none = the shipped kernel selection)'}
+
+
 def self_launch(a):
     """--gpus N > 1 outside torchrun: start the N ranks as a CHILD `torch.distributed.run` before anything here has touched
     the GPU (a process that has initialised the GPU must never exec / be replaced), relay rank 0's JSON line, exit with the
@@ -240,6 +264,7 @@ def self_launch(a):
 
 def main():
     a = parse()
+    prov = provenance(a.allow_experiment_lib)      # before anything touches the GPU: a refused JRR_LIB costs nothing
     if a.gpus > 1 and 'WORLD_SIZE' not in os.environ:
         self_launch(a)                 # does not return; nothing above has touched the GPU
     rank = int(os.environ.get('RANK', '0'))
@@ -276,7 +301,12 @@ def main():
 
     sm = importlib.import_module(PKG + '.smpl_model')
     eng_mod = importlib.import_module(PKG + '.engine')
-    B = a.batch
+    strong = a.scaling == 'strong'
+    if strong and a.batch % world:
+        raise SystemExit(f'bench.py --scaling strong: the global batch {a.batch} does not divide into {world} equal shards')
+    B = a.batch // world if strong else a.batch      # poses on THIS GPU
+    UB = a.batch                                      # the batch an "iteration" of `value` refers to: global (strong) / per GPU (weak)
+    agg = 1 if strong else world                      # `value` = agg x this job's iterations per second
     use_disc = a.config in (3, 5)
     use_sil = a.config == 5
     model_np = sm.synthetic_smpl(1234)
@@ -650,7 +680,7 @@ def main():
             e2.refine_run(fx, fb, fgt, fm, fv, fstep, 1e-2, n)
             return 0
         fel = statistics.median([timed_region(a.steps, 0, go)[0] for _ in range(3)])
-        out_ = {'value': round(a.steps / fel * world, 3), 'unit': f'it/s (x{Bs} poses)', 'ms_per_step': round(fel / a.steps * 1e3, 4),
+        out_ = {'value': round(a.steps / fel * agg, 3), 'unit': f'it/s (x{Bs * (world if strong else 1)} poses)', 'ms_per_step': round(fel / a.steps * 1e3, 4),
                 'joint_sparse': int(e2.info.get('joint_sparse') or 0)}
         if tiles:
             on, nt = e2.support_tiles()
@@ -877,14 +907,16 @@ def main():
     step_flop_dense = FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
     c1_ms = c1_el / a.steps * 1e3
     out = {
-        'metric': 'pose-refinement iters/sec, batch 4096, at 1/2/4/8 MI355X',   # BASELINE.json's metric string; batch = poses per GPU (weak scaling)
-        'value': round(it_s * world, 3), 'unit': f'it/s (x{B} poses)', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+        # BASELINE.json's metric string.  --scaling weak (default): batch = poses per GPU, `value` = N x iterations/s of 4096-pose batches;
+        # --scaling strong: batch = the global batch, sharded N ways, `value` = iterations/s of that one batch
+        'metric': 'pose-refinement iters/sec, batch 4096, at 1/2/4/8 MI355X',
+        'value': round(it_s * agg, 3), 'unit': f'it/s (x{UB} poses)', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
         'dtype': 'f32', 'data': 'synthetic',
         'config': {'workload': f'BASELINE configs[{a.config - 1}]: batch={B}/GPU inner loop, 3D-joint loss'
                                + (' + pose-discriminator adversarial term' if use_disc else '')
                                + (' + soft-silhouette loss (224x224 rasteriser)' if use_sil else ''),
-                   'global_batch': B * world, 'poses_per_sec': round(it_s * world * B, 1),
+                   'global_batch': B * world, 'poses_per_gpu': B, 'poses_per_sec': round(it_s * world * B, 1),
                    'j_step_every': cadence, 'j_steps_in_timed_regions': nj_region, 'parallelism': f'dp{world}', 'joint_loss_last': loss_joint,
                    'timed_regions': len(regions), 'timed_steps': len(regions) * a.steps,
                    'value_is': 'all timed regions: timed steps / timed seconds (the J step follows every j_step_every-th iteration, counted '
@@ -898,6 +930,7 @@ def main():
                                    'regressor\'s support -- what optimize.py runs by default -- is the separate block `support_tiles`)',
                    'geometry': dict(eng.info, **dmodel.info)},
         'collective': collective,
+        'provenance': prov,
         'per_rank_ms_per_step': {'min': round(min(per_rank_ms), 4), 'median': round(statistics.median(per_rank_ms), 4), 'max': round(max(per_rank_ms), 4),
                                  'each': [round(x, 4) for x in per_rank_ms],
                                  'note': 'every rank\'s own time per step over the headline regions (before the closing barrier); `ms_per_step` is the max over ranks incl. barriers'},
@@ -951,7 +984,7 @@ def main():
         'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
                    'allreduce_bytes': xch.nbytes, 'allreduce_payload': 'regressor support [17][128]' if xch.compact else 'dense (17,6890)',
                    'in_timed_regions': nj_region, 'host_calls': 2 + (1 if dist is not None else 0)},
-        'cadence1': {'value': round(a.steps / c1_el * world, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(c1_ms, 4),
+        'cadence1': {'value': round(a.steps / c1_el * agg, 3), 'unit': f'it/s (x{UB} poses)', 'ms_per_step': round(c1_ms, 4),
                      'j_step_every': 1, 'timed_regions': len(c1_regions), 'value_is': 'median region',
                      'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1_regions],
                      'spread_frac': round((max(c1_regions) - min(c1_regions)) / c1_el, 4),
@@ -976,8 +1009,8 @@ def main():
     # cadence, and everything after EVERY inner iteration (cadence 1).
     out['outer_step'] = {'j_step_ms': round(j_ms, 3), 'pose_d_update_ms': None if d_ms is None else round(d_ms, 3),
                          'inner_only_ms_per_step': round(inner_ms, 4),
-                         'it_s_incl_pose_d_update_at_cadence': round(world / ((ms_per_step + (d_ms or 0.0) / cadence) * 1e-3), 3),
-                         'it_s_all_outer_work_every_iteration': round(world / ((c1_ms + (d_ms or 0.0)) * 1e-3), 3),
+                         'it_s_incl_pose_d_update_at_cadence': round(agg / ((ms_per_step + (d_ms or 0.0) / cadence) * 1e-3), 3),
+                         'it_s_all_outer_work_every_iteration': round(agg / ((c1_ms + (d_ms or 0.0)) * 1e-3), 3),
                          'j_allreduce_bytes': xch.nbytes, 'pose_d_allreduce_bytes': 1840153 * 4 if use_disc else 0}
     if collective_cost is not None:
         out['collective_cost'] = collective_cost

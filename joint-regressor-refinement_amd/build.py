@@ -1,6 +1,6 @@
 """Build the gfx950 shared library (csrc/*.hip -> libjrr_hip.so) with hipcc, in-tree.
 
-    python joint-regressor-refinement_amd/build.py [--force] [--report]
+    python joint-regressor-refinement_amd/build.py [--force] [--report] [--clean]
 
 hipcc cross-compiles for gfx950 without a GPU.  The .so is git-ignored but travels with the
 repo snapshot to the GPU box.
@@ -17,8 +17,8 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libjrr_hip.so')
-SOURCES = ['api.hip', 'prep.hip', 'lbs.hip', 'gemm.hip', 'disc.hip', 'eval.hip', 'fold.hip', 'sil.hip']
-HEADERS = ['jrr_common.h', 'kernels.h', os.path.join('..', '..', 'include', 'jrr.h')]
+SOURCES = ['api.hip', 'prep.hip', 'lbs.hip', 'gemm.hip', 'disc.hip', 'eval.hip', 'fold.hip', 'sil.hip', 'sup.hip']
+HEADERS = ['jrr_common.h', 'kernels.h', 'dconv.h', 'supk.h', os.path.join('..', '..', 'include', 'jrr.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 
 
@@ -112,6 +112,21 @@ def _summarise(out: str) -> str:
     return txt
 
 
+def clean(verbose: bool = True) -> list:
+    """Remove every file of the object directory that is not the object of a source in SOURCES (experiment variants built by hand or by
+    older tools): they would otherwise travel to the GPU box with every snapshot.  Returns the removed names."""
+    keep = {s.replace('.hip', '.o') for s in SOURCES}
+    gone = []
+    if os.path.isdir(OBJ):
+        for name in sorted(os.listdir(OBJ)):
+            if name not in keep:
+                os.remove(os.path.join(OBJ, name))
+                gone.append(name)
+    if verbose and gone:
+        print(f'[jrr build] removed {len(gone)} stale objects from {OBJ}')
+    return gone
+
+
 def build(force: bool = False, report: bool = False, verbose: bool = True) -> str:
     os.makedirs(OBJ, exist_ok=True)
     hdrs = [os.path.join(CSRC, h) for h in HEADERS] + [os.path.abspath(__file__)]
@@ -157,5 +172,8 @@ if __name__ == '__main__':
     ap = argparse.ArgumentParser()
     ap.add_argument('--force', action='store_true')
     ap.add_argument('--report', action='store_true', help='print per-kernel VGPR/LDS/occupancy')
+    ap.add_argument('--clean', action='store_true', help='remove objects that do not belong to SOURCES (stale experiment variants)')
     a = ap.parse_args()
+    if a.clean:
+        clean()
     build(force=a.force, report=a.report)

@@ -466,6 +466,9 @@ struct jrr_engine {
   // JRR_FLAG_SUPPORT_TILES: the 32-vertex tiles that hold an entry of the regressor's support (ascending), taken when
   // jrr_j_support_info reports that the support fits; J steps only shrink the support, so the list stays a superset
   int* act_list; int nact; bool act_valid;
+  // ... and, when the support has at most SUP_NSV vertices, the joint-loss iteration runs per VERTEX in one workgroup per 32-pose group
+  // (supk.h): the gathered basis rows and skinning lists of the support, built with the tile list
+  SupTables sup; int sup_nsv; bool sup_valid;
   std::vector<hipEvent_t>* ev[JRR_PROF_CLASSES];
   const float* gt_j2d; float* cam; float* cam_m; float* cam_v;   // 2-D reprojection term (nullable)
   float *gcam, *sq2d;
@@ -625,6 +628,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
     t->jsup.tmask = (int*)c.take(256);
     t->jsup.tknown = (int*)c.take(256);
     t->act_list = (int*)c.take(256);
+    if (flags & JRR_FLAG_SUPPORT_TILES) { float* sb = c.take(sup_tables_floats()); if (sb) sup_tables_carve(t->sup, sb); }
   }
   if (e) {
     e->BP = BP; e->nvc = nvc; e->nvcb = (e->has_model && e->m.kjs && e->m.bwd16) ? nvcb16 : nvcb; e->nsplit = nsplit; e->nsplitJ = nsplitJ;
@@ -789,7 +793,7 @@ static int set_j_regressor_impl(jrr_engine_t* e, const float* J, const float* ma
   hipStream_t s = (hipStream_t)stream;
   e->jsup_fits_known = false;      // a regressor from outside: its support is not known to fit until jrr_j_support_info says so
   if (e->verts_partial) e->fwd_cached = false;      // the stored vertices cover the OLD regressor's support tiles only
-  e->act_valid = false;
+  e->act_valid = false; e->sup_valid = false;
   if (e->have_jsup && !step_inc) JRR_HIP(hipMemsetAsync(e->jsup.flag + JSUP_KNOWN, 0, sizeof(int32_t), s));   // (a J step keeps the baseline: step_inc != NULL)
   JRR_HIP(hipMemcpyAsync(e->Jraw, J, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
   if (mask) JRR_HIP(hipMemcpyAsync(e->Jmask, mask, (size_t)NH * V * 4, hipMemcpyDeviceToDevice, s));
@@ -940,6 +944,10 @@ static bool use_tile_list(const jrr_engine* e) {
   return (e->flags & JRR_FLAG_SUPPORT_TILES) && e->act_valid && e->have_jsup && e->jsup_fits_known && e->sil_mask == nullptr &&
          e->m.kjs && e->m.bwd16 && !(e->folded && e->fold_valid);
 }
+
+// ... per support VERTEX in one workgroup per 32-pose group (supk.h): the same condition, the support's vertex tables built, and no
+// 2-D term (its projection adjoint lives in k_joints_loss)
+static bool use_sup_vertices(const jrr_engine* e) { return use_tile_list(e) && e->sup_valid && e->gt_j2d == nullptr; }
 
 static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s, float* dJs = nullptr);
 
@@ -1430,6 +1438,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     }
   }
   bool reuse_next = reuse_first;
+  bool h2t_ready = false;      // k_sup_step of the previous iteration left the per-joint MLP forward of the current poses in H2T
   for (int it = 0; it < n_iters; ++it) {
     const bool folded = e->folded && e->fold_valid;
     const bool listed = use_tile_list(e);
@@ -1444,7 +1453,69 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     // The J step that preceded this call ran the SMPL forward on exactly these poses (jrr_j_regressor_grad keeps
     // v_posed, the skinning transforms and the vertices): the first iteration re-regresses the joints with the NEW
     // regressor from the stored vertices instead of repeating the 0.47 ms forward (jrr_refine_run_after_j_step).
-    const bool reuse = reuse_next && e->fwd_cached && !folded && e->sil_mask == nullptr &&
+    // the support-vertex iteration (supk.h): forward, loss and backward of a 32-pose group in one workgroup; its forward costs less than
+    // re-regressing the stored vertices, so a pending reuse is simply not taken
+    const bool supv = use_sup_vertices(e);
+    // JRR_SUPPORT_FUSED=2 (verification / A-B knob): the same iteration as separate launches (chain forward, k_sup_iter, per-joint MLP
+    // adjoint, chain adjoint) instead of the composed kernel k_sup_step
+    static const bool sup_split = [] { const char* v = getenv("JRR_SUPPORT_FUSED"); return v && v[0] == '2'; }();
+    if (supv && !sup_split) {
+      // ---- ONE launch per iteration and pose group (+ the four discriminator GEMMs before it): prep.hip k_sup_step ----
+      e->fwd_cached = false; reuse_next = false;
+      prof_mark(e, 0, s);
+      // per-joint MLP forward: left behind by the previous iteration's launch, except before the first one of a call
+      if (pd && !h2t_ready) launch_disc_conv_fwd(e->convL, x6d, e->H2T, nullptr, e->B, e->BP, s, 1);
+      prof_mark(e, 0, s);
+      if (pd) {
+        prof_mark(e, 5, s);
+        int rcd = disc_forward(e, x6d, nullptr, s, true, true);
+        if (rcd) return rcd;
+        rcd = disc_backward_input(e, x6d, nullptr, nullptr, dscale, 1.f, e->gx, s, e->dsq, true);
+        prof_mark(e, 5, s);
+        if (rcd) return rcd;
+      }
+      if (sd) {
+        prof_mark(e, 6, s);
+        launch_shape_disc(e->Ps, betas, nullptr, e->gb, sscale, 1.f, e->B, s, nullptr, e->ssq);
+        prof_mark(e, 6, s);
+      }
+      prof_mark(e, 1, s);
+      SupStepLaunch q;
+      q.t = e->sup; q.nsv = e->sup_nsv; q.Jn_vi = e->Jn_vi; q.gt_mm = gt_mm; q.scale = jscale;
+      q.FT = e->FT; q.FTq = e->FTq; q.AT = e->AT; q.R0T = e->R0T; q.joints_out = e->joints; q.sqerr = sqerr ? sqerr : e->sqerr;
+      q.dA = e->dA; q.dF = e->dF;
+      const bool js_next = js && (it + 1) % js->every == 0;
+      if (pd) {
+        q.conv_img = e->convL; q.dH2T = e->dH2T; q.dscale = dscale; q.gx = e->gx; q.dsq = e->dsq;
+        q.H2T_next = (it + 1 < n_iters) ? e->H2T : nullptr;
+      }
+      q.step = step; q.arrive = e->step_scratch;
+      PrepBwdLaunch L;
+      L.x6d_in = x6d; L.betas_in = betas; L.gx_extra = pd ? e->gx : nullptr; L.gb_extra = sd ? e->gb : nullptr;
+      L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step; L.lr = lr; L.B = e->B; L.BP = e->BP;
+      int rcq = launch_sup_step(e->m, q, L, s);
+      if (rcq) return rcq;
+      h2t_ready = pd && q.H2T_next != nullptr;
+      prof_mark(e, 1, s);
+      if (e->hist) {
+        if (e->hist_iter % e->hist_every == 0 && e->hist_n < e->hist_cap) {
+          hipLaunchKernelGGL(k_loss_record, dim3(1), dim3(1024), 0, s, sqerr ? sqerr : e->sqerr, nullptr, nullptr, pd ? e->dsq : nullptr,
+                             sd ? e->ssq : nullptr, e->B, e->BP, (float)e->bnorm, e->hist + (size_t)e->hist_n * 5, (float)(e->sil * e->sil));
+          ++e->hist_n;
+        }
+        ++e->hist_iter;
+      }
+      if (js_next) {
+        int rcj = j_step_local(e, x6d, betas, gt_mm, e->dJraw, js->sqerr, s, nullptr, nullptr, true);
+        if (rcj) return rcj;
+        rcj = j_step_apply(e, js->J, e->dJraw, js->m, js->v, js->step, js->lr, js->mask, s);
+        if (rcj) return rcj;
+        reuse_next = js->reuse;
+        if (!js->reuse) e->fwd_cached = false;
+      }
+      continue;
+    }
+    const bool reuse = !supv && reuse_next && e->fwd_cached && !folded && e->sil_mask == nullptr &&
                        !(e->verts_partial && !(e->have_jsup && e->jsup_fits_known));
     reuse_next = false;
     e->fwd_cached = false;
@@ -1467,6 +1538,10 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       int rcf = launch_gemm_128x64(g, EPI_STORE, 1, s);
       if (rcf) return rcf;
       launch_fold_fwd(e->MT, e->AT, e->G0, e->Jsum, e->BP, s);
+    } else if (supv) {
+      int rcs = launch_sup_iter(e->sup, e->sup_nsv, e->Jn_vi, e->FTq, e->AT, gt_mm, jscale, e->joints, sqerr ? sqerr : e->sqerr, e->dA, e->dF,
+                                e->B, e->BP, s);
+      if (rcs) return rcs;
     } else {
       const bool silf = e->sil_mask != nullptr;      // the silhouette term needs the vertices
       // (silhouette iterations: the vertices go to the pose-major buffer the rasteriser reads; VTb then only receives the
@@ -1478,9 +1553,10 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     prof_mark(e, 1, s);
     prof_mark(e, 2, s);
     ReprojLaunch rl{e->gt_j2d, e->cam, e->gcam, e->sq2d, (float)(2.0 * 0.01 / ((double)e->bnorm * 34.0))};   // weight 1/100
-    launch_joints_loss(reuse ? e->dFTp : folded ? e->Jsum : e->JP, reuse ? e->nsplit : folded ? 1 : e->nvc, gt_mm, nullptr, jscale,
-                       e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s, e->gt_j2d ? &rl : nullptr, reuse ? 32 : NH,
-                       (reuse && e->have_jsup) ? e->jsup.flag : nullptr);
+    if (!supv)
+      launch_joints_loss(reuse ? e->dFTp : folded ? e->Jsum : e->JP, reuse ? e->nsplit : folded ? 1 : e->nvc, gt_mm, nullptr, jscale,
+                         e->joints, sqerr ? sqerr : e->sqerr, e->dJT, e->B, e->BP, s, e->gt_j2d ? &rl : nullptr, reuse ? 32 : NH,
+                         (reuse && e->have_jsup) ? e->jsup.flag : nullptr);
     prof_mark(e, 2, s);
     int rc = 0;
     const bool sil = e->sil_mask != nullptr && !folded;
@@ -1495,7 +1571,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     }
     prof_mark(e, 3, s);
     if (folded) launch_fold_bwd(e->dJT, e->AT, e->MT, e->G0, e->dMT, e->dA, e->BP, s);
-    else {
+    else if (!supv) {
       int rcb = launch_lbs_bwd(e->m, e->Jn_iv, e->AT, e->VPb, e->dJT, sil ? e->VTb : nullptr, e->DVP, e->dATp, e->BP, e->nvcb, s, tl, ntl, slab_masks(e));
       if (rcb) return rcb;
     }
@@ -1506,7 +1582,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       g.A = e->Hm; g.lda = KFP; g.Bm = e->dMT; g.ldb = e->BP; g.Out = e->dFTp; g.ldo = e->BP;
       g.bias = nullptr; g.mask = nullptr; g.split_stride = (size_t)KFP * e->BP; g.M = KFP; g.N = e->BP; g.K = FOLD_M;
       rc = launch_gemm_224(g, EPI_STORE, e->nsplit, s);
-    } else {
+    } else if (!supv) {
       rc = blend_adjoint_gemm(e, s, tl, ntl, ns_adj);
     }
     prof_mark(e, 4, s);
@@ -1526,10 +1602,12 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     }
     prof_mark(e, 7, s);
     if (folded) launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
-    else reduce_adjoint_partials(e, s, pd ? x6d : nullptr, dscale, ns_adj);
+    else if (supv) {      // dA^T / dF^T arrive complete: nothing to sum; the per-joint MLP adjoint runs alone
+      if (pd) launch_disc_conv_bwd(e->convL, x6d, e->dH2T, nullptr, dscale, 1.f, e->gx, e->B, e->BP, s, e->dsq, 1);
+    } else reduce_adjoint_partials(e, s, pd ? x6d : nullptr, dscale, ns_adj);
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.betas_in = betas;
-    if (folded) { L.dATp = e->dA; L.dFTp = e->dF; } else set_adjoint_slabs(e, L);
+    if (folded || supv) { L.dATp = e->dA; L.dFTp = e->dF; } else set_adjoint_slabs(e, L);
     L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
     L.gx_extra = pd ? e->gx : nullptr; L.gb_extra = sd ? e->gb : nullptr;
     L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step;
@@ -1657,7 +1735,7 @@ extern "C" int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t
     JRR_HIP(hipMemcpy(&err, e->jsup.flag + JSUP_ERR, sizeof(int32_t), hipMemcpyDeviceToHost));
     if (err) {
       JRR_HIP(hipMemset(e->jsup.flag + JSUP_ERR, 0, 2 * sizeof(int32_t)));      // error word and KNOWN
-      e->jsup_fits_known = false; e->act_valid = false; e->fwd_cached = false;
+      e->jsup_fits_known = false; e->act_valid = false; e->sup_valid = false; e->fwd_cached = false;
       jrr_set_error("the J_regressor's support GREW behind the engine's back (%s): J or its mask was edited in place after "
                     "jrr_j_support_info; results since then are invalid -- announce a changed regressor with jrr_engine_set_j_regressor",
                     (err & 2) ? "a row no longer fits the support lists" : "entries outside the reported tiles");
@@ -1667,7 +1745,7 @@ extern "C" int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t
   if (counts_host) for (int i = 0; i < NH; ++i) counts_host[i] = cnt[i];
   *fits_host = flag;
   e->jsup_fits_known = flag != 0;      // stays true under J steps (ReLU' = 0: Adam never re-activates an entry); cleared by set_j_regressor
-  e->act_valid = false;
+  e->act_valid = false; e->sup_valid = false;
   {   // the baseline the device checks later supports against (k_jsup_tilemask)
     const int32_t known = flag ? 1 : 0;
     if (flag) JRR_HIP(hipMemcpy(e->jsup.tknown, e->jsup.tmask, VT * sizeof(int32_t), hipMemcpyDeviceToDevice));
@@ -1681,6 +1759,29 @@ extern "C" int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t
     if (n > 0) {
       JRR_HIP(hipMemcpy(e->act_list, list, n * sizeof(int32_t), hipMemcpyHostToDevice));
       e->nact = n; e->act_valid = true;
+    }
+    // the support's VERTICES (union of the rows' lists): up to SUP_NSV of them run the per-vertex iteration (supk.h).  J steps only
+    // shrink the support, so the set stays a superset; the regressor's values are read live (Jn_vi) at every iteration.
+    static const bool sup_off = [] { const char* v = getenv("JRR_SUPPORT_FUSED"); return v && v[0] == '0'; }();
+    if (n > 0 && !sup_off) {
+      std::vector<int32_t> col((size_t)NH * JSUP_CAP);
+      JRR_HIP(hipMemcpy(col.data(), e->jsup.col, col.size() * sizeof(int32_t), hipMemcpyDeviceToHost));
+      std::vector<char> seen(VP, 0);
+      bool in_range = true;
+      for (int i = 0; i < NH; ++i)
+        for (int k = 0; k < cnt[i] && k < JSUP_CAP; ++k) {
+          const int r = col[(size_t)i * JSUP_CAP + k];
+          if (r < 0 || r >= VP) { in_range = false; break; }
+          seen[r] = 1;
+        }
+      std::vector<int32_t> rows;
+      for (int r = 0; r < VP; ++r) if (seen[r]) rows.push_back(r);
+      if (in_range && !rows.empty() && (int)rows.size() <= SUP_NSV) {
+        JRR_HIP(hipMemcpy(e->sup.rows, rows.data(), rows.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        launch_sup_gather(e->m, e->sup, (int)rows.size(), (hipStream_t)stream);
+        JRR_HIP(hipStreamSynchronize((hipStream_t)stream));
+        e->sup_nsv = (int)rows.size(); e->sup_valid = true;
+      }
     }
   }
   return JRR_OK;

@@ -170,6 +170,35 @@ int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, co
                    const float* galpha, float scale, float* dverts, int ldv, float* gcam, int accumulate_cam, int B,
                    hipStream_t s, int S = 224);
 
+// sup.hip / supk.h: the joint-loss iteration on the regressor's support VERTICES, one workgroup per 32-pose group
+constexpr int SUP_NSV = 64;       // most support vertices the fused iteration is built for (192 coordinate rows)
+// tables of a support (engine workspace; built by launch_sup_gather whenever the engine learns a support, jrr_j_support_info):
+//   rows [SUP_NSV]                internal vertex rows of the support vertices, ascending
+//   Dsf  [6 tiles][28][64][4]     their blend-basis rows as the A operand of v_posed = Ds F   (lane l: row 32 t + l % 32, k = 8 g + 4 (l / 32) + 0..3)
+//   Dsb  [7 tiles][24][64][4]     the same as the A operand of dF = Ds^T dvp                  (lane l: k = 32 t + l % 32, row 8 g + 4 (l / 32) + 0..3)
+//   sk_* [SUP_NSV][24]            per vertex: its joints with a non-zero skinning weight (ascending) and the weights
+//   jl_* [24][SUP_NSV]            per joint: the support vertices it skins (ascending) and the weights
+struct SupTables { float* Dsf; float* Dsb; int* rows; int* sk_cnt; int* sk_j; float* sk_w; int* jl_cnt; int* jl_s; float* jl_w; };
+size_t sup_tables_floats();
+void sup_tables_carve(SupTables& t, float* base);
+int launch_sup_gather(const Model& m, const SupTables& t, int nsv, hipStream_t s);
+// one joint-loss forward + backward of the pose groups: F^T (K-quads) / A^T of k_prep_fwd in, joints / squared error / dA^T [288][BP] /
+// dF^T [224][BP] out (what k_chain_bwd reads as ONE slab)
+int launch_sup_iter(const SupTables& t, int nsv, const float* Jn_vi, const float* FTq, const float* AT, const float* gt_mm, float scale,
+                    float* joints_out, float* sqerr, float* dA, float* dF, int B, int BP, hipStream_t s);
+
+// ONE inner iteration per 32-pose group in one launch (prep.hip k_sup_step): chain forward, support-vertex forward / loss / backward,
+// [per-joint MLP adjoint], chain adjoint + Adam, [per-joint MLP forward of the next iteration].  The pose-update half takes a PrepBwdLaunch
+// (x6d_in / betas_in / gx_extra / gb_extra / x6d_io / betas_io / Adam state / step / lr / B / BP).
+struct SupStepLaunch {
+  SupTables t; int nsv; const float* Jn_vi; const float* gt_mm; float scale;
+  float* FT; float* FTq; float* AT; float* R0T; float* joints_out; float* sqerr; float* dA; float* dF;
+  const float* conv_img = nullptr; const float* dH2T = nullptr; float dscale = 0.f; float* gx = nullptr; float* dsq = nullptr;
+  float* H2T_next = nullptr;
+  int32_t* step = nullptr; int* arrive = nullptr;      // Adam's step counter (incremented once per launch) and the arrival counter
+};
+int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s);
+
 // fold.hip
 int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, const int* p2v, hipStream_t s);
 int launch_fold_fwd(const float* MT, const float* AT, const float* G0, float* Jsum, int BP, hipStream_t s);

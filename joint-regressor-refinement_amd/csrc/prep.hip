@@ -9,6 +9,7 @@
 #include "jrr_common.h"
 #include "kernels.h"
 #include "dconv.h"
+#include "supk.h"
 
 namespace jrr {
 
@@ -232,16 +233,18 @@ __device__ __forceinline__ void rest_joint(const float* __restrict__ Jt, const f
 // SMPL) with the world transforms exchanged through LDS.  Poses b >= B are written as zeros.
 // ------------------------------------------------------------------------------------------
 constexpr int PP = 32;   // poses per block of the (pose, joint)-parallel kernels
+constexpr int PREP_FWD_LDS = NJ * 15 * PP;      // floats: world transforms [24][12][PP] + rest joints [24][3][PP]
 
 __device__ __forceinline__ void prep_fwd_body(int blk, const float* __restrict__ x6d, const float* __restrict__ Rin,
                                               const float* __restrict__ betas, const float* __restrict__ Jt,
                                               const float* __restrict__ JS, const Parents& par, float* __restrict__ FT,
                                               float* __restrict__ AT, float* __restrict__ R0T, int B, int BP,
-                                              int32_t* step_inc, float* __restrict__ FTq) {
+                                              int32_t* step_inc, float* __restrict__ FTq, float* __restrict__ sh) {
   // FTq: the same features in K-quads [KFP / 4][BP][4] -- the B operand of k_lbs_fwd's blend product (one 16-byte LDS read = four
   // K steps); the row-major FT stays for the chain adjoint and the folded-regressor product
-  __shared__ float Gs[NJ][12][PP];
-  __shared__ float Js[NJ][3][PP];
+  // sh: PREP_FWD_LDS floats of the caller's LDS (the composed kernel k_sup_step hands every phase the same pool)
+  float (*Gs)[12][PP] = reinterpret_cast<float (*)[12][PP]>(sh);
+  float (*Js)[3][PP] = reinterpret_cast<float (*)[3][PP]>(sh + NJ * 12 * PP);
   const int bl = threadIdx.x & (PP - 1), j = threadIdx.x / PP;
   const int b = blk * PP + bl;
   auto fq = [&](int k) -> float& { return FTq[((size_t)(k >> 2) * BP + b) * 4 + (k & 3)]; };
@@ -326,7 +329,8 @@ __global__ __launch_bounds__(PP * NJ) void k_prep_fwd(const float* __restrict__ 
                                                       const float* __restrict__ JS, Parents par, float* __restrict__ FT,
                                                       float* __restrict__ AT, float* __restrict__ R0T, int B, int BP,
                                                       int32_t* step_inc, float* __restrict__ FTq) {
-  prep_fwd_body(blockIdx.x, x6d, Rin, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc, FTq);
+  __shared__ float sh[PREP_FWD_LDS];
+  prep_fwd_body(blockIdx.x, x6d, Rin, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc, FTq, sh);
 }
 
 // The 24 posed SMPL joints of the most recent chain forward (smplx lbs(): J_transformed = G_j[:3, 3], the `joints` field of the
@@ -365,8 +369,9 @@ __global__ __launch_bounds__(PP * NJ) void k_prep_fwd_dconv(const float* __restr
                                                             Parents par, float* __restrict__ FT, float* __restrict__ AT,
                                                             float* __restrict__ R0T, int B, int BP, int32_t* step_inc,
                                                             DconvFwdArgs d, int nprep, float* __restrict__ FTq) {
-  __shared__ __attribute__((aligned(16))) float L[CL_FLOATS];
-  if ((int)blockIdx.x < nprep) prep_fwd_body(blockIdx.x, x6d, nullptr, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc, FTq);
+  // (one pool: a workgroup is either a chain-forward or a per-joint-MLP workgroup)
+  __shared__ __attribute__((aligned(16))) float L[PREP_FWD_LDS > CL_FLOATS ? PREP_FWD_LDS : CL_FLOATS];
+  if ((int)blockIdx.x < nprep) prep_fwd_body(blockIdx.x, x6d, nullptr, betas, Jt, JS, par, FT, AT, R0T, B, BP, step_inc, FTq, L);
   else dconv_fwd_body<true>(L, blockIdx.x - nprep, d.img, x6d, d.H2T, d.out, B, BP);
 }
 
@@ -693,22 +698,27 @@ __device__ __forceinline__ void pose_update_cam(const PoseUpdateArgs& a, int b, 
 }
 
 constexpr int PPB = 32;   // poses per block of k_chain_bwd (16 halves the coalescing width: measured 1.5x slower)
-__global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict__ FT, const float* __restrict__ R0T,
-                                                        const float* __restrict__ AT, const float* __restrict__ Jt,
-                                                        const float* __restrict__ JS, Parents par,
-                                                        const float* __restrict__ dA_, int nslabA, size_t strideA,
-                                                        const float* __restrict__ dF_, PoseUpdateArgs ua, int B, int BP,
-                                                        const unsigned* __restrict__ dmask) {
+// LDS pool of the chain adjoint (floats): dG | Js | dBs | Jts | JSs | adam scalars (8) | child list (24 bytes in 8 floats)
+constexpr int CB_DG = 0, CB_JS = CB_DG + NJ * 12 * PPB, CB_DBS = CB_JS + NJ * 3 * PPB, CB_JTS = CB_DBS + NJ * NB * PPB,
+              CB_JSS = CB_JTS + NJ * 3, CB_ADAM = CB_JSS + NJ * 3 * NB, CB_CHILD = CB_ADAM + 8, CHAIN_BWD_LDS = CB_CHILD + 8;
+static_assert(sizeof(AdamScalars) <= 8 * sizeof(float), "adam scalars slot");
+__device__ __forceinline__ void chain_bwd_body(int blk, const float* __restrict__ FT, const float* __restrict__ R0T,
+                                               const float* __restrict__ AT, const float* __restrict__ Jt,
+                                               const float* __restrict__ JS, const Parents& par,
+                                               const float* __restrict__ dA_, int nslabA, size_t strideA,
+                                               const float* __restrict__ dF_, const PoseUpdateArgs& ua, int B, int BP,
+                                               const unsigned* __restrict__ dmask, float* __restrict__ sh, int step_now = -1) {
+  // step_now >= 0 (thread 0 only; the composed kernel k_sup_step): Adam's step count of this iteration, instead of ua.step[0]
   constexpr int PP = PPB;
-  __shared__ AdamScalars adam_sc;
+  AdamScalars& adam_sc = *reinterpret_cast<AdamScalars*>(sh + CB_ADAM);
   // one thread per (pose, joint); levels of the kinematic tree are processed deepest first.  Each child
   // leaves its contribution to the parent's dG in its own LDS slot; the parent sums its children in
   // index order (no atomics: bitwise reproducible).
-  __shared__ float dG[NJ][12][PP];
-  __shared__ float Js[NJ][3][PP];
-  __shared__ float dBs[NJ][NB][PP];
+  float (*dG)[12][PP] = reinterpret_cast<float (*)[12][PP]>(sh + CB_DG);
+  float (*Js)[3][PP] = reinterpret_cast<float (*)[3][PP]>(sh + CB_JS);
+  float (*dBs)[NB][PP] = reinterpret_cast<float (*)[NB][PP]>(sh + CB_DBS);
   const int bl = threadIdx.x & (PP - 1), j = threadIdx.x / PP;
-  const int b = blockIdx.x * PP + bl;
+  const int b = blk * PP + bl;
   const bool ok = b < B;
   const size_t bb = ok ? (size_t)b : 0;      // padded lanes read pose 0 and write nothing
   const int p = par.p[j];
@@ -716,11 +726,11 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
   // -- indexes the kernel arguments with a per-lane q: 23 dependent memory loads per working wave and tree level,
   // ~2 us per level, measured with wall-clock stamps: 17.6 of the kernel's 34 us.)
   const int c_lo = par.child_off[j], c_hi = par.child_off[j + 1];
-  __shared__ unsigned char childs[NJ];
+  unsigned char* const childs = reinterpret_cast<unsigned char*>(sh + CB_CHILD);
   if (threadIdx.x < NJ) childs[threadIdx.x] = par.child[threadIdx.x];
   // the rest-joint tables (72 + 720 floats) are read with per-lane (joint) indices: from LDS, not from memory
-  __shared__ float Jts[NJ * 3];
-  __shared__ float JSs[NJ * 3 * NB];
+  float* const Jts = sh + CB_JTS;
+  float* const JSs = sh + CB_JSS;
   for (int i = threadIdx.x; i < NJ * 3 * NB; i += PP * NJ) JSs[i] = JS[i];
   if (threadIdx.x < NJ * 3) Jts[threadIdx.x] = Jt[threadIdx.x];
   float beta[NB], dbeta[NB], Ji[3];
@@ -743,7 +753,7 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
   // (two slabs' loads -- 24 -- in flight together).  dmask (k_lbs_bwd16): bit j of word [slab][b / 64] says whether the slab holds
   // rows for joint j at all -- rows of joints its chunk never touched are neither written nor read (x + 0 = x: same sums)
   {
-    const int n_bt = BP / 64, bt = (int)(blockIdx.x * PP) / 64;
+    const int n_bt = BP / 64, bt = (int)(blk * PP) / 64;
 #pragma unroll
     for (int e = 0; e < 12; ++e) dA[e] = 0.f;
     for (int sl = 0; sl < nslabA; sl += 2) {
@@ -780,7 +790,7 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
     dFj[k] = (j > 0) ? df : 0.f;
   }
   // Adam's bias corrections (two fp64 pow: ~400 instructions, one thread) under the loads issued above, not before them
-  if (ua.x6d_io && threadIdx.x == 0) adam_sc = adam_scalars(ua.step[0], ua.lr, ua.beta1, ua.beta2, ua.eps);
+  if (ua.x6d_io && threadIdx.x == 0) adam_sc = adam_scalars(step_now >= 0 ? step_now : ua.step[0], ua.lr, ua.beta1, ua.beta2, ua.eps);
   __syncthreads();                              // tables staged
   rest_joint(Jts, JSs, j, beta, Ji);
 #pragma unroll
@@ -872,6 +882,16 @@ __global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict_
   }
 }
 
+__global__ __launch_bounds__(PPB * NJ) void k_chain_bwd(const float* __restrict__ FT, const float* __restrict__ R0T,
+                                                        const float* __restrict__ AT, const float* __restrict__ Jt,
+                                                        const float* __restrict__ JS, Parents par,
+                                                        const float* __restrict__ dA_, int nslabA, size_t strideA,
+                                                        const float* __restrict__ dF_, PoseUpdateArgs ua, int B, int BP,
+                                                        const unsigned* __restrict__ dmask) {
+  __shared__ __attribute__((aligned(16))) float sh[CHAIN_BWD_LDS];
+  chain_bwd_body(blockIdx.x, FT, R0T, AT, Jt, JS, par, dA_, nslabA, strideA, dF_, ua, B, BP, dmask, sh);
+}
+
 // out[i] (+)= sum_s P[s*stride + i]  (split-K / vertex-chunk partial slabs), float4-wide
 __global__ void k_reduce_slabs(const f32x4* __restrict__ P, int nslab, size_t stride4, f32x4* __restrict__ out,
                                size_t n4, int accumulate) {
@@ -948,6 +968,83 @@ int launch_reduce_slabs(const float* P, int nslab, size_t stride, float* out, si
   if (blocks > 4096) blocks = 4096;
   hipLaunchKernelGGL(k_reduce_slabs, dim3(blocks), dim3(256), 0, s, (const f32x4*)P, nslab, stride / 4, (f32x4*)out, n4,
                      accumulate);
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------
+// k_sup_step: ONE inner iteration of a 32-pose group in one workgroup (round 6; supk.h) -- the support-vertex form of
+// scripts/optimize.py:220-265 without the silhouette and 2-D terms:
+//   chain forward (k_prep_fwd's body) -> support-vertex SMPL forward, joint loss, backward (sup_body) -> [per-joint MLP adjoint of the
+//   pose discriminator, whose four GEMM launches PRECEDE this kernel] -> chain adjoint + 6-D rotation adjoint + Adam (k_chain_bwd's
+//   body) -> [per-joint MLP forward of the NEXT iteration on the updated poses].
+// The phases hand F^T / A^T / dA^T / dF^T / gx over through global memory (the arrays their stand-alone kernels use; a workgroup reads
+// only what it wrote itself, behind a workgroup barrier) and share one LDS pool.  With the discriminator an iteration is 4 GEMM
+// launches + this one (13 launches on the tile lists); without it, this launch alone.
+// Adam's step count: every workgroup reads the pre-increment value; the LAST workgroup to arrive (an agent-scope counter in the
+// engine workspace, reset by that workgroup) stores value + 1 -- after every other workgroup has read.
+// ------------------------------------------------------------------------------------------
+struct SupStepArgs {
+  const float* x6d; const float* betas; float* FT; float* FTq; float* AT; float* R0T;
+  SupArgs sup;
+  const float* conv_img;     // LDS image of the per-joint MLP, NULL without the pose discriminator
+  const float* dH2T; float dscale; float* gx; float* dsq; float* H2T_next;
+  PoseUpdateArgs ua;
+  int32_t* step; int* arrive;
+};
+constexpr int SUP_STEP_LDS = SUPL_FLOATS > CHAIN_BWD_LDS ? (SUPL_FLOATS > PREP_FWD_LDS ? SUPL_FLOATS : PREP_FWD_LDS)
+                                                         : (CHAIN_BWD_LDS > PREP_FWD_LDS ? CHAIN_BWD_LDS : PREP_FWD_LDS);
+static_assert(SUP_STEP_LDS >= CL_FLOATS && SUP_PP == PP && SUP_PP == PPB && SUP_THREADS == PP * NJ, "one geometry for every phase");
+__global__ __launch_bounds__(SUP_THREADS) void k_sup_step(SupStepArgs a, const float* __restrict__ Jt, const float* __restrict__ JS,
+                                                          Parents par) {
+  extern __shared__ __attribute__((aligned(16))) float pool[];
+  const int blk = blockIdx.x, B = a.sup.B, BP = a.sup.BP;
+  int step_now = -1;
+  if (threadIdx.x == 0 && a.step) {
+    const int s0 = __hip_atomic_load(a.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the value is in: only now may this workgroup count as arrived
+    step_now = s0 + 1;
+    const int prev = __hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (prev == (int)gridDim.x - 1) {
+      __hip_atomic_store(a.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(a.step, step_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+  prep_fwd_body(blk, a.x6d, nullptr, a.betas, Jt, JS, par, a.FT, a.AT, a.R0T, B, BP, nullptr, a.FTq, pool);
+  __syncthreads();
+  sup_body(pool, blk, a.sup);
+  __syncthreads();
+  if (a.conv_img) {      // both halves of the joints: wave w takes joint w, then joint 12 + w
+    dconv_bwd_body<true>(pool, 2 * blk, a.conv_img, a.x6d, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
+    __syncthreads();
+    dconv_bwd_body<true>(pool, 2 * blk + 1, a.conv_img, a.x6d, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
+    __syncthreads();
+  }
+  chain_bwd_body(blk, a.FT, a.R0T, a.AT, Jt, JS, par, a.sup.dA, 1, 0, a.sup.dF, a.ua, B, BP, nullptr, pool, step_now);
+  if (a.conv_img && a.H2T_next) {      // the updated poses of this group are complete: their per-joint MLP forward for the next iteration
+    __syncthreads();
+    dconv_fwd_body<true>(pool, 2 * blk, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
+    __syncthreads();
+    dconv_fwd_body<true>(pool, 2 * blk + 1, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
+  }
+}
+
+int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s) {
+  static const bool attr = [] {
+    return hipFuncSetAttribute((const void*)k_sup_step, hipFuncAttributeMaxDynamicSharedMemorySize, SUP_STEP_LDS * 4) == hipSuccess;
+  }();
+  if (!attr) { jrr_set_error("k_sup_step: %d bytes of LDS refused", SUP_STEP_LDS * 4); return JRR_ERR_HIP; }
+  SupStepArgs a;
+  a.x6d = L.x6d_in; a.betas = L.betas_in; a.FT = q.FT; a.FTq = q.FTq; a.AT = q.AT; a.R0T = q.R0T;
+  a.sup = SupArgs{q.t, q.nsv, q.Jn_vi, q.FTq, q.AT, q.gt_mm, q.scale, q.joints_out, q.sqerr, q.dA, q.dF, L.B, L.BP};
+  a.conv_img = q.conv_img; a.dH2T = q.dH2T; a.dscale = q.dscale; a.gx = q.gx; a.dsq = q.dsq; a.H2T_next = q.H2T_next;
+  PoseUpdateArgs& u = a.ua;
+  u.x6d_in = L.x6d_in; u.gx_extra = L.gx_extra; u.gb_extra = L.gb_extra;
+  u.dx6d = L.dx6d; u.dR = L.dR; u.dbetas = L.dbetas;
+  u.x6d_io = L.x6d_io; u.betas_io = L.betas_io; u.adam_m = L.adam_m; u.adam_v = L.adam_v; u.step = L.step;
+  u.lr = L.lr; u.beta1 = L.beta1; u.beta2 = L.beta2; u.eps = L.eps;
+  u.gcam = nullptr; u.cam_io = nullptr; u.cam_m = nullptr; u.cam_v = nullptr;
+  a.step = q.step; a.arrive = q.arrive;
+  hipLaunchKernelGGL(k_sup_step, dim3((L.B + SUP_PP - 1) / SUP_PP), dim3(SUP_THREADS), SUP_STEP_LDS * 4, s, a, m.Jt, m.JS, m.parents);
   return 0;
 }
 

@@ -1,0 +1,257 @@
+// The joint-loss iteration on the regressor's SUPPORT VERTICES, one workgroup per 32-pose group (round 6).
+//
+// scripts/optimize.py:220-265 without the silhouette term reads the SMPL vertices through J_regressor x V only
+// (scripts/utils.py:87-98), and the H36M regressor is positive in a few dozen of its 117 130 entries: the joints depend on
+// those vertices alone and every other vertex receives a zero adjoint.  The tile-restricted iteration of round 4
+// (JRR_FLAG_SUPPORT_TILES) still ran the three large LBS kernels -- over 6 tiles of 32 vertices for 58 support vertices -- as
+// separate launches with the pose group's v_posed / dvp / partial slabs travelling through HBM between them.  Here the restriction
+// is per VERTEX (n_sv <= 64 of them = 192 coordinate rows) and a 32-pose group never leaves its workgroup:
+//
+//   v_posed  [192 rows][32 poses] = Ds . F          6 row tiles x 112 v_mfma_f32_32x32x2_f32; A operand = the basis rows of the
+//                                                   support vertices, gathered once per support (k_sup_gather), read 16 B per lane
+//                                                   straight from L2; B operand = the pose group's feature quads in LDS
+//   T_v = sum_j W[v,j] A_j , verts = T v_posed      vector ALU, one thread per (pose, vertex): <= 4 joints per SMPL vertex
+//   joints = Jn[:, support] verts, loss, dj         one thread per (pose, H36M joint)            (scripts/utils.py:106-114)
+//   dverts = Jn^T dj , dvp = T^T dverts             one thread per (pose, vertex)
+//   dA_j  += W[v,j] dverts (x) [v_posed; 1]         one thread per (pose, SMPL joint), over the joint's vertex list (no atomics)
+//   dF [224][32] = Ds^T . dvp                       7 row tiles x 96 matrix instructions
+//
+// Everything is summed in a fixed order (bitwise reproducible).  Inputs F^T (K-quads) / A^T and outputs dA^T / dF^T are the
+// arrays k_prep_fwd writes and k_chain_bwd reads: the body composes with them inside one launch (prep.hip, k_sup_step) or runs
+// between them as a launch of its own (sup.hip, k_sup_iter).
+#pragma once
+#include "jrr_common.h"
+#include "kernels.h"
+
+namespace jrr {
+
+constexpr int SUP_ROWS = 3 * SUP_NSV;        // 192 coordinate rows (row 3 s + c = coordinate c of support vertex s)
+constexpr int SUP_RT = SUP_ROWS / 32;        // 6 row tiles of the forward product
+constexpr int SUP_FG = KFP / 8;              // 28 K groups (8 features: four matrix instructions) of the forward product
+constexpr int SUP_BG = SUP_ROWS / 8;         // 24 K groups of the adjoint product
+constexpr int SUP_MT = KFP / 32;             // 7 row tiles of the adjoint product
+constexpr int SUP_PP = 32;                   // poses per workgroup
+constexpr int SUP_THREADS = SUP_PP * NJ;     // 768: (pose, joint) threads, as k_prep_fwd / k_chain_bwd
+constexpr int SUP_JS = SUP_NSV;              // row pitch of the regressor's support columns in LDS
+constexpr int SUP_DSF_FLOATS = SUP_RT * SUP_FG * 256, SUP_DSB_FLOATS = SUP_MT * SUP_BG * 256;
+
+// LDS image (floats).  Fq is dead after the forward product and then holds dverts; the vertices are dead after the joints and
+// then hold dvp in row quads (the B operand of the adjoint product).
+constexpr int SUPL_FQ = 0;                              // [56 quads][32 poses][4]      -> dverts [192][32]
+constexpr int SUPL_AL = SUPL_FQ + (KFP / 4) * 32 * 4;   // [288][32]   A^T of the pose group
+constexpr int SUPL_VP = SUPL_AL + 12 * NJ * 32;         // [192][32]   v_posed
+constexpr int SUPL_V = SUPL_VP + SUP_ROWS * 32;         // [192][32]   vertices                   -> dvp [48 quads][32][4]
+constexpr int SUPL_JN = SUPL_V + SUP_ROWS * 32;         // [17][64]    regressor columns of the support vertices
+constexpr int SUPL_RED = SUPL_JN + NH * SUP_JS;         // [17][4][32] per-joint loss partials
+constexpr int SUPL_PEL = SUPL_RED + NH * 4 * 32;        // [3][32]
+constexpr int SUPL_DJ = SUPL_PEL + 3 * 32;              // [3][17][32] joint adjoint
+constexpr int SUPL_FLOATS = SUPL_DJ + 3 * NH * 32;
+static_assert(SUPL_FLOATS * 4 <= 160 * 1024, "LDS image of the support iteration");
+
+struct SupArgs {
+  SupTables t; int nsv;
+  const float* Jn_vi;        // normalised regressor [VP][32 i] (tile-major [VT][32 v][32 i]): live values, the J step rewrites them
+  const float* FTq;          // [KFP/4][BP][4]
+  const float* AT;           // [288][BP]
+  const float* gt_mm;        // (B,17,3) millimetres, pelvis-centred by the caller
+  float scale;               // 2 * weight / (batch_norm * 51)
+  float* joints_out;         // (B,17,3), nullable
+  float* sqerr;              // (B), nullable
+  float* dA;                 // [288][BP] out
+  float* dF;                 // [224][BP] out
+  int B, BP;
+};
+
+__device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const SupArgs& a) {
+  const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int p = tid & 31, jt = tid >> 5;               // pose column; SMPL joint / vertex slot / H36M joint of this thread
+  const int b0 = blk * SUP_PP, b = b0 + p;
+  const bool ok = b < a.B;
+  const int nsv = a.nsv, BP = a.BP;
+  float* const Fq = lds + SUPL_FQ;
+  float* const Al = lds + SUPL_AL;
+  float* const vpL = lds + SUPL_VP;
+  float* const vL = lds + SUPL_V;
+  float* const JnS = lds + SUPL_JN;
+  float* const red = lds + SUPL_RED;
+  float* const pel = lds + SUPL_PEL;
+  float* const djL = lds + SUPL_DJ;
+
+  // ---- the pose group's operands -> LDS ----
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.FTq);
+    f32x4* dst = reinterpret_cast<f32x4*>(Fq);
+    for (int i = tid; i < (KFP / 4) * 32; i += SUP_THREADS) dst[i] = src[(size_t)(i >> 5) * BP + b0 + (i & 31)];
+  }
+  {
+    const f32x4* src = reinterpret_cast<const f32x4*>(a.AT);
+    f32x4* dst = reinterpret_cast<f32x4*>(Al);
+    for (int i = tid; i < 12 * NJ * 8; i += SUP_THREADS) dst[i] = src[((size_t)(i >> 3) * BP + b0) / 4 + (i & 7)];
+  }
+  for (int i = tid; i < NH * SUP_JS; i += SUP_THREADS) {
+    const int ii = i / SUP_JS, s = i % SUP_JS;
+    JnS[i] = s < nsv ? a.Jn_vi[(size_t)a.t.rows[s] * 32 + ii] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- v_posed = Ds . F : wave w < 6 owns row tile w; two accumulator chains (even / odd K groups), added at the end ----
+  if (wv < SUP_RT) {
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a.t.Dsf) + (size_t)wv * SUP_FG * 64 + lane;
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(Fq) + half * 32 + l31;      // quad 2 g + half of K group g
+    f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+    for (int g = 0; g < SUP_FG; g += 2) {
+      const f32x4 x0 = a4[g * 64], x1 = a4[(g + 1) * 64];
+      const f32x4 y0 = b4[(2 * g) * 32], y1 = b4[(2 * g + 2) * 32];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc0 = mfma(x0[t], y0[t], acc0);
+        acc1 = mfma(x1[t], y1[t], acc1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) vpL[(32 * wv + acc_row(r, half)) * 32 + l31] = acc0[r] + acc1[r];
+  }
+  __syncthreads();
+
+  // ---- skinning: T = sum_j W[v,j] A_j over the vertex's own joints, verts = T [v_posed; 1] ----
+  for (int s = jt; s < nsv; s += NJ) {
+    float T[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) T[e] = 0.f;
+    const int cnt = a.t.sk_cnt[s];
+    for (int k = 0; k < cnt; ++k) {
+      const int j = a.t.sk_j[s * NJ + k];
+      const float w = a.t.sk_w[s * NJ + k];
+#pragma unroll
+      for (int e = 0; e < 12; ++e) T[e] = fmaf(w, Al[(e * NJ + j) * 32 + p], T[e]);
+    }
+    const float vx = vpL[(3 * s) * 32 + p], vy = vpL[(3 * s + 1) * 32 + p], vz = vpL[(3 * s + 2) * 32 + p];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) vL[(3 * s + r) * 32 + p] = fmaf(T[r * 4 + 2], vz, fmaf(T[r * 4 + 1], vy, fmaf(T[r * 4], vx, T[r * 4 + 3])));
+  }
+  __syncthreads();
+
+  // ---- joints (ascending vertex row), pelvis-centred squared error and its adjoint (k_joints_loss, prep.hip) ----
+  float j3[3] = {0.f, 0.f, 0.f}, g3[3] = {0.f, 0.f, 0.f};
+  if (jt < NH) {
+    for (int s = 0; s < nsv; ++s) {
+      const float w = JnS[jt * SUP_JS + s];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) j3[c] = fmaf(w, vL[(3 * s + c) * 32 + p], j3[c]);
+    }
+    if (a.joints_out && ok) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) a.joints_out[((size_t)b * NH + jt) * 3 + c] = j3[c];
+    }
+    if (jt == 0) { pel[p] = j3[0]; pel[32 + p] = j3[1]; pel[64 + p] = j3[2]; }
+  }
+  __syncthreads();
+  if (jt < NH) {
+    float err = 0.f;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const float gtv = ok ? a.gt_mm[((size_t)b * NH + jt) * 3 + c] / 1000.f : 0.f;
+      const float d = (jt == 0) ? -gtv : (j3[c] - pel[c * 32 + p]) - gtv;      // joint 0 is identically 0 after centring
+      err += d * d;
+      g3[c] = (jt == 0) ? 0.f : a.scale * d;
+      red[(jt * 4 + c) * 32 + p] = g3[c];
+    }
+    red[(jt * 4 + 3) * 32 + p] = err;
+  }
+  __syncthreads();
+  if (jt < NH) {
+    if (jt == 0) {      // fixed-order sums over the 17 joints
+      float sm[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < NH; ++q)
+#pragma unroll
+        for (int k = 0; k < 4; ++k) sm[k] += red[(q * 4 + k) * 32 + p];
+      if (ok && a.sqerr) a.sqerr[b] = sm[3];
+#pragma unroll
+      for (int c = 0; c < 3; ++c) g3[c] = -sm[c];      // move_pelvis adjoint: -sum_i g_i
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) djL[(c * NH + jt) * 32 + p] = ok ? g3[c] : 0.f;
+  }
+  __syncthreads();
+
+  // ---- vertex adjoint dverts = Jn^T dj, dvp = T^T dverts (T recomputed) ----
+  float* const dvL = Fq;       // [192][32]
+  float* const dvq = vL;       // row quads [48][32][4]
+  for (int s = jt; s < nsv; s += NJ) {
+    float dv[3] = {0.f, 0.f, 0.f};
+    for (int i = 0; i < NH; ++i) {
+      const float w = JnS[i * SUP_JS + s];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) dv[r] = fmaf(w, djL[(r * NH + i) * 32 + p], dv[r]);
+    }
+    float T[9];
+#pragma unroll
+    for (int e = 0; e < 9; ++e) T[e] = 0.f;
+    const int cnt = a.t.sk_cnt[s];
+    for (int k = 0; k < cnt; ++k) {
+      const int j = a.t.sk_j[s * NJ + k];
+      const float w = a.t.sk_w[s * NJ + k];
+#pragma unroll
+      for (int r = 0; r < 3; ++r)
+#pragma unroll
+        for (int c = 0; c < 3; ++c) T[r * 3 + c] = fmaf(w, Al[((r * 4 + c) * NJ + j) * 32 + p], T[r * 3 + c]);
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      const int rho = 3 * s + c;
+      dvq[((rho >> 2) * 32 + p) * 4 + (rho & 3)] = fmaf(T[6 + c], dv[2], fmaf(T[3 + c], dv[1], T[c] * dv[0]));
+      dvL[rho * 32 + p] = dv[c];
+    }
+  }
+  for (int i = tid; i < (SUP_ROWS - 3 * nsv) * 32; i += SUP_THREADS) {      // padding rows of the adjoint product's K range
+    const int rho = 3 * nsv + (i >> 5);
+    dvq[((rho >> 2) * 32 + (i & 31)) * 4 + (rho & 3)] = 0.f;
+  }
+  __syncthreads();
+
+  // ---- dA_j = sum_v W[v,j] dverts_v (x) [v_posed_v; 1]: one thread per (pose, joint), the joint's vertices in ascending order ----
+  {
+    float acc[12];
+#pragma unroll
+    for (int e = 0; e < 12; ++e) acc[e] = 0.f;
+    const int cnt = a.t.jl_cnt[jt];
+    for (int k = 0; k < cnt; ++k) {
+      const int s = a.t.jl_s[jt * SUP_NSV + k];
+      const float w = a.t.jl_w[jt * SUP_NSV + k];
+      const float vx = vpL[(3 * s) * 32 + p], vy = vpL[(3 * s + 1) * 32 + p], vz = vpL[(3 * s + 2) * 32 + p];
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        const float wd = w * dvL[(3 * s + r) * 32 + p];
+        acc[r * 4] = fmaf(wd, vx, acc[r * 4]);
+        acc[r * 4 + 1] = fmaf(wd, vy, acc[r * 4 + 1]);
+        acc[r * 4 + 2] = fmaf(wd, vz, acc[r * 4 + 2]);
+        acc[r * 4 + 3] += wd;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 12; ++e) a.dA[(size_t)(e * NJ + jt) * BP + b] = acc[e];
+  }
+
+  // ---- dF = Ds^T . dvp : wave w < 7 owns feature tile w ----
+  if (wv < SUP_MT) {
+    const f32x4* a4 = reinterpret_cast<const f32x4*>(a.t.Dsb) + (size_t)wv * SUP_BG * 64 + lane;
+    const f32x4* b4 = reinterpret_cast<const f32x4*>(dvq) + half * 32 + l31;
+    f32x16 acc0 = zero16(), acc1 = zero16();
+#pragma unroll
+    for (int g = 0; g < SUP_BG; g += 2) {
+      const f32x4 x0 = a4[g * 64], x1 = a4[(g + 1) * 64];
+      const f32x4 y0 = b4[(2 * g) * 32], y1 = b4[(2 * g + 2) * 32];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        acc0 = mfma(x0[t], y0[t], acc0);
+        acc1 = mfma(x1[t], y1[t], acc1);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) a.dF[(size_t)(32 * wv + acc_row(r, half)) * BP + b0 + l31] = acc0[r] + acc1[r];
+  }
+}
+
+}  // namespace jrr

@@ -71,6 +71,13 @@ def pytest_collection_finish(session):
         'bench8': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '1', '--j_step_every', '2', '--batch', '128',
                    '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5',
                    '--min_timed_ms', '50'],
+        # --scaling strong: the GLOBAL batch fixed (512), shards of 256 / 64 poses
+        'bench2s': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--j_step_every', '2', '--batch', '512',
+                    '--scaling', 'strong', '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5',
+                    '--min_timed_ms', '50'],
+        'bench8s': [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '4', '--warmup', '1', '--j_step_every', '2', '--batch', '512',
+                    '--scaling', 'strong', '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded', '--no_skin_variants', '--no_config5',
+                    '--min_timed_ms', '50'],
         # the same under an explicit torchrun (the README's / the contract's N > 1 command line)
         'bench2t': _torchrun(2, 29542, [os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '4', '--warmup', '1', '--j_step_every', '2', '--batch', '256',
                                         '--backend', 'gloo', '--single_device', '--no_cpu_baseline', '--no_folded',

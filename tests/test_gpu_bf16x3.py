@@ -89,10 +89,10 @@ def test_bf16x3_hundred_iteration_trajectory(eng_mod, dmodel, smpl_model_np, j_h
     o, p, b, hist = oracle.refine_poses(smpl, T(j_h36m_np), x6d[:, :1], x6d[:, 1:], betas, gt_c, n)
     Ro = oracle.rot6d_to_rotmat(torch.cat([o, p], 1).reshape(-1, 6)).view(B, 24, 3, 3)
     j_or = oracle.find_joints(smpl, b, Ro[:, :1], Ro[:, 1:], T(j_h36m_np), mask=oracle.find_j_reg_mask(T(j_h36m_np)))
-    for name in res:
-        dj = (res[name][2] - j_or).abs().max().item()
-        assert dj < 1e-4, (name, dj)                                  # north_star: regressed 3-D joints within 1e-4 m
-        np.testing.assert_allclose(float(res[name][3].sum()) / (B * 51), hist[-1]['joint_loss'], rtol=5e-3)
+    # (the exact-fp32 engine's own 100-iteration oracle tests live in tests/test_gpu_trajectory.py; here it is the yardstick)
+    dj = (res['bf16x3'][2] - j_or).abs().max().item()
+    assert dj < 1e-4, dj                                              # north_star: regressed 3-D joints within 1e-4 m
+    np.testing.assert_allclose(float(res['bf16x3'][3].sum()) / (B * 51), hist[-1]['joint_loss'], rtol=5e-3)
     dj = (res['bf16x3'][2] - res['f32'][2]).abs().max().item()
     assert dj < 1e-4, dj
     d = (res['bf16x3'][0] - res['f32'][0]).abs()

@@ -199,7 +199,8 @@ def test_two_rank_driver_moved_the_regressor_only_on_its_support():
     assert not moved[J0 <= 0].any()
 
 
-@pytest.mark.parametrize('name,world,batch', [('bench2', 2, 256), ('bench2t', 2, 256), ('bench8', 8, 128)])
+@pytest.mark.parametrize('name,world,batch', [('bench2', 2, 256), ('bench2t', 2, 256), ('bench8', 8, 128),
+                                              ('bench2s', 2, 256), ('bench8s', 8, 64)])
 def test_bench_n_ranks(name, world, batch):
     """`python bench.py --gpus N` (bench.py launches its own torchrun child before touching the GPU) and the explicit
     torchrun line both give ONE JSON line of an N-rank run, with the evidence of the rank count in it"""
@@ -207,8 +208,15 @@ def test_bench_n_ranks(name, world, batch):
     lines = [l for l in r['out'].splitlines() if l.startswith('{')]
     assert len(lines) == 1, r['out'][-2000:]
     j = json.loads(lines[0])
-    assert j['n_gpus'] == world and j['scaling'] == 'weak' and j['value'] > 0
+    strong = name.endswith('s')      # --scaling strong: `batch` here is the shard, the global batch was the command line's --batch
+    assert j['n_gpus'] == world and j['scaling'] == ('strong' if strong else 'weak') and j['value'] > 0
     assert j['config']['global_batch'] == world * batch and j['config']['parallelism'] == f'dp{world}'
+    assert j['config']['poses_per_gpu'] == batch
+    # weak: N x (iterations of a per-GPU batch) per second; strong: iterations of the one global batch per second
+    it_s = 1e3 / j['ms_per_step']
+    assert abs(j['value'] - it_s * (1 if strong else world)) < 1e-2 * j['value']
+    assert j['unit'] == f"it/s (x{world * batch if strong else batch} poses)"
+    assert j['provenance']['in_tree_lib'] is True and len(j['provenance']['lib_sha16']) == 16
     assert j['config']['j_steps_in_timed_regions'] >= 1
     assert j['j_step']['allreduce_bytes'] == 17 * 128 * 4          # the regressor's support, not the dense (17,6890) gradient
     assert np.isfinite(j['config']['joint_loss_last'])

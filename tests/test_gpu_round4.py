@@ -131,6 +131,21 @@ def test_j_step_gradient_vs_oracle(variant):
     assert torch.equal(dJ.cpu() != 0, dJ_ref != 0)
 
 
+def _near_zero_gradient_entries(records, k_ulp=64):
+    """(B,144) mask of the pose entries whose ORACLE gradient was within `k_ulp` units in the last place of zero -- relative to the largest
+    entry of that iteration's gradient, the magnitude of the terms a gradient entry is a sum of -- in any recorded iteration.  Adam's
+    update is lr * m_hat / (sqrt(v_hat) + eps): while every gradient an entry has seen is at rounding level, the update is decided by
+    rounding (a sign flip of a ~1e-8 gradient moves the parameter by up to 2 lr), whatever the order of the sums.  Everywhere else a
+    rounding difference of the gradient changes the update by ~1e-7 of a step."""
+    mask = None
+    for r in records:
+        g = torch.cat([r['g_orient'], r['g_pose']], 1).reshape(r['g_pose'].shape[0], -1)
+        thr = k_ulp * 2.0 ** -23 * g.abs().max().item()
+        near = g.abs() < thr
+        mask = near if mask is None else (mask | near)
+    return mask
+
+
 def test_three_iterations_with_pose_discriminator_vs_oracle(variant):
     v = variant
     B = 200
@@ -139,7 +154,9 @@ def test_three_iterations_with_pose_discriminator_vs_oracle(variant):
     gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
     dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
     smpl = oracle.OracleSMPL(v['model'])
-    o, p, b_, _ = oracle.refine_poses(smpl, T(v['J']), x6[:, :1], x6[:, 1:], betas, gt_c, 3, disc_sd=dsd)
+    records = []
+    o, p, b_, _ = oracle.refine_poses(smpl, T(v['J']), x6[:, :1], x6[:, 1:], betas, gt_c, 3, disc_sd=dsd,
+                                      record=lambda it, r: records.append(r))
     em = v['eng_mod']
     eng = em.RefineEngine(v['dm'], B, flags=em.FLAG_POSE_DISC)
     eng.set_j_regressor(T(v['J']))
@@ -147,12 +164,19 @@ def test_three_iterations_with_pose_discriminator_vs_oracle(variant):
     xd, bd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous()
     m, vv, step = _fresh_state(B)
     eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, vv, step, 1e-2, 3)
-    d = (xd.cpu() - torch.cat([o, p], 1)).abs()
+    d = (xd.cpu() - torch.cat([o, p], 1)).abs().reshape(B, -1)
     # Adam's first steps are lr * g / (|g| + eps): last-bit differences of the summation order are amplified wherever a gradient
-    # entry is ~ 0; the bound on the mean is what pins the trajectory.  The maximum is ONE such entry and moves
-    # with every change of a summation order (64 instead of 32 split-K slabs at this batch size, round 5: 7.7e-4 on one of the 26
-    # variants, mean 4.6e-8): it is held to a tenth of a first Adam step (lr = 1e-2)
-    assert d.max().item() < 1e-3 and d.mean().item() < 5e-6, (d.max().item(), d.mean().item())
+    # entry is ~ 0.  Those entries are identified EXPLICITLY from the oracle's own gradients (round 6; round 5
+    # had widened the maximum for every entry when the planner's split-K slab count changed a summation order): they keep the wide
+    # bound of a tenth of a first Adam step, every other entry the strict 6e-4, and the mean pins the trajectory.
+    near = _near_zero_gradient_entries(records)
+    assert near.float().mean().item() < 0.02, near.float().mean().item()         # a handful of entries, not a blanket
+    strict = d[~near].max().item()
+    worst = (d * (~near)).argmax().item()
+    assert strict < 6e-4, (strict, worst, [torch.cat([r['g_orient'], r['g_pose']], 1).reshape(B, -1).flatten()[worst].item() for r in records])
+    if near.any():
+        assert d[near].max().item() < 1e-3, d[near].max().item()
+    assert d.mean().item() < 5e-6, d.mean().item()
     assert (bd.cpu() - b_).abs().max().item() < 3e-4
 
 
