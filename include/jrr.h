@@ -186,9 +186,15 @@ int jrr_find_joints_after_j_step(jrr_engine_t* e, const float* x6d_dev, const fl
 
 /* The `joints` field of the SMPL operator's output (scripts/smpl.py:69-84: smplx's 24 posed joints J_transformed = G_j[:3, 3] of the
  * kinematic chain head the list the wrapper re-maps).  Must follow a forward on this engine (jrr_find_joints_forward,
- * jrr_refine_run, ...) with the SAME betas: reads the stored skinning transforms.  joints24_dev (B,24,3).  Not differentiated
+ * jrr_refine_run, ...) with the SAME betas: reads the stored skinning transforms.  joints24_dev (B,24,3).
  * (dead on the hot path: every caller of the reference reads `.vertices` only).        */
 int jrr_smpl_posed_joints(jrr_engine_t* e, const float* betas_dev, float* joints24_dev, void* stream);
+/* Its adjoint (smplx's `joints` are differentiable, scripts/smpl.py:69-84): djoints24_dev (B,24,3) -> the gradients w.r.t. the forward's
+ * inputs through the kinematic chain and the rest joints J(beta).  Exactly one of x6d_dev (B,24,6) / R_dev (B,24,3,3) names the rotation
+ * input of that forward; outputs dx6d_dev (B,24,6) or dR_dev (B,24,3,3), and dbetas_dev (B,10), nullable.  Must follow the forward
+ * like jrr_smpl_posed_joints.                                                                                          */
+int jrr_smpl_posed_joints_backward(jrr_engine_t* e, const float* x6d_dev, const float* R_dev, const float* betas_dev,
+                                   const float* djoints24_dev, float* dx6d_dev, float* dR_dev, float* dbetas_dev, void* stream);
 
 /* SMPL operator on its own: smpl(global_orient, body_pose, betas, pose2rot=False).vertices
  * (call sites scripts/utils.py:94-95, scripts/optimize.py:78-79, scripts/renderer.py:32-33).
@@ -361,6 +367,13 @@ int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t* fits_host
  * a silhouette term set, folded mode on, a model without the joint-sparse kernels).  No reference counterpart: the reference
  * multiplies all 6890 vertices by the (17,6890) regressor, zeros included (scripts/utils.py:87-92).                          */
 int jrr_engine_support_tiles(const jrr_engine_t* e, int32_t* n_tiles_host);
+/* ... and returns 1 when those iterations run per support VERTEX (*n_vertices_host = the vertices the regressor reads, nullable): the
+ * support then has at most 64 vertices, there is no 2-D term, and ONE launch per iteration takes a 32-pose group through chain
+ * forward, the SMPL forward of the support vertices, the joint loss (scripts/utils.py:87-114), its backward, the chain adjoint and
+ * Adam (scripts/optimize.py:220-265) -- preceded by the discriminator's four GEMM launches when it is on.  0: the tile lists above (or
+ * all tiles) run as separate launches.  Same numbers up to the order of the sums.  JRR_SUPPORT_FUSED=0 in the environment of
+ * jrr_j_support_info keeps the tile lists (verification).  No reference counterpart.                                              */
+int jrr_engine_support_vertices(const jrr_engine_t* e, int32_t* n_vertices_host);
 int jrr_j_regressor_grad_support(jrr_engine_t* e, const float* x6d_dev, const float* betas_dev, const float* gt_centred_mm_dev,
                                  float* dJs_dev, float* sqerr_dev, float* joints_dev, void* stream);
 int jrr_j_step_apply_support(jrr_engine_t* e, float* J_dev, const float* dJs_dev, float* m_dev, float* v_dev, int32_t* step_dev,

@@ -45,6 +45,7 @@ SIGNATURES = {
     'jrr_find_joints_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_smpl_vertices_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_smpl_posed_joints': (c_int, [_P, _P, _P, _P]),
+    'jrr_smpl_posed_joints_backward': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_find_joints_after_j_step': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_pose_disc_vjp_input': (c_int, [_P, _P, _P, _P, _P]),
     'jrr_joint_loss': (c_int, [_P, _P, c_float, c_int, c_int, _P, _P, _P]),
@@ -72,6 +73,7 @@ SIGNATURES = {
     'jrr_j_step_apply': (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     'jrr_j_support_info': (c_int, [_P, POINTER(c_int32), POINTER(c_int32), _P]),
     'jrr_engine_support_tiles': (c_int, [_P, POINTER(c_int32)]),
+    'jrr_engine_support_vertices': (c_int, [_P, POINTER(c_int32)]),
     'jrr_j_regressor_grad_support': (c_int, [_P, _P, _P, _P, _P, _P, _P, _P]),
     'jrr_j_step_apply_support': (c_int, [_P, _P, _P, _P, _P, _P, c_float, _P, _P]),
     'jrr_refine_run_after_j_step': (c_int, [_P, _P, _P, _P, _P, _P, _P, c_float, c_int, _P, _P]),

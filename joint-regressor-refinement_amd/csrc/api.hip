@@ -21,7 +21,7 @@ void jrr_set_error(const char* fmt, ...) {
   va_end(ap);
 }
 extern "C" const char* jrr_last_error(void) { return g_err; }
-extern "C" int jrr_version(void) { return 105; }      // 100 + round: entry points were added in rounds 2-5, none changed or removed
+extern "C" int jrr_version(void) { return 106; }      // 100 + round: entry points were added in rounds 2-6, none changed or removed
 
 #define CHECK_LAUNCH()                                                            \
   do {                                                                            \
@@ -1010,6 +1010,27 @@ extern "C" int jrr_smpl_posed_joints(jrr_engine_t* e, const float* betas, float*
   return JRR_OK;
 }
 
+// adjoint of jrr_smpl_posed_joints through the kinematic chain (the chain forward's F^T / A^T of the most recent forward are reused)
+extern "C" int jrr_smpl_posed_joints_backward(jrr_engine_t* e, const float* x6d, const float* R, const float* betas, const float* djoints24,
+                                              float* dx6d, float* dR, float* dbetas, void* stream) {
+  if (!e || !betas || !djoints24 || ((x6d == nullptr) == (R == nullptr))) { jrr_set_error("smpl_posed_joints_backward: bad argument"); return JRR_ERR_ARG; }
+  if (e->flags & JRR_FLAG_NO_MODEL) { jrr_set_error("smpl_posed_joints_backward: engine created without a body model"); return JRR_ERR_STATE; }
+  hipStream_t s = (hipStream_t)stream;
+  e->fwd_cached = false;
+  launch_posed_joints_bwd(e->m, e->AT, betas, djoints24, e->dA, e->dbT, e->B, e->BP, s);
+  JRR_HIP(hipMemsetAsync(e->dF, 0, (size_t)KFP * e->BP * sizeof(float), s));      // the posed joints do not read the blend features
+  PrepBwdLaunch L;
+  L.x6d_in = x6d; L.R_in = R; L.betas_in = betas;
+  L.dATp = e->dA; L.nslabA = 1; L.strideA = (size_t)12 * NJ * e->BP; L.dFTp = e->dF; L.dmaskA = nullptr;
+  L.FT = e->FT; L.R0T = e->R0T; L.AT = e->AT; L.dRT = e->dRT; L.dbT = e->dbT;
+  L.gb_extra = e->dbT;                                                             // (B,10): the direct term through J_j(beta)
+  L.dx6d = dx6d; L.dR = dR; L.dbetas = dbetas;
+  L.B = e->B; L.BP = e->BP;
+  launch_prep_bwd(L, e->m, s);
+  CHECK_LAUNCH();
+  return JRR_OK;
+}
+
 extern "C" int jrr_joint_loss(const float* joints, const float* gt_mm, float weight, int batch, int batch_norm,
                               float* sqerr, float* djoints, void* stream) {
   if (!joints || !gt_mm || batch <= 0 || batch_norm <= 0) return JRR_ERR_ARG;
@@ -1791,6 +1812,13 @@ extern "C" int jrr_engine_support_tiles(const jrr_engine_t* e, int32_t* n_tiles_
   if (!e) return JRR_ERR_ARG;
   const bool on = use_tile_list(e);
   if (n_tiles_host) *n_tiles_host = on ? e->nact : VT;
+  return on ? 1 : 0;
+}
+
+extern "C" int jrr_engine_support_vertices(const jrr_engine_t* e, int32_t* n_vertices_host) {
+  if (!e) return JRR_ERR_ARG;
+  const bool on = use_sup_vertices(e);
+  if (n_vertices_host) *n_vertices_host = on ? e->sup_nsv : 0;
   return on ? 1 : 0;
 }
 

@@ -61,12 +61,15 @@ __device__ __forceinline__ float conv_head(const float* __restrict__ L, int j, i
 
 // Workgroup `blk` of (BP / 32) * (24 / W) workgroups of W waves (W = blockDim.x / 64: 4 stand-alone, 12 inside the fused
 // launches): wave w owns poses [32 bt, +32) and joint W * group + w.  L = the workgroup's LDS image (CL_FLOATS floats).
-template <bool QUAD>
+// STAGED: the image already sits in L (a second call of the composed kernel k_sup_step on the same pool)
+template <bool QUAD, bool STAGED = false>
 __device__ __forceinline__ void dconv_fwd_body(float* __restrict__ L, int blk, const float* __restrict__ img,
                                                const float* __restrict__ x6d, float* __restrict__ H2T,
                                                float* __restrict__ out, int B, int BP) {
-  conv_stage_params(img, L);
-  __syncthreads();
+  if (!STAGED) {
+    conv_stage_params(img, L);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
   const int W = blockDim.x >> 6, ngrp = NJ / W;
   const int bt = blk / ngrp, j = (blk % ngrp) * W + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -94,13 +97,15 @@ __device__ __forceinline__ void dconv_fwd_body(float* __restrict__ L, int blk, c
 }
 
 // input gradient of the per-joint MLP + heads; dH2T = gradient arriving from fc0 (may be NULL), gout (B,25) nullable
-template <bool QUAD>
+template <bool QUAD, bool STAGED = false>
 __device__ __forceinline__ void dconv_bwd_body(float* __restrict__ L, int blk, const float* __restrict__ img,
                                                const float* __restrict__ x6d, const float* __restrict__ dH2T,
                                                const float* __restrict__ gout, float scale, float target,
                                                float* __restrict__ gx, int B, int BP, float* __restrict__ sqj) {
-  conv_stage_params(img, L);
-  __syncthreads();
+  if (!STAGED) {
+    conv_stage_params(img, L);
+    __syncthreads();
+  }
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
   const int W = blockDim.x >> 6, ngrp = NJ / W;
   const int bt = blk / ngrp, j = (blk % ngrp) * W + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

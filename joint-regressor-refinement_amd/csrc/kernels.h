@@ -59,6 +59,9 @@ int launch_rodrigues_bwd(const float* aa, const float* dR, float* daa, int n, hi
 int launch_prep_fwd(const Model& m, const float* x6d, const float* Rin, const float* betas, float* FT, float* FTq, float* AT,
                     float* R0T, int B, int BP, int32_t* step_inc, hipStream_t s);
 int launch_posed_joints(const Model& m, const float* AT, const float* betas, float* out, int B, int BP, hipStream_t s);
+// its adjoint: dj24 (B,24,3) -> dA^T [288][BP] (one slab) and the direct shape term gb (B,10)
+int launch_posed_joints_bwd(const Model& m, const float* AT, const float* betas, const float* dj24, float* dA, float* gb, int B, int BP,
+                            hipStream_t s);
 // horizontally fused launches of the inner loop (prep.hip): chain forward || per-joint MLP forward, and
 // per-joint MLP adjoint || dF^T slab sum
 int launch_prep_fwd_dconv(const Model& m, const float* x6d, const float* betas, float* FT, float* FTq, float* AT, float* R0T, int B,

@@ -898,7 +898,9 @@ __global__ __launch_bounds__(256, NG == 2 ? 1 : 2) void k_lbs_bwd16(const float*
                                                       float* __restrict__ dATp, int BP, int nvc, int n_bt,
                                                       const int* __restrict__ segid, const int* __restrict__ segj, int paired,
                                                       const int* __restrict__ tnj, const int* __restrict__ tl, int ntl,
-                                                      unsigned* __restrict__ dmask) {
+                                                      unsigned* __restrict__ dmask, int rev) {
+  // rev (experiment, JRR_BWD16_REV=1; DESIGN.md section 8 "stage B"): walk the chunk's tiles from the LAST to the first -- the tiles
+  // k_lbs_fwd wrote last are then read first, while they may still sit in the 256 MB Infinity Cache
   // dmask (nullable): [chunk][64-pose group] bit j = this workgroup wrote the rows of joint j of its dA slab.  The rows of the joints
   // no tile of the chunk touches are then NOT zero-filled (and not read: k_chain_bwd takes the mask) -- at 4096 poses the eight slabs
   // are 37.7 MB, about half of it rows of zeros (timing-only ablation of flush + fill: 18 us of the launch).
@@ -949,7 +951,7 @@ __global__ __launch_bounds__(256, NG == 2 ? 1 : 2) void k_lbs_bwd16(const float*
       if (o < R16_PIECES) dma16u(src + o * 256, lane_ln, dst + o * 256);
     }
   };
-  auto tile_of = [&](int ix) { return LIST ? tl[ix] : ix; };      // wave-uniform (scalar load)
+  auto tile_of = [&](int ix) { const int k = rev ? t_begin + t_end - 1 - ix : ix; return LIST ? tl[k] : k; };      // wave-uniform (scalar load)
   if (t_begin < t_end) issue(tile_of(t_begin), 0);
   if (t_begin + 1 < t_end) issue(tile_of(t_begin + 1), 1);
 
@@ -1671,30 +1673,31 @@ int launch_lbs_bwd(const Model& m, const float* Tb, const float* AT, const float
     // tiles take ~12 300 clocks, its partner's ~14 000 while both run and 7 400 once it is alone), 0 = no
     // pairing, -2 = chunk-major mapping without pairing
     static const int pair_env = [] { const char* e = getenv("JRR_BWD16_PAIRED"); return e ? atoi(e) : 540; }();
+    static const int rev16 = [] { const char* e = getenv("JRR_BWD16_REV"); return (e && e[0] == '1') ? 1 : 0; }();
     const int paired16 = ng == 2 ? 0 : (pair_env > 0) ? ((grid16.x == 512 && (nvc & 1) == 0 && (32 % (nvc / 2)) == 0) ? pair_env : 0) : pair_env;
 #define JRR_LBS_BWD16_K(DVM, KJV, WD)                                                                                           \
   do {                                                                                                                          \
     if constexpr (DVM == 0 && !WD) {                                                                                            \
       if (ng == 2) {                                                                                                            \
         hipLaunchKernelGGL((k_lbs_bwd16<0, 8, false, false, 2>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, \
-                           m.segid, m.segj, paired16, m.tnj, nullptr, 0, dmask);                                                \
+                           m.segid, m.segj, paired16, m.tnj, nullptr, 0, dmask, rev16);                                                \
         break;                                                                                                                  \
       }                                                                                                                         \
     }                                                                                                                           \
     hipLaunchKernelGGL((k_lbs_bwd16<DVM, KJV, WD, false, 1>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, \
-                       m.segid, m.segj, paired16, m.tnj, nullptr, 0, dmask);                                                    \
+                       m.segid, m.segj, paired16, m.tnj, nullptr, 0, dmask, rev16);                                                    \
   } while (0)
 #define JRR_LBS_BWD16_L(KJV, WD)                                                                                                \
   do {                                                                                                                          \
     if constexpr (!WD) {                                                                                                        \
       if (ng == 2) {                                                                                                            \
         hipLaunchKernelGGL((k_lbs_bwd16<0, 8, false, true, 2>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, \
-                           m.segid, m.segj, paired16, m.tnj, tl, ntl, dmask);                                                   \
+                           m.segid, m.segj, paired16, m.tnj, tl, ntl, dmask, rev16);                                                   \
         break;                                                                                                                  \
       }                                                                                                                         \
     }                                                                                                                           \
     hipLaunchKernelGGL((k_lbs_bwd16<0, KJV, WD, true, 1>), grid16, block16, 0, s, Tb, AT, VPb, dJT, dVT, DVP, dATp, BP, nvc, n_bt16, \
-                       m.segid, m.segj, paired16, m.tnj, tl, ntl, dmask);                                                       \
+                       m.segid, m.segj, paired16, m.tnj, tl, ntl, dmask, rev16);                                                       \
   } while (0)
 #define JRR_LBS_BWD16(DVM)                                                                                                      \
   do {                                                                                                                          \

@@ -6,6 +6,8 @@
 //   rigid chain / A matrices   smplx 0.1.26 lbs.batch_rigid_transform
 //   move_pelvis + MSELoss      scripts/utils.py:106-114, scripts/optimize.py:238-239
 //   Adam                       torch.optim.Adam defaults, scripts/optimize.py:201-202,263-265
+#include <cstdlib>
+
 #include "jrr_common.h"
 #include "kernels.h"
 #include "dconv.h"
@@ -353,6 +355,46 @@ __global__ __launch_bounds__(256) void k_posed_joints(const float* __restrict__ 
     for (int c = 0; c < 3; ++c) acc = fmaf(AT[(size_t)((r * 4 + c) * NJ + j) * BP + b], J[c], acc);
     out[((size_t)b * NJ + j) * 3 + r] = acc;
   }
+}
+// Adjoint of k_posed_joints: joints24[b][j][r] = A_{r,3}[j] + sum_c A_{r,c}[j] J_j(beta)[c]  ->  the skinning-transform adjoint dA^T
+// [288][BP] (ONE slab for k_chain_bwd) and the direct shape term through the rest joints, gb (B,10) = sum_{j,c} (sum_r A_{r,c}[j] dj_r) JS
+// (k_chain_bwd's gb_extra).  One thread per pose (a surface path: smpl(...).joints of scripts/smpl.py:69-84 is read by no caller).
+__global__ __launch_bounds__(256) void k_posed_joints_bwd(const float* __restrict__ AT, const float* __restrict__ betas,
+                                                          const float* __restrict__ Jt, const float* __restrict__ JS,
+                                                          const float* __restrict__ dj24, float* __restrict__ dA,
+                                                          float* __restrict__ gb, int B, int BP) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  float beta[NB], g[NB];
+#pragma unroll
+  for (int l = 0; l < NB; ++l) { beta[l] = betas[(size_t)b * NB + l]; g[l] = 0.f; }
+  for (int j = 0; j < NJ; ++j) {
+    float J[3], d[3];
+    rest_joint(Jt, JS, j, beta, J);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) d[r] = dj24[((size_t)b * NJ + j) * 3 + r];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+#pragma unroll
+      for (int c = 0; c < 3; ++c) dA[(size_t)((r * 4 + c) * NJ + j) * BP + b] = d[r] * J[c];
+      dA[(size_t)((r * 4 + 3) * NJ + j) * BP + b] = d[r];
+    }
+#pragma unroll
+    for (int c = 0; c < 3; ++c) {
+      float dJ = 0.f;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) dJ = fmaf(AT[(size_t)((r * 4 + c) * NJ + j) * BP + b], d[r], dJ);
+#pragma unroll
+      for (int l = 0; l < NB; ++l) g[l] = fmaf(dJ, JS[(j * 3 + c) * NB + l], g[l]);
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < NB; ++l) gb[(size_t)b * NB + l] = g[l];
+}
+int launch_posed_joints_bwd(const Model& m, const float* AT, const float* betas, const float* dj24, float* dA, float* gb, int B, int BP,
+                            hipStream_t s) {
+  hipLaunchKernelGGL(k_posed_joints_bwd, dim3((B + 255) / 256), dim3(256), 0, s, AT, betas, m.Jt, m.JS, dj24, dA, gb, B, BP);
+  return 0;
 }
 int launch_posed_joints(const Model& m, const float* AT, const float* betas, float* out, int B, int BP, hipStream_t s) {
   hipLaunchKernelGGL(k_posed_joints, dim3((B * NJ + 255) / 256), dim3(256), 0, s, AT, betas, m.Jt, m.JS, out, B, BP);
@@ -990,6 +1032,7 @@ struct SupStepArgs {
   const float* dH2T; float dscale; float* gx; float* dsq; float* H2T_next;
   PoseUpdateArgs ua;
   int32_t* step; int* arrive;
+  long long* stamps;         // experiments (tools/exp/sup_stamps.py): phase boundaries of workgroup 0 on the 100 MHz counter, NULL otherwise
 };
 constexpr int SUP_STEP_LDS = SUPL_FLOATS > CHAIN_BWD_LDS ? (SUPL_FLOATS > PREP_FWD_LDS ? SUPL_FLOATS : PREP_FWD_LDS)
                                                          : (CHAIN_BWD_LDS > PREP_FWD_LDS ? CHAIN_BWD_LDS : PREP_FWD_LDS);
@@ -998,6 +1041,8 @@ __global__ __launch_bounds__(SUP_THREADS) void k_sup_step(SupStepArgs a, const f
                                                           Parents par) {
   extern __shared__ __attribute__((aligned(16))) float pool[];
   const int blk = blockIdx.x, B = a.sup.B, BP = a.sup.BP;
+  auto stamp = [&](int i) { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = wall_clock64(); };
+  stamp(0);
   int step_now = -1;
   if (threadIdx.x == 0 && a.step) {
     const int s0 = __hip_atomic_load(a.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1011,21 +1056,27 @@ __global__ __launch_bounds__(SUP_THREADS) void k_sup_step(SupStepArgs a, const f
   }
   prep_fwd_body(blk, a.x6d, nullptr, a.betas, Jt, JS, par, a.FT, a.AT, a.R0T, B, BP, nullptr, a.FTq, pool);
   __syncthreads();
-  sup_body(pool, blk, a.sup);
+  stamp(1);
+  sup_body(pool, blk, a.sup, a.stamps && blockIdx.x == 0 ? a.stamps + 8 : nullptr);
   __syncthreads();
+  stamp(2);
   if (a.conv_img) {      // both halves of the joints: wave w takes joint w, then joint 12 + w
+    // (the image is staged once; nothing else touches the pool between the two calls, and the second needs no barrier before it:
+    // both only read the image)
     dconv_bwd_body<true>(pool, 2 * blk, a.conv_img, a.x6d, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
-    __syncthreads();
-    dconv_bwd_body<true>(pool, 2 * blk + 1, a.conv_img, a.x6d, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
+    dconv_bwd_body<true, true>(pool, 2 * blk + 1, a.conv_img, a.x6d, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
     __syncthreads();
   }
+  stamp(3);
   chain_bwd_body(blk, a.FT, a.R0T, a.AT, Jt, JS, par, a.sup.dA, 1, 0, a.sup.dF, a.ua, B, BP, nullptr, pool, step_now);
   if (a.conv_img && a.H2T_next) {      // the updated poses of this group are complete: their per-joint MLP forward for the next iteration
     __syncthreads();
+    stamp(4);
     dconv_fwd_body<true>(pool, 2 * blk, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
-    __syncthreads();
-    dconv_fwd_body<true>(pool, 2 * blk + 1, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
+    dconv_fwd_body<true, true>(pool, 2 * blk + 1, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
   }
+  __syncthreads();
+  stamp(5);
 }
 
 int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s) {
@@ -1044,6 +1095,8 @@ int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch&
   u.lr = L.lr; u.beta1 = L.beta1; u.beta2 = L.beta2; u.eps = L.eps;
   u.gcam = nullptr; u.cam_io = nullptr; u.cam_m = nullptr; u.cam_v = nullptr;
   a.step = q.step; a.arrive = q.arrive;
+  static long long* const stamps = [] { const char* v = getenv("JRR_SUP_STAMPS"); return v ? (long long*)strtoull(v, nullptr, 0) : (long long*)nullptr; }();
+  a.stamps = stamps;
   hipLaunchKernelGGL(k_sup_step, dim3((L.B + SUP_PP - 1) / SUP_PP), dim3(SUP_THREADS), SUP_STEP_LDS * 4, s, a, m.Jt, m.JS, m.parents);
   return 0;
 }

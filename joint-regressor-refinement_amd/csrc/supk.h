@@ -45,7 +45,8 @@ constexpr int SUPL_JN = SUPL_V + SUP_ROWS * 32;         // [17][64]    regressor
 constexpr int SUPL_RED = SUPL_JN + NH * SUP_JS;         // [17][4][32] per-joint loss partials
 constexpr int SUPL_PEL = SUPL_RED + NH * 4 * 32;        // [3][32]
 constexpr int SUPL_DJ = SUPL_PEL + 3 * 32;              // [3][17][32] joint adjoint
-constexpr int SUPL_FLOATS = SUPL_DJ + 3 * NH * 32;
+constexpr int SUPL_MASK = SUPL_DJ + 3 * NH * 32;        // [17][2] row masks + [64] column masks of the regressor's non-zeros (32-bit words)
+constexpr int SUPL_FLOATS = SUPL_MASK + 2 * 32 + SUP_NSV;
 static_assert(SUPL_FLOATS * 4 <= 160 * 1024, "LDS image of the support iteration");
 
 struct SupArgs {
@@ -62,7 +63,9 @@ struct SupArgs {
   int B, BP;
 };
 
-__device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const SupArgs& a) {
+// stamps (nullable; experiments): phase boundaries on the 100 MHz counter, written by thread 0
+__device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const SupArgs& a, long long* stamps = nullptr) {
+  auto stamp = [&](int i) { if (stamps && threadIdx.x == 0) stamps[i] = wall_clock64(); };
   const int tid = threadIdx.x, lane = tid & 63, half = lane >> 5, l31 = lane & 31;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int p = tid & 31, jt = tid >> 5;               // pose column; SMPL joint / vertex slot / H36M joint of this thread
@@ -77,6 +80,8 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
   float* const red = lds + SUPL_RED;
   float* const pel = lds + SUPL_PEL;
   float* const djL = lds + SUPL_DJ;
+  unsigned* const rowm = reinterpret_cast<unsigned*>(lds + SUPL_MASK);      // rowm[2 i], rowm[2 i + 1]: support vertices 0..31 / 32..63 of joint i
+  unsigned* const colm = rowm + 2 * 32;                                     // colm[s]: the H36M joints that read support vertex s
 
   // ---- the pose group's operands -> LDS ----
   {
@@ -94,6 +99,7 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
     JnS[i] = s < nsv ? a.Jn_vi[(size_t)a.t.rows[s] * 32 + ii] : 0.f;
   }
   __syncthreads();
+  stamp(0);
 
   // ---- v_posed = Ds . F : wave w < 6 owns row tile w; two accumulator chains (even / odd K groups), added at the end ----
   if (wv < SUP_RT) {
@@ -112,8 +118,21 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) vpL[(32 * wv + acc_row(r, half)) * 32 + l31] = acc0[r] + acc1[r];
+  } else {
+    // the waves without a row tile: where the regressor's support columns are non-zero (62 of 17 x 58 entries with the H36M
+    // regressor), as bit masks -- the joints and the vertex adjoint then visit those entries only, in the same ascending order
+    for (int i = wv - SUP_RT; i < NH; i += SUP_THREADS / 64 - SUP_RT) {
+      const unsigned long long m = __ballot(JnS[i * SUP_JS + lane] != 0.f);
+      if (lane == 0) { rowm[2 * i] = (unsigned)m; rowm[2 * i + 1] = (unsigned)(m >> 32); }
+    }
+    if (wv == SUP_THREADS / 64 - 1) {
+      unsigned m = 0u;
+      for (int i = 0; i < NH; ++i) m |= (JnS[i * SUP_JS + lane] != 0.f ? 1u : 0u) << i;
+      colm[lane] = m;
+    }
   }
   __syncthreads();
+  stamp(1);
 
   // ---- skinning: T = sum_j W[v,j] A_j over the vertex's own joints, verts = T [v_posed; 1] ----
   for (int s = jt; s < nsv; s += NJ) {
@@ -132,14 +151,21 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
     for (int r = 0; r < 3; ++r) vL[(3 * s + r) * 32 + p] = fmaf(T[r * 4 + 2], vz, fmaf(T[r * 4 + 1], vy, fmaf(T[r * 4], vx, T[r * 4 + 3])));
   }
   __syncthreads();
+  stamp(2);
 
   // ---- joints (ascending vertex row), pelvis-centred squared error and its adjoint (k_joints_loss, prep.hip) ----
   float j3[3] = {0.f, 0.f, 0.f}, g3[3] = {0.f, 0.f, 0.f};
   if (jt < NH) {
-    for (int s = 0; s < nsv; ++s) {
-      const float w = JnS[jt * SUP_JS + s];
 #pragma unroll
-      for (int c = 0; c < 3; ++c) j3[c] = fmaf(w, vL[(3 * s + c) * 32 + p], j3[c]);
+    for (int h = 0; h < 2; ++h) {
+      unsigned m = rowm[2 * jt + h];
+      while (m) {
+        const int s = 32 * h + __builtin_ctz(m);
+        m &= m - 1u;
+        const float w = JnS[jt * SUP_JS + s];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) j3[c] = fmaf(w, vL[(3 * s + c) * 32 + p], j3[c]);
+      }
     }
     if (a.joints_out && ok) {
 #pragma unroll
@@ -175,13 +201,15 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
     for (int c = 0; c < 3; ++c) djL[(c * NH + jt) * 32 + p] = ok ? g3[c] : 0.f;
   }
   __syncthreads();
+  stamp(3);
 
   // ---- vertex adjoint dverts = Jn^T dj, dvp = T^T dverts (T recomputed) ----
   float* const dvL = Fq;       // [192][32]
   float* const dvq = vL;       // row quads [48][32][4]
   for (int s = jt; s < nsv; s += NJ) {
     float dv[3] = {0.f, 0.f, 0.f};
-    for (int i = 0; i < NH; ++i) {
+    for (unsigned m = colm[s]; m; m &= m - 1u) {
+      const int i = __builtin_ctz(m);
       const float w = JnS[i * SUP_JS + s];
 #pragma unroll
       for (int r = 0; r < 3; ++r) dv[r] = fmaf(w, djL[(r * NH + i) * 32 + p], dv[r]);
@@ -210,6 +238,7 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
     dvq[((rho >> 2) * 32 + (i & 31)) * 4 + (rho & 3)] = 0.f;
   }
   __syncthreads();
+  stamp(4);
 
   // ---- dA_j = sum_v W[v,j] dverts_v (x) [v_posed_v; 1]: one thread per (pose, joint), the joint's vertices in ascending order ----
   {
@@ -233,6 +262,7 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
 #pragma unroll
     for (int e = 0; e < 12; ++e) a.dA[(size_t)(e * NJ + jt) * BP + b] = acc[e];
   }
+  stamp(5);
 
   // ---- dF = Ds^T . dvp : wave w < 7 owns feature tile w ----
   if (wv < SUP_MT) {

@@ -294,6 +294,17 @@ class RefineEngine:
         check(self.lib.jrr_smpl_posed_joints(self.handle, ptr(betas), ptr(out), self._s()), 'smpl_posed_joints')
         return out
 
+    def posed_joints_backward(self, betas, djoints24, x6d=None, R=None):
+        """adjoint of posed_joints: (B,24,3) -> (dx6d or dR, dbetas) through the kinematic chain of the most recent forward"""
+        B = self.batch
+        self._chk(djoints24, (B, NUM_JOINTS, 3), 'djoints24')
+        dx = torch.empty(B, NUM_JOINTS, 6, device=self.device) if x6d is not None else None
+        dR = torch.empty(B, NUM_JOINTS, 3, 3, device=self.device) if R is not None else None
+        db = torch.empty(B, NUM_BETAS, device=self.device)
+        check(self.lib.jrr_smpl_posed_joints_backward(self.handle, ptr(x6d), ptr(R), ptr(betas), ptr(djoints24), ptr(dx), ptr(dR),
+                                                      ptr(db), self._s()), 'smpl_posed_joints_backward')
+        return (dx if x6d is not None else dR), db
+
     def smpl_vertices_backward(self, betas, dverts, x6d=None, R=None):
         B = self.batch
         self._chk(dverts, (B, NUM_VERTS, 3), 'dverts')
@@ -461,6 +472,15 @@ class RefineEngine:
         rc = self.lib.jrr_engine_support_tiles(self.handle, byref(n))
         if rc < 0:
             check(rc, 'support_tiles')
+        return bool(rc), int(n.value)
+
+    def support_vertices(self):
+        """(active, n_vertices): whether those iterations run per support VERTEX, one launch per iteration and 32-pose group
+        (include/jrr.h jrr_engine_support_vertices: the support has at most 64 vertices, no 2-D term), and on how many vertices"""
+        n = c_int32(0)
+        rc = self.lib.jrr_engine_support_vertices(self.handle, byref(n))
+        if rc < 0:
+            check(rc, 'support_vertices')
         return bool(rc), int(n.value)
 
     def j_regressor_grad_support(self, x6d, betas, gt_centred_mm, out, sqerr=None, joints=None):

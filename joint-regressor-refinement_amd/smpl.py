@@ -7,7 +7,8 @@ Mirrors the wrapper the reference constructs as `SMPL("SPIN/data/smpl", batch_si
 is consumed on this path.  `.vertices` is differentiable w.r.t. all three inputs (analytic adjoint kernels).
 `.joints` (dead on the path: no caller of the reference reads it) holds the 24 posed joints of the kinematic chain
 (jrr_smpl_posed_joints) and -- when the wrapper's `J_regressor_extra.npy` is found -- the reference's 49 re-mapped joints
-(scripts/smpl.py:61-84); it is not differentiated.
+(scripts/smpl.py:61-84); like smplx's it is differentiable w.r.t. all three inputs: the posed joints through the chain adjoint
+(jrr_smpl_posed_joints_backward), the vertex-derived joints through `.vertices`.
 """
 from __future__ import annotations
 
@@ -56,6 +57,28 @@ class _SMPLVerticesFn(torch.autograd.Function):
             eng.find_joints_forward(betas, R=R)
             ctx.gen = eng.generation
         dR, db = eng.smpl_vertices_backward(betas, dverts.contiguous(), R=R)
+        return dR, db, None
+
+
+class _PosedJointsFn(torch.autograd.Function):
+    """the 24 posed joints of the forward `_SMPLVerticesFn` has just run on `eng` (same R, betas)"""
+
+    @staticmethod
+    def forward(ctx, R, betas, eng):
+        R, betas = R.detach().contiguous(), betas.detach().contiguous()
+        joints = eng.posed_joints(betas)
+        ctx.eng, ctx.gen = eng, eng.generation
+        ctx.save_for_backward(R, betas)
+        return joints
+
+    @staticmethod
+    def backward(ctx, dj):
+        R, betas = ctx.saved_tensors
+        eng = ctx.eng
+        if eng.generation != ctx.gen:          # engine state overwritten by a later forward: re-run this one
+            eng.find_joints_forward(betas, R=R)
+            ctx.gen = eng.generation
+        dR, db = eng.posed_joints_backward(betas, dj.contiguous(), R=R)
         return dR, db, None
 
 
@@ -136,9 +159,8 @@ class SMPL:
             R = torch.cat([global_orient.reshape(B, 1, 3, 3), body_pose.reshape(B, 23, 3, 3)], dim=1).float()
         eng = self.engine(B)
         verts = _SMPLVerticesFn.apply(R, betas.float(), eng)
-        joints = eng.posed_joints(betas.detach().float().contiguous())      # the chain's 24 posed joints of THIS forward
+        joints = _PosedJointsFn.apply(R, betas.float(), eng)                 # the chain's 24 posed joints of THIS forward
         if self.J_regressor_extra is not None:                               # scripts/smpl.py:75-78
-            v = verts.detach()
-            extra = torch.einsum('jv,bvc->bjc', self.J_regressor_extra.to(v.device), v)
-            joints = torch.cat([joints, v[:, list(SMPL_VERTEX_JOINTS)], extra], dim=1)[:, list(JOINT_MAP_49)]
+            extra = torch.einsum('jv,bvc->bjc', self.J_regressor_extra.to(verts.device), verts)
+            joints = torch.cat([joints, verts[:, list(SMPL_VERTEX_JOINTS)], extra], dim=1)[:, list(JOINT_MAP_49)]
         return SMPLOutput(verts, global_orient, body_pose, betas, joints)

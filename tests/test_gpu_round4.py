@@ -131,18 +131,18 @@ def test_j_step_gradient_vs_oracle(variant):
     assert torch.equal(dJ.cpu() != 0, dJ_ref != 0)
 
 
-def _near_zero_gradient_entries(records, k_ulp=64):
-    """(B,144) mask of the pose entries whose ORACLE gradient was within `k_ulp` units in the last place of zero -- relative to the largest
-    entry of that iteration's gradient, the magnitude of the terms a gradient entry is a sum of -- in any recorded iteration.  Adam's
-    update is lr * m_hat / (sqrt(v_hat) + eps): while every gradient an entry has seen is at rounding level, the update is decided by
-    rounding (a sign flip of a ~1e-8 gradient moves the parameter by up to 2 lr), whatever the order of the sums.  Everywhere else a
-    rounding difference of the gradient changes the update by ~1e-7 of a step."""
+def _rounding_dominated_entries(records32, records64, rel=5e-3):
+    """(B,144) mask of the pose entries whose fp32 ORACLE gradient is dominated by rounding: it differs from the float64 oracle's gradient of
+    the same iteration by more than `rel` of its value (a sum of large terms that cancel to ~0; the two oracle trajectories themselves
+    differ by ~1e-7 over three iterations, far below `rel`).  Adam's update is lr * m_hat / (sqrt(v_hat) + eps): a gradient entry known to
+    a few per cent moves the parameter by a few per cent of a step -- 7.7e-4 was one such entry when round 5 changed a summation order --
+    whatever the order of the sums; every other entry sees a rounding difference as ~1e-7 of a step."""
     mask = None
-    for r in records:
-        g = torch.cat([r['g_orient'], r['g_pose']], 1).reshape(r['g_pose'].shape[0], -1)
-        thr = k_ulp * 2.0 ** -23 * g.abs().max().item()
-        near = g.abs() < thr
-        mask = near if mask is None else (mask | near)
+    for r32, r64 in zip(records32, records64):
+        g32 = torch.cat([r32['g_orient'], r32['g_pose']], 1).reshape(r32['g_pose'].shape[0], -1).double()
+        g64 = torch.cat([r64['g_orient'], r64['g_pose']], 1).reshape(r64['g_pose'].shape[0], -1)
+        bad = (g32 - g64).abs() > rel * g64.abs()
+        mask = bad if mask is None else (mask | bad)
     return mask
 
 
@@ -154,9 +154,12 @@ def test_three_iterations_with_pose_discriminator_vs_oracle(variant):
     gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
     dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
     smpl = oracle.OracleSMPL(v['model'])
-    records = []
+    records, records64 = [], []
     o, p, b_, _ = oracle.refine_poses(smpl, T(v['J']), x6[:, :1], x6[:, 1:], betas, gt_c, 3, disc_sd=dsd,
                                       record=lambda it, r: records.append(r))
+    oracle.refine_poses(oracle.OracleSMPL(v['model'], dtype=torch.float64), T(v['J']).double(), x6[:, :1].double(), x6[:, 1:].double(),
+                        betas.double(), gt_c.double(), 3, disc_sd={k: t.double() for k, t in dsd.items()},
+                        record=lambda it, r: records64.append(r))
     em = v['eng_mod']
     eng = em.RefineEngine(v['dm'], B, flags=em.FLAG_POSE_DISC)
     eng.set_j_regressor(T(v['J']))
@@ -166,11 +169,12 @@ def test_three_iterations_with_pose_discriminator_vs_oracle(variant):
     eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, vv, step, 1e-2, 3)
     d = (xd.cpu() - torch.cat([o, p], 1)).abs().reshape(B, -1)
     # Adam's first steps are lr * g / (|g| + eps): last-bit differences of the summation order are amplified wherever a gradient
-    # entry is ~ 0.  Those entries are identified EXPLICITLY from the oracle's own gradients (round 6; round 5
-    # had widened the maximum for every entry when the planner's split-K slab count changed a summation order): they keep the wide
-    # bound of a tenth of a first Adam step, every other entry the strict 6e-4, and the mean pins the trajectory.
-    near = _near_zero_gradient_entries(records)
-    assert near.float().mean().item() < 0.02, near.float().mean().item()         # a handful of entries, not a blanket
+    # entry is ~ 0.  Those entries are identified EXPLICITLY (round 6; round 5 had widened the maximum for every
+    # entry when the planner's split-K slab count changed a summation order): where the fp32 oracle's own gradient is off its float64
+    # twin by more than 0.5 %.  They keep the wide bound of a tenth of a first Adam step, every other entry the strict 6e-4, and the
+    # mean pins the trajectory.
+    near = _rounding_dominated_entries(records, records64)
+    assert near.float().mean().item() < 0.01, near.float().mean().item()         # a handful of entries, not a blanket
     strict = d[~near].max().item()
     worst = (d * (~near)).argmax().item()
     assert strict < 6e-4, (strict, worst, [torch.cat([r['g_orient'], r['g_pose']], 1).reshape(B, -1).flatten()[worst].item() for r in records])

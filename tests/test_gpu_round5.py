@@ -206,6 +206,52 @@ def test_smpl_output_joints(smpl_model_np, tmp_path):
     assert len(m) == 49 and m[8] == 0 and m[0] == 24 and m[27] == 45 and m[43] == 53 and m[44] == 24
 
 
+def test_smpl_output_joints_are_differentiable(smpl_model_np, tmp_path):
+    """smplx's `joints` are differentiable (/root/reference/scripts/smpl.py:69-84 passes them on): a loss on the 49 re-mapped joints AND the
+    vertices, back-propagated through the operator (axis-angle input, pose2rot=True: batch_rodrigues -> chain adjoint of the 24 posed
+    joints, jrr_smpl_posed_joints_backward, + the vertex adjoint for the vertex-derived joints), against the float64 oracle's autograd"""
+    smpl_mod = _mod('smpl')
+    B = 6
+    gen = torch.Generator().manual_seed(22)
+    aa = torch.randn(B, 24, 3, generator=gen) * 0.4
+    betas = torch.randn(B, 10, generator=gen)
+    rng = np.random.RandomState(4)
+    Jx = np.zeros((9, 6890), np.float32)
+    for r in range(9):
+        cols = rng.choice(6890, 12, replace=False)
+        Jx[r, cols] = rng.dirichlet(np.ones(12)).astype(np.float32)
+    path = str(tmp_path / 'J_regressor_extra.npy')
+    np.save(path, Jx)
+    wj = torch.randn(B, 49, 3, generator=gen)
+    wv = torch.randn(B, 6890, 3, generator=gen) * 0.01
+    # oracle, float64
+    a64, b64 = aa.double().requires_grad_(True), betas.double().requires_grad_(True)
+    R64 = oracle.rodrigues(a64.reshape(-1, 3)).view(B, 24, 3, 3)
+    ref = oracle.OracleSMPL(smpl_model_np, dtype=torch.float64)(R64[:, :1], R64[:, 1:], b64)
+    full = torch.cat([ref.joints, ref.vertices[:, list(smpl_mod.SMPL_VERTEX_JOINTS)], torch.einsum('jv,bvc->bjc', T(Jx).double(), ref.vertices)], 1)
+    ((full[:, list(smpl_mod.JOINT_MAP_49)] * wj.double()).sum() + (ref.vertices * wv.double()).sum()).backward()
+    # the operator
+    smpl = smpl_mod.SMPL(model=smpl_model_np, joint_regressor_extra=path).to(DEV)
+    ad, bd = aa.clone().to(DEV).requires_grad_(True), betas.clone().to(DEV).requires_grad_(True)
+    out = smpl(global_orient=ad[:, :1].reshape(B, 3), body_pose=ad[:, 1:].reshape(B, 69), betas=bd, pose2rot=True)
+    assert out.joints.requires_grad
+    ((out.joints * wj.to(DEV)).sum() + (out.vertices * wv.to(DEV)).sum()).backward()
+
+    def relerr(a, b):
+        return ((a.double().cpu() - b).abs().max() / b.abs().max()).item()
+    assert relerr(ad.grad, a64.grad) < 2e-4, relerr(ad.grad, a64.grad)
+    assert relerr(bd.grad, b64.grad) < 2e-4, relerr(bd.grad, b64.grad)
+    # the posed joints alone (no vertex path): the chain adjoint by itself
+    ad2, bd2 = aa.clone().to(DEV).requires_grad_(True), betas.clone().to(DEV).requires_grad_(True)
+    smpl24 = smpl_mod.SMPL(model=smpl_model_np).to(DEV)
+    o24 = smpl24(global_orient=ad2[:, :1].reshape(B, 3), body_pose=ad2[:, 1:].reshape(B, 69), betas=bd2, pose2rot=True)
+    (o24.joints * wj[:, :24].to(DEV)).sum().backward()
+    a3, b3 = aa.double().requires_grad_(True), betas.double().requires_grad_(True)
+    R3 = oracle.rodrigues(a3.reshape(-1, 3)).view(B, 24, 3, 3)
+    (oracle.OracleSMPL(smpl_model_np, dtype=torch.float64)(R3[:, :1], R3[:, 1:], b3).joints * wj[:, :24].double()).sum().backward()
+    assert relerr(ad2.grad, a3.grad) < 2e-4 and relerr(bd2.grad, b3.grad) < 2e-4
+
+
 def test_support_growing_behind_the_engines_back_is_reported(smpl_model_np, j_h36m_np):
     """The engine enqueues support-restricted J-step work only once jrr_j_support_info has said the support fits (J steps can only
     shrink it).  A caller that edits J IN PLACE afterwards -- new positive entries in tiles the engine does not run -- used to get

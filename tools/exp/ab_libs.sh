@@ -4,7 +4,7 @@
 # through JRR_LIB (honoured by _lib.load()): the in-tree library is never overwritten.
 TAG=$1; BF=$2; shift; shift
 mkdir -p gpurun_out/$TAG
-FLAGS="--no_cpu_baseline --no_folded --no_config5 --no_skin_variants --no_config2 --no_rccl_one_rank --no_support_tiles --no_driver_blocks --min_timed_ms 1200 $BF"
+FLAGS="--allow_experiment_lib --no_cpu_baseline --no_folded --no_config5 --no_skin_variants --no_config2 --no_rccl_one_rank --no_support_tiles --no_driver_blocks --min_timed_ms 1200 $BF"
 for round in 1 2; do
   for which in base "$@"; do
     if [ $which = base ]; then unset JRR_LIB; else export JRR_LIB=$PWD/tools/probe/libjrr_$which.so; fi

@@ -3,7 +3,7 @@
 # in-tree library untouched), printing the skin_variants block
 TAG=$1; shift
 mkdir -p gpurun_out/$TAG
-FLAGS="--no_cpu_baseline --no_folded --no_config5 --no_config2 --no_rccl_one_rank --no_support_tiles --no_driver_blocks --min_timed_ms 800"
+FLAGS="--allow_experiment_lib --no_cpu_baseline --no_folded --no_config5 --no_config2 --no_rccl_one_rank --no_support_tiles --no_driver_blocks --min_timed_ms 800"
 for round in 1 2; do
   for which in base "$@"; do
     if [ $which = base ]; then unset JRR_LIB; else export JRR_LIB=$PWD/tools/probe/libjrr_$which.so; fi

@@ -3,7 +3,9 @@
 
     python tools/exp/build_variant.py <name> <file.hip> 'old text' 'new text' ['old2' 'new2' ...]
 
--> tools/probe/libjrr_<name>.so (git-ignored, travels to the GPU box); tools/exp/ab_libs.sh times it against the in-tree build."""
+-> tools/probe/libjrr_<name>.so (git-ignored, travels to the GPU box); tools/exp/ab_libs.sh times it against the in-tree build
+(bench.py refuses JRR_LIB unless --allow_experiment_lib is given, and prints the library's hash and every JRR_* knob).  The variant's
+object is compiled into a scratch directory: nothing is written inside the package."""
 import os
 import shutil
 import subprocess
@@ -12,7 +14,6 @@ import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 PKG = os.path.join(ROOT, 'joint-regressor-refinement_amd')
-SOURCES = ['api.hip', 'prep.hip', 'lbs.hip', 'gemm.hip', 'disc.hip', 'eval.hip', 'fold.hip', 'sil.hip']
 
 
 def main():
@@ -31,12 +32,12 @@ def main():
         assert src.count(old) >= 1, f'pattern not found: {old[:60]!r}'
         src = src.replace(old, new)
     open(os.path.join(csrc, fname), 'w').write(src)
-    obj = os.path.join(PKG, 'build', fname.replace('.hip', f'.{name}.o'))
-    flags = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wno-unused-function']
-    subprocess.check_call(['/opt/rocm/bin/hipcc'] + flags + ['-c', os.path.join(csrc, fname), '-o', obj])
-    objs = [os.path.join(PKG, 'build', s.replace('.hip', '.o')) for s in SOURCES if s != fname] + [obj]
+    obj = os.path.join(tmp, fname.replace('.hip', f'.{name}.o'))          # scratch: the package's build/ holds the objects of SOURCES only
+    subprocess.check_call([_build._hipcc()] + _build.FLAGS + ['-c', os.path.join(csrc, fname), '-o', obj])
+    objs = [os.path.join(PKG, 'build', s.replace('.hip', '.o')) for s in _build.SOURCES if s != fname] + [obj]
     out = os.path.join(ROOT, 'tools', 'probe', f'libjrr_{name}.so')
-    subprocess.check_call(['/opt/rocm/bin/hipcc', '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out])
+    os.makedirs(os.path.dirname(out), exist_ok=True)
+    subprocess.check_call([_build._hipcc(), '--offload-arch=gfx950', '-shared', '-fPIC'] + objs + ['-o', out])
     shutil.rmtree(tmp)
     print(out)
 

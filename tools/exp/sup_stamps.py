@@ -1,0 +1,53 @@
+"""Phase stamps of the composed support-vertex kernel k_sup_step (prep.hip): workgroup 0's phase boundaries on the 100 MHz counter.
+usage: python tools/exp/sup_stamps.py [B] [pose_disc 0/1]"""
+import importlib
+import os
+import sys
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+PKG = 'joint-regressor-refinement_amd'
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+pd = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+dev = torch.device('cuda:0')
+stamps = torch.zeros(32, dtype=torch.int64, device=dev)
+os.environ['JRR_SUP_STAMPS'] = str(stamps.data_ptr())          # read once, at the first launch of the kernel
+sm = importlib.import_module(PKG + '.smpl_model')
+em = importlib.import_module(PKG + '.engine')
+model = sm.synthetic_smpl(1234)
+J_np = sm.default_h36m_regressor()
+batch = sm.synthetic_batch(model, J_np, B, seed=5)
+dm = em.DeviceModel(model, dev, hint_vertices=np.nonzero((J_np > 0).any(0))[0])
+eng = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS | em.FLAG_SUPPORT_TILES | (em.FLAG_POSE_DISC if pd else 0))
+J = torch.from_numpy(J_np).to(dev).clone()
+eng.set_j_regressor(J)
+if pd:
+    eng.set_pose_disc(torch.randn(1840153, device=dev) * 0.02)
+print('support', eng.j_support_info()[1], eng.support_tiles())
+x = torch.from_numpy(batch['pose6d']).to(dev).contiguous()
+b = torch.from_numpy(batch['betas']).to(dev).contiguous()
+gt = torch.from_numpy(batch['gt_j3d']).to(dev)
+gt = (gt - gt[:, :1]).contiguous()
+m, v = torch.zeros(B, 154, device=dev), torch.zeros(B, 154, device=dev)
+st = torch.zeros(1, dtype=torch.int32, device=dev)
+acc = np.zeros(32)
+n = 0
+for rep in range(20):
+    eng.refine_run(x, b, gt, m, v, st, 1e-2, 5)
+    torch.cuda.synchronize()
+    s = stamps.cpu().numpy().astype(np.float64)
+    if rep >= 5:
+        acc += s - s[0]
+        n += 1
+acc /= n
+names = ['start', 'chain forward', 'support fwd+bwd (whole)', 'per-joint MLP adjoint x2', 'chain adjoint + Adam', 'per-joint MLP forward x2 (end)']
+print('k_sup_step, workgroup 0, us since its start:')
+for i in range(1, 6):
+    print(f'  {names[i]:40s} ends at {acc[i] / 100:8.2f}   (+{(acc[i] - acc[i - 1]) / 100:6.2f})')
+sub = ['operands -> LDS', 'v_posed = Ds F (matrix)', 'skinning', 'joints + loss', 'dverts, dvp', 'dA (then dF = Ds^T dvp follows)']
+print('inside the support body (us since the kernel start):')
+for i in range(6):
+    print(f'  {sub[i]:40s} ends at {acc[8 + i] / 100:8.2f}')
