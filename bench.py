@@ -262,6 +262,211 @@ def self_launch(a):
     sys.exit(r.returncode if r.returncode != 0 or json_lines else 1)
 
 
+def block_folded(c):
+    """folded-regressor mode (a different algorithm with its own denominator)"""
+    # ---- folded-regressor mode (DESIGN.md section 3; a different algorithm with its own denominator) ----
+    folded = None
+    if not c.a.no_folded and not c.use_sil:
+        folded = c.side_run(c.eng_mod.FLAG_FOLDED | (c.eng_mod.FLAG_POSE_DISC if c.use_disc else 0))
+        folded.update({'algorithmic_flop_per_pose_iter': 2 * (2 * 1224 * 218) + 4 * (17 * 3 * 24 * 4 * 2),
+                       'note': 'joints = A.(H F) with H = sum_v Jn W D contracted once per J update (exact re-association, '
+                               'same losses/updates; no vertices).  Separate mode, separate denominator: not the headline.'})
+    return folded
+
+
+def block_bf16x3(c):
+    """SIDE MODE JRR_FLAG_BLEND_BF16X3: separately labelled, its own denominator, never `value`"""
+    # ---- SIDE MODE, a different arithmetic type: the blend-basis adjoint as a split-bf16 product (JRR_FLAG_BLEND_BF16X3).  Reported
+    #      like folded_mode: separately labelled, its own denominator, NEVER `value` (the reference computes in fp32; so does the
+    #      headline).  Its parity bounds are its own: tests/test_gpu_bf16x3.py ----
+    bf16x3 = None
+    if not c.a.no_bf16x3 and not c.use_sil and c.use_disc and hasattr(c.eng_mod, 'FLAG_BLEND_BF16X3'):
+        bf16x3 = c.side_run(c.eng_mod.FLAG_KEEP_VERTS | c.eng_mod.FLAG_POSE_DISC | c.eng_mod.FLAG_BLEND_BF16X3, force_profile=True)
+        adj_ms = bf16x3.get('kernels_ms', {}).get('k_gemm_tn_blend_adjoint')
+        # issued work of the kernel: three 32x32x16 bf16 matrix instructions per accumulator tile and 16 vertices
+        bf_flop = 3 * 2.0 * 224 * (3 * 6912) * c.B
+        bf16x3.update({
+            'dtype': 'bf16x3, f32 accumulate (blend adjoint only; every other kernel exact f32)',
+            'blend_adjoint': {'avg_launch_ms': adj_ms, 'exact_f32_kernel_ms': round(c.prof['k_gemm_tn_blend_adjoint'][0], 4),
+                              'issued_bf16_mfma_flop_per_launch': bf_flop,
+                              'achieved_tflops_bf16_issued': round(bf_flop / (adj_ms * 1e-3) / 1e12, 1) if adj_ms else None,
+                              'peak_bf16_mfma_tflops': PEAK_BF16_MFMA_TFLOPS,
+                              'frac_of_bf16_mfma_peak': round(bf_flop / (adj_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if adj_ms else None,
+                              'operand_bytes_through_lds_per_launch': int((c.B // 128) * 1296 * (14336 + 8192)),
+                              'bound': 'operand traffic (the split operands are as large as the f32 ones; the matrix part is 5.3 x shorter)'},
+            'note': 'NOT the headline and not the reference\'s arithmetic: operands of the blend-basis adjoint taken as bf16 hi + lo, three bf16 '
+                    'products per exact one, f32 accumulation (relative error of the product ~3e-5; joints after 100 iterations within 1e-4 m of '
+                    'the exact engine and of the oracle: tests/test_gpu_bf16x3.py).  `value` stays the exact-f32 run above.'})
+    return bf16x3
+
+
+def block_support_tiles(c):
+    """the iteration optimize.py runs by default: on the vertices / tiles of the regressor's support"""
+    # ---- the same iteration on the vertex tiles of the regressor's SUPPORT only (JRR_FLAG_SUPPORT_TILES; what optimize.py runs by
+    #      default).  Exact: the other tiles meet a zero block of the regressor and a zero vertex adjoint.  Reported beside the
+    #      headline, which keeps running all 6890 vertices (north_star: "linear blend skinning over 6890 vertices") ----
+    support_tiles = None
+    if not c.a.no_support_tiles and not c.use_sil:
+        # the body uploaded as optimize.py uploads it: with the regressor's positive columns as a hint for the library's internal vertex
+        # order (jrr_model_create_hinted: the support stored first -- ceil(58 / 32) = 2 tiles instead of one per entry)
+        hmodel = c.eng_mod.DeviceModel(c.model_np, c.dev, hint_vertices=np.nonzero((c.J_np > 0).any(0))[0])
+        support_tiles = c.side_run(c.eng_mod.FLAG_KEEP_VERTS | (c.eng_mod.FLAG_POSE_DISC if c.use_disc else 0), tiles=True, model=hmodel)
+        support_tiles['model'] = hmodel.info
+        unhinted = c.side_run(c.eng_mod.FLAG_KEEP_VERTS | (c.eng_mod.FLAG_POSE_DISC if c.use_disc else 0), tiles=True)
+        support_tiles['without_vertex_order_hint'] = {k: unhinted[k] for k in ('value', 'ms_per_step', 'vertex_tiles', 'kernels_ms')}
+        nt = support_tiles['vertex_tiles']['run']
+        km = support_tiles.get('kernels_ms', {})
+        support_tiles['small_launches_ms'] = round(sum(km.get(k_, 0.0) for k_ in ('k_prep_fwd', 'k_joints_loss', 'k_prep_bwd', 'k_shape_disc')), 4)
+        support_tiles['skinning_launches_ms'] = round(sum(km.get(k_, 0.0) for k_ in ('k_lbs_fwd', 'k_lbs_bwd', 'k_gemm_tn_blend_adjoint', 'k_sup_step')), 4)
+        per_vertex = support_tiles['support_vertices']['per_vertex_iteration']
+        # FLOP it runs: the listed tiles at the 8-slot rate + a second pass for each of them that is wide (all, with the hint); per
+        # vertex (round 6): the two 192 x 224 products of the support's coordinate rows, the rest is vector work
+        fl = (flop_lbs_fwd(c.dmodel.info) + flop_lbs_bwd(c.dmodel.info) + FLOP_BLEND_ADJ_PER_POSE) * nt / 216 + (FLOP_DISC_PER_POSE if c.use_disc else 0)
+        if per_vertex:
+            fl = 2 * (2 * 192 * 224) + (FLOP_DISC_PER_POSE if c.use_disc else 0)
+        support_tiles.update({
+            'flop_per_pose_iter_it_runs': round(fl), 'achieved_tflops': round(fl * c.B / (support_tiles['ms_per_step'] * 1e-3) / 1e12, 2),
+            'frac_of_f32_mfma_peak': round(fl * c.B / (support_tiles['ms_per_step'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+            'note': 'joint-loss iterations read the vertices through the regressor only: a vertex without a positive regressor entry '
+                    'adds exact zeros to the joints and receives a zero adjoint.  Round 6: when the support has <= 64 vertices (58 here) the '
+                    'iteration runs per VERTEX in ONE launch per 32-pose group (prep.hip k_sup_step: chain forward, support-vertex SMPL '
+                    'forward, loss, backward, per-joint MLP adjoint, chain adjoint + Adam, per-joint MLP forward of the next iteration) behind '
+                    'the four discriminator GEMM launches -- 5 launches where the tile lists of round 4 took 13; results equal the all-tiles '
+                    'run up to the order of the sums (tests/test_gpu_round4.py, tests/test_gpu_trajectory.py).  NOT the headline: `value` '
+                    'runs all 216 tiles.'})
+        if c.B >= 1024 and c.a.config == 3 and not c.a.no_config2:
+            c2t = c.side_run(c.eng_mod.FLAG_KEEP_VERTS, Bs=1024, disc=False, tiles=True, model=hmodel)
+            support_tiles['config2_batch1024_joint_loss_only'] = c2t
+    return support_tiles
+
+
+def block_config5(c):
+    """BASELINE configs[4]: + soft-silhouette loss inside the inner loop"""
+    # ---- BASELINE configs[4]: + soft-silhouette loss inside the inner loop, separately timed ----
+    config5 = None
+    if not c.a.no_config5 and not c.use_sil and c.use_disc:
+        config5 = c.side_run(c.eng_mod.FLAG_KEEP_VERTS | c.eng_mod.FLAG_POSE_DISC | c.eng_mod.FLAG_SILHOUETTE, c.silhouette_setup)
+        config5['workload'] = 'BASELINE configs[4]: configs[2] + soft-silhouette loss (224x224 rasteriser as HIP kernel) in the inner loop'
+        # the rasteriser is integer / vector-ALU work, not a GEMM: its line is the VALU issue rate (wave-instructions per launch
+        # from the PMC pass of tools/prof_c5.sh, static) over the live duration, against 1 wave-instruction per SIMD per 2 clocks
+        try:
+            pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('k_sil_raster_adj_pmc_per_launch_b4096') if c.B == 4096 else None
+        except Exception:
+            pm = None
+        ras_ms = config5.get('kernels_ms', {}).get('silhouette_fwd_bwd')
+        if pm and ras_ms:
+            peak = 256 * 4 * 2.4e9 / 2
+            config5['rasteriser_issue'] = {'bound': 'valu issue', 'valu_wave_insts_per_launch': pm['SQ_INSTS_VALU'],
+                                           'valu_wave_insts_per_pose': round(pm['SQ_INSTS_VALU'] / c.B), 'avg_launch_ms': ras_ms,
+                                           'achieved_ginst_s': round(pm['SQ_INSTS_VALU'] / (ras_ms * 1e-3) / 1e9, 1), 'peak_ginst_s': round(peak / 1e9, 1),
+                                           'frac': round(pm['SQ_INSTS_VALU'] / (ras_ms * 1e-3) / peak, 4),
+                                           'parked_wave_cycle_frac': round(pm['SQ_WAIT_ANY'] / pm['SQ_WAVE_CYCLES'], 3),
+                                           'source': 'profiles/pmc_traffic.json (static PMC counts, live duration)'}
+    return config5
+
+
+def block_config2(c):
+    """BASELINE configs[1]: batch 1024, 3D-joint loss only, all tiles"""
+    # ---- BASELINE configs[1]: batch 1024, 3D-joint loss only, separately timed with its own roofline fraction ----
+    config2 = None
+    if not c.a.no_config2 and c.a.config == 3 and c.B >= 1024:
+        config2 = c.side_run(c.eng_mod.FLAG_KEEP_VERTS, Bs=1024, disc=False)
+        fl2 = flop_lbs_fwd(c.dmodel.info) + flop_lbs_bwd(c.dmodel.info) + FLOP_BLEND_ADJ_PER_POSE
+        config2.update({'workload': 'BASELINE configs[1]: batch=1024 pose optimisation, 3D-joint L2 loss only',
+                        'whole_step': {'flop_per_pose_iter': fl2, 'achieved': round(fl2 * 1024 / (config2['ms_per_step'] * 1e-3) / 1e12, 2),
+                                       'frac': round(fl2 * 1024 / (config2['ms_per_step'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                       'dense_formulation_flop_per_pose_iter': FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE}})
+    return config2
+
+
+def block_skin_variants(c):
+    """the 12-slot / dense / wide-tile / random-file-order bodies"""
+    # ---- what a body model with a less coherent vertex order runs: the 12-joint-per-tile kernels and the dense kernels
+    #      (the synthetic body's ring-major vertex order is what lets the headline use the 8-joint kernels) ----
+    skin_variants = None
+    if not c.a.no_skin_variants and not c.use_sil:
+        skin_variants = {}
+        variants = [('skin12', {'JRR_SKIN_JOINTS': '12'}, c.model_np), ('dense', {'JRR_DENSE_SKINNING': '1'}, c.model_np),
+                    # a body whose FILE order means nothing to the tiles (seeded random): the library stores it in its own order along the
+                    # kinematic chains (invisible at the API); tiles that are still wide would pay a second pass themselves
+                    ('capsules_random_file_order', {}, c.sm.synthetic_smpl(1234, kind='capsules')),
+                    # the benchmarked body with ONE tile skinned by 13 joints: it pays a second pass itself, the model stays in its class
+                    ('one_13_joint_tile', {}, c.sm.with_wide_tile(c.model_np, 100, 13)),
+                    # ... and both together: the 12-slot kernels WITH a wide tile (the instantiation that used to spill registers)
+                    ('one_13_joint_tile_skin12', {'JRR_SKIN_JOINTS': '12'}, c.sm.with_wide_tile(c.model_np, 100, 13))]
+        for name, env, mnp in variants:
+            old = {k: os.environ.get(k) for k in env}
+            os.environ.update(env)                       # read by jrr_model_create
+            try:
+                mdl = c.eng_mod.DeviceModel(mnp, c.dev)
+            finally:
+                for k, vv in old.items():
+                    if vv is None:
+                        os.environ.pop(k, None)
+                    else:
+                        os.environ[k] = vv
+            r = c.side_run(c.eng_mod.FLAG_KEEP_VERTS | (c.eng_mod.FLAG_POSE_DISC if c.use_disc else 0), model=mdl)
+            fl = flop_lbs_fwd(mdl.info) + flop_lbs_bwd(mdl.info) + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if c.use_disc else 0)
+            r.update({'flop_per_pose_iter': fl, 'achieved_tflops': round(fl * c.B / (r['ms_per_step'] * 1e-3) / 1e12, 2),
+                      'frac_of_f32_mfma_peak': round(fl * c.B / (r['ms_per_step'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                      'forced_by': env, 'model': mdl.info})
+            skin_variants[name] = r
+            del mdl
+    return skin_variants
+
+
+def block_driver(c, support_tiles):
+    """the ENTRY POINT per outer batch: optimize_pose_refiner() on synthetic batches (driver_outer_batch, reference_default)"""
+    # ---- the ENTRY POINT, per outer batch (/root/reference/scripts/optimize.py:144-337 is one call of optimize_pose_refiner() per run:
+    #      H->D copy, [camera pre-fit], 100 inner iterations, D updates, J step, two evaluations, a log record).  The real driver of the
+    #      package on synthetic batches; the first batch (engine set-up, code-object loads) is discarded ----
+    def driver_run(batch, extra, n_batches=7, inner=100):
+        argsmod = importlib.import_module(PKG + '.args')
+        argsmod._LazyArgs._ns = argsmod.get_args(['--batch_size', str(batch), '--synthetic_batches', str(n_batches), '--inner_iters', str(inner),
+                                                   '--synthetic', '--device', str(c.dev), '--smpl_dir', '/nonexistent', '--j_regressor_init',
+                                                   '/nonexistent'] + list(extra))
+        optm = importlib.import_module(PKG + '.optimize')
+        recs = []
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        optm.optimize_pose_refiner(log=recs.append)
+        torch.cuda.synchronize()
+        wall = time.perf_counter() - t0
+        kept = recs[1:] or recs
+        sec = statistics.median([r['seconds_batch'] for r in kept])
+        return {'flags': ' '.join(extra) or '(defaults)', 'batch': batch, 'inner_iters': inner, 'outer_batches_run': len(recs), 'first_batch_discarded': len(recs) > 1,
+                'seconds_per_outer_batch': round(sec, 5), 'seconds_per_outer_batch_each': [round(r['seconds_batch'], 5) for r in recs],
+                'loop_and_outer_step_seconds': round(statistics.median([r['seconds'] for r in kept]), 5),
+                'it_s_through_the_entry_point': round(inner / sec, 2), 'vertex_tiles_run': kept[-1]['vertex_tiles_run'],
+                'whole_call_seconds_incl_synthetic_batch_generation_and_setup': round(wall, 3),
+                'joint_loss_last': kept[-1]['joint_loss'], 'mpjpe_last': kept[-1].get('mpjpe')}
+
+    driver_outer, ref_default = None, None
+    if c.dist is None and not c.a.no_driver_blocks and c.a.config == 3 and not c.use_sil:
+        outer_ms = (c.d_ms or 0.0) + c.j_ms                  # pose-D update + J step as timed above (stand-alone, this engine)
+        driver_outer = {}
+        for name, extra, step_ms in (('all_vertex_tiles', ['--all_vertex_tiles'], c.inner_ms),
+                                     ('support_tiles_default', [], support_tiles['ms_per_step'] if support_tiles else None)):
+            r = driver_run(c.B, extra)
+            if step_ms:
+                kern = (r['inner_iters'] * step_ms + outer_ms) * 1e-3
+                r.update({'inner_ms_per_step_of_this_mode': round(step_ms, 4), 'outer_step_ms': round(outer_ms, 3),
+                          'kernel_seconds_expected': round(kern, 5),
+                          'share_not_inner_loop_or_outer_step': round(1.0 - kern / r['seconds_per_outer_batch'], 4)})
+            driver_outer[name] = r
+        driver_outer['note'] = ('optimize_pose_refiner() of this package (the reference entry point restated) on 7 synthetic outer batches, first one '
+                                'discarded, median of the rest; seconds_per_outer_batch = wall time from the batch arriving to its record (H->D copies, fresh Adam '
+                                'state, 100 inner iterations in ONE C call, D update, J step, evaluations, the one read-back); '
+                                'share_not_inner_loop_or_outer_step = 1 - (100 x ms_per_step + pose-D update + J step) / that')
+        # the reference's OWN default run (scripts/args.py:8 batch 256; all five terms of scripts/optimize.py:252-253 with the 1000-step
+        # camera pre-fit of :187-199)
+        ref_default = driver_run(256, ['--shape_disc', '--reprojection', '--silhouette'], n_batches=6)
+        ref_default['workload'] = ('scripts/args.py:8 default batch 256, all five loss terms (2-D joints, silhouette, 3-D joints, pose-D, shape-D), '
+                                   '1000-step camera pre-fit, 100 inner iterations, D updates + J step per outer batch')
+    return driver_outer, ref_default
+
+
+
 def main():
     a = parse()
     prov = provenance(a.allow_experiment_lib)      # before anything touches the GPU: a refused JRR_LIB costs nothing
@@ -718,176 +923,18 @@ def main():
                     km_['k_dconv_fwd_first_iteration_only'] = km_.pop('k_prep_fwd')
         return out_
 
-    # ---- folded-regressor mode (a different algorithm with its own denominator) ----
-    folded = None
-    if not a.no_folded and not use_sil:
-        folded = side_run(eng_mod.FLAG_FOLDED | (eng_mod.FLAG_POSE_DISC if use_disc else 0))
-        folded.update({'algorithmic_flop_per_pose_iter': 2 * (2 * 1224 * 218) + 4 * (17 * 3 * 24 * 4 * 2),
-                       'note': 'joints = A.(H F) with H = sum_v Jn W D contracted once per J update (exact re-association, '
-                               'same losses/updates; no vertices).  Separate mode, separate denominator: not the headline.'})
-    # ---- SIDE MODE, a different arithmetic type: the blend-basis adjoint as a split-bf16 product (JRR_FLAG_BLEND_BF16X3).  Reported
-    #      like folded_mode: separately labelled, its own denominator, NEVER `value` (the reference computes in fp32; so does the
-    #      headline).  Its parity bounds are its own: tests/test_gpu_bf16x3.py ----
-    bf16x3 = None
-    if not a.no_bf16x3 and not use_sil and use_disc and hasattr(eng_mod, 'FLAG_BLEND_BF16X3'):
-        bf16x3 = side_run(eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_POSE_DISC | eng_mod.FLAG_BLEND_BF16X3, force_profile=True)
-        adj_ms = bf16x3.get('kernels_ms', {}).get('k_gemm_tn_blend_adjoint')
-        # issued work of the kernel: three 32x32x16 bf16 matrix instructions per accumulator tile and 16 vertices
-        bf_flop = 3 * 2.0 * 224 * (3 * 6912) * B
-        bf16x3.update({
-            'dtype': 'bf16x3, f32 accumulate (blend adjoint only; every other kernel exact f32)',
-            'blend_adjoint': {'avg_launch_ms': adj_ms, 'exact_f32_kernel_ms': round(prof['k_gemm_tn_blend_adjoint'][0], 4),
-                              'issued_bf16_mfma_flop_per_launch': bf_flop,
-                              'achieved_tflops_bf16_issued': round(bf_flop / (adj_ms * 1e-3) / 1e12, 1) if adj_ms else None,
-                              'peak_bf16_mfma_tflops': PEAK_BF16_MFMA_TFLOPS,
-                              'frac_of_bf16_mfma_peak': round(bf_flop / (adj_ms * 1e-3) / 1e12 / PEAK_BF16_MFMA_TFLOPS, 4) if adj_ms else None,
-                              'operand_bytes_through_lds_per_launch': int((B // 128) * 1296 * (14336 + 8192)),
-                              'bound': 'operand traffic (the split operands are as large as the f32 ones; the matrix part is 5.3 x shorter)'},
-            'note': 'NOT the headline and not the reference\'s arithmetic: operands of the blend-basis adjoint taken as bf16 hi + lo, three bf16 '
-                    'products per exact one, f32 accumulation (relative error of the product ~3e-5; joints after 100 iterations within 1e-4 m of '
-                    'the exact engine and of the oracle: tests/test_gpu_bf16x3.py).  `value` stays the exact-f32 run above.'})
-    # ---- the same iteration on the vertex tiles of the regressor's SUPPORT only (JRR_FLAG_SUPPORT_TILES; what optimize.py runs by
-    #      default).  Exact: the other tiles meet a zero block of the regressor and a zero vertex adjoint.  Reported beside the
-    #      headline, which keeps running all 6890 vertices (north_star: "linear blend skinning over 6890 vertices") ----
-    support_tiles = None
-    if not a.no_support_tiles and not use_sil:
-        # the body uploaded as optimize.py uploads it: with the regressor's positive columns as a hint for the library's internal vertex
-        # order (jrr_model_create_hinted: the support stored first -- ceil(58 / 32) = 2 tiles instead of one per entry)
-        hmodel = eng_mod.DeviceModel(model_np, dev, hint_vertices=np.nonzero((J_np > 0).any(0))[0])
-        support_tiles = side_run(eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0), tiles=True, model=hmodel)
-        support_tiles['model'] = hmodel.info
-        unhinted = side_run(eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0), tiles=True)
-        support_tiles['without_vertex_order_hint'] = {k: unhinted[k] for k in ('value', 'ms_per_step', 'vertex_tiles', 'kernels_ms')}
-        nt = support_tiles['vertex_tiles']['run']
-        km = support_tiles.get('kernels_ms', {})
-        support_tiles['small_launches_ms'] = round(sum(km.get(k_, 0.0) for k_ in ('k_prep_fwd', 'k_joints_loss', 'k_prep_bwd', 'k_shape_disc')), 4)
-        support_tiles['skinning_launches_ms'] = round(sum(km.get(k_, 0.0) for k_ in ('k_lbs_fwd', 'k_lbs_bwd', 'k_gemm_tn_blend_adjoint', 'k_sup_step')), 4)
-        per_vertex = support_tiles['support_vertices']['per_vertex_iteration']
-        # FLOP it runs: the listed tiles at the 8-slot rate + a second pass for each of them that is wide (all, with the hint); per
-        # vertex (round 6): the two 192 x 224 products of the support's coordinate rows, the rest is vector work
-        fl = (flop_lbs_fwd(dmodel.info) + flop_lbs_bwd(dmodel.info) + FLOP_BLEND_ADJ_PER_POSE) * nt / 216 + (FLOP_DISC_PER_POSE if use_disc else 0)
-        if per_vertex:
-            fl = 2 * (2 * 192 * 224) + (FLOP_DISC_PER_POSE if use_disc else 0)
-        support_tiles.update({
-            'flop_per_pose_iter_it_runs': round(fl), 'achieved_tflops': round(fl * B / (support_tiles['ms_per_step'] * 1e-3) / 1e12, 2),
-            'frac_of_f32_mfma_peak': round(fl * B / (support_tiles['ms_per_step'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-            'note': 'joint-loss iterations read the vertices through the regressor only: a vertex without a positive regressor entry '
-                    'adds exact zeros to the joints and receives a zero adjoint.  Round 6: when the support has <= 64 vertices (58 here) the '
-                    'iteration runs per VERTEX in ONE launch per 32-pose group (prep.hip k_sup_step: chain forward, support-vertex SMPL '
-                    'forward, loss, backward, per-joint MLP adjoint, chain adjoint + Adam, per-joint MLP forward of the next iteration) behind '
-                    'the four discriminator GEMM launches -- 5 launches where the tile lists of round 4 took 13; results equal the all-tiles '
-                    'run up to the order of the sums (tests/test_gpu_round4.py, tests/test_gpu_trajectory.py).  NOT the headline: `value` '
-                    'runs all 216 tiles.'})
-        if B >= 1024 and a.config == 3 and not a.no_config2:
-            c2t = side_run(eng_mod.FLAG_KEEP_VERTS, Bs=1024, disc=False, tiles=True, model=hmodel)
-            support_tiles['config2_batch1024_joint_loss_only'] = c2t
-    # ---- BASELINE configs[4]: + soft-silhouette loss inside the inner loop, separately timed ----
-    config5 = None
-    if not a.no_config5 and not use_sil and use_disc:
-        config5 = side_run(eng_mod.FLAG_KEEP_VERTS | eng_mod.FLAG_POSE_DISC | eng_mod.FLAG_SILHOUETTE, silhouette_setup)
-        config5['workload'] = 'BASELINE configs[4]: configs[2] + soft-silhouette loss (224x224 rasteriser as HIP kernel) in the inner loop'
-        # the rasteriser is integer / vector-ALU work, not a GEMM: its line is the VALU issue rate (wave-instructions per launch
-        # from the PMC pass of tools/prof_c5.sh, static) over the live duration, against 1 wave-instruction per SIMD per 2 clocks
-        try:
-            pm = json.load(open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'))).get('k_sil_raster_adj_pmc_per_launch_b4096') if B == 4096 else None
-        except Exception:
-            pm = None
-        ras_ms = config5.get('kernels_ms', {}).get('silhouette_fwd_bwd')
-        if pm and ras_ms:
-            peak = 256 * 4 * 2.4e9 / 2
-            config5['rasteriser_issue'] = {'bound': 'valu issue', 'valu_wave_insts_per_launch': pm['SQ_INSTS_VALU'],
-                                           'valu_wave_insts_per_pose': round(pm['SQ_INSTS_VALU'] / B), 'avg_launch_ms': ras_ms,
-                                           'achieved_ginst_s': round(pm['SQ_INSTS_VALU'] / (ras_ms * 1e-3) / 1e9, 1), 'peak_ginst_s': round(peak / 1e9, 1),
-                                           'frac': round(pm['SQ_INSTS_VALU'] / (ras_ms * 1e-3) / peak, 4),
-                                           'parked_wave_cycle_frac': round(pm['SQ_WAIT_ANY'] / pm['SQ_WAVE_CYCLES'], 3),
-                                           'source': 'profiles/pmc_traffic.json (static PMC counts, live duration)'}
-    # ---- BASELINE configs[1]: batch 1024, 3D-joint loss only, separately timed with its own roofline fraction ----
-    config2 = None
-    if not a.no_config2 and a.config == 3 and B >= 1024:
-        config2 = side_run(eng_mod.FLAG_KEEP_VERTS, Bs=1024, disc=False)
-        fl2 = flop_lbs_fwd(dmodel.info) + flop_lbs_bwd(dmodel.info) + FLOP_BLEND_ADJ_PER_POSE
-        config2.update({'workload': 'BASELINE configs[1]: batch=1024 pose optimisation, 3D-joint L2 loss only',
-                        'whole_step': {'flop_per_pose_iter': fl2, 'achieved': round(fl2 * 1024 / (config2['ms_per_step'] * 1e-3) / 1e12, 2),
-                                       'frac': round(fl2 * 1024 / (config2['ms_per_step'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                       'dense_formulation_flop_per_pose_iter': FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE}})
-    # ---- what a body model with a less coherent vertex order runs: the 12-joint-per-tile kernels and the dense kernels
-    #      (the synthetic body's ring-major vertex order is what lets the headline use the 8-joint kernels) ----
-    skin_variants = None
-    if not a.no_skin_variants and not use_sil:
-        skin_variants = {}
-        variants = [('skin12', {'JRR_SKIN_JOINTS': '12'}, model_np), ('dense', {'JRR_DENSE_SKINNING': '1'}, model_np),
-                    # a body whose FILE order means nothing to the tiles (seeded random): the library stores it in its own order along the
-                    # kinematic chains (invisible at the API); tiles that are still wide would pay a second pass themselves
-                    ('capsules_random_file_order', {}, sm.synthetic_smpl(1234, kind='capsules')),
-                    # the benchmarked body with ONE tile skinned by 13 joints: it pays a second pass itself, the model stays in its class
-                    ('one_13_joint_tile', {}, sm.with_wide_tile(model_np, 100, 13)),
-                    # ... and both together: the 12-slot kernels WITH a wide tile (the instantiation that used to spill registers)
-                    ('one_13_joint_tile_skin12', {'JRR_SKIN_JOINTS': '12'}, sm.with_wide_tile(model_np, 100, 13))]
-        for name, env, mnp in variants:
-            old = {k: os.environ.get(k) for k in env}
-            os.environ.update(env)                       # read by jrr_model_create
-            try:
-                mdl = eng_mod.DeviceModel(mnp, dev)
-            finally:
-                for k, vv in old.items():
-                    if vv is None:
-                        os.environ.pop(k, None)
-                    else:
-                        os.environ[k] = vv
-            r = side_run(eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_POSE_DISC if use_disc else 0), model=mdl)
-            fl = flop_lbs_fwd(mdl.info) + flop_lbs_bwd(mdl.info) + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
-            r.update({'flop_per_pose_iter': fl, 'achieved_tflops': round(fl * B / (r['ms_per_step'] * 1e-3) / 1e12, 2),
-                      'frac_of_f32_mfma_peak': round(fl * B / (r['ms_per_step'] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                      'forced_by': env, 'model': mdl.info})
-            skin_variants[name] = r
-            del mdl
-
-    # ---- the ENTRY POINT, per outer batch (/root/reference/scripts/optimize.py:144-337 is one call of optimize_pose_refiner() per run:
-    #      H->D copy, [camera pre-fit], 100 inner iterations, D updates, J step, two evaluations, a log record).  The real driver of the
-    #      package on synthetic batches; the first batch (engine set-up, code-object loads) is discarded ----
-    def driver_run(batch, extra, n_batches=7, inner=100):
-        argsmod = importlib.import_module(PKG + '.args')
-        argsmod._LazyArgs._ns = argsmod.get_args(['--batch_size', str(batch), '--synthetic_batches', str(n_batches), '--inner_iters', str(inner),
-                                                   '--synthetic', '--device', str(dev), '--smpl_dir', '/nonexistent', '--j_regressor_init',
-                                                   '/nonexistent'] + list(extra))
-        optm = importlib.import_module(PKG + '.optimize')
-        recs = []
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        optm.optimize_pose_refiner(log=recs.append)
-        torch.cuda.synchronize()
-        wall = time.perf_counter() - t0
-        kept = recs[1:] or recs
-        sec = statistics.median([r['seconds_batch'] for r in kept])
-        return {'flags': ' '.join(extra) or '(defaults)', 'batch': batch, 'inner_iters': inner, 'outer_batches_run': len(recs), 'first_batch_discarded': len(recs) > 1,
-                'seconds_per_outer_batch': round(sec, 5), 'seconds_per_outer_batch_each': [round(r['seconds_batch'], 5) for r in recs],
-                'loop_and_outer_step_seconds': round(statistics.median([r['seconds'] for r in kept]), 5),
-                'it_s_through_the_entry_point': round(inner / sec, 2), 'vertex_tiles_run': kept[-1]['vertex_tiles_run'],
-                'whole_call_seconds_incl_synthetic_batch_generation_and_setup': round(wall, 3),
-                'joint_loss_last': kept[-1]['joint_loss'], 'mpjpe_last': kept[-1].get('mpjpe')}
-
-    driver_outer, ref_default = None, None
-    if dist is None and not a.no_driver_blocks and a.config == 3 and not use_sil:
-        outer_ms = (d_ms or 0.0) + j_ms                  # pose-D update + J step as timed above (stand-alone, this engine)
-        driver_outer = {}
-        for name, extra, step_ms in (('all_vertex_tiles', ['--all_vertex_tiles'], inner_ms),
-                                     ('support_tiles_default', [], support_tiles['ms_per_step'] if support_tiles else None)):
-            r = driver_run(B, extra)
-            if step_ms:
-                kern = (r['inner_iters'] * step_ms + outer_ms) * 1e-3
-                r.update({'inner_ms_per_step_of_this_mode': round(step_ms, 4), 'outer_step_ms': round(outer_ms, 3),
-                          'kernel_seconds_expected': round(kern, 5),
-                          'share_not_inner_loop_or_outer_step': round(1.0 - kern / r['seconds_per_outer_batch'], 4)})
-            driver_outer[name] = r
-        driver_outer['note'] = ('optimize_pose_refiner() of this package (the reference entry point restated) on 7 synthetic outer batches, first one '
-                                'discarded, median of the rest; seconds_per_outer_batch = wall time from the batch arriving to its record (H->D copies, fresh Adam '
-                                'state, 100 inner iterations in ONE C call, D update, J step, evaluations, the one read-back); '
-                                'share_not_inner_loop_or_outer_step = 1 - (100 x ms_per_step + pose-D update + J step) / that')
-        # the reference's OWN default run (scripts/args.py:8 batch 256; all five terms of scripts/optimize.py:252-253 with the 1000-step
-        # camera pre-fit of :187-199)
-        ref_default = driver_run(256, ['--shape_disc', '--reprojection', '--silhouette'], n_batches=6)
-        ref_default['workload'] = ('scripts/args.py:8 default batch 256, all five loss terms (2-D joints, silhouette, 3-D joints, pose-D, shape-D), '
-                                   '1000-step camera pre-fit, 100 inner iterations, D updates + J step per outer batch')
+    # ---- the separately reported blocks (one function each, above main()): never part of `value` ----
+    import types
+    c = types.SimpleNamespace(a=a, dev=dev, world=world, dist=dist, B=B, use_disc=use_disc, use_sil=use_sil, eng_mod=eng_mod, sm=sm, dmodel=dmodel,
+                              model_np=model_np, J_np=J_np, batch_np=batch_np, side_run=side_run, silhouette_setup=silhouette_setup, prof=prof,
+                              inner_ms=inner_ms, d_ms=d_ms, j_ms=j_ms, strong=strong, agg=agg)
+    folded = block_folded(c)
+    bf16x3 = block_bf16x3(c)
+    support_tiles = block_support_tiles(c)
+    config5 = block_config5(c)
+    config2 = block_config2(c)
+    skin_variants = block_skin_variants(c)
+    driver_outer, ref_default = block_driver(c, support_tiles)
 
     if rank != 0:
         if dist is not None:

@@ -810,6 +810,22 @@ int launch_disc_gemm_q(const GemmArgs& g, int epi, int btr, hipStream_t s, int* 
   }
   // (256 x 64 tiles on eight waves -- one workgroup per CU, two waves per SIMD behind ONE barrier -- measured equal: 0.2676-0.2689 vs
   // 0.2684-0.2685 ms for the four launches, round 5; not kept)
+  // SMALL BATCHES (round 6): below 512 workgroups of 128 x 64 -- fewer than 4096 pose columns: the reference's default batch of 256, a
+  // 512-pose shard of a strong-scaling run, BASELINE configs[1]'s 1024 -- most CUs would hold no workgroup at all (1024 poses: 128 of them
+  // on 256 CUs).  Those launches take 128 x 32 tiles: twice the workgroups, the same four waves each (two K halves per row block: KS = 2),
+  // and per output element the SAME sequence of operations as the wide tile -- a wave still owns 64 rows x 32 columns, K is still summed in
+  // the two-set order, the fc4 partial dots keep their 64-row groups -- so engines of different batch sizes stay bit-identical.
+  // JRR_DISC_NARROW=0 (experiments) keeps the wide tiles.
+  static const bool narrow_ok = [] { const char* e = getenv("JRR_DISC_NARROW"); return !(e && e[0] == '0'); }();
+  if (narrow_ok && (g.M / 128) * (g.N / 64) < 512) {
+    dim3 gridn((g.M / 128) * (g.N / 32)), blockn(256);
+    if (epi == EPI_BIAS_RELU && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 1, EPI_BIAS_RELU, 0, 2>), gridn, blockn, 0, s, g);
+    else if (epi == EPI_BIAS_RELU_DOT && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 1, EPI_BIAS_RELU_DOT, 0, 2>), gridn, blockn, 0, s, g);
+    else if (epi == EPI_STORE && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 1, EPI_STORE, 0, 2>), gridn, blockn, 0, s, g);
+    else if (epi == EPI_MASK && btr == 2) hipLaunchKernelGGL((k_disc_gemm<2, 2, 1, EPI_MASK, 2, 2>), gridn, blockn, 0, s, g);
+    else { jrr_set_error("disc_gemm_q: unsupported epilogue %d / transform %d", epi, btr); return JRR_ERR_ARG; }
+    return 0;
+  }
   dim3 grid((g.M / 128) * (g.N / 64)), block(256);
   if (epi == EPI_BIAS_RELU && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_BIAS_RELU, 0>), grid, block, 0, s, g);
   else if (epi == EPI_BIAS_RELU_DOT && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_BIAS_RELU_DOT, 0>), grid, block, 0, s, g);

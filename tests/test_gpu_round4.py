@@ -291,6 +291,47 @@ def test_support_tiles_with_j_steps_equal_the_all_tiles_run(variant, every):
     assert torch.equal(Ja != T(v['J']), Jt != T(v['J']))
 
 
+def test_support_wider_than_64_vertices_runs_the_tile_lists(smpl_model_np):
+    """the per-vertex iteration (supk.h) is built for a support of at most 64 vertices: a regressor that reads 102 of them keeps the
+    tile lists of round 4 -- reported by support_vertices() -- and both forms equal the oracle; with the shipped H36M regressor (56
+    vertices) the per-vertex iteration is the one that runs"""
+    import conftest
+    sm, em = _mod('smpl_model'), _mod('engine')
+    rng = np.random.RandomState(11)
+    J_wide = np.zeros((17, 6890), np.float32)
+    cols = rng.choice(6890, 17 * 6, replace=False).reshape(17, 6)
+    for i in range(17):
+        J_wide[i, cols[i]] = rng.dirichlet(np.ones(6)).astype(np.float32)
+    dm = em.DeviceModel(smpl_model_np, DEV, hint_vertices=np.nonzero((J_wide > 0).any(0))[0])
+    B = 70
+    batch = sm.synthetic_batch(smpl_model_np, J_wide, B, seed=17)
+    x6, betas = T(batch['pose6d']), T(batch['betas'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    o, p, b_, _ = oracle.refine_poses(smpl, T(J_wide), x6[:, :1], x6[:, 1:], betas, gt_c, 3)
+    eng = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS | em.FLAG_SUPPORT_TILES)
+    eng.set_j_regressor(T(J_wide))
+    counts, fits = eng.j_support_info()
+    assert fits and sum(counts) == 102
+    assert eng.support_tiles()[0] == conftest.support_tiles_available()
+    assert eng.support_vertices() == (False, 0)                       # 102 > 64: the tile lists
+    xd, bd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous()
+    m, vv, step = _fresh_state(B)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, vv, step, 1e-2, 3)
+    d = (xd.cpu() - torch.cat([o, p], 1)).abs()
+    assert d.max().item() < 6e-4 and d.mean().item() < 1e-5, (d.max().item(), d.mean().item())
+    # ... and the shipped regressor on the same body engages the per-vertex iteration
+    t = conftest.load_golden('j_regressor_triplets.npz')
+    J_h36m = sm.j_regressor_from_triplets(t['rows'], t['cols'], t['vals'])
+    eng2 = em.RefineEngine(dm, B, flags=em.FLAG_KEEP_VERTS | em.FLAG_SUPPORT_TILES)
+    eng2.set_j_regressor(T(J_h36m))
+    eng2.j_support_info()
+    on, n_sv = eng2.support_vertices()
+    import os
+    fused_off = os.environ.get('JRR_SUPPORT_FUSED') == '0'
+    assert on == (conftest.support_tiles_available() and not fused_off) and (n_sv == int((J_h36m > 0).any(0).sum()) or not on)
+
+
 @pytest.mark.parametrize('B', [1, 37])
 def test_support_tiles_ragged_batches_vs_oracle(smpl_model_np, j_h36m_np, B):
     """batches far below one pose group (padded to 128 columns): three listed iterations + a J step against the oracle, on the body

@@ -1,10 +1,10 @@
 #!/usr/bin/env python3
-"""Substitute the @PLACEHOLDER@ figures of DESIGN.md / README.md from a bench line (profiles/bench_r05_steps20.json by default):
+"""Substitute the @PLACEHOLDER@ figures of DESIGN.md / README.md from a bench line (profiles/bench_r06_steps20.json by default):
     python tools/fill_docs.py [bench.json]
 so that the state tables quote the measured line itself, not a transcription."""
 import json, os, re, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-j = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'bench_r05_steps20.json')))
+j = json.load(open(sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, 'profiles', 'bench_r06_steps20.json')))
 k, kr, rf = j['kernels_ms'], j['kernels_roofline'], j['roofline']
 small = k['k_prep_fwd'] + k['k_joints_loss'] + k['k_prep_bwd'] + k.get('k_shape_disc', 0.0)
 do = j.get('driver_outer_batch') or {}
@@ -16,7 +16,10 @@ val = {
     'ADJ': f(k['k_gemm_tn_blend_adjoint']), 'ADJF': f(kr['k_blend_adjoint']['frac'], 3),
     'DISC': f(k['pose_disc_gemms']), 'DISCF': f(kr['pose_disc_gemms (4 launches)']['frac'], 3), 'SMALL': f(small, 3),
     'C1': f(j['cadence1']['ms_per_step'], 3), 'C1H': f(j['cadence1_host_driven']['ms_per_step'], 3), 'C1R': f(c1r.get('ms_per_step'), 3),
-    'ST': f(j['support_tiles']['ms_per_step'], 3), 'C2': f(j['config2']['ms_per_step'], 3), 'C2F': f(j['config2']['whole_step']['frac'], 3),
+    'ST': f(j['support_tiles']['ms_per_step'], 3), 'STG': f(j['support_tiles']['kernels_ms'].get('pose_disc_gemms'), 3),
+    'STK': f(j['support_tiles']['kernels_ms'].get('k_sup_step'), 3),
+    'STC2': f((j['support_tiles'].get('config2_batch1024_joint_loss_only') or {}).get('ms_per_step'), 3),
+    'BF': f((j.get('bf16x3_mode') or {}).get('ms_per_step'), 3), 'C2': f(j['config2']['ms_per_step'], 3), 'C2F': f(j['config2']['whole_step']['frac'], 3),
     'C5': f(j['config5']['ms_per_step'], 2), 'RAS': f(j['config5']['kernels_ms']['silhouette_fwd_bwd'], 2),
     'DOA': f(do.get('all_vertex_tiles', {}).get('seconds_per_outer_batch', 0) * 1e3, 1), 'DOAS': '%.1f %%' % (100 * do.get('all_vertex_tiles', {}).get('share_not_inner_loop_or_outer_step', 0)),
     'DOS': f(do.get('support_tiles_default', {}).get('seconds_per_outer_batch', 0) * 1e3, 1), 'DOSS': '%.1f %%' % (100 * do.get('support_tiles_default', {}).get('share_not_inner_loop_or_outer_step', 0)),
