@@ -62,6 +62,11 @@ enum {
   JRR_FLAG_SIL_256 = 64,    /* with JRR_FLAG_SILHOUETTE: 256 x 256 silhouettes (the reference constructor's default,
                                scripts/mesh_renderer.py:25; focal length 5000 / 256) instead of 224 x 224 (scripts/optimize.py:110):
                                every (B,224,224) below then reads (B,256,256) */
+  JRR_FLAG_SIL_SIZE_MASK = 15 << 16, /* with JRR_FLAG_SILHOUETTE: JRR_FLAG_SIL_SIZE(size) below -- an explicit image size, any multiple of 32
+                               up to 256 (Mesh_Renderer(image_size), scripts/mesh_renderer.py:25,34-38; focal length 5000 / size).  Sizes other
+                               than 224 and 256 serve the stand-alone renderer (jrr_silhouette_forward / _backward / _pix_to_face); the
+                               silhouette term INSIDE the loop (jrr_engine_set_silhouette) is built for 224 and 256, the sizes the reference
+                               instantiates.  0 = 224, or 256 with JRR_FLAG_SIL_256 */
   JRR_FLAG_SUPPORT_TILES = 128,/* with JRR_FLAG_KEEP_VERTS: once jrr_j_support_info has reported that the regressor's support fits,
                                the iterations of jrr_refine_run* whose loss reads the JOINTS only (no silhouette term) run their three
                                skinning kernels on the 32-vertex tiles that hold a support entry -- every other tile multiplies
@@ -77,6 +82,8 @@ enum {
                                other kernel, and the support-tile iterations, are unchanged.  bench.py reports it as a separately
                                labelled block (`bf16x3_mode`); it is never the headline. */
 };
+
+#define JRR_FLAG_SIL_SIZE(size) ((((size) / 32) & 15) << 16)
 
 typedef struct jrr_model jrr_model_t;   /* device-resident, re-laid-out SMPL constants */
 typedef struct jrr_engine jrr_engine_t; /* per-batch plan: workspace carve-up + launch geometry */
@@ -368,9 +375,9 @@ int jrr_j_support_info(jrr_engine_t* e, int32_t* counts_host, int32_t* fits_host
  * multiplies all 6890 vertices by the (17,6890) regressor, zeros included (scripts/utils.py:87-92).                          */
 int jrr_engine_support_tiles(const jrr_engine_t* e, int32_t* n_tiles_host);
 /* ... and returns 1 when those iterations run per support VERTEX (*n_vertices_host = the vertices the regressor reads, nullable): the
- * support then has at most 64 vertices, there is no 2-D term, and ONE launch per iteration takes a 32-pose group through chain
- * forward, the SMPL forward of the support vertices, the joint loss (scripts/utils.py:87-114), its backward, the chain adjoint and
- * Adam (scripts/optimize.py:220-265) -- preceded by the discriminator's four GEMM launches when it is on.  0: the tile lists above (or
+ * support then has at most 64 vertices and ONE launch per iteration takes a 32-pose group through chain forward, the SMPL forward
+ * of the support vertices, the joint loss [+ the 2-D term] (scripts/utils.py:87-114, scripts/optimize.py:231-233), its backward, the
+ * chain adjoint and Adam (scripts/optimize.py:220-265) -- preceded by the discriminator's four GEMM launches when it is on.  0: the tile lists above (or
  * all tiles) run as separate launches.  Same numbers up to the order of the sums.  JRR_SUPPORT_FUSED=0 in the environment of
  * jrr_j_support_info keeps the tile lists (verification).  No reference counterpart.                                              */
 int jrr_engine_support_vertices(const jrr_engine_t* e, int32_t* n_vertices_host);

@@ -18,7 +18,7 @@ CSRC = os.path.join(HERE, 'csrc')
 OBJ = os.path.join(HERE, 'build')
 LIB = os.path.join(HERE, 'libjrr_hip.so')
 SOURCES = ['api.hip', 'prep.hip', 'lbs.hip', 'gemm.hip', 'disc.hip', 'eval.hip', 'fold.hip', 'sil.hip', 'sup.hip']
-HEADERS = ['jrr_common.h', 'kernels.h', 'dconv.h', 'supk.h', os.path.join('..', '..', 'include', 'jrr.h')]
+HEADERS = ['jrr_common.h', 'kernels.h', 'dconv.h', 'supk.h', 'proj.h', os.path.join('..', '..', 'include', 'jrr.h')]
 FLAGS = ['--offload-arch=gfx950', '-O3', '-fPIC', '-std=c++17', '-Wall', '-Wno-unused-function']
 
 

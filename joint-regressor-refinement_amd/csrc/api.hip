@@ -526,6 +526,12 @@ struct Carver {
   }
 };
 
+// silhouette image size of an engine: JRR_FLAG_SIL_SIZE(size) if given, else 256 with JRR_FLAG_SIL_256, else 224
+static int sil_size_of(int flags) {
+  const int k = (flags & JRR_FLAG_SIL_SIZE_MASK) >> 16;
+  return k ? 32 * k : (flags & JRR_FLAG_SIL_256) ? 256 : 224;
+}
+
 static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   const int BP = (int)round_up((size_t)B, BG);
   int nvc, nvcb, nvcb16, nsplit, nsplitJ;
@@ -600,7 +606,7 @@ static size_t carve(jrr_engine* e, void* ws, int B, int flags) {
   if (flags & (JRR_FLAG_SILHOUETTE | JRR_FLAG_KEEP_VERTS)) t->VTb = c.take((size_t)3 * VP * BP);
   if (flags & JRR_FLAG_SILHOUETTE) {
     t->ndc = c.take((size_t)BP * V * 4);
-    const size_t S = (flags & JRR_FLAG_SIL_256) ? 256 : 224;
+    const size_t S = (size_t)sil_size_of(flags);
     t->cover = (unsigned*)c.take((size_t)BP * S * S);
     t->ncover = (int*)c.take((size_t)BP);
     t->sqsil = c.take((size_t)BP);
@@ -644,7 +650,11 @@ extern "C" size_t jrr_engine_workspace_bytes(int batch, int flags) {
 extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_norm, void* ws, size_t ws_bytes,
                                  int flags, jrr_engine_t** out) {
   if (!ws || !out || batch <= 0) { jrr_set_error("jrr_engine_create: bad argument"); return JRR_ERR_ARG; }
-  if ((flags & JRR_FLAG_SIL_256) && !(flags & JRR_FLAG_SILHOUETTE)) { jrr_set_error("jrr_engine_create: JRR_FLAG_SIL_256 without JRR_FLAG_SILHOUETTE"); return JRR_ERR_ARG; }
+  if ((flags & (JRR_FLAG_SIL_256 | JRR_FLAG_SIL_SIZE_MASK)) && !(flags & JRR_FLAG_SILHOUETTE)) { jrr_set_error("jrr_engine_create: a silhouette size without JRR_FLAG_SILHOUETTE"); return JRR_ERR_ARG; }
+  if ((flags & JRR_FLAG_SIL_SIZE_MASK) && ((flags & JRR_FLAG_SIL_256) || ((flags & JRR_FLAG_SIL_SIZE_MASK) >> 16) > 8)) {
+    jrr_set_error("jrr_engine_create: JRR_FLAG_SIL_SIZE takes a multiple of 32 up to 256 (and excludes JRR_FLAG_SIL_256)");
+    return JRR_ERR_ARG;
+  }
   if (!model && (flags & ~(JRR_FLAG_POSE_DISC | JRR_FLAG_SHAPE_DISC | JRR_FLAG_NO_MODEL))) {
     jrr_set_error("jrr_engine_create: a model-less engine serves the discriminators only");
     return JRR_ERR_ARG;
@@ -661,7 +671,7 @@ extern "C" int jrr_engine_create(const jrr_model_t* model, int batch, int batch_
   e->B = batch;
   e->bnorm = batch_norm > 0 ? batch_norm : batch;
   e->flags = flags;
-  e->sil = (flags & JRR_FLAG_SIL_256) ? 256 : 224;
+  e->sil = sil_size_of(flags);
   carve(e, ws, batch, flags);
   e->have_jsup = (flags & JRR_FLAG_KEEP_VERTS) != 0;
   if (flags & JRR_FLAG_BLEND_BF16X3) {      // side mode: the basis is split once, here
@@ -945,9 +955,8 @@ static bool use_tile_list(const jrr_engine* e) {
          e->m.kjs && e->m.bwd16 && !(e->folded && e->fold_valid);
 }
 
-// ... per support VERTEX in one workgroup per 32-pose group (supk.h): the same condition, the support's vertex tables built, and no
-// 2-D term (its projection adjoint lives in k_joints_loss)
-static bool use_sup_vertices(const jrr_engine* e) { return use_tile_list(e) && e->sup_valid && e->gt_j2d == nullptr; }
+// ... per support VERTEX in one workgroup per 32-pose group (supk.h): the same condition and the support's vertex tables built
+static bool use_sup_vertices(const jrr_engine* e) { return use_tile_list(e) && e->sup_valid; }
 
 static int j_grad_from_verts(jrr_engine* e, float* dJ, hipStream_t s, float* dJs = nullptr);
 
@@ -1344,6 +1353,11 @@ extern "C" int jrr_engine_set_silhouette(jrr_engine_t* e, const float* mask, flo
     int rc = sil_check(e);
     if (rc) return rc;
     if (!cam || !cam_m || !cam_v) { jrr_set_error("set_silhouette: cam / cam_m / cam_v required"); return JRR_ERR_ARG; }
+    if (e->sil != 224 && e->sil != 256) {
+      jrr_set_error("set_silhouette: the silhouette term inside the loop is built for 224 x 224 and 256 x 256 images (this engine: %d); "
+                    "the other sizes serve the stand-alone renderer", e->sil);
+      return JRR_ERR_STATE;
+    }
     e->cam = cam; e->cam_m = cam_m; e->cam_v = cam_v;
   }
   e->sil_mask = mask;
@@ -1367,8 +1381,9 @@ extern "C" int jrr_silhouette_loss_grad(jrr_engine_t* e, const float* x6d, const
   launch_mask_sq(mask, e->smask, e->B, s, e->sil);
   e->smask_valid = false;
   const float silscale = (float)(2.0 * 100.0 / ((double)e->bnorm * (double)e->sil * (double)e->sil));      // optimize.py:252 weight 100
-  launch_sil_raster_adj(e->VTb, e->BP, cam, e->m.faces_int_pk ? e->m.faces_int_pk : e->m.faces_pk, e->m.nfaces, mask, e->smask, e->cover,
-                        e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s, e->sil, e->VPM);
+  { int rcs = launch_sil_raster_adj(e->VTb, e->BP, cam, e->m.faces_int_pk ? e->m.faces_int_pk : e->m.faces_pk, e->m.nfaces, mask, e->smask, e->cover,
+                                    e->ncover, e->sqsil, silscale, e->gcam, 0, e->B, s, e->sil, e->VPM);
+    if (rcs) return rcs; }      // (sizes other than 224 / 256: the stand-alone forward / backward pair only)
   if (sqsil) JRR_HIP(hipMemcpyAsync(sqsil, e->sqsil, (size_t)e->B * 4, hipMemcpyDeviceToDevice, s));
   if (dverts) launch_verts_untranspose(e->VTb, dverts, V * 3, V, nullptr, nullptr, e->B, e->BP, s, e->m.p2v);
   if (dcam) JRR_HIP(hipMemcpyAsync(dcam, e->gcam, (size_t)e->B * 3 * 4, hipMemcpyDeviceToDevice, s));
@@ -1514,13 +1529,17 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       PrepBwdLaunch L;
       L.x6d_in = x6d; L.betas_in = betas; L.gx_extra = pd ? e->gx : nullptr; L.gb_extra = sd ? e->gb : nullptr;
       L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step; L.lr = lr; L.B = e->B; L.BP = e->BP;
+      if (e->gt_j2d) {      // 2-D term, weight 1/100 (optimize.py:231-233,252): the camera translation is a parameter of the same Adam
+        q.gt_j2d = e->gt_j2d; q.cam = e->cam; q.gcam = e->gcam; q.sq2d = e->sq2d; q.scale2d = (float)(2.0 * 0.01 / ((double)e->bnorm * 34.0));
+        L.gcam = e->gcam; L.cam_io = e->cam; L.cam_m = e->cam_m; L.cam_v = e->cam_v;
+      }
       int rcq = launch_sup_step(e->m, q, L, s);
       if (rcq) return rcq;
       h2t_ready = pd && q.H2T_next != nullptr;
       prof_mark(e, 1, s);
       if (e->hist) {
         if (e->hist_iter % e->hist_every == 0 && e->hist_n < e->hist_cap) {
-          hipLaunchKernelGGL(k_loss_record, dim3(1), dim3(1024), 0, s, sqerr ? sqerr : e->sqerr, nullptr, nullptr, pd ? e->dsq : nullptr,
+          hipLaunchKernelGGL(k_loss_record, dim3(1), dim3(1024), 0, s, sqerr ? sqerr : e->sqerr, e->gt_j2d ? e->sq2d : nullptr, nullptr, pd ? e->dsq : nullptr,
                              sd ? e->ssq : nullptr, e->B, e->BP, (float)e->bnorm, e->hist + (size_t)e->hist_n * 5, (float)(e->sil * e->sil));
           ++e->hist_n;
         }
@@ -1560,8 +1579,9 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       if (rcf) return rcf;
       launch_fold_fwd(e->MT, e->AT, e->G0, e->Jsum, e->BP, s);
     } else if (supv) {
+      ReprojLaunch rls{e->gt_j2d, e->cam, e->gcam, e->sq2d, (float)(2.0 * 0.01 / ((double)e->bnorm * 34.0))};
       int rcs = launch_sup_iter(e->sup, e->sup_nsv, e->Jn_vi, e->FTq, e->AT, gt_mm, jscale, e->joints, sqerr ? sqerr : e->sqerr, e->dA, e->dF,
-                                e->B, e->BP, s);
+                                e->B, e->BP, s, e->gt_j2d ? &rls : nullptr);
       if (rcs) return rcs;
     } else {
       const bool silf = e->sil_mask != nullptr;      // the silhouette term needs the vertices

@@ -188,7 +188,7 @@ int launch_sup_gather(const Model& m, const SupTables& t, int nsv, hipStream_t s
 // one joint-loss forward + backward of the pose groups: F^T (K-quads) / A^T of k_prep_fwd in, joints / squared error / dA^T [288][BP] /
 // dF^T [224][BP] out (what k_chain_bwd reads as ONE slab)
 int launch_sup_iter(const SupTables& t, int nsv, const float* Jn_vi, const float* FTq, const float* AT, const float* gt_mm, float scale,
-                    float* joints_out, float* sqerr, float* dA, float* dF, int B, int BP, hipStream_t s);
+                    float* joints_out, float* sqerr, float* dA, float* dF, int B, int BP, hipStream_t s, const ReprojLaunch* r = nullptr);
 
 // ONE inner iteration per 32-pose group in one launch (prep.hip k_sup_step): chain forward, support-vertex forward / loss / backward,
 // [per-joint MLP adjoint], chain adjoint + Adam, [per-joint MLP forward of the next iteration].  The pose-update half takes a PrepBwdLaunch
@@ -199,6 +199,8 @@ struct SupStepLaunch {
   const float* conv_img = nullptr; const float* dH2T = nullptr; float dscale = 0.f; float* gx = nullptr; float* dsq = nullptr;
   float* H2T_next = nullptr;
   int32_t* step = nullptr; int* arrive = nullptr;      // Adam's step counter (incremented once per launch) and the arrival counter
+  // 2-D reprojection term (nullable gt_j2d: off); the camera's Adam state travels in the PrepBwdLaunch (gcam / cam_io / cam_m / cam_v)
+  const float* gt_j2d = nullptr; const float* cam = nullptr; float* gcam = nullptr; float* sq2d = nullptr; float scale2d = 0.f;
 };
 int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s);
 

@@ -11,6 +11,7 @@
 #include "jrr_common.h"
 #include "kernels.h"
 #include "dconv.h"
+#include "proj.h"
 #include "supk.h"
 
 namespace jrr {
@@ -430,36 +431,7 @@ __global__ __launch_bounds__(PP * NJ) void k_prep_fwd_dconv(const float* __restr
 // SURVEY.md Appendix B):  X = -2x + tx, Y = -2y + ty, Z = 2z + tz ;  x_ndc = f X / Z ;
 // x_screen = (W-1)/2 (1 - x_ndc)  (same for y).
 // ------------------------------------------------------------------------------------------
-constexpr float PROJ_F = 5000.f / 224.f;
-constexpr float PROJ_HALF = (224.f - 1.f) * 0.5f;
-
-__device__ __forceinline__ void project_point(const float p[3], const float t[3], float& xs, float& ys, float& invZ,
-                                              float& X, float& Y) {
-  X = -2.f * p[0] + t[0];
-  Y = -2.f * p[1] + t[1];
-  const float Z = 2.f * p[2] + t[2];
-  invZ = 1.f / Z;
-  xs = PROJ_HALF * (1.f - PROJ_F * X * invZ);
-  ys = PROJ_HALF * (1.f - PROJ_F * Y * invZ);
-}
-
-// adjoint of the 2-D squared error of one joint: g2 = dL/d(xs,ys) -> accumulates dL/dp (3) and dL/dt (3)
-__device__ __forceinline__ void project_point_bwd(float gxs, float gys, float invZ, float X, float Y, float gp[3],
-                                                  float gt[3]) {
-  const float gxn = -PROJ_HALF * gxs, gyn = -PROJ_HALF * gys;       // d/dx_ndc
-  const float gX = gxn * PROJ_F * invZ, gY = gyn * PROJ_F * invZ;
-  const float gZ = -(gxn * X + gyn * Y) * PROJ_F * invZ * invZ;
-  gp[0] += -2.f * gX; gp[1] += -2.f * gY; gp[2] += 2.f * gZ;
-  gt[0] += gX; gt[1] += gY; gt[2] += gZ;
-}
-
-struct Reproj {
-  const float* gt_j2d;   // (B,17,2) or NULL (term disabled)
-  const float* cam;      // (B,3)
-  float* gcam;           // (B,3) out: dL/dcam
-  float* sq2d;           // (B) out: sum of squared 2-D errors (nullable)
-  float scale2d;         // 2*weight/(batch_norm*34)
-};
+// (project_point / project_point_bwd / Reproj: proj.h -- shared with the support-vertex iteration, supk.h)
 
 // ------------------------------------------------------------------------------------------
 // k_joints_loss: joints (from the reduced partials [3][17][BP]) -> joints (B,17,3), per-pose squared
@@ -1086,14 +1058,15 @@ int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch&
   if (!attr) { jrr_set_error("k_sup_step: %d bytes of LDS refused", SUP_STEP_LDS * 4); return JRR_ERR_HIP; }
   SupStepArgs a;
   a.x6d = L.x6d_in; a.betas = L.betas_in; a.FT = q.FT; a.FTq = q.FTq; a.AT = q.AT; a.R0T = q.R0T;
-  a.sup = SupArgs{q.t, q.nsv, q.Jn_vi, q.FTq, q.AT, q.gt_mm, q.scale, q.joints_out, q.sqerr, q.dA, q.dF, L.B, L.BP};
+  a.sup = SupArgs{q.t, q.nsv, q.Jn_vi, q.FTq, q.AT, q.gt_mm, q.scale, q.joints_out, q.sqerr, q.dA, q.dF, L.B, L.BP,
+                  Reproj{q.gt_j2d, q.cam, q.gcam, q.sq2d, q.scale2d}};
   a.conv_img = q.conv_img; a.dH2T = q.dH2T; a.dscale = q.dscale; a.gx = q.gx; a.dsq = q.dsq; a.H2T_next = q.H2T_next;
   PoseUpdateArgs& u = a.ua;
   u.x6d_in = L.x6d_in; u.gx_extra = L.gx_extra; u.gb_extra = L.gb_extra;
   u.dx6d = L.dx6d; u.dR = L.dR; u.dbetas = L.dbetas;
   u.x6d_io = L.x6d_io; u.betas_io = L.betas_io; u.adam_m = L.adam_m; u.adam_v = L.adam_v; u.step = L.step;
   u.lr = L.lr; u.beta1 = L.beta1; u.beta2 = L.beta2; u.eps = L.eps;
-  u.gcam = nullptr; u.cam_io = nullptr; u.cam_m = nullptr; u.cam_v = nullptr;
+  u.gcam = L.gcam; u.cam_io = L.cam_io; u.cam_m = L.cam_m; u.cam_v = L.cam_v;      // the camera translation steps with the poses (2-D term)
   a.step = q.step; a.arrive = q.arrive;
   static long long* const stamps = [] { const char* v = getenv("JRR_SUP_STAMPS"); return v ? (long long*)strtoull(v, nullptr, 0) : (long long*)nullptr; }();
   a.stamps = stamps;

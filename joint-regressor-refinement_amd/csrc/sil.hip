@@ -644,19 +644,25 @@ int launch_sil_pix_to_face(const unsigned* cover, const int* ncover, int* p2f, i
 
 static bool g_sil_attr = false;
 constexpr int SIL_LDS_BYTES = SIL_VPAD * 4 + SIL_ZPIX * 8;
+// Image sizes.  The in-loop silhouette term (ADJ) is built for the two sizes the reference instantiates: 224 (scripts/optimize.py:110) and 256
+// (the constructor's default, scripts/mesh_renderer.py:25).  The stand-alone forward / backward pair behind `Mesh_Renderer(image_size)` takes
+// every multiple of 32 up to 256 (round 6): the image size is a template parameter of the strip arithmetic and of the pixel-centre table.
+#define JRR_SIL_SIZES(X) X(32) X(64) X(96) X(128) X(160) X(192) X(224) X(256)
 static void sil_attrs() {
   if (g_sil_attr) return;
-  (void)hipFuncSetAttribute((const void*)k_sil_raster<false, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
+#define JRR_SIL_ATTR(S_)                                                                                                           \
+  (void)hipFuncSetAttribute((const void*)k_sil_raster<false, S_>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);       \
+  (void)hipFuncSetAttribute((const void*)k_sil_bwd<S_>, hipFuncAttributeMaxDynamicSharedMemorySize, V * 2 * 4);
+  JRR_SIL_SIZES(JRR_SIL_ATTR)
+#undef JRR_SIL_ATTR
   (void)hipFuncSetAttribute((const void*)k_sil_raster<true, 224>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
-  (void)hipFuncSetAttribute((const void*)k_sil_raster<false, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
   (void)hipFuncSetAttribute((const void*)k_sil_raster<true, 256>, hipFuncAttributeMaxDynamicSharedMemorySize, SIL_LDS_BYTES);
-  (void)hipFuncSetAttribute((const void*)k_sil_bwd<224>, hipFuncAttributeMaxDynamicSharedMemorySize, V * 2 * 4);
-  (void)hipFuncSetAttribute((const void*)k_sil_bwd<256>, hipFuncAttributeMaxDynamicSharedMemorySize, V * 2 * 4);
   g_sil_attr = true;
 }
-static int sil_size_ok(int S) {
-  if (S == 224 || S == 256) return 0;
-  jrr_set_error("silhouette: image size %d (the kernels are built for 224 and 256)", S);
+static int sil_size_ok(int S, bool in_loop = false) {
+  if (in_loop ? (S == 224 || S == 256) : (S >= 32 && S <= 256 && S % 32 == 0)) return 0;
+  if (in_loop) jrr_set_error("silhouette term inside the loop: image size %d (built for 224 and 256, the sizes the reference instantiates)", S);
+  else jrr_set_error("silhouette: image size %d (the stand-alone renderer takes the multiples of 32 up to 256)", S);
   return JRR_ERR_ARG;
 }
 int launch_sil_project(const float* verts, int ldv, const float* cam, float* ndc, int B, hipStream_t s, int S) {
@@ -668,12 +674,16 @@ int launch_sil_raster(const float* ndc, const unsigned* faces_pk, int nfaces, un
   sil_attrs();
   if (sil_size_ok(S)) return JRR_ERR_ARG;
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
-  if (S == 224)
-    hipLaunchKernelGGL((k_sil_raster<false, 224>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc, reinterpret_cast<const uint2*>(faces_pk), nfaces, nullptr, cover,
-                       ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr, nullptr);
-  else
-    hipLaunchKernelGGL((k_sil_raster<false, 256>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc, reinterpret_cast<const uint2*>(faces_pk), nfaces, nullptr, cover,
-                       ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, B, nullptr, 0, nullptr, nullptr);
+  switch (S) {
+#define JRR_SIL_FWD(S_)                                                                                                            \
+  case S_:                                                                                                                         \
+    hipLaunchKernelGGL((k_sil_raster<false, S_>), dim3(B), dim3(SIL_RT), SIL_LDS_BYTES, s, (const NdcV*)ndc,                        \
+                       reinterpret_cast<const uint2*>(faces_pk), nfaces, nullptr, cover, ncover, alpha, nullptr, 0.f, nullptr, 0, nullptr, \
+                       B, nullptr, 0, nullptr, nullptr);                                                                            \
+    break;
+    JRR_SIL_SIZES(JRR_SIL_FWD)
+#undef JRR_SIL_FWD
+  }
   return 0;
 }
 // fused loop: project the pose's vertices from the row-quad buffer VQ [3][VP/4][BP][4], rasterise, squared error against
@@ -683,7 +693,7 @@ int launch_sil_raster_adj(float* VQ, int BP, const float* cam, const unsigned* f
                           unsigned* cover, int* ncover, float* sqsil, float scale, float* gcam, int accumulate_cam, int B,
                           hipStream_t s, int S, const float* VPM) {
   sil_attrs();
-  if (sil_size_ok(S)) return JRR_ERR_ARG;
+  if (sil_size_ok(S, true)) return JRR_ERR_ARG;
   if (nfaces > SIL_FPT * SIL_RT) { jrr_set_error("silhouette: at most %d faces supported", SIL_FPT * SIL_RT); return JRR_ERR_ARG; }
   const int grid = BP < 256 ? BP : 256;    // persistent: one workgroup per CU (a multiple of 8: BP is a multiple of 128); padded poses zero their pieces
   if (S == 224)
@@ -700,12 +710,15 @@ int launch_sil_bwd(const float* ndc, const int* faces, const unsigned* cover, co
                    hipStream_t s, int S) {
   sil_attrs();
   if (sil_size_ok(S)) return JRR_ERR_ARG;
-  if (S == 224)
-    hipLaunchKernelGGL(k_sil_bwd<224>, dim3(B), dim3(SIL_BT), V * 2 * 4, s, (const NdcV*)ndc, faces, cover, ncover, mask, galpha, scale, dverts,
-                       ldv, gcam, accumulate_cam);
-  else
-    hipLaunchKernelGGL(k_sil_bwd<256>, dim3(B), dim3(SIL_BT), V * 2 * 4, s, (const NdcV*)ndc, faces, cover, ncover, mask, galpha, scale, dverts,
-                       ldv, gcam, accumulate_cam);
+  switch (S) {
+#define JRR_SIL_BWD(S_)                                                                                                            \
+  case S_:                                                                                                                         \
+    hipLaunchKernelGGL(k_sil_bwd<S_>, dim3(B), dim3(SIL_BT), V * 2 * 4, s, (const NdcV*)ndc, faces, cover, ncover, mask, galpha, scale, \
+                       dverts, ldv, gcam, accumulate_cam);                                                                          \
+    break;
+    JRR_SIL_SIZES(JRR_SIL_BWD)
+#undef JRR_SIL_BWD
+  }
   return 0;
 }
 

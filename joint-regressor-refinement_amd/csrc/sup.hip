@@ -72,12 +72,13 @@ __global__ __launch_bounds__(SUP_THREADS) void k_sup_iter(SupArgs a) {
 }
 
 int launch_sup_iter(const SupTables& t, int nsv, const float* Jn_vi, const float* FTq, const float* AT, const float* gt_mm, float scale,
-                    float* joints_out, float* sqerr, float* dA, float* dF, int B, int BP, hipStream_t s) {
+                    float* joints_out, float* sqerr, float* dA, float* dF, int B, int BP, hipStream_t s, const ReprojLaunch* r) {
   static const bool attr = [] {
     return hipFuncSetAttribute((const void*)k_sup_iter, hipFuncAttributeMaxDynamicSharedMemorySize, SUPL_FLOATS * 4) == hipSuccess;
   }();
   if (!attr) { jrr_set_error("k_sup_iter: %d bytes of LDS refused", SUPL_FLOATS * 4); return JRR_ERR_HIP; }
-  SupArgs a{t, nsv, Jn_vi, FTq, AT, gt_mm, scale, joints_out, sqerr, dA, dF, B, BP};
+  SupArgs a{t, nsv, Jn_vi, FTq, AT, gt_mm, scale, joints_out, sqerr, dA, dF, B, BP,
+            r ? Reproj{r->gt_j2d, r->cam, r->gcam, r->sq2d, r->scale2d} : Reproj{nullptr, nullptr, nullptr, nullptr, 0.f}};
   hipLaunchKernelGGL(k_sup_iter, dim3((B + SUP_PP - 1) / SUP_PP), dim3(SUP_THREADS), SUPL_FLOATS * 4, s, a);
   return 0;
 }

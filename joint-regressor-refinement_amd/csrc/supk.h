@@ -22,6 +22,7 @@
 #pragma once
 #include "jrr_common.h"
 #include "kernels.h"
+#include "proj.h"
 
 namespace jrr {
 
@@ -42,8 +43,8 @@ constexpr int SUPL_AL = SUPL_FQ + (KFP / 4) * 32 * 4;   // [288][32]   A^T of th
 constexpr int SUPL_VP = SUPL_AL + 12 * NJ * 32;         // [192][32]   v_posed
 constexpr int SUPL_V = SUPL_VP + SUP_ROWS * 32;         // [192][32]   vertices                   -> dvp [48 quads][32][4]
 constexpr int SUPL_JN = SUPL_V + SUP_ROWS * 32;         // [17][64]    regressor columns of the support vertices
-constexpr int SUPL_RED = SUPL_JN + NH * SUP_JS;         // [17][4][32] per-joint loss partials
-constexpr int SUPL_PEL = SUPL_RED + NH * 4 * 32;        // [3][32]
+constexpr int SUPL_RED = SUPL_JN + NH * SUP_JS;         // [17][8][32] per-joint loss partials: 0..2 g, 3 err, 4 e2d, 5..7 gcam
+constexpr int SUPL_PEL = SUPL_RED + NH * 8 * 32;        // [3][32]
 constexpr int SUPL_DJ = SUPL_PEL + 3 * 32;              // [3][17][32] joint adjoint
 constexpr int SUPL_MASK = SUPL_DJ + 3 * NH * 32;        // [17][2] row masks + [64] column masks of the regressor's non-zeros (32-bit words)
 constexpr int SUPL_FLOATS = SUPL_MASK + 2 * 32 + SUP_NSV;
@@ -61,6 +62,7 @@ struct SupArgs {
   float* dA;                 // [288][BP] out
   float* dF;                 // [224][BP] out
   int B, BP;
+  Reproj rp;                 // 2-D reprojection term on the un-centred joints (scripts/optimize.py:231-233); gt_j2d == NULL: off
 };
 
 // stamps (nullable; experiments): phase boundaries on the 100 MHz counter, written by thread 0
@@ -174,6 +176,7 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
     if (jt == 0) { pel[p] = j3[0]; pel[32 + p] = j3[1]; pel[64 + p] = j3[2]; }
   }
   __syncthreads();
+  float g2[3] = {0.f, 0.f, 0.f};      // adjoint of the 2-D term w.r.t. this joint
   if (jt < NH) {
     float err = 0.f;
 #pragma unroll
@@ -182,23 +185,40 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
       const float d = (jt == 0) ? -gtv : (j3[c] - pel[c * 32 + p]) - gtv;      // joint 0 is identically 0 after centring
       err += d * d;
       g3[c] = (jt == 0) ? 0.f : a.scale * d;
-      red[(jt * 4 + c) * 32 + p] = g3[c];
+      red[(jt * 8 + c) * 32 + p] = g3[c];
     }
-    red[(jt * 4 + 3) * 32 + p] = err;
+    float e2 = 0.f, gc[3] = {0.f, 0.f, 0.f};
+    if (a.rp.gt_j2d && ok) {      // k_joints_loss's statements (prep.hip)
+      float t[3] = {a.rp.cam[(size_t)b * 3], a.rp.cam[(size_t)b * 3 + 1], a.rp.cam[(size_t)b * 3 + 2]};
+      float xs, ys, invZ, X, Y;
+      project_point(j3, t, xs, ys, invZ, X, Y);
+      const float dx = xs - a.rp.gt_j2d[((size_t)b * NH + jt) * 2], dy = ys - a.rp.gt_j2d[((size_t)b * NH + jt) * 2 + 1];
+      e2 = dx * dx + dy * dy;
+      project_point_bwd(a.rp.scale2d * dx, a.rp.scale2d * dy, invZ, X, Y, g2, gc);
+    }
+    red[(jt * 8 + 3) * 32 + p] = err;
+    red[(jt * 8 + 4) * 32 + p] = e2;
+#pragma unroll
+    for (int c = 0; c < 3; ++c) red[(jt * 8 + 5 + c) * 32 + p] = gc[c];
   }
   __syncthreads();
   if (jt < NH) {
     if (jt == 0) {      // fixed-order sums over the 17 joints
-      float sm[4] = {0.f, 0.f, 0.f, 0.f};
+      float sm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       for (int q = 0; q < NH; ++q)
 #pragma unroll
-        for (int k = 0; k < 4; ++k) sm[k] += red[(q * 4 + k) * 32 + p];
+        for (int k = 0; k < 8; ++k) sm[k] += red[(q * 8 + k) * 32 + p];
       if (ok && a.sqerr) a.sqerr[b] = sm[3];
+      if (ok && a.rp.gt_j2d) {
+        if (a.rp.sq2d) a.rp.sq2d[b] = sm[4];
+#pragma unroll
+        for (int c = 0; c < 3; ++c) a.rp.gcam[(size_t)b * 3 + c] = sm[5 + c];
+      }
 #pragma unroll
       for (int c = 0; c < 3; ++c) g3[c] = -sm[c];      // move_pelvis adjoint: -sum_i g_i
     }
 #pragma unroll
-    for (int c = 0; c < 3; ++c) djL[(c * NH + jt) * 32 + p] = ok ? g3[c] : 0.f;
+    for (int c = 0; c < 3; ++c) djL[(c * NH + jt) * 32 + p] = ok ? g3[c] + g2[c] : 0.f;
   }
   __syncthreads();
   stamp(3);

@@ -22,6 +22,13 @@ FLAG_FOLDED = 8
 FLAG_SILHOUETTE = 16
 FLAG_NO_MODEL = 32
 FLAG_SIL_256 = 64      # with FLAG_SILHOUETTE: 256 x 256 silhouettes (the reference constructor's default) instead of 224 x 224
+def FLAG_SIL_SIZE(size: int) -> int:
+    """with FLAG_SILHOUETTE: an explicit silhouette size, any multiple of 32 up to 256 (include/jrr.h JRR_FLAG_SIL_SIZE)"""
+    if size % 32 or not 32 <= size <= 256:
+        raise ValueError(f'silhouette size {size}: a multiple of 32 up to 256')
+    return (size // 32) << 16
+
+
 FLAG_SUPPORT_TILES = 128      # joint-loss iterations on the tiles of the regressor's support only (see include/jrr.h)
 FLAG_BLEND_BF16X3 = 256       # SIDE MODE, not the reference's arithmetic: split-bf16 blend adjoint (see include/jrr.h); never the default
 SIL = 224
@@ -117,7 +124,7 @@ class RefineEngine:
         self.batch = int(batch)
         self.batch_norm = int(batch_norm or batch)
         self.flags = int(flags) | (FLAG_NO_MODEL if model is None else 0)   # no SMPL workspace for a discriminator-only engine
-        self.sil = 256 if (self.flags & FLAG_SIL_256) else SIL              # silhouette image size of this engine
+        self.sil = 32 * ((self.flags >> 16) & 15) or (256 if (self.flags & FLAG_SIL_256) else SIL)      # silhouette image size of this engine
         # Forward-generation counter: the adjoint entry points read the engine's internal state of the MOST RECENT
         # forward (include/jrr.h: "must follow it"), while autograd defers backward.  Every call that overwrites that
         # state bumps the counter; the autograd wrappers compare it with the value saved at forward time and re-run
@@ -476,7 +483,7 @@ class RefineEngine:
 
     def support_vertices(self):
         """(active, n_vertices): whether those iterations run per support VERTEX, one launch per iteration and 32-pose group
-        (include/jrr.h jrr_engine_support_vertices: the support has at most 64 vertices, no 2-D term), and on how many vertices"""
+        (include/jrr.h jrr_engine_support_vertices: the support has at most 64 vertices), and on how many vertices"""
         n = c_int32(0)
         rc = self.lib.jrr_engine_support_vertices(self.handle, byref(n))
         if rc < 0:

@@ -41,19 +41,20 @@ class Mesh_Renderer(nn.Module):
 
     def __init__(self, image_size: int = 256, smpl=None):
         # the reference constructor's signature and default (scripts/mesh_renderer.py:25); its loop instantiates 224
-        # (scripts/optimize.py:110).  The HIP rasteriser is built for exactly these two sizes (include/jrr.h, JRR_FLAG_SIL_256);
-        # the camera's focal length is 5000 / image_size as in the reference (mesh_renderer.py:52-53).
+        # (scripts/optimize.py:110).  The stand-alone HIP rasteriser takes every multiple of 32 up to 256 (include/jrr.h,
+        # JRR_FLAG_SIL_SIZE; the image size is a template parameter of its strip arithmetic); the camera's focal length is
+        # 5000 / image_size as in the reference (mesh_renderer.py:52-53).
         super().__init__()
-        if image_size not in (224, 256):
-            raise NotImplementedError(f'Mesh_Renderer(image_size={image_size}): the HIP rasteriser is built for 224 (scripts/optimize.py:110) '
-                                      'and 256 (the reference constructor\'s default) -- include/jrr.h, jrr_silhouette_forward')
+        if image_size % 32 or not 32 <= image_size <= 256:
+            raise NotImplementedError(f'Mesh_Renderer(image_size={image_size}): the HIP rasteriser takes the multiples of 32 up to 256 '
+                                      '(include/jrr.h, JRR_FLAG_SIL_SIZE)')
         self.image_size = image_size
         self.smpl = smpl
         self._engines = {}
 
     def _engine(self, batch):
         if batch not in self._engines:
-            flags = _engine.FLAG_SILHOUETTE | (_engine.FLAG_SIL_256 if self.image_size == 256 else 0)
+            flags = _engine.FLAG_SILHOUETTE | (0 if self.image_size == 224 else _engine.FLAG_SIL_SIZE(self.image_size))
             self._engines[batch] = _engine.RefineEngine(self.smpl.device_model, batch, flags=flags)
         return self._engines[batch]
 

@@ -607,3 +607,49 @@ def test_silhouette_at_the_reference_constructors_default_size(smpl_model_np, j_
     assert out.shape == (B, 4, 256, 256) and torch.equal(out[:, 3], al)
     with pytest.raises(NotImplementedError):
         mr.Mesh_Renderer(300, smpl_hip)
+
+
+@pytest.mark.parametrize('S', [96, 160])
+def test_mesh_renderer_at_other_image_sizes(smpl_model_np, j_h36m_np, S):
+    """Mesh_Renderer(image_size) takes any size in the reference (scripts/mesh_renderer.py:25,34-38; focal length 5000 / size, :52-53):
+    the stand-alone rasteriser and its adjoint at the multiples of 32 up to 256 -- alpha and the winning faces against the restated
+    rasteriser, the adjoint against the oracle's autograd through the module, the in-loop term refused at sizes it is not built for"""
+    from oracle import silhouette_port as sp
+    sm, em, mr = _mod('smpl_model'), _mod('engine'), _mod('mesh_renderer')
+    B = 5
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=93)
+    x6, betas, cam = T(batch['pose6d']), T(batch['betas']), T(batch['cam'])
+    smpl_hip = _mod('smpl').SMPL(model=smpl_model_np).to(DEV)
+    eng = em.RefineEngine(smpl_hip.device_model, B, flags=em.FLAG_SILHOUETTE | em.FLAG_KEEP_VERTS | em.FLAG_SIL_SIZE(S))
+    assert eng.sil == S
+    eng.set_j_regressor(T(j_h36m_np))
+    xd, bd, cd = x6.to(DEV).contiguous(), betas.to(DEV).contiguous(), cam.to(DEV).contiguous()
+    _, verts = eng.find_joints_forward(bd, x6d=xd, return_verts=True)
+    alpha = eng.silhouette_forward(verts, cd)
+    assert alpha.shape == (B, S, S)
+    p2f = eng.silhouette_pix_to_face().cpu()
+    ref, p2f_o = sp.soft_silhouette(verts.cpu(), smpl_model_np['faces'], cam, image_size=S, return_pix_to_face=True)
+    ref, p2f_o = ref[:, 0], torch.from_numpy(p2f_o)
+    agree = (p2f == p2f_o) & ((alpha.cpu() - ref).abs() < 2e-3)
+    covered = (p2f_o >= 0).sum().item()
+    assert covered > 4000 * B * (S / 224) ** 2 * 0.8
+    assert (~agree).sum().item() < 5e-3 * covered, ((~agree).sum().item(), covered)
+    assert torch.equal(p2f >= 0, alpha.cpu() > 0)
+    # the module: forward + backward (stand-alone adjoint kernel) against the oracle's autograd on the pixels both rasterisers agree on
+    w = torch.randn(B, S, S, generator=torch.Generator().manual_seed(S)) * agree.float()
+    vd = verts.clone().requires_grad_(True)
+    out = mr.Mesh_Renderer(S, smpl_hip)({'cam': cd}, vd * vd.new_tensor([-2.0, -2.0, 2.0]))
+    assert out.shape == (B, 4, S, S) and torch.equal(out[:, 3].detach(), alpha)
+    (out[:, 3] * w.to(DEV)).sum().backward()
+    vo = verts.cpu().clone().requires_grad_(True)
+    img = sp.soft_silhouette(vo, smpl_model_np['faces'], cam, image_size=S)
+    (img[:, 0] * w).sum().backward()
+    rel = ((vd.grad.cpu().double() - vo.grad.double()).norm() / vo.grad.double().norm()).item()
+    assert rel < 2e-2, rel
+    # the silhouette term INSIDE the loop exists at 224 and 256 only
+    lib_mod = _mod('_lib')
+    cm, cv = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV)
+    with pytest.raises(lib_mod.JrrError, match='224'):
+        eng.set_silhouette((alpha > 0).float().contiguous(), cd, cm, cv)
+    with pytest.raises(ValueError):
+        em.FLAG_SIL_SIZE(100)

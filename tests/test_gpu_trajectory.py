@@ -180,3 +180,40 @@ def test_hundred_iterations_with_j_steps_vs_oracle(em, dmodels, j_h36m_np, confi
     joints = eng2.find_joints_forward(bd, x6d=xd).cpu()
     dj = (joints - c['joints']).abs().max().item()
     assert dj < 1e-4, dj
+
+
+def test_support_iteration_with_2d_term_and_pose_disc_vs_oracle(em, sm, dmodels, smpl_model_np, j_h36m_np):
+    """the per-vertex iteration with the 2-D reprojection term (scripts/optimize.py:231-233: un-centred joints through the camera, weight
+    1/100; the camera translation is a parameter of the same Adam) and the pose discriminator: 10 iterations against the oracle"""
+    B, n = 48, 10
+    batch = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=47)
+    x6, betas, cam0 = T(batch['pose6d']), T(batch['betas']), T(batch['cam'])
+    gt_c = oracle.move_pelvis(T(batch['gt_j3d']))
+    dsd = oracle.formula_state_dict(oracle.DISC_PARAM_SHAPES, seed=0)
+    smpl = oracle.OracleSMPL(smpl_model_np)
+    R = oracle.rot6d_to_rotmat(x6.reshape(-1, 6)).view(B, 24, 3, 3)
+    j0 = oracle.find_joints(smpl, betas, R[:, :1], R[:, 1:], T(j_h36m_np))
+    gen = torch.Generator().manual_seed(5)
+    cam_true = torch.tensor([0.0, 0.0, 2 * 5000 / (224 * 0.9)]).repeat(B, 1) + torch.randn(B, 3, generator=gen) * torch.tensor([0.3, 0.3, 3.0])
+    gt2d = oracle.project_joints(j0, cam_true) + torch.randn(B, 17, 2, generator=gen) * 2.0
+    o, p, b, hist, c = oracle.refine_poses(smpl, T(j_h36m_np), x6[:, :1], x6[:, 1:], betas, gt_c, n, disc_sd=dsd, gt_j2d=gt2d, cam=cam0)
+    eng = _engine(em, dmodels['hinted'], B, True, dsd, T(j_h36m_np))
+    xd, bd, cd = x6.clone().to(DEV), betas.clone().to(DEV), cam0.clone().to(DEV)
+    cm, cv = torch.zeros(B, 3, device=DEV), torch.zeros(B, 3, device=DEV)
+    eng.set_reprojection(gt2d.to(DEV).contiguous(), cd, cm, cv)
+    if support_tiles_available():
+        import os
+        assert eng.support_vertices()[0] == (os.environ.get('JRR_SUPPORT_FUSED') != '0')      # the 2-D term does not leave the per-vertex iteration
+    eng.set_loss_history(n, 1)
+    m, v, step = _state(B)
+    eng.refine_run(xd, bd, gt_c.to(DEV).contiguous(), m, v, step, 1e-2, n)
+    rec = eng.loss_history().cpu()
+    eng.set_reprojection(None)
+    for k in range(n):
+        np.testing.assert_allclose(rec[k, 0].item(), hist[k]['loss_j2d'] * 0.01, rtol=5e-3, err_msg=f'2-D term, iteration {k}')
+        np.testing.assert_allclose(rec[k, 2].item(), hist[k]['joint_loss'] * 10000, rtol=5e-3, err_msg=f'joint term, iteration {k}')
+    assert (xd.cpu() - torch.cat([o, p], 1)).abs().max().item() < 6e-4
+    assert (xd.cpu() - torch.cat([o, p], 1)).abs().mean().item() < 5e-6
+    assert (bd.cpu() - b).abs().max().item() < 3e-4
+    assert (cd.cpu() - c).abs().max().item() < 3e-4
+    assert (cd.cpu() - cam0).abs().max().item() > 1e-2           # the camera really moved

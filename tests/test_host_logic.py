@@ -191,13 +191,15 @@ def test_dataset_tensor_layout(tmp_path):
 
 
 def test_pixel_centre_f64_product_equals_fp32_division():
-    """csrc/sil.hip pix_x(): fl32((2i+1) * (1/224) in f64) must equal the IEEE fp32 quotient (2i+1)/224 for every
-    pixel index, so the rasteriser's pixel centres are those of the fp32 formula (pytorch3d 0.3.0 arithmetic)."""
-    i = np.arange(224)
-    ref = np.float32(1) - (np.float32(2) * i.astype(np.float32) + np.float32(1)) / np.float32(224)
-    got = np.float32(1) - ((2 * i + 1).astype(np.float64) * (1.0 / 224.0)).astype(np.float32)
-    assert ref.dtype == np.float32 and got.dtype == np.float32
-    assert np.array_equal(ref, got)
+    """csrc/sil.hip pix_x<S>(): fl32((2i+1) * (1/S) in f64) must equal the IEEE fp32 quotient (2i+1)/S for every pixel index of every
+    image size the rasteriser is instantiated for (the multiples of 32 up to 256), so that its pixel centres are those of the fp32
+    formula (pytorch3d 0.3.0 arithmetic)."""
+    for S in range(32, 257, 32):
+        i = np.arange(S)
+        ref = np.float32(1) - (np.float32(2) * i.astype(np.float32) + np.float32(1)) / np.float32(S)
+        got = np.float32(1) - ((2 * i + 1).astype(np.float64) * (1.0 / float(S))).astype(np.float32)
+        assert ref.dtype == np.float32 and got.dtype == np.float32
+        assert np.array_equal(ref, got), S
 
 
 def test_shared_bucket_layout():
