@@ -97,18 +97,12 @@ __device__ __forceinline__ void dconv_fwd_body(float* __restrict__ L, int blk, c
 }
 
 // input gradient of the per-joint MLP + heads; dH2T = gradient arriving from fc0 (may be NULL), gout (B,25) nullable
-template <bool QUAD, bool STAGED = false>
-__device__ __forceinline__ void dconv_bwd_body(float* __restrict__ L, int blk, const float* __restrict__ img,
-                                               const float* __restrict__ x6d, const float* __restrict__ dH2T,
-                                               const float* __restrict__ gout, float scale, float target,
+// the adjoint of ONE (32-pose tile bt, joint j) pair on the calling wave: no staging, no barrier (L holds the image)
+template <bool QUAD>
+__device__ __forceinline__ void dconv_bwd_tile(const float* __restrict__ L, int bt, int j, const float* __restrict__ x6d,
+                                               const float* __restrict__ dH2T, const float* __restrict__ gout, float scale, float target,
                                                float* __restrict__ gx, int B, int BP, float* __restrict__ sqj) {
-  if (!STAGED) {
-    conv_stage_params(img, L);
-    __syncthreads();
-  }
   const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
-  const int W = blockDim.x >> 6, ngrp = NJ / W;
-  const int bt = blk / ngrp, j = (blk % ngrp) * W + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int b = bt * 32 + l31;
   const bool ok = b < B;
   f32x16 h1, h2;
@@ -152,6 +146,108 @@ __device__ __forceinline__ void dconv_bwd_body(float* __restrict__ L, int blk, c
     dst[0] = f32x2{accx[0], accx[1]};
     if (half == 0) dst[1] = f32x2{accx[2], accx[3]};
   }
+}
+
+// TWO (tile, joint) adjoints on the calling wave, their dependent chains interleaved stage by stage (round 6): one tile is a chain of 51
+// matrix instructions with an LDS operand read and a vector step between any two of them -- 7 us for a wave on its own, of which the
+// matrix pipe is busy 1.4.  Two independent chains in one instruction stream fill each other's gaps.  Per tile the arithmetic and its
+// order are those of dconv_bwd_tile (bit-identical results).  Quad layouts only (the loop's).
+__device__ __forceinline__ void dconv_bwd_pair(const float* __restrict__ L, int bt, int j0, int j1, const float* __restrict__ x6d,
+                                               const float* __restrict__ dH2T, float scale, float target, float* __restrict__ gx, int B,
+                                               int BP, float* __restrict__ sqj) {
+  const int lane = threadIdx.x & 63, half = lane >> 5, l31 = lane & 31;
+  const int b = bt * 32 + l31;
+  const bool ok = b < B;
+  const int jj[2] = {j0, j1};
+  const unsigned qoff = (unsigned)half * (unsigned)BP + (unsigned)b;
+  // everything that comes from global memory, for both tiles, first
+  float xv[2][3];
+  f32x4 dq[2][4];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+#pragma unroll
+    for (int kk = 0; kk < 3; ++kk) xv[n][kk] = ok ? x6d[((size_t)b * NJ + jj[n]) * 6 + 2 * kk + half] : 0.f;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) dq[n][g] = *quad_ptr(dH2T, (size_t)jj[n] * 8, g, BP, qoff);
+  }
+  f32x16 acc[2] = {zero16(), zero16()}, h1[2], h2[2];
+#pragma unroll
+  for (int kk = 0; kk < 3; ++kk) {
+    const float w = L[CL_W0P + (2 * kk + half) * 32 + l31];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[n] = mfma(w, xv[n][kk], acc[n]);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float bq = L[CL_B0 + acc_row(q, half)];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) h1[n][q] = fmaxf(acc[n][q] + bq, 0.f);
+  }
+  acc[0] = zero16(); acc[1] = zero16();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float w = L[CL_W2T + acc_row(q, half) * 32 + l31];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) acc[n] = mfma(w, h1[n][q], acc[n]);
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float bq = L[CL_B2 + acc_row(q, half)];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) h2[n][q] = fmaxf(acc[n][q] + bq, 0.f);
+  }
+  float dz[2];
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const float z = conv_head(L, jj[n], half, h2[n]);
+    const float sg = sigmoidf(z);
+    if (sqj && ok && half == 0) sqj[(size_t)(1 + jj[n]) * BP + b] = (sg - target) * (sg - target);
+    dz[n] = ok ? scale * (sg - target) * sg * (1.f - sg) : 0.f;
+  }
+  acc[0] = zero16(); acc[1] = zero16();
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float w = L[CL_W2 + acc_row(q, half) * 32 + l31];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const float g = dz[n] * L[CL_WH + jj[n] * 33 + acc_row(q, half)] + dq[n][q >> 2][q & 3];
+      const float dh2 = (h2[n][q] > 0.f) ? g : 0.f;
+      acc[n] = mfma(w, dh2, acc[n]);
+    }
+  }
+  f32x16 accx[2] = {zero16(), zero16()};
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const float w = L[CL_W0A + acc_row(q, half) * 32 + l31];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      const float dh1 = (h1[n][q] > 0.f) ? acc[n][q] : 0.f;
+      accx[n] = mfma(w, dh1, accx[n]);
+    }
+  }
+  if (ok) {
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+      f32x2* dst = reinterpret_cast<f32x2*>(gx + ((size_t)b * NJ + jj[n]) * 6 + 4 * half);
+      dst[0] = f32x2{accx[n][0], accx[n][1]};
+      if (half == 0) dst[1] = f32x2{accx[n][2], accx[n][3]};
+    }
+  }
+}
+
+template <bool QUAD, bool STAGED = false>
+__device__ __forceinline__ void dconv_bwd_body(float* __restrict__ L, int blk, const float* __restrict__ img,
+                                               const float* __restrict__ x6d, const float* __restrict__ dH2T,
+                                               const float* __restrict__ gout, float scale, float target,
+                                               float* __restrict__ gx, int B, int BP, float* __restrict__ sqj) {
+  if (!STAGED) {
+    conv_stage_params(img, L);
+    __syncthreads();
+  }
+  const int W = blockDim.x >> 6, ngrp = NJ / W;
+  const int bt = blk / ngrp, j = (blk % ngrp) * W + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  dconv_bwd_tile<QUAD>(L, bt, j, x6d, dH2T, gout, scale, target, gx, B, BP, sqj);
 }
 
 }  // namespace jrr

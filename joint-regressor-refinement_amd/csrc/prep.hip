@@ -1032,20 +1032,16 @@ __global__ __launch_bounds__(SUP_THREADS) void k_sup_step(SupStepArgs a, const f
   sup_body(pool, blk, a.sup, a.stamps && blockIdx.x == 0 ? a.stamps + 8 : nullptr);
   __syncthreads();
   stamp(2);
-  if (a.conv_img) {      // both halves of the joints: wave w takes joint w, then joint 12 + w
-    // (the image is staged once; nothing else touches the pool between the two calls, and the second needs no barrier before it:
-    // both only read the image)
-    dconv_bwd_body<true>(pool, 2 * blk, a.conv_img, a.x6d, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
-    dconv_bwd_body<true, true>(pool, 2 * blk + 1, a.conv_img, a.x6d, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
-    __syncthreads();
-  }
+  // (the per-joint MLP adjoint closed the support body: one interleaved pair of joints per wave, supk.h)
   stamp(3);
   chain_bwd_body(blk, a.FT, a.R0T, a.AT, Jt, JS, par, a.sup.dA, 1, 0, a.sup.dF, a.ua, B, BP, nullptr, pool, step_now);
   if (a.conv_img && a.H2T_next) {      // the updated poses of this group are complete: their per-joint MLP forward for the next iteration
     __syncthreads();
     stamp(4);
-    dconv_fwd_body<true>(pool, 2 * blk, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
-    dconv_fwd_body<true, true>(pool, 2 * blk + 1, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
+    // (the image the support body staged for the adjoint is still in place: the chain adjoint's pool ends far below it)
+    static_assert(CHAIN_BWD_LDS <= SUPL_CONV && PREP_FWD_LDS <= SUPL_CONV, "the per-joint MLP image survives the chain phases");
+    dconv_fwd_body<true, true>(pool + SUPL_CONV, 2 * blk, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
+    dconv_fwd_body<true, true>(pool + SUPL_CONV, 2 * blk + 1, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
   }
   __syncthreads();
   stamp(5);
@@ -1059,7 +1055,8 @@ int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch&
   SupStepArgs a;
   a.x6d = L.x6d_in; a.betas = L.betas_in; a.FT = q.FT; a.FTq = q.FTq; a.AT = q.AT; a.R0T = q.R0T;
   a.sup = SupArgs{q.t, q.nsv, q.Jn_vi, q.FTq, q.AT, q.gt_mm, q.scale, q.joints_out, q.sqerr, q.dA, q.dF, L.B, L.BP,
-                  Reproj{q.gt_j2d, q.cam, q.gcam, q.sq2d, q.scale2d}};
+                  Reproj{q.gt_j2d, q.cam, q.gcam, q.sq2d, q.scale2d},
+                  q.conv_img, L.x6d_in, q.dH2T, q.dscale, q.gx, q.dsq};
   a.conv_img = q.conv_img; a.dH2T = q.dH2T; a.dscale = q.dscale; a.gx = q.gx; a.dsq = q.dsq; a.H2T_next = q.H2T_next;
   PoseUpdateArgs& u = a.ua;
   u.x6d_in = L.x6d_in; u.gx_extra = L.gx_extra; u.gb_extra = L.gb_extra;

@@ -78,7 +78,8 @@ int launch_sup_iter(const SupTables& t, int nsv, const float* Jn_vi, const float
   }();
   if (!attr) { jrr_set_error("k_sup_iter: %d bytes of LDS refused", SUPL_FLOATS * 4); return JRR_ERR_HIP; }
   SupArgs a{t, nsv, Jn_vi, FTq, AT, gt_mm, scale, joints_out, sqerr, dA, dF, B, BP,
-            r ? Reproj{r->gt_j2d, r->cam, r->gcam, r->sq2d, r->scale2d} : Reproj{nullptr, nullptr, nullptr, nullptr, 0.f}};
+            r ? Reproj{r->gt_j2d, r->cam, r->gcam, r->sq2d, r->scale2d} : Reproj{nullptr, nullptr, nullptr, nullptr, 0.f},
+            nullptr, nullptr, nullptr, 0.f, nullptr, nullptr};      // (the per-joint MLP adjoint is its own launch in this form)
   hipLaunchKernelGGL(k_sup_iter, dim3((B + SUP_PP - 1) / SUP_PP), dim3(SUP_THREADS), SUPL_FLOATS * 4, s, a);
   return 0;
 }

@@ -23,6 +23,7 @@
 #include "jrr_common.h"
 #include "kernels.h"
 #include "proj.h"
+#include "dconv.h"
 
 namespace jrr {
 
@@ -47,7 +48,8 @@ constexpr int SUPL_RED = SUPL_JN + NH * SUP_JS;         // [17][8][32] per-joint
 constexpr int SUPL_PEL = SUPL_RED + NH * 8 * 32;        // [3][32]
 constexpr int SUPL_DJ = SUPL_PEL + 3 * 32;              // [3][17][32] joint adjoint
 constexpr int SUPL_MASK = SUPL_DJ + 3 * NH * 32;        // [17][2] row masks + [64] column masks of the regressor's non-zeros (32-bit words)
-constexpr int SUPL_FLOATS = SUPL_MASK + 2 * 32 + SUP_NSV;
+constexpr int SUPL_CONV = SUPL_MASK + 2 * 32 + SUP_NSV;  // LDS image of the pose discriminator's per-joint MLP (dconv.h), staged with the operands
+constexpr int SUPL_FLOATS = SUPL_CONV + CL_FLOATS;
 static_assert(SUPL_FLOATS * 4 <= 160 * 1024, "LDS image of the support iteration");
 
 struct SupArgs {
@@ -63,6 +65,9 @@ struct SupArgs {
   float* dF;                 // [224][BP] out
   int B, BP;
   Reproj rp;                 // 2-D reprojection term on the un-centred joints (scripts/optimize.py:231-233); gt_j2d == NULL: off
+  // The pose discriminator's per-joint MLP adjoint (dconv.h) closes the body: its LDS image is staged with the operands.
+  // conv_img == NULL: no discriminator / the caller runs the adjoint itself.
+  const float* conv_img; const float* x6d; const float* dH2T; float dscale; float* gx; float* dsq;
 };
 
 // stamps (nullable; experiments): phase boundaries on the 100 MHz counter, written by thread 0
@@ -100,6 +105,8 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
     const int ii = i / SUP_JS, s = i % SUP_JS;
     JnS[i] = s < nsv ? a.Jn_vi[(size_t)a.t.rows[s] * 32 + ii] : 0.f;
   }
+  float* const convL = lds + SUPL_CONV;
+  if (a.conv_img) conv_stage_params(a.conv_img, convL);
   __syncthreads();
   stamp(0);
 
@@ -205,6 +212,7 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
   if (jt < NH) {
     if (jt == 0) {      // fixed-order sums over the 17 joints
       float sm[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll 1      // (fully unrolled, its 136 LDS reads in flight cost the composed kernel 22 spilled registers)
       for (int q = 0; q < NH; ++q)
 #pragma unroll
         for (int k = 0; k < 8; ++k) sm[k] += red[(q * 8 + k) * 32 + p];
@@ -302,6 +310,10 @@ __device__ __forceinline__ void sup_body(float* __restrict__ lds, int blk, const
 #pragma unroll
     for (int r = 0; r < 16; ++r) a.dF[(size_t)(32 * wv + acc_row(r, half)) * BP + b0 + l31] = acc0[r] + acc1[r];
   }
+  // ---- the pose discriminator's per-joint MLP adjoint: wave w takes joints w and w + 12 as ONE interleaved pair (dconv.h).  (Measured
+  //      first, and dropped: the same tiles on the waves that own no row tile during the two matrix phases -- a tile is a 7 us dependent
+  //      chain for a lone wave, so two tiles per idle wave doubled those phases: 63.6 -> 68.9 us for the kernel.) ----
+  if (a.conv_img) dconv_bwd_pair(convL, blk, wv, wv + 12, a.x6d, a.dH2T, a.dscale, 1.f, a.gx, a.B, BP, a.dsq);
 }
 
 }  // namespace jrr

@@ -43,11 +43,11 @@ for rep in range(20):
         acc += s - s[0]
         n += 1
 acc /= n
-names = ['start', 'chain forward', 'support fwd+bwd (whole)', 'per-joint MLP adjoint x2', 'chain adjoint + Adam', 'per-joint MLP forward x2 (end)']
+names = ['start', 'chain forward', 'support fwd+bwd + per-joint MLP adjoint (one interleaved pair of joints per wave)', '(nothing)', 'chain adjoint + Adam', 'per-joint MLP forward x2 (end)']
 print('k_sup_step, workgroup 0, us since its start:')
 for i in range(1, 6):
-    print(f'  {names[i]:40s} ends at {acc[i] / 100:8.2f}   (+{(acc[i] - acc[i - 1]) / 100:6.2f})')
-sub = ['operands -> LDS', 'v_posed = Ds F (matrix)', 'skinning', 'joints + loss', 'dverts, dvp', 'dA (then dF = Ds^T dvp follows)']
+    print(f'  {names[i]:100s} ends at {acc[i] / 100:8.2f}   (+{(acc[i] - acc[i - 1]) / 100:6.2f})')
+sub = ['operands + MLP image -> LDS', 'v_posed = Ds F (matrix)', 'skinning', 'joints + loss', 'dverts, dvp', 'dA (then dF = Ds^T dvp and the MLP adjoint pairs follow)']
 print('inside the support body (us since the kernel start):')
 for i in range(6):
-    print(f'  {sub[i]:40s} ends at {acc[8 + i] / 100:8.2f}')
+    print(f'  {sub[i]:70s} ends at {acc[8 + i] / 100:8.2f}')
