@@ -467,6 +467,166 @@ def block_driver(c, support_tiles):
 
 
 
+def build_line(c):
+    """the JSON line of rank 0 from the measurements of main() (c: its locals): headline, roofline of the dominant kernel and of the whole
+    step, per-kernel times, cadence-1 blocks, outer-step rates, and the separately reported blocks"""
+    ms_per_step = c.elapsed / c.a.steps * 1e3
+    it_s = c.a.steps / c.elapsed
+    dom_ms, dom_n = c.prof['k_lbs_fwd']
+    kjs = int(c.eng.info.get('joint_sparse') or 0)      # joint slots per vertex tile and pass the LBS kernels multiply by (0: all 24)
+    sparse = kjs > 0
+    flop_fwd = flop_lbs_fwd(c.dmodel.info)
+    flop_bwd = flop_lbs_bwd(c.dmodel.info)
+    achieved = flop_fwd * c.B / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
+    traffic, pmc = None, {}
+    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
+    if os.path.exists(tpath):
+        try:
+            pmc = json.load(open(tpath)) if c.B == 4096 else {}
+            traffic = pmc.get('k_lbs_fwd_hbm_bytes_per_launch')
+        except Exception:
+            traffic, pmc = None, {}
+
+    def issued(name, ms):
+        """the ISSUED matrix work of a kernel: SQ_INSTS_MFMA of one launch (static PMC pass, profiles/pmc_traffic.json:
+        `mfma_issued_b4096`) x FLOP per instruction over the LIVE duration -- beside the algorithmic figure so that a reader
+        sees the two agree; only for the benchmarked body at batch 4096"""
+        rec = (pmc.get('mfma_issued_b4096') or {}).get(name)
+        if not rec or not ms or c.dmodel.info['wide_tiles'] or not sparse:
+            return None
+        fl = rec['flop_per_launch']
+        return {'sq_insts_mfma': rec['sq_insts_mfma'], 'flop_per_launch': fl, 'tflops': round(fl / (ms * 1e-3) / 1e12, 2),
+                'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'source': 'profiles/pmc_traffic.json (static count, live duration)'}
+    step_flop = flop_fwd + flop_bwd + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if c.use_disc else 0)
+    step_flop_dense = FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if c.use_disc else 0)
+    c1_ms = c.c1_el / c.a.steps * 1e3
+    out = {
+        # BASELINE.json's metric string.  --scaling weak (default): batch = poses per GPU, `value` = N x iterations/s of 4096-pose batches;
+        # --scaling strong: batch = the global batch, sharded N ways, `value` = iterations/s of that one batch
+        'metric': 'pose-refinement iters/sec, batch 4096, at 1/2/4/8 MI355X',
+        'value': round(it_s * c.agg, 3), 'unit': f'it/s (x{c.UB} poses)', 'n_gpus': c.world, 'steps': c.a.steps, 'warmup': c.a.warmup,
+        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': c.a.scaling, 'vs_baseline': None,
+        'dtype': 'f32', 'data': 'synthetic',
+        'config': {'workload': f'BASELINE configs[{c.a.config - 1}]: batch={c.B}/GPU inner loop, 3D-joint loss'
+                               + (' + pose-discriminator adversarial term' if c.use_disc else '')
+                               + (' + soft-silhouette loss (224x224 rasteriser)' if c.use_sil else ''),
+                   'global_batch': c.B * c.world, 'poses_per_gpu': c.B, 'poses_per_sec': round(it_s * c.world * c.B, 1),
+                   'j_step_every': c.cadence, 'j_steps_in_timed_regions': c.nj_region, 'parallelism': f'dp{c.world}', 'joint_loss_last': c.loss_joint,
+                   'timed_regions': len(c.regions), 'timed_steps': len(c.regions) * c.a.steps,
+                   'value_is': 'all timed regions: timed steps / timed seconds (the J step follows every j_step_every-th iteration, counted '
+                               'across regions: the reference cadence, not one J step per region)',
+                   'median_region_ms_per_step': round(statistics.median(c.regions) / c.a.steps * 1e3, 4),
+                   'j_steps_per_region': c.region_nj if len(set(c.region_nj)) > 1 else c.region_nj[0],
+                   'repeat_ms_per_step': [round(r / c.a.steps * 1e3, 4) for r in c.regions],
+                   'host_calls_per_region': 'one C call (jrr_refine_run_j_steps)' if c.dist is None else 'refine_run + j_regressor_grad + all_reduce + j_step_apply per J step',
+                   'forward_reuse_after_j_step': False,
+                   'vertex_tiles': 'all 216 (every iteration skins all 6890 vertices; the iteration restricted to the tiles of the '
+                                   'regressor\'s support -- what optimize.py runs by default -- is the separate block `support_tiles`)',
+                   'geometry': dict(c.eng.info, **c.dmodel.info)},
+        'collective': c.collective,
+        'provenance': c.prov,
+        'per_rank_ms_per_step': {'min': round(min(c.per_rank_ms), 4), 'median': round(statistics.median(c.per_rank_ms), 4), 'max': round(max(c.per_rank_ms), 4),
+                                 'each': [round(x, 4) for x in c.per_rank_ms],
+                                 'note': 'every rank\'s own time per step over the headline regions (before the closing barrier); `ms_per_step` is the max over ranks incl. barriers'},
+        'roofline': {'bound': 'mfma', 'kernel': 'k_lbs_fwd<true,false>', 'achieved': round(achieved, 2),
+                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
+                     'traffic': traffic,
+                     'traffic_source': 'profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of an earlier '
+                                       'run of this command, gfx950-corrected; NOT measured in this run)' if traffic else None,
+                     'avg_launch_ms': round(dom_ms, 4), 'launches_timed': dom_n,
+                     # HBM side of the same kernel (PMC bytes per launch / live duration) against the 8 TB/s spec
+                     'hbm_gb_s': round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms > 0 else None,
+                     'hbm_frac_of_8tb_s': round(traffic / (dom_ms * 1e-3) / 8e12, 4) if traffic and dom_ms > 0 else None,
+                     'algorithmic_flop_per_launch': flop_fwd * c.B,
+                     'issued_work': issued('k_lbs_fwd', dom_ms),
+                     'formulation': (f'joint-sparse skinning: each 32-vertex tile multiplies by its own joints only, {kjs} slots per pass '
+                                     f"({c.dmodel.info['wide_tiles']} wide tiles run a second pass; exact: the skipped terms are zeros); "
+                                     'FLOP counted for THIS formulation') if sparse
+                                    else 'dense skinning (SURVEY.md section 8d counts)',
+                     'dense_formulation': {'flop_per_launch': FLOP_LBS_FWD_PER_POSE * c.B,
+                                           'rate_tflops': round(FLOP_LBS_FWD_PER_POSE * c.B / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
+                                           'note': 'the reference formulation\'s FLOP over the same time; not a roofline figure'},
+                     # the WHOLE inner iteration against the same peak: algorithmic FLOP of its four MFMA stages
+                     # (k_lbs_fwd + k_lbs_bwd + blend adjoint + discriminator fwd/input-grad) over the time of a region of
+                     # inner iterations ONLY (no J step, no forward reuse; median of 3 regions)
+                     'whole_step': {'flop_per_pose_iter': step_flop,
+                                    'achieved': round(step_flop * c.B / (c.inner_ms * 1e-3) / 1e12, 2),
+                                    'frac': round(step_flop * c.B / (c.inner_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                    'inner_only_ms_per_step': round(c.inner_ms, 4), 'timed': 'its own regions: no J step, no forward reuse',
+                                    'dense_formulation_flop_per_pose_iter': step_flop_dense,
+                                    'dense_formulation_rate_tflops': round(step_flop_dense * c.B / (c.inner_ms * 1e-3) / 1e12, 2)},
+                     # in-kernel probe (s_memtime / s_memrealtime, workgroup 0 / wave 0): the clock the chip holds on
+                     # this kernel (`peak` assumes 2.4 GHz), hence the MFMA-pipe utilisation of the whole launch, and
+                     # how much of the launch the FIRST-dispatched workgroup is resident (the two workgroups of a CU
+                     # do not progress evenly: the older one finishes early)
+                     'sustained_clock_ghz': round(c.probe[0] / c.probe[4], 3) if c.probe[4] else None,
+                     # matrix-pipe busy fraction of the launch: issue clocks of every matrix instruction (32x32x2: 64 clocks, the 48
+                     # four-block regressor instructions per tile: 33) per SIMD over the launch duration at the sustained clock
+                     'mfma_pipe_utilisation': round(216 * (c.eng.info['BP'] / 32) * fwd_pipe_clocks_per_tile(c.dmodel.info) / 1024
+                                                    / (dom_ms * 1e-3 * c.probe[0] / c.probe[4] * 1e9), 4) if c.probe[4] and dom_ms > 0 else None,
+                     'mfma_pipe_utilisation_note': 'instruction-priced (64 / 33 issue clocks); the algorithmic-FLOP ratio achieved / (peak x clock / 2.4) reads ~1 % higher',
+                     'first_workgroup_resident_frac': round(c.probe[4] * 1e-6 / dom_ms, 3) if c.probe[4] and dom_ms > 0 else None},
+        'kernels_ms': {k: round(t, 4) for k, (t, n) in c.prof.items() if n},
+        # the other matrix-core launches of the iteration against the same peak, each on the FLOP of the formulation it runs
+        'kernels_roofline': {name: {'flop_per_launch': fl * c.B, 'achieved_tflops': round(fl * c.B / (c.prof[cls][0] * 1e-3) / 1e12, 2),
+                                    'frac': round(fl * c.B / (c.prof[cls][0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
+                                    'issued_work': issued(pm_name, c.prof[cls][0])}
+                             for name, cls, fl, pm_name in (('k_lbs_bwd', 'k_lbs_bwd', flop_bwd, 'k_lbs_bwd'),
+                                                            ('k_blend_adjoint', 'k_gemm_tn_blend_adjoint', FLOP_BLEND_ADJ_PER_POSE, 'k_blend_adjoint'),
+                                                            ('pose_disc_gemms (4 launches)', 'pose_disc_gemms', FLOP_DISC_GEMMS_PER_POSE, 'pose_disc_gemms'))
+                             if c.prof.get(cls, (0, 0))[1] and c.prof[cls][0] > 0},
+        'j_step': {'ms': round(c.j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
+                   'allreduce_bytes': c.xch.nbytes, 'allreduce_payload': 'regressor support [17][128]' if c.xch.compact else 'dense (17,6890)',
+                   'in_timed_regions': c.nj_region, 'host_calls': 2 + (1 if c.dist is not None else 0)},
+        'cadence1': {'value': round(c.a.steps / c.c1_el * c.agg, 3), 'unit': f'it/s (x{c.UB} poses)', 'ms_per_step': round(c1_ms, 4),
+                     'j_step_every': 1, 'timed_regions': len(c.c1_regions), 'value_is': 'median region',
+                     'repeat_ms_per_step': [round(r / c.a.steps * 1e3, 4) for r in c.c1_regions],
+                     'spread_frac': round((max(c.c1_regions) - min(c.c1_regions)) / c.c1_el, 4),
+                     'forward_reuse_after_j_step': True,
+                     'note': 'BASELINE configs[3] / north_star "all-reduce on the J_regressor gradient each step": '
+                             'the J step (+ its all-reduce) after EVERY inner iteration, timed like `value`; the iteration after a J '
+                             'step re-regresses its joints from the J step\'s stored vertices (same poses: explicit reuse)'},
+    }
+    if c.c1h_el is not None:
+        out['cadence1_host_driven'] = {
+            'value': round(c.a.steps / c.c1h_el, 3), 'unit': f'it/s (x{c.B} poses)', 'ms_per_step': round(c.c1h_el / c.a.steps * 1e3, 4),
+            'timed_regions': len(c.c1h_regions), 'value_is': 'median region',
+            'repeat_ms_per_step': [round(r / c.a.steps * 1e3, 4) for r in c.c1h_regions],
+            'spread_frac': round((max(c.c1h_regions) - min(c.c1h_regions)) / c.c1h_el, 4),
+            'allreduce_bytes_it_would_send': c.xch.nbytes,
+            'with_rccl_one_rank_allreduce': None,
+            'note': 'cadence 1 through the call sequence N > 1 ranks execute (refine_run_after_j_step -> j_regressor_grad_support -> '
+                    '[all-reduce: a no-op at world size 1] -> j_step_apply_support per iteration, host-driven): bounds the multi-GPU '
+                    'cadence-1 cost of everything but the collective itself'}
+    # outer-step work (SURVEY.md section 8d).  `value` already contains the J step (+ all-reduce) at cadence
+    # `j_step_every`; the pose-D update is timed separately.  Two derived rates: everything at the measured
+    # cadence, and everything after EVERY inner iteration (cadence 1).
+    out['outer_step'] = {'j_step_ms': round(c.j_ms, 3), 'pose_d_update_ms': None if c.d_ms is None else round(c.d_ms, 3),
+                         'inner_only_ms_per_step': round(c.inner_ms, 4),
+                         'it_s_incl_pose_d_update_at_cadence': round(c.agg / ((ms_per_step + (c.d_ms or 0.0) / c.cadence) * 1e-3), 3),
+                         'it_s_all_outer_work_every_iteration': round(c.agg / ((c1_ms + (c.d_ms or 0.0)) * 1e-3), 3),
+                         'j_allreduce_bytes': c.xch.nbytes, 'pose_d_allreduce_bytes': 1840153 * 4 if c.use_disc else 0}
+    if c.collective_cost is not None:
+        out['collective_cost'] = c.collective_cost
+    if c.driver_outer is not None:
+        out['driver_outer_batch'] = c.driver_outer
+    if c.ref_default is not None:
+        out['reference_default'] = c.ref_default
+    if c.folded is not None:
+        out['folded_mode'] = c.folded
+    if c.bf16x3 is not None:
+        out['bf16x3_mode'] = c.bf16x3
+    if c.support_tiles is not None:
+        out['support_tiles'] = c.support_tiles
+    if c.config2 is not None:
+        out['config2'] = c.config2
+    if c.config5 is not None:
+        out['config5'] = c.config5
+    if c.skin_variants is not None:
+        out['skin_variants'] = c.skin_variants
+    return out
+
+
 def main():
     a = parse()
     prov = provenance(a.allow_experiment_lib)      # before anything touches the GPU: a refused JRR_LIB costs nothing
@@ -941,160 +1101,8 @@ def main():
             dist.destroy_process_group()
         return
 
-    ms_per_step = elapsed / a.steps * 1e3
-    it_s = a.steps / elapsed
-    dom_ms, dom_n = prof['k_lbs_fwd']
-    kjs = int(eng.info.get('joint_sparse') or 0)      # joint slots per vertex tile and pass the LBS kernels multiply by (0: all 24)
-    sparse = kjs > 0
-    flop_fwd = flop_lbs_fwd(dmodel.info)
-    flop_bwd = flop_lbs_bwd(dmodel.info)
-    achieved = flop_fwd * B / (dom_ms * 1e-3) / 1e12 if dom_ms > 0 else 0.0
-    traffic, pmc = None, {}
-    tpath = os.path.join(ROOT, 'profiles', 'pmc_traffic.json')
-    if os.path.exists(tpath):
-        try:
-            pmc = json.load(open(tpath)) if B == 4096 else {}
-            traffic = pmc.get('k_lbs_fwd_hbm_bytes_per_launch')
-        except Exception:
-            traffic, pmc = None, {}
-
-    def issued(name, ms):
-        """the ISSUED matrix work of a kernel: SQ_INSTS_MFMA of one launch (static PMC pass, profiles/pmc_traffic.json:
-        `mfma_issued_b4096`) x FLOP per instruction over the LIVE duration -- beside the algorithmic figure so that a reader
-        sees the two agree; only for the benchmarked body at batch 4096"""
-        rec = (pmc.get('mfma_issued_b4096') or {}).get(name)
-        if not rec or not ms or dmodel.info['wide_tiles'] or not sparse:
-            return None
-        fl = rec['flop_per_launch']
-        return {'sq_insts_mfma': rec['sq_insts_mfma'], 'flop_per_launch': fl, 'tflops': round(fl / (ms * 1e-3) / 1e12, 2),
-                'frac': round(fl / (ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4), 'source': 'profiles/pmc_traffic.json (static count, live duration)'}
-    step_flop = flop_fwd + flop_bwd + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
-    step_flop_dense = FLOP_LBS_FWD_PER_POSE + FLOP_LBS_BWD_PER_POSE + FLOP_BLEND_ADJ_PER_POSE + (FLOP_DISC_PER_POSE if use_disc else 0)
-    c1_ms = c1_el / a.steps * 1e3
-    out = {
-        # BASELINE.json's metric string.  --scaling weak (default): batch = poses per GPU, `value` = N x iterations/s of 4096-pose batches;
-        # --scaling strong: batch = the global batch, sharded N ways, `value` = iterations/s of that one batch
-        'metric': 'pose-refinement iters/sec, batch 4096, at 1/2/4/8 MI355X',
-        'value': round(it_s * agg, 3), 'unit': f'it/s (x{UB} poses)', 'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup,
-        'ms_per_step': round(ms_per_step, 4), 'higher_is_better': True, 'scaling': a.scaling, 'vs_baseline': None,
-        'dtype': 'f32', 'data': 'synthetic',
-        'config': {'workload': f'BASELINE configs[{a.config - 1}]: batch={B}/GPU inner loop, 3D-joint loss'
-                               + (' + pose-discriminator adversarial term' if use_disc else '')
-                               + (' + soft-silhouette loss (224x224 rasteriser)' if use_sil else ''),
-                   'global_batch': B * world, 'poses_per_gpu': B, 'poses_per_sec': round(it_s * world * B, 1),
-                   'j_step_every': cadence, 'j_steps_in_timed_regions': nj_region, 'parallelism': f'dp{world}', 'joint_loss_last': loss_joint,
-                   'timed_regions': len(regions), 'timed_steps': len(regions) * a.steps,
-                   'value_is': 'all timed regions: timed steps / timed seconds (the J step follows every j_step_every-th iteration, counted '
-                               'across regions: the reference cadence, not one J step per region)',
-                   'median_region_ms_per_step': round(statistics.median(regions) / a.steps * 1e3, 4),
-                   'j_steps_per_region': region_nj if len(set(region_nj)) > 1 else region_nj[0],
-                   'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in regions],
-                   'host_calls_per_region': 'one C call (jrr_refine_run_j_steps)' if dist is None else 'refine_run + j_regressor_grad + all_reduce + j_step_apply per J step',
-                   'forward_reuse_after_j_step': False,
-                   'vertex_tiles': 'all 216 (every iteration skins all 6890 vertices; the iteration restricted to the tiles of the '
-                                   'regressor\'s support -- what optimize.py runs by default -- is the separate block `support_tiles`)',
-                   'geometry': dict(eng.info, **dmodel.info)},
-        'collective': collective,
-        'provenance': prov,
-        'per_rank_ms_per_step': {'min': round(min(per_rank_ms), 4), 'median': round(statistics.median(per_rank_ms), 4), 'max': round(max(per_rank_ms), 4),
-                                 'each': [round(x, 4) for x in per_rank_ms],
-                                 'note': 'every rank\'s own time per step over the headline regions (before the closing barrier); `ms_per_step` is the max over ranks incl. barriers'},
-        'roofline': {'bound': 'mfma', 'kernel': 'k_lbs_fwd<true,false>', 'achieved': round(achieved, 2),
-                     'peak': PEAK_F32_MFMA_TFLOPS, 'unit': 'TFLOP/s', 'frac': round(achieved / PEAK_F32_MFMA_TFLOPS, 4),
-                     'traffic': traffic,
-                     'traffic_source': 'profiles/pmc_traffic.json (static: rocprofv3 --pmc FETCH_SIZE/WRITE_SIZE passes of an earlier '
-                                       'run of this command, gfx950-corrected; NOT measured in this run)' if traffic else None,
-                     'avg_launch_ms': round(dom_ms, 4), 'launches_timed': dom_n,
-                     # HBM side of the same kernel (PMC bytes per launch / live duration) against the 8 TB/s spec
-                     'hbm_gb_s': round(traffic / (dom_ms * 1e-3) / 1e9, 1) if traffic and dom_ms > 0 else None,
-                     'hbm_frac_of_8tb_s': round(traffic / (dom_ms * 1e-3) / 8e12, 4) if traffic and dom_ms > 0 else None,
-                     'algorithmic_flop_per_launch': flop_fwd * B,
-                     'issued_work': issued('k_lbs_fwd', dom_ms),
-                     'formulation': (f'joint-sparse skinning: each 32-vertex tile multiplies by its own joints only, {kjs} slots per pass '
-                                     f"({dmodel.info['wide_tiles']} wide tiles run a second pass; exact: the skipped terms are zeros); "
-                                     'FLOP counted for THIS formulation') if sparse
-                                    else 'dense skinning (SURVEY.md section 8d counts)',
-                     'dense_formulation': {'flop_per_launch': FLOP_LBS_FWD_PER_POSE * B,
-                                           'rate_tflops': round(FLOP_LBS_FWD_PER_POSE * B / (dom_ms * 1e-3) / 1e12, 2) if dom_ms > 0 else None,
-                                           'note': 'the reference formulation\'s FLOP over the same time; not a roofline figure'},
-                     # the WHOLE inner iteration against the same peak: algorithmic FLOP of its four MFMA stages
-                     # (k_lbs_fwd + k_lbs_bwd + blend adjoint + discriminator fwd/input-grad) over the time of a region of
-                     # inner iterations ONLY (no J step, no forward reuse; median of 3 regions)
-                     'whole_step': {'flop_per_pose_iter': step_flop,
-                                    'achieved': round(step_flop * B / (inner_ms * 1e-3) / 1e12, 2),
-                                    'frac': round(step_flop * B / (inner_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                    'inner_only_ms_per_step': round(inner_ms, 4), 'timed': 'its own regions: no J step, no forward reuse',
-                                    'dense_formulation_flop_per_pose_iter': step_flop_dense,
-                                    'dense_formulation_rate_tflops': round(step_flop_dense * B / (inner_ms * 1e-3) / 1e12, 2)},
-                     # in-kernel probe (s_memtime / s_memrealtime, workgroup 0 / wave 0): the clock the chip holds on
-                     # this kernel (`peak` assumes 2.4 GHz), hence the MFMA-pipe utilisation of the whole launch, and
-                     # how much of the launch the FIRST-dispatched workgroup is resident (the two workgroups of a CU
-                     # do not progress evenly: the older one finishes early)
-                     'sustained_clock_ghz': round(probe[0] / probe[4], 3) if probe[4] else None,
-                     # matrix-pipe busy fraction of the launch: issue clocks of every matrix instruction (32x32x2: 64 clocks, the 48
-                     # four-block regressor instructions per tile: 33) per SIMD over the launch duration at the sustained clock
-                     'mfma_pipe_utilisation': round(216 * (eng.info['BP'] / 32) * fwd_pipe_clocks_per_tile(dmodel.info) / 1024
-                                                    / (dom_ms * 1e-3 * probe[0] / probe[4] * 1e9), 4) if probe[4] and dom_ms > 0 else None,
-                     'mfma_pipe_utilisation_note': 'instruction-priced (64 / 33 issue clocks); the algorithmic-FLOP ratio achieved / (peak x clock / 2.4) reads ~1 % higher',
-                     'first_workgroup_resident_frac': round(probe[4] * 1e-6 / dom_ms, 3) if probe[4] and dom_ms > 0 else None},
-        'kernels_ms': {k: round(t, 4) for k, (t, n) in prof.items() if n},
-        # the other matrix-core launches of the iteration against the same peak, each on the FLOP of the formulation it runs
-        'kernels_roofline': {name: {'flop_per_launch': fl * B, 'achieved_tflops': round(fl * B / (prof[cls][0] * 1e-3) / 1e12, 2),
-                                    'frac': round(fl * B / (prof[cls][0] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, 4),
-                                    'issued_work': issued(pm_name, prof[cls][0])}
-                             for name, cls, fl, pm_name in (('k_lbs_bwd', 'k_lbs_bwd', flop_bwd, 'k_lbs_bwd'),
-                                                            ('k_blend_adjoint', 'k_gemm_tn_blend_adjoint', FLOP_BLEND_ADJ_PER_POSE, 'k_blend_adjoint'),
-                                                            ('pose_disc_gemms (4 launches)', 'pose_disc_gemms', FLOP_DISC_GEMMS_PER_POSE, 'pose_disc_gemms'))
-                             if prof.get(cls, (0, 0))[1] and prof[cls][0] > 0},
-        'j_step': {'ms': round(j_ms, 3), 'includes': 'SMPL fwd + dJ product + all-reduce + Adam(J) + renormalise',
-                   'allreduce_bytes': xch.nbytes, 'allreduce_payload': 'regressor support [17][128]' if xch.compact else 'dense (17,6890)',
-                   'in_timed_regions': nj_region, 'host_calls': 2 + (1 if dist is not None else 0)},
-        'cadence1': {'value': round(a.steps / c1_el * agg, 3), 'unit': f'it/s (x{UB} poses)', 'ms_per_step': round(c1_ms, 4),
-                     'j_step_every': 1, 'timed_regions': len(c1_regions), 'value_is': 'median region',
-                     'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1_regions],
-                     'spread_frac': round((max(c1_regions) - min(c1_regions)) / c1_el, 4),
-                     'forward_reuse_after_j_step': True,
-                     'note': 'BASELINE configs[3] / north_star "all-reduce on the J_regressor gradient each step": '
-                             'the J step (+ its all-reduce) after EVERY inner iteration, timed like `value`; the iteration after a J '
-                             'step re-regresses its joints from the J step\'s stored vertices (same poses: explicit reuse)'},
-    }
-    if c1h_el is not None:
-        out['cadence1_host_driven'] = {
-            'value': round(a.steps / c1h_el, 3), 'unit': f'it/s (x{B} poses)', 'ms_per_step': round(c1h_el / a.steps * 1e3, 4),
-            'timed_regions': len(c1h_regions), 'value_is': 'median region',
-            'repeat_ms_per_step': [round(r / a.steps * 1e3, 4) for r in c1h_regions],
-            'spread_frac': round((max(c1h_regions) - min(c1h_regions)) / c1h_el, 4),
-            'allreduce_bytes_it_would_send': xch.nbytes,
-            'with_rccl_one_rank_allreduce': None,
-            'note': 'cadence 1 through the call sequence N > 1 ranks execute (refine_run_after_j_step -> j_regressor_grad_support -> '
-                    '[all-reduce: a no-op at world size 1] -> j_step_apply_support per iteration, host-driven): bounds the multi-GPU '
-                    'cadence-1 cost of everything but the collective itself'}
-    # outer-step work (SURVEY.md section 8d).  `value` already contains the J step (+ all-reduce) at cadence
-    # `j_step_every`; the pose-D update is timed separately.  Two derived rates: everything at the measured
-    # cadence, and everything after EVERY inner iteration (cadence 1).
-    out['outer_step'] = {'j_step_ms': round(j_ms, 3), 'pose_d_update_ms': None if d_ms is None else round(d_ms, 3),
-                         'inner_only_ms_per_step': round(inner_ms, 4),
-                         'it_s_incl_pose_d_update_at_cadence': round(agg / ((ms_per_step + (d_ms or 0.0) / cadence) * 1e-3), 3),
-                         'it_s_all_outer_work_every_iteration': round(agg / ((c1_ms + (d_ms or 0.0)) * 1e-3), 3),
-                         'j_allreduce_bytes': xch.nbytes, 'pose_d_allreduce_bytes': 1840153 * 4 if use_disc else 0}
-    if collective_cost is not None:
-        out['collective_cost'] = collective_cost
-    if driver_outer is not None:
-        out['driver_outer_batch'] = driver_outer
-    if ref_default is not None:
-        out['reference_default'] = ref_default
-    if folded is not None:
-        out['folded_mode'] = folded
-    if bf16x3 is not None:
-        out['bf16x3_mode'] = bf16x3
-    if support_tiles is not None:
-        out['support_tiles'] = support_tiles
-    if config2 is not None:
-        out['config2'] = config2
-    if config5 is not None:
-        out['config5'] = config5
-    if skin_variants is not None:
-        out['skin_variants'] = skin_variants
+    import types as _types
+    out = build_line(_types.SimpleNamespace(**{k_: v_ for k_, v_ in locals().items() if not k_.startswith('_')}))
     if not a.no_cpu_baseline and world == 1:   # the CPU baseline leg runs at N = 1 only
         cb = min(a.cpu_batch or B, B)
         variants, nthreads = cpu_baseline(model_np, J_np, batch_np, disc_sd, cb, a.cpu_seconds, use_disc, B)
