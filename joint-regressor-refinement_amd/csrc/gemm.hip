@@ -827,6 +827,18 @@ int launch_disc_gemm_q(const GemmArgs& g, int epi, int btr, hipStream_t s, int* 
     return 0;
   }
   dim3 grid((g.M / 128) * (g.N / 64)), block(256);
+  // JRR_DISC_KS128=2 (experiment, round 6): the full-size 128 x 64 tile on EIGHT waves, two K halves per position like the 96-row tile
+  // (same tile, same order of the sums: bit-identical) -- four waves per SIMD instead of two
+  static const bool ks128 = [] { const char* e = getenv("JRR_DISC_KS128"); return e && e[0] == '2'; }();
+  if (ks128) {
+    dim3 block8(512);
+    if (epi == EPI_BIAS_RELU && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_BIAS_RELU, 0, 2>), grid, block8, 0, s, g);
+    else if (epi == EPI_BIAS_RELU_DOT && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_BIAS_RELU_DOT, 0, 2>), grid, block8, 0, s, g);
+    else if (epi == EPI_STORE && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_STORE, 0, 2>), grid, block8, 0, s, g);
+    else if (epi == EPI_MASK && btr == 2) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_MASK, 2, 2>), grid, block8, 0, s, g);
+    else { jrr_set_error("disc_gemm_q: unsupported epilogue %d / transform %d", epi, btr); return JRR_ERR_ARG; }
+    return 0;
+  }
   if (epi == EPI_BIAS_RELU && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_BIAS_RELU, 0>), grid, block, 0, s, g);
   else if (epi == EPI_BIAS_RELU_DOT && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_BIAS_RELU_DOT, 0>), grid, block, 0, s, g);
   else if (epi == EPI_STORE && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 2, EPI_STORE, 0>), grid, block, 0, s, g);
