@@ -438,6 +438,7 @@ def block_driver(c, support_tiles):
                 'seconds_per_outer_batch': round(sec, 5), 'seconds_per_outer_batch_each': [round(r['seconds_batch'], 5) for r in recs],
                 'loop_and_outer_step_seconds': round(statistics.median([r['seconds'] for r in kept]), 5),
                 'it_s_through_the_entry_point': round(inner / sec, 2), 'vertex_tiles_run': kept[-1]['vertex_tiles_run'],
+                'support_vertices_run': kept[-1].get('support_vertices_run'),
                 'whole_call_seconds_incl_synthetic_batch_generation_and_setup': round(wall, 3),
                 'joint_loss_last': kept[-1]['joint_loss'], 'mpjpe_last': kept[-1].get('mpjpe')}
 

@@ -1474,6 +1474,7 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     }
   }
   bool reuse_next = reuse_first;
+  bool pre_done = false;       // k_tail_step of the previous iteration ran this iteration's chain forward [+ MLP forward] and counted its step
   bool h2t_ready = false;      // k_sup_step of the previous iteration left the per-joint MLP forward of the current poses in H2T
   for (int it = 0; it < n_iters; ++it) {
     const bool folded = e->folded && e->fold_valid;
@@ -1563,7 +1564,12 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     // with the pose discriminator its per-joint MLP rides in the chain-forward launch, and its adjoint in the launch of
     // the dF^T slab sum (two independent latency-bound kernels side by side: prep.hip)
     const bool fuse_conv = pd && !reuse;
+    // k_tail_step (round 6; prep.hip): the previous iteration's last launch already ran THIS iteration's chain forward (and its per-joint
+    // MLP forward, and counted the Adam step) on the poses it had just updated -- `pre_done`
+    const bool pre = pre_done && !reuse;
+    pre_done = false;
     if (reuse) { if (!e->have_jsup) launch_step_inc(step, s); }      // (with support lists the count rides in k_rejoints_sparse)
+    else if (pre) { /* nothing to launch */ }
     else if (fuse_conv) launch_prep_fwd_dconv(e->m, x6d, betas, e->FT, e->FTq, e->AT, e->R0T, e->B, e->BP, step, e->convL, e->H2T, nullptr, s);
     else launch_prep_fwd(e->m, x6d, nullptr, betas, e->FT, e->FTq, e->AT, e->R0T, e->B, e->BP, step, s);
     prof_mark(e, 0, s);
@@ -1642,10 +1648,15 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
       prof_mark(e, 6, s);
     }
     prof_mark(e, 7, s);
+    // JRR_TAIL_STEP=1 (experiment, round 6: built, parity-green over the whole GPU suite, measured SLOWER -- 1.1355 against 1.1302 ms per
+    // iteration): slab sum + k_tail_step instead of the three launches of rounds 2-5 (slab sum || MLP adjoint,
+    // k_chain_bwd, the next iteration's chain forward || MLP forward).  Off by default.
+    static const bool tail_on = [] { const char* v = getenv("JRR_TAIL_STEP"); return v && v[0] == '1'; }();
+    const bool tail = tail_on && !folded && !supv;
     if (folded) launch_reduce_slabs(e->dFTp, e->nsplit, (size_t)KFP * e->BP, e->dF, (size_t)KFP * e->BP, s);
     else if (supv) {      // dA^T / dF^T arrive complete: nothing to sum; the per-joint MLP adjoint runs alone
       if (pd) launch_disc_conv_bwd(e->convL, x6d, e->dH2T, nullptr, dscale, 1.f, e->gx, e->B, e->BP, s, e->dsq, 1);
-    } else reduce_adjoint_partials(e, s, pd ? x6d : nullptr, dscale, ns_adj);
+    } else reduce_adjoint_partials(e, s, (pd && !tail) ? x6d : nullptr, dscale, ns_adj);      // (tail: the MLP adjoint rides in k_tail_step)
     PrepBwdLaunch L;
     L.x6d_in = x6d; L.betas_in = betas;
     if (folded || supv) { L.dATp = e->dA; L.dFTp = e->dF; } else set_adjoint_slabs(e, L);
@@ -1654,7 +1665,19 @@ static int refine_run_impl(jrr_engine_t* e, float* x6d, float* betas, const floa
     L.x6d_io = x6d; L.betas_io = betas; L.adam_m = adam_m; L.adam_v = adam_v; L.step = step;
     L.lr = lr; L.B = e->B; L.BP = e->BP;
     if (e->gt_j2d || sil) { L.gcam = e->gcam; L.cam_io = e->cam; L.cam_m = e->cam_m; L.cam_v = e->cam_v; }
-    launch_prep_bwd(L, e->m, s);
+    if (tail) {
+      // the next iteration is a plain one (no J step in between, which would overwrite F^T / A^T with its own forward): its chain forward
+      // [+ per-joint MLP forward] runs at the end of this launch, on the poses Adam has just written
+      const bool js_next_ = js && (it + 1) % js->every == 0;
+      TailStepLaunch q;
+      if (pd) { q.conv_img = e->convL; q.dH2T = e->dH2T; q.dscale = dscale; q.gx = e->gx; q.dsq = e->dsq; }
+      q.do_next = (it + 1 < n_iters) && !js_next_;
+      q.FTw = e->FT; q.FTq = e->FTq; q.ATw = e->AT; q.R0Tw = e->R0T; q.H2T_next = pd ? e->H2T : nullptr;
+      q.step = step; q.arrive = e->step_scratch;
+      int rct = launch_tail_step(e->m, q, L, s);
+      if (rct) return rct;
+      pre_done = q.do_next;
+    } else launch_prep_bwd(L, e->m, s);
     prof_mark(e, 7, s);
     if (e->hist) {      // scripts/optimize.py:255-261: the five weighted terms every `hist_every`-th iteration
       if (e->hist_iter % e->hist_every == 0 && e->hist_n < e->hist_cap) {

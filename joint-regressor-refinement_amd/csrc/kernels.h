@@ -204,6 +204,15 @@ struct SupStepLaunch {
 };
 int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s);
 
+// the END of an all-tiles iteration + the BEGINNING of the next in one launch (prep.hip k_tail_step): per-joint MLP adjoint, chain adjoint +
+// Adam (the PrepBwdLaunch, as launch_prep_bwd takes it), then -- do_next -- the chain forward [+ MLP forward] of the next iteration
+struct TailStepLaunch {
+  const float* conv_img = nullptr; const float* dH2T = nullptr; float dscale = 0.f; float* gx = nullptr; float* dsq = nullptr;
+  bool do_next = false; float* FTw = nullptr; float* FTq = nullptr; float* ATw = nullptr; float* R0Tw = nullptr; float* H2T_next = nullptr;
+  int32_t* step = nullptr; int* arrive = nullptr;
+};
+int launch_tail_step(const Model& m, const TailStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s);
+
 // fold.hip
 int launch_fold_jw(const float* Jn, const float* Wjv, float* JW, float* G0, const int* p2v, hipStream_t s);
 int launch_fold_fwd(const float* MT, const float* AT, const float* G0, float* Jsum, int BP, hipStream_t s);

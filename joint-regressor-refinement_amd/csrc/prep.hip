@@ -1047,6 +1047,83 @@ __global__ __launch_bounds__(SUP_THREADS) void k_sup_step(SupStepArgs a, const f
   stamp(5);
 }
 
+// ------------------------------------------------------------------------------------------
+// k_tail_step (round 6): the END of an all-tiles iteration and the BEGINNING of the next one, per 32-pose group in one workgroup --
+//   per-joint MLP adjoint (interleaved pairs) -> chain adjoint + 6-D rotation adjoint + Adam (k_chain_bwd's body)
+//   -> [chain forward of the NEXT iteration on the updated poses (k_prep_fwd's body) -> its per-joint MLP forward].
+// Replaces three launches of the loop (slab sum || MLP adjoint, k_chain_bwd, the next iteration's k_prep_fwd || MLP forward) by the slab
+// sum + this one: the same device bodies, one LDS pool, the hand-overs through the arrays the stand-alone kernels use.  The step counter:
+// every workgroup reads THIS iteration's count (already incremented by its chain forward, wherever that ran); when the next iteration's
+// chain forward runs here, the last workgroup to arrive stores count + 1 for it -- after every other workgroup has read.
+// ------------------------------------------------------------------------------------------
+constexpr int TAIL_CONV = CHAIN_BWD_LDS > PREP_FWD_LDS ? CHAIN_BWD_LDS : PREP_FWD_LDS;      // the MLP image sits behind the chain pools
+constexpr int TAIL_LDS = TAIL_CONV + CL_FLOATS;
+struct TailStepArgs {
+  const float* conv_img; const float* dH2T; float dscale; float* gx; float* dsq;      // per-joint MLP adjoint (conv_img NULL: none)
+  const float* FT; const float* R0T; const float* AT;                                 // this iteration's chain forward
+  const float* dA; int nslabA; size_t strideA; const float* dF; const unsigned* dmask;
+  PoseUpdateArgs ua;
+  int do_next; float* FTw; float* FTq; float* ATw; float* R0Tw; float* H2T_next;      // next iteration's chain forward (+ MLP forward)
+  int32_t* step; int* arrive; int B, BP;
+};
+__global__ __launch_bounds__(PPB * NJ) void k_tail_step(TailStepArgs a, const float* __restrict__ Jt, const float* __restrict__ JS,
+                                                        Parents par) {
+  extern __shared__ __attribute__((aligned(16))) float pool[];
+  const int blk = blockIdx.x, B = a.B, BP = a.BP;
+  int step_now = -1;
+  if (threadIdx.x == 0 && a.ua.x6d_io) {
+    step_now = __hip_atomic_load(a.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the value is in: only now may this workgroup count as arrived
+    if (a.do_next) {
+      const int prev = __hip_atomic_fetch_add(a.arrive, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (prev == (int)gridDim.x - 1) {
+        __hip_atomic_store(a.arrive, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(a.step, step_now + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+  }
+  float* const convL = pool + TAIL_CONV;
+  if (a.conv_img) {
+    conv_stage_params(a.conv_img, convL);
+    __syncthreads();
+    // (two single tiles per wave, not dconv_bwd_pair: in THIS kernel the compiler's back end refuses the pair's row pointers --
+    // "illegal VGPR to SGPR copy" -- with any run-time joint index; the pair is 2.5 us faster where it compiles, k_sup_step)
+    dconv_bwd_body<true, true>(convL, 2 * blk, a.conv_img, a.ua.x6d_in, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
+    dconv_bwd_body<true, true>(convL, 2 * blk + 1, a.conv_img, a.ua.x6d_in, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
+    __syncthreads();      // gx of this pose group is complete
+  }
+  chain_bwd_body(blk, a.FT, a.R0T, a.AT, Jt, JS, par, a.dA, a.nslabA, a.strideA, a.dF, a.ua, B, BP, a.dmask, pool, step_now);
+  if (a.do_next) {
+    __syncthreads();      // the updated poses of this group are complete, and nobody reads this iteration's F^T / A^T any more
+    prep_fwd_body(blk, a.ua.x6d_io, nullptr, a.ua.betas_io, Jt, JS, par, a.FTw, a.ATw, a.R0Tw, B, BP, nullptr, a.FTq, pool);
+    if (a.conv_img && a.H2T_next) {
+      dconv_fwd_body<true, true>(convL, 2 * blk, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
+      dconv_fwd_body<true, true>(convL, 2 * blk + 1, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
+    }
+  }
+}
+
+int launch_tail_step(const Model& m, const TailStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s) {
+  static const bool attr = [] {
+    return hipFuncSetAttribute((const void*)k_tail_step, hipFuncAttributeMaxDynamicSharedMemorySize, TAIL_LDS * 4) == hipSuccess;
+  }();
+  if (!attr) { jrr_set_error("k_tail_step: %d bytes of LDS refused", TAIL_LDS * 4); return JRR_ERR_HIP; }
+  TailStepArgs a;
+  a.conv_img = q.conv_img; a.dH2T = q.dH2T; a.dscale = q.dscale; a.gx = q.gx; a.dsq = q.dsq;
+  a.FT = L.FT; a.R0T = L.R0T; a.AT = L.AT;
+  a.dA = L.dATp; a.nslabA = L.nslabA; a.strideA = L.strideA; a.dF = L.dFTp; a.dmask = L.dmaskA;
+  PoseUpdateArgs& u = a.ua;
+  u.x6d_in = L.x6d_in; u.gx_extra = L.gx_extra; u.gb_extra = L.gb_extra;
+  u.dx6d = L.dx6d; u.dR = L.dR; u.dbetas = L.dbetas;
+  u.x6d_io = L.x6d_io; u.betas_io = L.betas_io; u.adam_m = L.adam_m; u.adam_v = L.adam_v; u.step = L.step;
+  u.lr = L.lr; u.beta1 = L.beta1; u.beta2 = L.beta2; u.eps = L.eps;
+  u.gcam = L.gcam; u.cam_io = L.cam_io; u.cam_m = L.cam_m; u.cam_v = L.cam_v;
+  a.do_next = q.do_next ? 1 : 0; a.FTw = q.FTw; a.FTq = q.FTq; a.ATw = q.ATw; a.R0Tw = q.R0Tw; a.H2T_next = q.H2T_next;
+  a.step = q.step; a.arrive = q.arrive; a.B = L.B; a.BP = L.BP;
+  hipLaunchKernelGGL(k_tail_step, dim3((L.B + PPB - 1) / PPB), dim3(PPB * NJ), TAIL_LDS * 4, s, a, m.Jt, m.JS, m.parents);
+  return 0;
+}
+
 int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s) {
   static const bool attr = [] {
     return hipFuncSetAttribute((const void*)k_sup_step, hipFuncAttributeMaxDynamicSharedMemorySize, SUP_STEP_LDS * 4) == hipSuccess;

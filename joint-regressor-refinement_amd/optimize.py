@@ -269,6 +269,7 @@ def optimize_pose_refiner(log=print) -> Dict:
                 xch.step(J_regressor, J_opt.m, J_opt.v, J_opt.step, J_opt.lr, x6d, betas, gt_j3d, mask=j_reg_mask)
         eng.refine_run(x6d, betas, gt_j3d, m, v, step, 1e-2, args.inner_iters - n_inloop, sqerr=sq, after_j_step=n_inloop > 0)
         tiles_run = eng.support_tiles()[1]          # vertex tiles the inner iterations ran (asked while the silhouette term is still set)
+        sv_on, sv_n = eng.support_vertices()          # ... or, per support VERTEX, one launch per iteration (include/jrr.h)
         bucket.flat.zero_()
         bucket.put(0, sq)                                                                   # joint_loss (:238-239)
         pose_disc_sq, shape_disc_sq = eng.refine_aux_losses(use_pd, use_sd) if args.inner_iters > 0 else (None, None)
@@ -332,6 +333,7 @@ def optimize_pose_refiner(log=print) -> Dict:
                'seconds': time.perf_counter() - t0,                                         # inner loop + outer step, as the reference times nothing finer
                'seconds_batch': time.perf_counter() - t_batch,                              # + H->D copies, camera pre-fit, target set-up
                'vertex_tiles_run': tiles_run,     # 216, or the tiles of the regressor's support (FLAG_SUPPORT_TILES engaged)
+               'support_vertices_run': sv_n if sv_on else None,      # the vertices the per-vertex iteration ran on (None: tile kernels)
                'body_model': smpl.provenance, 'data': 'dataset' if args.data_root else 'synthetic'}
         rec = {k: (float(x) if isinstance(x, np.floating) else x) for k, x in rec.items()}
         pending = (rec, B_global)

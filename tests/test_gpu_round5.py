@@ -11,6 +11,7 @@
 The 2-rank (gloo) == 1-rank comparisons of the same two flag sets live in tests/test_gpu_dp.py.
 """
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -58,6 +59,10 @@ def test_driver_outer_step_in_both_tile_modes_vs_oracle(smpl_model_np, j_h36m_np
     import conftest
     restricted = tiles == 'support_tiles' and conftest.support_tiles_available()      # (forced dense / role kernels run all tiles)
     assert 0 < rec['vertex_tiles_run'] < 60 if restricted else rec['vertex_tiles_run'] == 216, rec['vertex_tiles_run']
+    if not restricted:
+        assert rec['support_vertices_run'] is None            # all tiles: the tile kernels
+    elif os.environ.get('JRR_SUPPORT_FUSED') != '0':
+        assert rec['support_vertices_run'] == int((j_h36m_np > 0).any(0).sum())      # the default: one launch per iteration on the support's vertices
     sm, eng_mod = _mod('smpl_model'), _mod('engine')
     dsd, ssd = _oracle_discs()
     full = sm.synthetic_batch(smpl_model_np, j_h36m_np, B, seed=0)
