@@ -13,8 +13,12 @@ for it in range(30):
     T = lambda k: torch.from_numpy(batch[k]).cuda().contiguous()
     dm = eng_mod.DeviceModel(model, 'cuda:0')
     flags = eng_mod.FLAG_POSE_DISC | eng_mod.FLAG_KEEP_VERTS | (eng_mod.FLAG_SILHOUETTE if it % 2 else 0) | (eng_mod.FLAG_FOLDED if it % 3 == 0 else 0)
+    if it % 5 in (1, 2):      # the default mode of optimize.py: support tiles / support vertices (k_sup_step), round 6
+        flags |= eng_mod.FLAG_SUPPORT_TILES
     eng = eng_mod.RefineEngine(dm, B, flags=flags)
     eng.set_j_regressor(torch.from_numpy(J))
+    if flags & eng_mod.FLAG_SUPPORT_TILES:
+        eng.j_support_info()
     eng.set_pose_disc(disc.Discriminator().flat_parameters())
     x, b = T('pose6d'), T('betas'); gt = T('gt_j3d'); gt = (gt - gt[:, :1]).contiguous()
     m, v = torch.zeros(B, 154, device='cuda'), torch.zeros(B, 154, device='cuda'); st = torch.zeros(1, dtype=torch.int32, device='cuda')
