@@ -495,7 +495,14 @@ static int pick_chunks(int wg_per_chunk, int max_chunks) {
 
 static void plan_geometry(int BP, int& nvc, int& nvcb, int& nvcb16, int& nsplit, int& nsplitJ) {
   const int nbg = BP / BG;
-  nvc = pick_chunks(nbg, 54);                       // forward: one workgroup per (128 poses, chunk)
+  // forward: one workgroup per (128 poses, chunk).  At most 54 chunks (4 tiles each) -- 108 for batches of up to 256 poses (round 6), whose
+  // one or two pose groups would otherwise put 54 / 108 workgroups on 512 slots with 4 tiles to walk each (256 poses, the reference's
+  // default batch, all five terms: k_lbs_fwd 67 -> 40 us, k_joints_loss 12 -> 17 us for twice the partials, the iteration 0.390 -> 0.367 ms;
+  // 216 chunks: 0.378; at 512 poses 108 chunks are two workgroups per CU and gain nothing: tools/exp/fwd_chunk_cap_ab.sh).
+  // JRR_FWD_CHUNK_CAP (experiments) overrides the cap.
+  int fwd_cap = nbg <= 2 ? 108 : 54;
+  { const char* e = getenv("JRR_FWD_CHUNK_CAP"); if (e && atoi(e) >= 1 && atoi(e) <= 216) fwd_cap = atoi(e); }
+  nvc = pick_chunks(nbg, fwd_cap);
   // exactly one round of 512 workgroups with an even chunk count lets k_lbs_fwd pair the two workgroups of a CU (lbs.hip)
   { const char* e = getenv("JRR_FWD_ROUND"); if (!(e && e[0] == '0') && 512 % nbg == 0 && 512 / nbg <= 64 && ((512 / nbg) & 1) == 0 && 32 % (512 / nbg / 2) == 0) nvc = 512 / nbg; }
   nvcb = pick_chunks(BP / BT, 36);                  // backward, role kernel: one workgroup per (32 poses, chunk)
