@@ -754,6 +754,12 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KS) void k_disc_gemm(GemmA
   // epilogue: registers 4q4 .. 4q4+3 of tile i = rows r0 + {0..3}, r0 = m0 + (wm WM + i) 32 + 8 q4 + 4 half: one output quad
   const int n = n0 + wn * 32 + l31;
   float dot = 0.f;
+  // 64-row tiles (WM = 1, two row waves): the fc4 partial dot of a 64-row group is ONE chain over its two 32-row tiles in the wide tile's
+  // wave -- here the second row wave CONTINUES the first one's chain, lane by lane (through LDS, one barrier: the K-split partner waves
+  // have left), so that the group's partial is bit-identical whatever the tile shape
+  constexpr bool DOT_CHAIN = EPI == EPI_BIAS_RELU_DOT && WM == 1 && WAVES_M == 2 && WAVES_N == 1;
+  float* const dotx = lds + 2 * (WM * 16 * 64) + 1024;      // behind the K-split reduction's slots
+  if (DOT_CHAIN && wm == 1) { __syncthreads(); dot = dotx[lane]; }
 #pragma unroll
   for (int i = 0; i < WM; ++i)
 #pragma unroll
@@ -785,7 +791,13 @@ __global__ __launch_bounds__(64 * WAVES_M * WAVES_N * KS) void k_disc_gemm(GemmA
       // left for the write-back at its end (measured: the four GEMMs 0.2596 -> 0.2553 ms)
       __builtin_nontemporal_store(v, &reinterpret_cast<f32x4*>(g.Out)[qi]);
     }
-  if (EPI == EPI_BIAS_RELU_DOT) {      // rows of the two lane halves are disjoint: add them, one store per column
+  if (DOT_CHAIN) {
+    if (wm == 0) { dotx[lane] = dot; __syncthreads(); }      // hand the chain to the second row wave
+    else {
+      const float t = dot + __shfl_xor(dot, 32);
+      if (half == 0) g.dot_out[(size_t)mt * g.ldo + n] = t;      // one partial per 64-row group, as the wide tile's (mt WAVES_M + wm)
+    }
+  } else if (EPI == EPI_BIAS_RELU_DOT) {      // rows of the two lane halves are disjoint: add them, one store per column
     const float t = dot + __shfl_xor(dot, 32);
     if (half == 0) g.dot_out[(size_t)(mt * WAVES_M + wm) * g.ldo + n] = t;
   }
@@ -818,6 +830,20 @@ int launch_disc_gemm_q(const GemmArgs& g, int epi, int btr, hipStream_t s, int* 
   // JRR_DISC_NARROW=0 (experiments) keeps the wide tiles.
   static const bool narrow_ok = [] { const char* e = getenv("JRR_DISC_NARROW"); return !(e && e[0] == '0'); }();
   if (narrow_ok && (g.M / 128) * (g.N / 64) < 512) {
+    // ... and below 2048 pose columns, where even those are fewer than 512 workgroups, 64 x 32 tiles: a wave owns ONE 32 x 32 tile and half
+    // the K steps, so its own chain of matrix instructions -- what a launch of a few dozen workgroups lasts -- is half as long.  Per
+    // output element still the same operations in the same order; the fc4 partial dots keep their 64-row groups as one chain (DOT_CHAIN
+    // in the kernel).  JRR_DISC_NARROW=1 keeps 128 x 32 everywhere.
+    static const bool tiny_ok = [] { const char* e = getenv("JRR_DISC_NARROW"); return !(e && e[0] == '1'); }();
+    if (tiny_ok && (g.M / 128) * (g.N / 32) < 512 && g.M % 64 == 0) {
+      dim3 gridt((g.M / 64) * (g.N / 32)), blockt(256);
+      if (epi == EPI_BIAS_RELU_DOT && !btr) hipLaunchKernelGGL((k_disc_gemm<1, 2, 1, EPI_BIAS_RELU_DOT, 0, 2>), gridt, blockt, 0, s, g);
+      else if (epi == EPI_BIAS_RELU && !btr) hipLaunchKernelGGL((k_disc_gemm<1, 2, 1, EPI_BIAS_RELU, 0, 2>), gridt, blockt, 0, s, g);
+      else if (epi == EPI_STORE && !btr) hipLaunchKernelGGL((k_disc_gemm<1, 2, 1, EPI_STORE, 0, 2>), gridt, blockt, 0, s, g);
+      else if (epi == EPI_MASK && btr == 2) hipLaunchKernelGGL((k_disc_gemm<1, 2, 1, EPI_MASK, 2, 2>), gridt, blockt, 0, s, g);
+      else { jrr_set_error("disc_gemm_q: unsupported epilogue %d / transform %d", epi, btr); return JRR_ERR_ARG; }
+      return 0;
+    }
     dim3 gridn((g.M / 128) * (g.N / 32)), blockn(256);
     if (epi == EPI_BIAS_RELU && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 1, EPI_BIAS_RELU, 0, 2>), gridn, blockn, 0, s, g);
     else if (epi == EPI_BIAS_RELU_DOT && !btr) hipLaunchKernelGGL((k_disc_gemm<2, 2, 1, EPI_BIAS_RELU_DOT, 0, 2>), gridn, blockn, 0, s, g);
