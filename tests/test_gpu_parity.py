@@ -462,6 +462,15 @@ def test_full_size_pose_disc_parity(eng_mod, dmodel, smpl_model_np, j_h36m_np):
         dxs = small.pose_disc_backward_input(x[sl].contiguous(), 10.0, 1.0)
         assert torch.equal(out[sl], outs)                # per-pose columns: identical arithmetic in every geometry
         assert torch.equal(dx[sl], dxs)
+    # ... and a 2048-pose engine: the third tile tier (128 x 64 at 4096 columns, 128 x 32 from 2048, 64 x 32 below)
+    Bm = 2048
+    mid = eng_mod.RefineEngine(dmodel, Bm, batch_norm=B, flags=eng_mod.FLAG_POSE_DISC)
+    mid.set_j_regressor(T(j_h36m_np)); mid.set_pose_disc(flat)
+    for k in (0, 1):
+        sl = slice(k * Bm, (k + 1) * Bm)
+        assert torch.equal(out[sl], mid.pose_disc_forward(x[sl].contiguous()))
+        assert torch.equal(dx[sl], mid.pose_disc_backward_input(x[sl].contiguous(), 10.0, 1.0))
+    del mid
     # the fused loop with the adversarial term: big engine vs shards, 3 iterations
     xb, bb = x.clone(), b.clone()
     m, v = torch.zeros(B, 154, device=DEV), torch.zeros(B, 154, device=DEV)
