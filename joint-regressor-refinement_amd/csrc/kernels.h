@@ -202,7 +202,8 @@ struct SupStepLaunch {
   // 2-D reprojection term (nullable gt_j2d: off); the camera's Adam state travels in the PrepBwdLaunch (gcam / cam_io / cam_m / cam_v)
   const float* gt_j2d = nullptr; const float* cam = nullptr; float* gcam = nullptr; float* sq2d = nullptr; float scale2d = 0.f;
 };
-int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s);
+// phase 0: the whole iteration; 1 / 2: its halves before / after the point where the discriminator GEMMs' results are read
+int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s, int phase = 0);
 
 // the END of an all-tiles iteration + the BEGINNING of the next in one launch (prep.hip k_tail_step): per-joint MLP adjoint, chain adjoint +
 // Adam (the PrepBwdLaunch, as launch_prep_bwd takes it), then -- do_next -- the chain forward [+ MLP forward] of the next iteration

@@ -1009,14 +1009,20 @@ struct SupStepArgs {
 constexpr int SUP_STEP_LDS = SUPL_FLOATS > CHAIN_BWD_LDS ? (SUPL_FLOATS > PREP_FWD_LDS ? SUPL_FLOATS : PREP_FWD_LDS)
                                                          : (CHAIN_BWD_LDS > PREP_FWD_LDS ? CHAIN_BWD_LDS : PREP_FWD_LDS);
 static_assert(SUP_STEP_LDS >= CL_FLOATS && SUP_PP == PP && SUP_PP == PPB && SUP_THREADS == PP * NJ, "one geometry for every phase");
+// PHASE 0: the whole iteration.  PHASE 1 / 2 (JRR_SUP_OVERLAP, api.hip): its two halves as launches of their own -- 1 = everything that
+// does not read the discriminator GEMMs' results (chain forward, support-vertex forward / loss / backward), on a second stream beside
+// those GEMMs; 2 = the rest (per-joint MLP adjoint, chain adjoint + Adam, the next iteration's per-joint MLP forward), behind both.
+constexpr int SUP_TAIL_CONV = CHAIN_BWD_LDS > PREP_FWD_LDS ? CHAIN_BWD_LDS : PREP_FWD_LDS;      // phase 2: the MLP image behind the chain pool
+constexpr int SUP_TAIL_LDS = SUP_TAIL_CONV + CL_FLOATS;
+template <int PHASE>
 __global__ __launch_bounds__(SUP_THREADS) void k_sup_step(SupStepArgs a, const float* __restrict__ Jt, const float* __restrict__ JS,
                                                           Parents par) {
   extern __shared__ __attribute__((aligned(16))) float pool[];
   const int blk = blockIdx.x, B = a.sup.B, BP = a.sup.BP;
-  auto stamp = [&](int i) { if (a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = wall_clock64(); };
+  auto stamp = [&](int i) { if (PHASE == 0 && a.stamps && blockIdx.x == 0 && threadIdx.x == 0) a.stamps[i] = wall_clock64(); };
   stamp(0);
   int step_now = -1;
-  if (threadIdx.x == 0 && a.step) {
+  if (PHASE != 1 && threadIdx.x == 0 && a.step) {
     const int s0 = __hip_atomic_load(a.step, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");            // the value is in: only now may this workgroup count as arrived
     step_now = s0 + 1;
@@ -1026,22 +1032,33 @@ __global__ __launch_bounds__(SUP_THREADS) void k_sup_step(SupStepArgs a, const f
       __hip_atomic_store(a.step, step_now, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
   }
-  prep_fwd_body(blk, a.x6d, nullptr, a.betas, Jt, JS, par, a.FT, a.AT, a.R0T, B, BP, nullptr, a.FTq, pool);
-  __syncthreads();
-  stamp(1);
-  sup_body(pool, blk, a.sup, a.stamps && blockIdx.x == 0 ? a.stamps + 8 : nullptr);
-  __syncthreads();
-  stamp(2);
-  // (the per-joint MLP adjoint closed the support body: one interleaved pair of joints per wave, supk.h)
-  stamp(3);
+  constexpr int CONV_AT = PHASE == 2 ? SUP_TAIL_CONV : SUPL_CONV;
+  if (PHASE != 2) {
+    prep_fwd_body(blk, a.x6d, nullptr, a.betas, Jt, JS, par, a.FT, a.AT, a.R0T, B, BP, nullptr, a.FTq, pool);
+    __syncthreads();
+    stamp(1);
+    sup_body(pool, blk, a.sup, a.stamps && blockIdx.x == 0 ? a.stamps + 8 : nullptr);
+    if (PHASE == 1) return;
+    __syncthreads();
+    stamp(2);
+    // (the per-joint MLP adjoint closed the support body: one interleaved pair of joints per wave, supk.h)
+    stamp(3);
+  } else if (a.conv_img) {      // phase 2 opens with that adjoint (the first phase's launch ran the support body without it)
+    conv_stage_params(a.conv_img, pool + CONV_AT);
+    __syncthreads();
+    // (two single tiles per wave: outside sup_body the compiler's back end refuses dconv_bwd_pair, see k_tail_step)
+    dconv_bwd_body<true, true>(pool + CONV_AT, 2 * blk, a.conv_img, a.x6d, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
+    dconv_bwd_body<true, true>(pool + CONV_AT, 2 * blk + 1, a.conv_img, a.x6d, a.dH2T, nullptr, a.dscale, 1.f, a.gx, B, BP, a.dsq);
+    __syncthreads();
+  }
   chain_bwd_body(blk, a.FT, a.R0T, a.AT, Jt, JS, par, a.sup.dA, 1, 0, a.sup.dF, a.ua, B, BP, nullptr, pool, step_now);
   if (a.conv_img && a.H2T_next) {      // the updated poses of this group are complete: their per-joint MLP forward for the next iteration
     __syncthreads();
     stamp(4);
     // (the image the support body staged for the adjoint is still in place: the chain adjoint's pool ends far below it)
     static_assert(CHAIN_BWD_LDS <= SUPL_CONV && PREP_FWD_LDS <= SUPL_CONV, "the per-joint MLP image survives the chain phases");
-    dconv_fwd_body<true, true>(pool + SUPL_CONV, 2 * blk, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
-    dconv_fwd_body<true, true>(pool + SUPL_CONV, 2 * blk + 1, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
+    dconv_fwd_body<true, true>(pool + CONV_AT, 2 * blk, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
+    dconv_fwd_body<true, true>(pool + CONV_AT, 2 * blk + 1, a.conv_img, a.ua.x6d_io, a.H2T_next, nullptr, B, BP);
   }
   __syncthreads();
   stamp(5);
@@ -1124,16 +1141,18 @@ int launch_tail_step(const Model& m, const TailStepLaunch& q, const PrepBwdLaunc
   return 0;
 }
 
-int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s) {
+int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch& L, hipStream_t s, int phase) {
   static const bool attr = [] {
-    return hipFuncSetAttribute((const void*)k_sup_step, hipFuncAttributeMaxDynamicSharedMemorySize, SUP_STEP_LDS * 4) == hipSuccess;
+    return hipFuncSetAttribute((const void*)k_sup_step<0>, hipFuncAttributeMaxDynamicSharedMemorySize, SUP_STEP_LDS * 4) == hipSuccess &&
+           hipFuncSetAttribute((const void*)k_sup_step<1>, hipFuncAttributeMaxDynamicSharedMemorySize, SUP_STEP_LDS * 4) == hipSuccess &&
+           hipFuncSetAttribute((const void*)k_sup_step<2>, hipFuncAttributeMaxDynamicSharedMemorySize, SUP_TAIL_LDS * 4) == hipSuccess;
   }();
   if (!attr) { jrr_set_error("k_sup_step: %d bytes of LDS refused", SUP_STEP_LDS * 4); return JRR_ERR_HIP; }
   SupStepArgs a;
   a.x6d = L.x6d_in; a.betas = L.betas_in; a.FT = q.FT; a.FTq = q.FTq; a.AT = q.AT; a.R0T = q.R0T;
   a.sup = SupArgs{q.t, q.nsv, q.Jn_vi, q.FTq, q.AT, q.gt_mm, q.scale, q.joints_out, q.sqerr, q.dA, q.dF, L.B, L.BP,
                   Reproj{q.gt_j2d, q.cam, q.gcam, q.sq2d, q.scale2d},
-                  q.conv_img, L.x6d_in, q.dH2T, q.dscale, q.gx, q.dsq};
+                  phase == 0 ? q.conv_img : nullptr, L.x6d_in, q.dH2T, q.dscale, q.gx, q.dsq};      // (phases 1 / 2: the adjoint opens phase 2)
   a.conv_img = q.conv_img; a.dH2T = q.dH2T; a.dscale = q.dscale; a.gx = q.gx; a.dsq = q.dsq; a.H2T_next = q.H2T_next;
   PoseUpdateArgs& u = a.ua;
   u.x6d_in = L.x6d_in; u.gx_extra = L.gx_extra; u.gb_extra = L.gb_extra;
@@ -1144,7 +1163,10 @@ int launch_sup_step(const Model& m, const SupStepLaunch& q, const PrepBwdLaunch&
   a.step = q.step; a.arrive = q.arrive;
   static long long* const stamps = [] { const char* v = getenv("JRR_SUP_STAMPS"); return v ? (long long*)strtoull(v, nullptr, 0) : (long long*)nullptr; }();
   a.stamps = stamps;
-  hipLaunchKernelGGL(k_sup_step, dim3((L.B + SUP_PP - 1) / SUP_PP), dim3(SUP_THREADS), SUP_STEP_LDS * 4, s, a, m.Jt, m.JS, m.parents);
+  const dim3 grid((L.B + SUP_PP - 1) / SUP_PP), block(SUP_THREADS);
+  if (phase == 1) hipLaunchKernelGGL(k_sup_step<1>, grid, block, SUP_STEP_LDS * 4, s, a, m.Jt, m.JS, m.parents);
+  else if (phase == 2) hipLaunchKernelGGL(k_sup_step<2>, grid, block, SUP_TAIL_LDS * 4, s, a, m.Jt, m.JS, m.parents);
+  else hipLaunchKernelGGL(k_sup_step<0>, grid, block, SUP_STEP_LDS * 4, s, a, m.Jt, m.JS, m.parents);
   return 0;
 }
 
