@@ -6,7 +6,7 @@
 # writes gpurun_out/<tag>/: the kernel trace + PMC passes of the headline command (tools/prof.sh), the rasteriser's counters
 # (tools/prof_c5.sh), the two bench lines the driver produces (--steps 20 --warmup 5, and the defaults), BASELINE configs[1] and [4] as
 # their own lines, the GPU suite and smoke().  `variants` runs INSTEAD the GPU suite under each forced kernel-selection variant
-# (11 x ~6.5 minutes: more than one gpurun call of 60 minutes -- VARIANTS="A=1 B=2" selects a subset).
+# (13 x ~6.5 minutes: more than one gpurun call of 60 minutes -- VARIANTS="A=1 B=2" selects a subset).
 # Copy what DESIGN.md / profiles/README.md cite into profiles/ afterwards -- gpurun_out/ is scratch.
 TAG=${1:?usage: bash tools/final.sh <tag> [variants]}
 OUT=gpurun_out/$TAG
@@ -15,7 +15,7 @@ if [ "$2" = variants ]; then
   {
     echo "GPU suite (pytest -m gpu) under each forced kernel variant, one MI355X box, $(date +%F):"
     for v in ${VARIANTS:-JRR_SKIN_JOINTS=12 JRR_DENSE_SKINNING=1 JRR_BWD16=0 JRR_VERTEX_ORDER=sorted JRR_BWD16_NG=2 JRR_DISC_KS=1 JRR_DISC_NARROW=0 JRR_DISC_NARROW=1 \
-             JRR_BWD16_REV=1 JRR_SUPPORT_FUSED=0 JRR_SUPPORT_FUSED=2}; do
+             JRR_BWD16_REV=1 JRR_SUPPORT_FUSED=0 JRR_SUPPORT_FUSED=2 JRR_SUP_OVERLAP=0 JRR_SUP_OVERLAP=1}; do
       echo "== $v"
       env $v python -m pytest tests -m gpu -q 2>&1 | tail -1
     done
