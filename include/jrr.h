@@ -13,7 +13,7 @@
  *    tensors and pose-granular contiguous slices of them are);
  *    every `*_host` pointer is host memory read synchronously during the call.
  *  - `stream` is a hipStream_t passed as void* (torch.cuda.current_stream().cuda_stream);
- *    kernels are enqueued on it, no entry point synchronises the device unless stated.
+ *    kernels are enqueued on it, no entry point synchronises the device unless stated.  (jrr_refine_run* may put part of an iteration on an engine-owned side stream, forked from and joined back into `stream` by events within the call: ordering as seen from `stream` is unchanged.)
  *  - return value: 0 on success, negative jrr_status otherwise; nothing throws.
  *  - one caller thread per engine; engines on different devices/processes are independent.
  *  - all floating point is IEEE fp32 (the reference runs `.float()`, optimize.py:160);
