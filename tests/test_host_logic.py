@@ -357,3 +357,20 @@ def test_no_kernel_spills_registers():
                 assert r['occ'] == 1                        # the JRR_BWD16_NG=2 experiment: ONE 512-register wave per SIMD, by design
                 continue
             assert r['occ'] >= 2 and r['vgpr'] <= 256, r
+
+
+def test_every_environment_knob_is_documented():
+    """every JRR_* variable the library or the host side reads appears in DESIGN.md (section 3's list of verification knobs)"""
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pkg = os.path.join(root, 'joint-regressor-refinement_amd')
+    knobs = set()
+    for f in glob.glob(os.path.join(pkg, 'csrc', '*.h*')):
+        knobs |= set(re.findall(r'getenv\("(JRR_[A-Z0-9_]+)"\)', open(f).read()))
+    for f in glob.glob(os.path.join(pkg, '*.py')) + [os.path.join(root, 'bench.py')]:
+        knobs |= set(re.findall(r"environ\.get\(['\"](JRR_[A-Z0-9_]+)", open(f).read()))
+    assert len(knobs) > 10
+    design = open(os.path.join(root, 'DESIGN.md')).read()
+    missing = sorted(k for k in knobs if k not in design)
+    assert not missing, missing
